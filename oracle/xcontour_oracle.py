@@ -1,0 +1,515 @@
+# -*- coding: utf-8 -*-
+"""
+CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  NOT a product path, NOT a fallback.
+
+A numpy-only restatement of the contour-coordinate hot path of
+miniufo/xcontour @ 2024_10_08 (`xcontour/core.py`, `xcontour/utils.py`),
+operating on plain ndarrays.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import this file, and only as the checker.
+`xcontour_amd` never imports it and fails loudly without its HIP library.
+
+PARITY UNPINNED
+---------------
+The reference cannot be imported in the build container (needs xarray,
+xhistogram, numba, skimage, xgcm -- none installed, no network) and its own
+tests contain no assertions / golden numbers (all 11 files under
+/root/reference/tests are plot scripts; .travis.yml is `script: true`).
+The arithmetic of the path lives in un-vendored third-party packages:
+
+  * xhistogram (README.md:23 says 0.3.0; setup.py:40-45 unpinned) -- call
+    sites core.py:1284, 1307.  Published algorithm: np.digitize against the
+    explicit edges, out-of-range and NaN dropped, np.bincount(weights) in
+    float64.  Restated here as `weighted_histogram` (digitize + bincount),
+    cross-checked against `np.histogram` (numpy IS installed).
+    Last-bin rule: numpy closes the last bin on the right.  xhistogram 0.1.2 -
+    0.3.x (from memory of its core.py `_bincount_2d_vectorized`; source not
+    available offline) instead replaces the last edge by `edge + 1e-8` (in the
+    edge dtype) and keeps the bin half-open.  Both are implemented:
+    `right_edge='numpy'` (default, the SURVEY.md contract) and
+    `right_edge='xhistogram'`.
+  * xarray (README 0.15.1): min/max/where/sum/cumsum/differentiate/fillna/
+    apply_ufunc(vectorize=True) -- restated with the numpy calls xarray
+    dispatches to (np.nanmin, np.nansum, np.cumsum, np.gradient, np.vectorize).
+  * numpy: np.interp, np.gradient, np.insert -- called directly.
+
+What pins this file: (i) line-by-line citations below, (ii) the survey's
+independently derived known-answer vectors on the reference's bundled
+`Data/barotropic_vorticity.nc` (asserted in
+tests/test_oracle_golden.py), (iii) identities the reference's own demo
+scripts rely on (hist API == conditional API away from edges,
+tests/test_hist.py:132-167; table end point == total area, core.py:133-140).
+
+All `core.py:` / `utils.py:` citations are into /root/reference/xcontour/.
+"""
+import numpy as np
+
+Rearth = 6371200.0   # utils.py:19
+
+
+# ---------------------------------------------------------------------------
+# a2  contour levels                                        core.py:205-266
+# ---------------------------------------------------------------------------
+def cal_contours(q, levels, increase=True, dtype=np.float32):
+    """Per-slab contour levels.  `q` is (..., ny, nx); returns (..., N).
+
+    int `levels` (core.py:222-249): N equally spaced levels from the slab's
+    NaN-skipping min to max (max to min if not `increase`).  The arithmetic
+    is what `xr.apply_ufunc(mylinspace, ..., vectorize=True,
+    output_dtypes=[dtype])` evaluates: `stop-start` in the tracer dtype,
+    `1.0/np.int64(N-1)` in f64, product / `*arange` / `+start` in f64, cast
+    to `dtype` at the end.
+    array `levels` (core.py:251-264): `tracer_min - tracer_min + levs`
+    broadcast to every slab (NaN for an all-NaN slab), cast to `dtype`.
+    """
+    q = np.asarray(q)
+    lead = q.shape[:-2]
+    flat = q.reshape((-1,) + q.shape[-2:])
+    if isinstance(levels, (int, np.integer)):
+        N = int(levels)
+        out = np.empty((flat.shape[0], N), dtype=dtype)
+        inv = np.float64(1.0) / np.int64(N - 1)            # core.py:229-230
+        for s in range(flat.shape[0]):
+            mmin = _nanmin(flat[s])                          # core.py:224
+            mmax = _nanmax(flat[s])                          # core.py:225
+            start, stop = (mmin, mmax) if increase else (mmax, mmin)
+            steps = inv * (stop - start)                     # f64 * T -> f64
+            ctr = steps * np.arange(N) + np.float64(start)   # core.py:232
+            out[s] = ctr.astype(dtype)                       # core.py:246
+        return out.reshape(lead + (N,))
+    levs = np.asarray(levels)
+    out = np.empty((flat.shape[0], levs.size), dtype=dtype)
+    for s in range(flat.shape[0]):
+        mmin = _nanmin(flat[s])
+        out[s] = (mmin - mmin + levs).astype(dtype)          # core.py:254
+    return out.reshape(lead + (levs.size,))
+
+
+def _nanmin(a):
+    """xarray `.min()` on floats: NaN-skipping; all-NaN slab -> NaN."""
+    a = np.asarray(a)
+    if a.dtype.kind != 'f':
+        return a.min()
+    m = ~np.isnan(a)
+    return a[m].min() if m.any() else a.dtype.type(np.nan)
+
+
+def _nanmax(a):
+    a = np.asarray(a)
+    if a.dtype.kind != 'f':
+        return a.max()
+    m = ~np.isnan(a)
+    return a[m].max() if m.any() else a.dtype.type(np.nan)
+
+
+# ---------------------------------------------------------------------------
+# a3  _histogram                                            core.py:1202-1325
+# ---------------------------------------------------------------------------
+def hist_edges(b):
+    """Ascending N+1 edges from N levels `b` (in b's dtype)  core.py:1296-1305.
+
+    Returns (edges, bincrease).  A dummy left edge one `step` below the lowest
+    level is prepended so that #bins == #levels.  Raises like the reference if
+    any two adjacent levels coincide (core.py:1233-1234).
+    """
+    b = np.asarray(b)
+    if b.ndim != 1:
+        raise Exception('bins should be numpy.array or xarray.DataArray')
+    if not np.diff(b).all():
+        raise Exception('non monotonic bins')
+    bincrease = bool(b[0] < b[-1])
+    n1 = len(b) - 1
+    if bincrease:
+        step = (b[-1] - b[0]) / n1
+        edges = np.insert(b, 0, b[0] - step)
+    else:
+        step = (b[0] - b[-1]) / n1
+        edges = np.insert(b[::-1], 0, b[-1] - step)
+    return edges, bincrease
+
+
+def weighted_histogram(x, edges, weights=None, right_edge='numpy'):
+    """N-bin histogram of `x` over ascending `edges` (xhistogram semantics).
+
+    bin k = [edges[k], edges[k+1]); NaN and out-of-range values dropped;
+    weights summed in float64 by np.bincount (what xhistogram dispatches to).
+    right_edge='numpy'      : last bin closed on the right (np.histogram rule).
+    right_edge='xhistogram' : last edge replaced by `edges[-1] + 1e-8`
+                              evaluated in the edge dtype, bin stays half-open.
+    Returns (sums_f64[N], counts_int64[N]).
+    """
+    x = np.asarray(x).ravel()
+    edges = np.asarray(edges)
+    nb = len(edges) - 1
+    if right_edge == 'xhistogram':
+        edges = np.concatenate((edges[:-1], edges[-1:] + 1e-8))
+    elif right_edge != 'numpy':
+        raise Exception('right_edge should be "numpy" or "xhistogram"')
+    idx = np.digitize(x, edges)              # 0: below, nb+1: >= last / NaN
+    if right_edge == 'numpy':
+        idx = np.where(x == edges[-1], nb, idx)
+    counts = np.bincount(idx, minlength=nb + 2)[1:nb + 1].astype(np.int64)
+    if weights is None:
+        return counts.astype(np.float64), counts
+    w = np.asarray(weights, dtype=np.float64).ravel()
+    sums = np.bincount(idx, weights=w, minlength=nb + 2)[1:nb + 1]
+    return sums, counts
+
+
+def histogram_cdf(q, b, weights, lt, right_edge='numpy'):
+    """`_histogram(var, bins, dim, weights, lt)` for one slab (core.py:1296-1325).
+
+    Result is in ASCENDING-VALUE order (position i <-> i-th smallest level),
+    exactly as `_histogram` returns its data; the caller (a4) reverses it when
+    the levels were decreasing.  Returns (cdf, pdf, counts, bincrease).
+    """
+    edges, bincrease = hist_edges(b)
+    q = np.asarray(q)
+    w = np.broadcast_to(np.asarray(weights), q.shape)
+    pdf, counts = weighted_histogram(q, edges, w, right_edge)
+    cdf = np.cumsum(pdf)                                     # core.py:1320
+    if not lt:
+        cdf = cdf[-1] - cdf                                  # core.py:1322-1323
+    return cdf, pdf, counts, bincrease
+
+
+# ---------------------------------------------------------------------------
+# a4  conditional integrals                                 core.py:363-460
+# ---------------------------------------------------------------------------
+def _weights(dA, integrand, shape):
+    """`wei = (integrand*dA or dA).fillna(0)`  core.py:443-449 (result dtype of
+    the product is numpy's promotion of the two operands)."""
+    dA = np.asarray(dA)
+    if dA.ndim == 1:                  # per-row metric, broadcast along X
+        dA = dA[:, None]
+    wei = dA if integrand is None else np.asarray(integrand) * dA
+    wei = np.broadcast_to(wei, shape)
+    return np.where(np.isnan(wei), wei.dtype.type(0), wei)
+
+
+def cal_integral_within_contours_hist(q, ctr, dA, integrand=None, lt=False,
+                                      right_edge='numpy', return_counts=False):
+    """core.py:412-460 for one slab: out[k] <-> ctr[k] whatever the direction."""
+    q = np.asarray(q)
+    wei = _weights(dA, integrand, q.shape)
+    cdf, pdf, counts, binc = histogram_cdf(q, ctr, wei, lt, right_edge)
+    if not binc:                                             # core.py:454-455
+        cdf, pdf, counts = cdf[::-1], pdf[::-1], counts[::-1]
+    if return_counts:
+        return cdf, counts
+    return cdf
+
+
+def cal_integral_within_contours(q, ctr, dA, integrand=None, lt=False):
+    """The xarray conditional-integration twin (core.py:363-409), intended
+    semantics: NaN-skipping sum over the two plane dims of
+    `integrand.where(q < c_k) * dA`, strict comparison at every k."""
+    q = np.asarray(q)
+    ctr = np.asarray(ctr)
+    dA2 = np.asarray(dA)
+    if dA2.ndim == 1:
+        dA2 = dA2[:, None]
+    if integrand is None:
+        integrand = q - q + 1                                # core.py:396
+    f = np.asarray(integrand) * dA2
+    out = np.empty(ctr.shape[-1], dtype=np.float64)
+    for k in range(ctr.shape[-1]):
+        cond = (q < ctr[k]) if lt else (q > ctr[k])          # core.py:398-401
+        out[k] = np.nansum(np.where(cond, f, np.nan), dtype=np.float64)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# a5  area <-> equivalent-coordinate table                  core.py:73-203
+# ---------------------------------------------------------------------------
+def cal_area_eqCoord_table_hist(mask, dA, coord, increase=True, lt=False,
+                                right_edge='numpy'):
+    """core.py:150-203.  Returns (tbl, coord_ascending)."""
+    mask = np.asarray(mask)
+    coord = np.asarray(coord)
+    ctrVar = np.broadcast_to(coord[:, None], mask.shape)     # core.py:176
+    ctrVar = np.where(mask == 1, ctrVar, np.nan)             # core.py:178
+    yIncre = not (coord[-1] < coord[0])                      # core.py:180-182
+    ylt = lt if (increase == yIncre) else (not lt)           # core.py:184-188
+    dA2 = np.asarray(dA)
+    if dA2.ndim == 1:
+        dA2 = dA2[:, None]
+    w = np.broadcast_to(dA2, mask.shape)                     # no fillna here
+    cdf, _, _, _ = histogram_cdf(ctrVar, coord, w, ylt, right_edge)
+    cs = coord if yIncre else coord[::-1]                    # core.py:195-198
+    return cdf, cs.copy()
+
+
+def cal_area_eqCoord_table(mask, dA, coord, increase=True, lt=False):
+    """core.py:73-147 (xarray twin), intended semantics.  Keeps the original
+    coordinate order; end point overwritten with the total masked area."""
+    mask = np.asarray(mask, dtype=np.float64)
+    coord = np.asarray(coord)
+    dA2 = np.asarray(dA)
+    if dA2.ndim == 1:
+        dA2 = dA2[:, None]
+    eqDimIncre = coord[-1] > coord[0]
+    same = (eqDimIncre == increase)
+    less = (same if lt else (not same))      # core.py:103-128: '<' or '>' case
+    J = len(coord)
+    tbl = np.empty(J, dtype=np.float64)
+    cv = coord[:, None]
+    for j in range(J):
+        cond = (cv < coord[j]) if less else (cv > coord[j])
+        tbl[j] = abs(np.nansum(np.where(cond, mask, np.nan) * dA2))
+    maxArea = abs(np.nansum(mask * dA2))                     # core.py:133
+    if tbl[-1] > tbl[0]:                                     # core.py:136-140
+        tbl[-1] = maxArea
+    else:
+        tbl[0] = maxArea
+    return tbl, coord.copy()
+
+
+# ---------------------------------------------------------------------------
+# a6  Table.lookup_coordinates / _interp1d                  core.py:1103-1174, 1405-1434
+# ---------------------------------------------------------------------------
+def interp1d(x, xf, yf, inc=True):
+    if inc:
+        return np.interp(x, xf, yf)                          # core.py:1427
+    return np.interp(x, xf[::-1], yf[::-1])                  # core.py:1430
+
+
+def table_increasing(tbl):
+    """Table.__init__ direction flag (core.py:1122-1128)."""
+    return bool(tbl[-1] > tbl[0])
+
+
+def lookup_coordinates(values, tbl, coord):
+    """Table.lookup_coordinates (core.py:1136-1174); output dtype = table dtype."""
+    tbl = np.asarray(tbl)
+    return interp1d(np.asarray(values), tbl, np.asarray(coord),
+                    table_increasing(tbl)).astype(tbl.dtype)
+
+
+# ---------------------------------------------------------------------------
+# a7  O(N) epilogue                                         core.py:463-488, 619-637, 945-966
+# ---------------------------------------------------------------------------
+def differentiate_contour(var):
+    """`DataArray.differentiate('contour')`: np.gradient w.r.t. the contour
+    coordinate 0..N-1 (float32 by default, core.py:248 / 1255), edge_order=1."""
+    var = np.asarray(var)
+    k = np.arange(var.shape[-1], dtype=np.float32)
+    return np.gradient(var, k, axis=-1, edge_order=1)
+
+
+def cal_gradient_wrt_area(var, area):
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return differentiate_contour(var) / differentiate_contour(area)   # core.py:480-483
+
+
+def cal_sqared_equivalent_length(dgrdSdA, dqdA):
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return dgrdSdA / dqdA ** 2                           # core.py:635
+
+
+def cal_normalized_Keff(Leq2, Lmin, mask=1e5):
+    with np.errstate(divide='ignore', invalid='ignore'):
+        nkeff = Leq2 / Lmin / Lmin                           # core.py:963
+        return np.where(nkeff < mask, nkeff, np.nan)         # core.py:964
+
+
+def equivalent_latitudes(areas, Rearth=Rearth):
+    areas = np.asarray(areas)
+    ratio = areas / 2.0 / np.pi / Rearth / Rearth - 1.0      # utils.py:506
+    ratio = np.where(ratio < -1, -1.0, ratio)
+    ratio = np.where(ratio > 1, 1.0, ratio)
+    return np.rad2deg(np.arcsin(ratio)).astype(areas.dtype)  # utils.py:512
+
+
+def latitude_lengths_at(lats, Rearth=Rearth):
+    lats = np.asarray(lats)
+    return (2.0 * np.pi * Rearth * np.cos(np.deg2rad(lats))).astype(lats.dtype)  # utils.py:532
+
+
+# ---------------------------------------------------------------------------
+# a8  interpolation to prescribed equivalent coordinates    core.py:1050-1100
+# ---------------------------------------------------------------------------
+def interp_to_coords(predef, eqCoords, var):
+    """One slab: direction taken from eqCoords[0] < eqCoords[-1] (core.py:1085)."""
+    eqCoords = np.asarray(eqCoords)
+    inc = bool(eqCoords[0] < eqCoords[-1])
+    return interp1d(np.asarray(predef), eqCoords, np.asarray(var), inc)
+
+
+# ---------------------------------------------------------------------------
+# a10  local wave activity / local APE                      core.py:696-799, 908-942
+# ---------------------------------------------------------------------------
+def cal_local_wave_activity(q, Q, coord, dA, increase=True, part='all',
+                            mask_idx=None, metric=None):
+    """q (ny,nx); Q (J=ny,); coord (ny,).  Returns lwa (J,nx) [, contours, masks].
+
+    `metric=None` follows the snapshot text (core.py:789): M = dA.
+    `metric=<array>` is the legacy length metric (commented core.py:787-788).
+    """
+    q = np.asarray(q)
+    Q = np.asarray(Q)
+    coord = np.asarray(coord)
+    dA2 = np.asarray(dA)
+    if dA2.ndim == 1:
+        dA2 = dA2[:, None]
+    wei = dA2 / np.nanmax(dA2)                               # core.py:723-724
+    M = dA2 if metric is None else np.asarray(metric)
+    if M.ndim == 1:
+        M = M[:, None]
+    part = part.lower()
+    if part not in ['all', 'upper', 'lower']:                # core.py:732-733
+        raise Exception("invalid part, should be in ['all', 'upper', 'lower']")
+    coord_incre = not (coord[-1] < coord[0])                 # core.py:736-738
+    J = len(coord)
+    returnmask = mask_idx is not None
+    if returnmask and max(mask_idx) >= J:                    # core.py:747-748
+        raise Exception('indices in mask_idx out of boundary')
+    mask_idx = list(mask_idx) if returnmask else []
+    lwa = np.empty((J, q.shape[1]), dtype=np.float64)
+    contours, masks = [], []
+    for j in range(J):                                       # core.py:752
+        qe = q - Q[j]                                        # core.py:754
+        m = (coord >= coord[j]) if coord_incre else (coord <= coord[j])
+        m = m[:, None]
+        if increase:                                         # core.py:759-766
+            mask1 = np.where(qe > 0, -1, 0)
+            mask2 = np.where(m, 0, mask1)
+            mask3 = np.where(np.logical_and(qe < 0, m), 1, mask2)
+        else:
+            mask1 = np.where(qe < 0, -1, 0)
+            mask2 = np.where(m, 0, mask1)
+            mask3 = np.where(np.logical_and(qe > 0, m), 1, mask2)
+        if j in mask_idx:
+            contours.append(Q[j])
+            masks.append(mask3.astype(np.int64))
+        if part == 'all':                                    # core.py:773-784
+            mf = mask3.astype(np.float64)
+        else:
+            pos = (part == 'upper') == bool(increase)
+            mf = np.where(mask3 > 0 if pos else mask3 < 0, mask3, np.nan)
+        lwa[j] = -np.nansum(qe * mf * wei * M, axis=0)       # core.py:789
+    if returnmask:
+        return lwa, contours, masks
+    return lwa
+
+
+# ---------------------------------------------------------------------------
+# Build-defined pieces (no reference call site: SURVEY F6, F7)
+# ---------------------------------------------------------------------------
+def cell_area(lat, lon, Rearth=Rearth, to_poles=True):
+    """2-D f64 cell areas R^2 |sin(phi_n) - sin(phi_s)| dlambda (the `rA`
+    formula of utils.py:179-208) with mid-point cell edges.  BUILD-DEFINED
+    input helper (the reference builds metrics with xgcm, off the hot path).
+    `to_poles=True`: the two end cells reach the poles (sum == 4 pi R^2 on a
+    global grid); False: end edges extrapolated half a spacing and clipped to
+    +-90 like utils.py:186-190."""
+    lat = np.asarray(lat, dtype=np.float64)
+    lon = np.asarray(lon, dtype=np.float64)
+    mid = 0.5 * (lat[1:] + lat[:-1])
+    first = lat[0] - 0.5 * (lat[1] - lat[0])
+    last = lat[-1] + 0.5 * (lat[-1] - lat[-2])
+    if to_poles:
+        first = np.sign(lat[0]) * 90.0
+        last = np.sign(lat[-1]) * 90.0
+    lo = np.clip(np.concatenate(([first], mid)), -90.0, 90.0)
+    hi = np.clip(np.concatenate((mid, [last])), -90.0, 90.0)
+    dlam = np.deg2rad(abs(lon[1] - lon[0]))
+    band = Rearth * Rearth * np.abs(np.sin(np.deg2rad(hi)) - np.sin(np.deg2rad(lo))) * dlam
+    return np.repeat(band[:, None], len(lon), axis=1)
+
+
+def grad2_sphere(q, lat, lon, Rearth=Rearth):
+    """|grad q|^2 on a regular lat-lon grid, float64.
+
+    BUILD-DEFINED (the reference takes grdS as an input computed by the
+    external GeoApps/xinvert packages): X periodic centred
+    difference, Y centred interior / one-sided edges on the (possibly
+    non-uniform) latitude index, metrics dx = R cos(phi) dlambda,
+    dy = R dphi.  NaN neighbours propagate NaN (-> weight 0 via fillna).
+    The arithmetic below is the normative order of operations for the kernel:
+        gx = (q[j,i+1] - q[j,i-1]) * rdx[j]       rdx = 1 / (2 R cos(phi_j) dlambda)
+        gy = (q[jn,i]  - q[js,i])  * rdy[j]       rdy = 1 / (R (phi_jn - phi_js))
+        g2 = gx*gx + gy*gy
+    """
+    q = np.asarray(q, dtype=np.float64)
+    rdx, rdy = grad_metrics(lat, lon, Rearth)
+    ny = q.shape[0]
+    gx = (np.roll(q, -1, axis=1) - np.roll(q, 1, axis=1)) * rdx[:, None]
+    jn = np.minimum(np.arange(ny) + 1, ny - 1)
+    js = np.maximum(np.arange(ny) - 1, 0)
+    gy = (q[jn, :] - q[js, :]) * rdy[:, None]
+    return gx * gx + gy * gy
+
+
+def grad_metrics(lat, lon, Rearth=Rearth):
+    """Per-row reciprocal metrics used by `grad2_sphere` (f64)."""
+    lat = np.asarray(lat, dtype=np.float64)
+    lon = np.asarray(lon, dtype=np.float64)
+    ny = len(lat)
+    phi = np.deg2rad(lat)
+    dlam = np.deg2rad(lon[1] - lon[0])
+    with np.errstate(divide='ignore'):
+        rdx = 1.0 / (2.0 * Rearth * np.cos(phi) * dlam)
+    jn = np.minimum(np.arange(ny) + 1, ny - 1)
+    js = np.maximum(np.arange(ny) - 1, 0)
+    rdy = 1.0 / (Rearth * (phi[jn] - phi[js]))
+    return rdx, rdy
+
+
+def sorted_profile(q, dA, tbl_targets, mask=None):
+    """Exact adiabatic rearrangement (a9, build-defined; increasing / lt case).
+
+    Stable ascending sort of the valid cells by q carrying dA;
+    Acum = cumsum(dA_sorted); Q_exact(target) = q_sorted[searchsorted(Acum,
+    target, 'right')] clipped to the last cell.  Returns (Q_exact, q_sorted,
+    Acum).
+    """
+    q = np.asarray(q)
+    dA2 = np.asarray(dA, dtype=np.float64)
+    if dA2.ndim == 1:
+        dA2 = dA2[:, None]
+    w = np.broadcast_to(dA2, q.shape).ravel()
+    x = q.ravel()
+    ok = ~np.isnan(x)
+    if mask is not None:
+        ok &= (np.asarray(mask).ravel() == 1)
+    x, w = x[ok], w[ok]
+    order = np.argsort(x, kind='stable')
+    xs, ws = x[order], w[order]
+    acum = np.cumsum(ws)
+    idx = np.searchsorted(acum, np.asarray(tbl_targets, dtype=np.float64), side='right')
+    idx = np.minimum(idx, len(xs) - 1)
+    return xs[idx], xs, acum
+
+
+# ---------------------------------------------------------------------------
+# The reference's Keff call sequence (tests/test_Keff_atmos.py:75-92)
+# ---------------------------------------------------------------------------
+def keff_pipeline(q, dA, lat, N, grdS=None, lon=None, mask=None, increase=True,
+                  lt=True, dtype=np.float32, preLats=None, right_edge='numpy',
+                  nkeff_mask=1e5):
+    """One slab, hist API, steps 1-10 of SURVEY 3.1.  Returns a dict of
+    ndarrays on the contour dim (+ '<name>_eq' on preLats if given)."""
+    q = np.asarray(q)
+    if mask is None:
+        mask = np.ones(q.shape, dtype=q.dtype)
+    if grdS is None:
+        grdS = grad2_sphere(q, lat, lon)
+    tbl, cs = cal_area_eqCoord_table_hist(mask, dA, lat, increase, lt, right_edge)
+    ctr = cal_contours(q, N, increase, dtype)
+    area, counts = cal_integral_within_contours_hist(q, ctr, dA, None, lt,
+                                                     right_edge, return_counts=True)
+    intgrdS = cal_integral_within_contours_hist(q, ctr, dA, grdS, lt, right_edge)
+    latEq = lookup_coordinates(area, tbl, cs)
+    Lmin = latitude_lengths_at(latEq)
+    dintSdA = cal_gradient_wrt_area(intgrdS, area)
+    dqdA = cal_gradient_wrt_area(ctr, area)
+    Leq2 = cal_sqared_equivalent_length(dintSdA, dqdA)
+    nkeff = cal_normalized_Keff(Leq2, Lmin, nkeff_mask)
+    out = dict(ctr=ctr, counts=counts, area=area, intgrdS=intgrdS, tbl=tbl,
+               tbl_coord=cs, latEq=latEq, Lmin=Lmin, dintSdA=dintSdA,
+               dqdA=dqdA, Leq2=Leq2, nkeff=nkeff)
+    if preLats is not None:
+        for name in ('ctr', 'area', 'intgrdS', 'latEq', 'dintSdA', 'dqdA',
+                     'Leq2', 'Lmin', 'nkeff'):
+            out[name + '_eq'] = interp_to_coords(preLats, latEq, out[name])
+    return out
