@@ -1,0 +1,220 @@
+/*
+ * xcontour_hip.h -- C ABI of libxcontour_hip.so: the MI355X (gfx950) implementation
+ * of the contour-coordinate hot path of miniufo/xcontour.
+ *
+ * The reference (pure Python, /root/reference/xcontour/core.py) has no FFI seam of
+ * its own; the seam this library fills is the pair of third-party calls that touch
+ * every grid cell,
+ *     xhistogram.xarray.histogram(var, bins=[edges], dim=dims, weights=w)   core.py:1284, 1307
+ *     (var * dA).sum(dims)                                                  core.py:1376
+ * plus the per-slab reductions and O(N) contour-space algebra around them.  Each
+ * entry point below names the reference lines it replaces.  INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, ints, doubles.  No C++ types cross.
+ *   - every function returns an int status (XC_OK == 0, negative on error);
+ *     xc_last_error(ctx) gives a message for the calling thread's last failure.
+ *   - a "slab" is one (time, level) 2-D field of ny rows (the equivalent dim,
+ *     lat/Z) by nx columns (lon/X), row-major with X fastest; slabs of a batch
+ *     are contiguous: [nslab][ny][nx].
+ *   - functions ending in _dev take DEVICE pointers and only enqueue work on the
+ *     context's HIP stream (call xc_sync to wait); the same name without _dev
+ *     takes HOST pointers (caller-owned, C-contiguous), stages them through a
+ *     context-owned device arena and returns after the results are in the
+ *     caller's buffers.
+ *   - one context == one HIP device + one stream; calls on one context must be
+ *     serialised by the caller; different contexts may be used concurrently.
+ */
+#ifndef XCONTOUR_HIP_H
+#define XCONTOUR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xc_ctx xc_ctx;
+
+/* status codes */
+#define XC_OK        0
+#define XC_EBADARG  (-1)   /* bad argument (null pointer, size, dtype, unsupported shape) */
+#define XC_EEDGES   (-2)   /* bin edges not strictly ascending (reference: 'non monotonic bins', core.py:1233-1251) */
+#define XC_EHIP     (-3)   /* HIP runtime error */
+#define XC_ENOMEM   (-4)   /* device or host allocation failed */
+#define XC_ENODEV   (-5)   /* no usable gfx950 device */
+
+/* element types */
+#define XC_F32 0
+#define XC_F64 1
+
+/* rank of the area-weight array dA (always passed as float64) */
+#define XC_DA_NONE  0      /* weight 1 for every cell                       */
+#define XC_DA_ROW   1      /* dA[ny]          one value per row             */
+#define XC_DA_PLANE 2      /* dA[ny][nx]      shared by all slabs           */
+#define XC_DA_SLAB  3      /* dA[nslab][ny][nx]                             */
+
+/* last-bin rule (see oracle/xcontour_oracle.py header) */
+#define XC_EDGE_NUMPY      0   /* last bin closed on the right (np.histogram)          */
+#define XC_EDGE_XHISTOGRAM 1   /* last edge += 1e-8 in the edge dtype, bin half-open   */
+
+#define XC_MAX_INTEGRANDS 2
+
+/* ------------------------------------------------------------------ context */
+int         xc_create(int device_id, xc_ctx** out);
+int         xc_destroy(xc_ctx* ctx);
+const char* xc_last_error(xc_ctx* ctx);          /* ctx may be NULL (creation errors) */
+const char* xc_version(void);
+int         xc_device_name(xc_ctx* ctx, char* buf, size_t buflen);
+int         xc_device_cus(xc_ctx* ctx, int* out_cus);
+int         xc_sync(xc_ctx* ctx);
+void*       xc_stream(xc_ctx* ctx);              /* the hipStream_t, for interop */
+
+/* device memory + HIP-event timing on the context's stream */
+int xc_malloc(xc_ctx* ctx, size_t bytes, void** out_dptr);
+int xc_free(xc_ctx* ctx, void* dptr);
+int xc_memcpy_h2d(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int xc_memcpy_d2h(xc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int xc_memset(xc_ctx* ctx, void* dptr, int value, size_t bytes);
+int xc_event_create(xc_ctx* ctx, void** out_event);
+int xc_event_destroy(xc_ctx* ctx, void* event);
+int xc_event_record(xc_ctx* ctx, void* event);
+int xc_event_elapsed_ms(xc_ctx* ctx, void* start, void* stop, float* out_ms);  /* waits for `stop` */
+
+/* ------------------------------------------------------------------ K1  min / max
+ * Replaces tracer.min(dim=dimVs), tracer.max(dim=dimVs)            core.py:224-225
+ * NaN-skipping; an all-NaN slab gives NaN, NaN.  out_minmax: double[nslab][2].    */
+int xc_minmax_dev(xc_ctx* ctx, const void* q, int q_dtype,
+                  int64_t nslab, int64_t ncell, double* out_minmax);
+int xc_minmax(xc_ctx* ctx, const void* q, int q_dtype,
+              int64_t nslab, int64_t ncell, double* out_minmax);
+
+/* ------------------------------------------------------------------ levels + edges
+ * Replaces cal_contours(int levels)   core.py:222-249  (exact dtype rules: SURVEY 8-a2)
+ * and the edge construction of _histogram  core.py:1296-1305.
+ * minmax: double[nslab][2] as produced by xc_minmax.
+ * ctr:    double[nslab][N]   levels rounded to ctr_dtype, in level order
+ *         (ctr[0] == min if increase else max).
+ * edges:  double[nslab][N+1] ascending histogram edges (dummy left edge first).
+ * status: int32[nslab] 0 ok, 1 = two adjacent levels coincide (reference raises).    */
+int xc_levels_dev(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab,
+                  int N, int increase, int ctr_dtype, int right_edge,
+                  double* ctr, double* edges, int32_t* status);
+int xc_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab,
+              int N, int increase, int ctr_dtype, int right_edge,
+              double* ctr, double* edges, int32_t* status);
+
+/* ------------------------------------------------------------------ K3+K5  weighted multi-channel histogram + CDF
+ * Replaces histogram(var, bins=[edges], dim=dims, weights=w) + cumsum + lt flip
+ *          core.py:1307-1323 (and the per-time loop 1259-1294: edges may differ per slab)
+ *          and the weights of cal_integral_within_contours_hist   core.py:443-449.
+ * One pass over the tracer accumulates nchan = 1 + nint + (grad ? 1 : 0) channels:
+ *   channel 0            : dA                      (fillna(0))
+ *   channel 1..nint      : integrand_i * dA        (fillna(0); product in f32 if prod_f32)
+ *   last (if grad != 0)  : |grad q|^2 * dA computed in-kernel from q (build-defined
+ *                          stencil, oracle grad2_sphere), using per-row rdx, rdy.
+ * bin k = [edges[k], edges[k+1]); NaN / out-of-range cells dropped; last bin closed
+ * iff last_closed.  nbin = nedge - 1.
+ * Outputs (any may be NULL): pdf double[nslab][nchan][nbin]; counts uint64[nslab][nbin];
+ * cdf double[nslab][nchan][nbin] = cumsum(pdf) (if !lt: cdf[-1]-cdf), reversed along
+ * the bin axis iff reverse (decreasing levels, core.py:454-455).                     */
+typedef struct xc_hist_desc {
+    const void*   q;            int32_t q_dtype;  int32_t _pad0;
+    int64_t       nslab, ny, nx;
+    const double* edges;        int64_t nedge;    int32_t edges_per_slab; int32_t last_closed;
+    const double* dA;           int32_t dA_rank;  int32_t prod_f32;
+    int32_t       nint;         int32_t grad;
+    const void*   integrand[XC_MAX_INTEGRANDS];
+    int32_t       integrand_dtype[XC_MAX_INTEGRANDS];
+    const double* rdx;          /* [ny] 1/(2 dx)  per row (grad only)            */
+    const double* rdy;          /* [ny] 1/(y[jn]-y[js]) per row (grad only)      */
+    int32_t       periodic_x;   int32_t lt;
+    int32_t       reverse;      int32_t _pad1;
+    double*       pdf;
+    uint64_t*     counts;
+    double*       cdf;
+} xc_hist_desc;
+int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d);
+int xc_hist(xc_ctx* ctx, const xc_hist_desc* d);
+
+/* ------------------------------------------------------------------ K2  row sums for the A(Yeq) table
+ * Replaces the degenerate histogram of cal_area_eqCoord_table_hist   core.py:176-193
+ * rows[i] = sum_x dA[i,x] * [mask[i,x] == 1]; the prefix / end-point rules
+ * are O(ny) host work.  mask may be NULL (all ones).                                 */
+int xc_rowsum_dev(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
+                  int64_t ny, int64_t nx, double* out_rows);
+int xc_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
+              int64_t ny, int64_t nx, double* out_rows);
+
+/* ------------------------------------------------------------------ K4  |grad q|^2 (stand-alone)
+ * No reference call site (grdS is an input there); build-defined stencil.
+ * out: double[nslab][ny][nx].                                                        */
+int xc_grad2_dev(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                 const double* rdx, const double* rdy, int periodic_x, double* out);
+int xc_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+             const double* rdx, const double* rdy, int periodic_x, double* out);
+
+/* ------------------------------------------------------------------ K7  local wave activity / local APE
+ * Replaces the python loop of cal_local_wave_activity   core.py:752-791
+ *   lwa[j,x] = - sum_y' (q[y',x]-Q[j]) * mask3(j,y',x) * (dA[y',x]/dAmax) * M[y',x]
+ * coord: double[ny] equivalent-coordinate values; Q: double[nslab][ny];
+ * dA / M: float64, rank XC_DA_ROW or XC_DA_PLANE (M_rank may be XC_DA_NONE -> M = dA,
+ * the snapshot text core.py:789).  part: 0 all, 1 upper, 2 lower.
+ * out_lwa: double[nslab][ny][nx].  mask_idx: int32[nmask] rows whose mask3 is returned
+ * in out_masks int8[nslab][nmask][ny][nx] (values -1/0/1); nmask may be 0.           */
+int xc_lwa_dev(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
+               const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
+               int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+               const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks);
+int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
+           const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
+           int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+           const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks);
+
+/* ------------------------------------------------------------------ fused, batched Keff pipeline
+ * The reference's call sequence SURVEY 3.1 steps 2-10 for a batch of slabs resident
+ * in HBM: min/max -> levels/edges -> one histogram pass (dA, |grad q|^2 dA or grdS dA)
+ * -> CDF -> table lookup -> d/dA -> Leq2 -> Lmin -> nkeff [-> interpolation to preY].
+ * Replaces core.py:205-249, 412-460, 1136-1174, 463-488, 619-637, 945-966, 1050-1100
+ * and utils.py:518-534.  Three kernel launches per batch, no host round trip.
+ * All pointers are DEVICE pointers.  Outputs are double[nslab][N] unless noted and any
+ * of them may be NULL except ctr/area.                                               */
+typedef struct xc_keff_desc {
+    const void*   q;            int32_t q_dtype;  int32_t ctr_dtype;
+    int64_t       nslab, ny, nx;
+    int32_t       N;            int32_t increase; int32_t lt; int32_t right_edge;
+    const double* dA;           int32_t dA_rank;  int32_t grad;       /* grad: 1 in-kernel, 0 use grdS */
+    const void*   grdS;         int32_t grdS_dtype; int32_t prod_f32;
+    const double* rdx;          const double* rdy;  int32_t periodic_x; int32_t npre;
+    const double* tbl;          /* double[ny] area table A(Yeq), ascending-coordinate order */
+    const double* tbl_coord;    /* double[ny] ascending coordinate values                   */
+    const double* preY;         /* double[npre] prescribed equivalent coordinates (or NULL) */
+    double        nkeff_mask;   /* values >= this become NaN (reference default 1e5)        */
+    double        lmin_scale;   /* 2*pi*R: Lmin = lmin_scale*cos(deg2rad(latEq))            */
+    double*       ctr;          double* area;   double* intgrdS; double* latEq;
+    double*       dqdA;         double* dintSdA; double* Leq2;   double* Lmin;  double* nkeff;
+    uint64_t*     counts;       /* uint64[nslab][N] */
+    double*       interp;       /* double[nslab][9][npre]: ctr, area, intgrdS, latEq, dintSdA, dqdA, Leq2, Lmin, nkeff on preY */
+    int32_t*      status;       /* int32[nslab] 0 ok, 1 degenerate levels */
+} xc_keff_desc;
+int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
+
+/* time of the dominant kernel (the histogram pass) of the last xc_keff_dev / xc_hist_dev
+ * call, from HIP events recorded on the context's stream around that launch only.
+ * Enable with xc_set_kernel_timing(ctx, 1); xc_last_hist_ms waits for the launch.     */
+int xc_set_kernel_timing(xc_ctx* ctx, int enable);
+int xc_last_hist_ms(xc_ctx* ctx, float* out_ms);
+
+/* ------------------------------------------------------------------ synthetic slabs (bench / tests)
+ * PV-like tracer q = sin(phi) + 0.25 sum_k a_k cos(k lambda + theta_k) cos^2(phi) + 0.02 eps
+ * generated on device from a counter-based RNG.  variant 0: PV-like,
+ * 1: pure noise, 2: sin(phi) only.  out: q_dtype[nslab][ny][nx]; slab s uses seed+s. */
+int xc_synth_dev(xc_ctx* ctx, void* out, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                 const double* lat_deg, const double* lon_deg, uint64_t seed, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XCONTOUR_HIP_H */

@@ -1,0 +1,395 @@
+# -*- coding: utf-8 -*-
+"""
+ctypes binding of libxcontour_hip.so (C ABI: include/xcontour_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or no gfx950 device
+is visible, every compute entry point raises.  `load()` only dlopen()s the
+library (works on a GPU-less build box so that symbol / ABI checks can run);
+`Context()` is what needs the device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libxcontour_hip.so')
+
+XC_OK, XC_EBADARG, XC_EEDGES, XC_EHIP, XC_ENOMEM, XC_ENODEV = 0, -1, -2, -3, -4, -5
+XC_F32, XC_F64 = 0, 1
+XC_DA_NONE, XC_DA_ROW, XC_DA_PLANE, XC_DA_SLAB = 0, 1, 2, 3
+XC_EDGE_NUMPY, XC_EDGE_XHISTOGRAM = 0, 1
+XC_MAX_INTEGRANDS = 2
+
+_vp, _i32, _i64, _u64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+
+
+class HistDesc(C.Structure):
+    """struct xc_hist_desc (include/xcontour_hip.h)"""
+    _fields_ = [
+        ('q', _vp), ('q_dtype', _i32), ('_pad0', _i32),
+        ('nslab', _i64), ('ny', _i64), ('nx', _i64),
+        ('edges', _vp), ('nedge', _i64), ('edges_per_slab', _i32), ('last_closed', _i32),
+        ('dA', _vp), ('dA_rank', _i32), ('prod_f32', _i32),
+        ('nint', _i32), ('grad', _i32),
+        ('integrand', _vp * XC_MAX_INTEGRANDS),
+        ('integrand_dtype', _i32 * XC_MAX_INTEGRANDS),
+        ('rdx', _vp), ('rdy', _vp),
+        ('periodic_x', _i32), ('lt', _i32),
+        ('reverse', _i32), ('_pad1', _i32),
+        ('pdf', _vp), ('counts', _vp), ('cdf', _vp),
+    ]
+
+
+class KeffDesc(C.Structure):
+    """struct xc_keff_desc (include/xcontour_hip.h)"""
+    _fields_ = [
+        ('q', _vp), ('q_dtype', _i32), ('ctr_dtype', _i32),
+        ('nslab', _i64), ('ny', _i64), ('nx', _i64),
+        ('N', _i32), ('increase', _i32), ('lt', _i32), ('right_edge', _i32),
+        ('dA', _vp), ('dA_rank', _i32), ('grad', _i32),
+        ('grdS', _vp), ('grdS_dtype', _i32), ('prod_f32', _i32),
+        ('rdx', _vp), ('rdy', _vp), ('periodic_x', _i32), ('npre', _i32),
+        ('tbl', _vp), ('tbl_coord', _vp), ('preY', _vp),
+        ('nkeff_mask', _f64), ('lmin_scale', _f64),
+        ('ctr', _vp), ('area', _vp), ('intgrdS', _vp), ('latEq', _vp),
+        ('dqdA', _vp), ('dintSdA', _vp), ('Leq2', _vp), ('Lmin', _vp), ('nkeff', _vp),
+        ('counts', _vp), ('interp', _vp), ('status', _vp),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/xcontour_hip.h declares
+PROTOTYPES = {
+    'xc_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    'xc_destroy': (C.c_int, [_vp]),
+    'xc_last_error': (C.c_char_p, [_vp]),
+    'xc_version': (C.c_char_p, []),
+    'xc_device_name': (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    'xc_device_cus': (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    'xc_sync': (C.c_int, [_vp]),
+    'xc_stream': (_vp, [_vp]),
+    'xc_malloc': (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    'xc_free': (C.c_int, [_vp, _vp]),
+    'xc_memcpy_h2d': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    'xc_memcpy_d2h': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    'xc_memset': (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
+    'xc_event_create': (C.c_int, [_vp, C.POINTER(_vp)]),
+    'xc_event_destroy': (C.c_int, [_vp, _vp]),
+    'xc_event_record': (C.c_int, [_vp, _vp]),
+    'xc_event_elapsed_ms': (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
+    'xc_minmax_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp]),
+    'xc_minmax': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp]),
+    'xc_levels_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'xc_levels': (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'xc_hist_dev': (C.c_int, [_vp, C.POINTER(HistDesc)]),
+    'xc_hist': (C.c_int, [_vp, C.POINTER(HistDesc)]),
+    'xc_rowsum_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _i64, _i64, _vp]),
+    'xc_rowsum': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _i64, _i64, _vp]),
+    'xc_grad2_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp]),
+    'xc_grad2': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp]),
+    'xc_lwa_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _vp, C.c_int,
+                             _i64, _i64, _i64, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+    'xc_lwa': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _vp, C.c_int,
+                         _i64, _i64, _i64, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+    'xc_keff_dev': (C.c_int, [_vp, C.POINTER(KeffDesc)]),
+    'xc_set_kernel_timing': (C.c_int, [_vp, C.c_int]),
+    'xc_last_hist_ms': (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    'xc_synth_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _u64, C.c_int]),
+}
+
+_lib = None
+
+
+class XContourHipError(Exception):
+    """Raised for every non-zero status of the C ABI (the reference raises bare
+    `Exception`, core.py:53-57, 1233-1251; this subclasses it)."""
+
+    def __init__(self, code, msg):
+        Exception.__init__(self, msg)
+        self.code = code
+
+
+def load():
+    """dlopen the in-tree library and attach prototypes.  Raises (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XContourHipError(
+            XC_ENODEV,
+            'xcontour_amd: %s not found -- build it with `python -c "import '
+            '__graft_entry__ as g; g.build()"` or `make -C xcontour_amd/csrc`. '
+            'There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return XC_F32
+    if dt == np.float64:
+        return XC_F64
+    raise XContourHipError(XC_EBADARG, 'unsupported dtype %s (float32/float64 only)' % dt)
+
+
+def _ptr(a):
+    """Host pointer of a C-contiguous ndarray (or None)."""
+    if a is None:
+        return None
+    assert a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(_vp)
+
+
+class DeviceBuffer(object):
+    """A device allocation owned by a Context (freed with the context or explicitly)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = _vp()
+        ctx._check(ctx.lib.xc_malloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        ctx._buffers.append(self)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.xc_memcpy_h2d(self.ctx.handle, self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, _ptr(out), self.ptr + offset_bytes, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.xc_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+            if self in self.ctx._buffers:
+                self.ctx._buffers.remove(self)
+
+
+class Context(object):
+    """One HIP device + stream (xc_create / xc_destroy)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.xc_create(int(device), C.byref(h))
+        if rc != XC_OK:
+            raise XContourHipError(rc, (self.lib.xc_last_error(None) or b'').decode())
+        self.handle = h
+        self.device = int(device)
+        self._buffers = []
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != XC_OK:
+            raise XContourHipError(rc, (self.lib.xc_last_error(self.handle) or b'').decode())
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            for b in list(self._buffers):
+                b.free()
+            self.lib.xc_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self.lib.xc_sync(self.handle))
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.xc_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def device_cus(self):
+        n = C.c_int()
+        self._check(self.lib.xc_device_cus(self.handle, C.byref(n)))
+        return n.value
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 1)).upload(arr)
+
+    def event(self):
+        e = _vp()
+        self._check(self.lib.xc_event_create(self.handle, C.byref(e)))
+        return e
+
+    def record(self, ev):
+        self._check(self.lib.xc_event_record(self.handle, ev))
+
+    def elapsed_ms(self, e0, e1):
+        ms = C.c_float()
+        self._check(self.lib.xc_event_elapsed_ms(self.handle, e0, e1, C.byref(ms)))
+        return ms.value
+
+    def set_kernel_timing(self, on):
+        self._check(self.lib.xc_set_kernel_timing(self.handle, 1 if on else 0))
+
+    def last_hist_ms(self):
+        ms = C.c_float()
+        self._check(self.lib.xc_last_hist_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    # -- host-pointer compute entry points (numpy in, numpy out)
+    def minmax(self, q):
+        """q: (nslab, ny, nx) or (nslab, ncell) f32/f64 -> (nslab, 2) f64"""
+        q = np.ascontiguousarray(q)
+        nslab = q.shape[0]
+        out = np.empty((nslab, 2), dtype=np.float64)
+        self._check(self.lib.xc_minmax(self.handle, _ptr(q), dtype_code(q.dtype), nslab,
+                                       int(q.size // nslab), _ptr(out)))
+        return out
+
+    def levels(self, minmax, q_dtype, N, increase, ctr_dtype, right_edge=XC_EDGE_NUMPY):
+        minmax = np.ascontiguousarray(minmax, dtype=np.float64)
+        nslab = minmax.shape[0]
+        ctr = np.empty((nslab, N), dtype=np.float64)
+        edges = np.empty((nslab, N + 1), dtype=np.float64)
+        status = np.empty(nslab, dtype=np.int32)
+        self._check(self.lib.xc_levels(self.handle, _ptr(minmax), dtype_code(q_dtype), nslab, int(N),
+                                       int(bool(increase)), dtype_code(ctr_dtype), int(right_edge),
+                                       _ptr(ctr), _ptr(edges), _ptr(status)))
+        return ctr, edges, status
+
+    def hist(self, q, edges, dA=None, integrands=(), grad=None, last_closed=True, lt=True,
+             reverse=False, prod_f32=False, want=('pdf', 'counts', 'cdf')):
+        """q: (nslab, ny, nx); edges: (nedge,) or (nslab, nedge) ascending f64.
+        dA: None | (ny,) | (ny,nx) | (nslab,ny,nx) (converted to f64).
+        grad: None or (rdx, rdy, periodic_x).  Returns dict of requested outputs."""
+        q = np.ascontiguousarray(q)
+        assert q.ndim == 3
+        nslab, ny, nx = q.shape
+        edges = np.ascontiguousarray(edges, dtype=np.float64)
+        d = HistDesc()
+        keep = [q, edges]
+        d.q, d.q_dtype = _ptr(q), dtype_code(q.dtype)
+        d.nslab, d.ny, d.nx = nslab, ny, nx
+        d.edges, d.nedge = _ptr(edges), edges.shape[-1]
+        d.edges_per_slab = 1 if edges.ndim == 2 else 0
+        if edges.ndim == 2 and edges.shape[0] != nslab:
+            raise XContourHipError(XC_EBADARG, 'edges must be (nedge,) or (nslab, nedge)')
+        d.last_closed = 1 if last_closed else 0
+        if dA is None:
+            d.dA, d.dA_rank = None, XC_DA_NONE
+        else:
+            dA = np.ascontiguousarray(dA, dtype=np.float64)
+            keep.append(dA)
+            if dA.shape == (ny,):
+                d.dA_rank = XC_DA_ROW
+            elif dA.shape == (ny, nx):
+                d.dA_rank = XC_DA_PLANE
+            elif dA.shape == (nslab, ny, nx):
+                d.dA_rank = XC_DA_SLAB
+            else:
+                raise XContourHipError(XC_EBADARG, 'dA must be (ny,), (ny,nx) or (nslab,ny,nx)')
+            d.dA = _ptr(dA)
+        d.prod_f32 = 1 if prod_f32 else 0
+        d.nint = len(integrands)
+        if d.nint > XC_MAX_INTEGRANDS:
+            raise XContourHipError(XC_EBADARG, 'at most %d integrands per pass' % XC_MAX_INTEGRANDS)
+        for i, v in enumerate(integrands):
+            v = np.ascontiguousarray(v)
+            if v.shape != q.shape:
+                raise XContourHipError(XC_EBADARG, 'integrand shape must equal tracer shape')
+            keep.append(v)
+            d.integrand[i], d.integrand_dtype[i] = v.ctypes.data, dtype_code(v.dtype)
+        if grad is not None:
+            rdx = np.ascontiguousarray(grad[0], dtype=np.float64)
+            rdy = np.ascontiguousarray(grad[1], dtype=np.float64)
+            assert rdx.shape == (ny,) and rdy.shape == (ny,)
+            keep += [rdx, rdy]
+            d.grad, d.rdx, d.rdy, d.periodic_x = 1, _ptr(rdx), _ptr(rdy), 1 if grad[2] else 0
+        d.lt, d.reverse = 1 if lt else 0, 1 if reverse else 0
+        nch, nbin = 1 + d.nint + d.grad, d.nedge - 1
+        out = {}
+        if 'pdf' in want:
+            out['pdf'] = np.empty((nslab, nch, nbin), dtype=np.float64)
+            d.pdf = _ptr(out['pdf'])
+        if 'cdf' in want:
+            out['cdf'] = np.empty((nslab, nch, nbin), dtype=np.float64)
+            d.cdf = _ptr(out['cdf'])
+        if 'counts' in want:
+            out['counts'] = np.empty((nslab, nbin), dtype=np.uint64)
+            d.counts = _ptr(out['counts'])
+        self._check(self.lib.xc_hist(self.handle, C.byref(d)))
+        return out
+
+    def rowsum(self, mask, dA, ny, nx):
+        if mask is not None:
+            mask = np.ascontiguousarray(mask)
+            if mask.dtype not in (np.float32, np.float64):
+                mask = mask.astype(np.float64)
+            assert mask.shape == (ny, nx)
+        rank = XC_DA_NONE
+        if dA is not None:
+            dA = np.ascontiguousarray(dA, dtype=np.float64)
+            rank = XC_DA_ROW if dA.shape == (ny,) else XC_DA_PLANE
+            assert dA.shape in ((ny,), (ny, nx))
+        out = np.empty(ny, dtype=np.float64)
+        self._check(self.lib.xc_rowsum(self.handle, _ptr(mask), dtype_code(mask.dtype) if mask is not None else XC_F64,
+                                       _ptr(dA), rank, ny, nx, _ptr(out)))
+        return out
+
+    def grad2(self, q, rdx, rdy, periodic_x=True):
+        q = np.ascontiguousarray(q)
+        assert q.ndim == 3
+        nslab, ny, nx = q.shape
+        rdx = np.ascontiguousarray(rdx, dtype=np.float64)
+        rdy = np.ascontiguousarray(rdy, dtype=np.float64)
+        out = np.empty(q.shape, dtype=np.float64)
+        self._check(self.lib.xc_grad2(self.handle, _ptr(q), dtype_code(q.dtype), nslab, ny, nx,
+                                      _ptr(rdx), _ptr(rdy), 1 if periodic_x else 0, _ptr(out)))
+        return out
+
+    def lwa(self, q, Q, coord, dA, dA_max, M=None, increase=True, part=0, mask_idx=None):
+        q = np.ascontiguousarray(q)
+        assert q.ndim == 3
+        nslab, ny, nx = q.shape
+        Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(nslab, ny)
+        coord = np.ascontiguousarray(coord, dtype=np.float64)
+        dA = np.ascontiguousarray(dA, dtype=np.float64)
+        dr = XC_DA_ROW if dA.shape == (ny,) else XC_DA_PLANE
+        assert dA.shape in ((ny,), (ny, nx))
+        mr = XC_DA_NONE
+        if M is not None:
+            M = np.ascontiguousarray(M, dtype=np.float64)
+            mr = XC_DA_ROW if M.shape == (ny,) else XC_DA_PLANE
+            assert M.shape in ((ny,), (ny, nx))
+        out = np.empty(q.shape, dtype=np.float64)
+        nmask = 0 if mask_idx is None else len(mask_idx)
+        mi = np.ascontiguousarray(mask_idx, dtype=np.int32) if nmask else None
+        mo = np.empty((nslab, nmask, ny, nx), dtype=np.int8) if nmask else None
+        self._check(self.lib.xc_lwa(self.handle, _ptr(q), dtype_code(q.dtype), _ptr(Q), _ptr(coord),
+                                    _ptr(dA), dr, float(dA_max), _ptr(M), mr, nslab, ny, nx,
+                                    1 if increase else 0, int(part), _ptr(mi), nmask, _ptr(out), _ptr(mo)))
+        return out, mo
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use)."""
+    ctx = _default_ctx.get(device)
+    if ctx is None or ctx.handle is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,543 @@
+// C ABI of libxcontour_hip.so (declared in include/xcontour_hip.h): context, device
+// memory, HIP-event timing, and the orchestration of the kernels in xc_hist.hip,
+// xc_misc.hip, xc_lwa.hip.  No C++ type or exception crosses this boundary.
+#include "xc_internal.h"
+#include <string.h>
+#include <stdio.h>
+#include <new>
+
+namespace xc {
+
+static thread_local std::string g_err;   // errors without a context (xc_create)
+
+int fail(xc_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg; else g_err = msg;
+    return code;
+}
+
+int hipfail(xc_ctx* ctx, hipError_t e, const char* what)
+{
+    std::string m = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+    (void)hipGetLastError();
+    return fail(ctx, e == hipErrorOutOfMemory ? XC_ENOMEM : XC_EHIP, m);
+}
+
+static int grow(xc_ctx* ctx, void** p, size_t* have, size_t need)
+{
+    if (need <= *have) return XC_OK;
+    size_t want = *have ? *have : (size_t)1 << 20;
+    while (want < need) want *= 2;
+    if (*p) {
+        XC_HIP(ctx, hipStreamSynchronize(ctx->stream));    // nothing in flight may still use the old block
+        XC_HIP(ctx, hipFree(*p));
+        *p = nullptr; *have = 0;
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) { want = need; e = hipMalloc(p, want); }
+    if (e != hipSuccess) return hipfail(ctx, e, "hipMalloc(scratch)");
+    *have = want;
+    return XC_OK;
+}
+
+int ensure_scratch(xc_ctx* ctx, size_t bytes) { return grow(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes); }
+int ensure_arena(xc_ctx* ctx, size_t bytes)   { return grow(ctx, &ctx->arena, &ctx->arena_bytes, bytes); }
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline size_t esize(int dtype) { return dtype == XC_F32 ? 4 : 8; }
+
+// bump allocator over the staging arena
+struct Stage {
+    xc_ctx* ctx; char* base; size_t off = 0;
+    explicit Stage(xc_ctx* c) : ctx(c), base((char*)c->arena) {}
+    void* take(size_t bytes) { void* p = base + off; off += al(bytes); return p; }
+};
+
+static int h2d(xc_ctx* ctx, void* d, const void* h, size_t n)
+{
+    XC_HIP(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream));
+    return XC_OK;
+}
+static int d2h(xc_ctx* ctx, void* h, const void* d, size_t n)
+{
+    XC_HIP(ctx, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->stream));
+    return XC_OK;
+}
+
+}  // namespace xc
+
+using namespace xc;
+
+#define XC_TRY(expr) do { int _rc = (expr); if (_rc != XC_OK) return _rc; } while (0)
+#define XC_CTX(ctx) do { if (!(ctx)) return fail(nullptr, XC_EBADARG, "null context"); \
+                         hipError_t _e = hipSetDevice((ctx)->device); \
+                         if (_e != hipSuccess) return hipfail((ctx), _e, "hipSetDevice"); } while (0)
+
+extern "C" {
+
+const char* xc_version(void) { return "xcontour_hip 0.1.0 (gfx950)"; }
+
+const char* xc_last_error(xc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int xc_create(int device_id, xc_ctx** out)
+{
+    if (!out) return fail(nullptr, XC_EBADARG, "xc_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        return fail(nullptr, XC_ENODEV, "xc_create: no HIP device visible (this library has no CPU fallback)");
+    }
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, XC_EBADARG, "xc_create: device_id out of range");
+    xc_ctx* ctx = new (std::nothrow) xc_ctx();
+    if (!ctx) return fail(nullptr, XC_ENOMEM, "xc_create: out of host memory");
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
+        int rc = hipfail(nullptr, e, "hipSetDevice/hipGetDeviceProperties"); delete ctx; return rc;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string m = std::string("xc_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        delete ctx; return fail(nullptr, XC_ENODEV, m);
+    }
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    ctx->cus = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        int rc = hipfail(nullptr, e, "hipStreamCreate"); delete ctx; return rc;
+    }
+    if ((e = hipEventCreate(&ctx->ev_hist0)) != hipSuccess || (e = hipEventCreate(&ctx->ev_hist1)) != hipSuccess) {
+        int rc = hipfail(nullptr, e, "hipEventCreate"); delete ctx; return rc;
+    }
+    *out = ctx;
+    return XC_OK;
+}
+
+int xc_destroy(xc_ctx* ctx)
+{
+    if (!ctx) return XC_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->ev_hist0) (void)hipEventDestroy(ctx->ev_hist0);
+    if (ctx->ev_hist1) (void)hipEventDestroy(ctx->ev_hist1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return XC_OK;
+}
+
+int xc_device_name(xc_ctx* ctx, char* buf, size_t buflen)
+{
+    if (!ctx || !buf || buflen == 0) return fail(ctx, XC_EBADARG, "xc_device_name: bad arguments");
+    snprintf(buf, buflen, "%s", ctx->name);
+    return XC_OK;
+}
+
+int xc_device_cus(xc_ctx* ctx, int* out_cus)
+{
+    if (!ctx || !out_cus) return fail(ctx, XC_EBADARG, "xc_device_cus: bad arguments");
+    *out_cus = ctx->cus;
+    return XC_OK;
+}
+
+int xc_sync(xc_ctx* ctx) { XC_CTX(ctx); XC_HIP(ctx, hipStreamSynchronize(ctx->stream)); return XC_OK; }
+
+void* xc_stream(xc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int xc_malloc(xc_ctx* ctx, size_t bytes, void** out_dptr)
+{
+    XC_CTX(ctx);
+    if (!out_dptr) return fail(ctx, XC_EBADARG, "xc_malloc: out is NULL");
+    *out_dptr = nullptr;
+    XC_HIP(ctx, hipMalloc(out_dptr, bytes ? bytes : 1));
+    return XC_OK;
+}
+
+int xc_free(xc_ctx* ctx, void* dptr)
+{
+    XC_CTX(ctx);
+    if (!dptr) return XC_OK;
+    XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    XC_HIP(ctx, hipFree(dptr));
+    return XC_OK;
+}
+
+int xc_memcpy_h2d(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
+{
+    XC_CTX(ctx);
+    if (bytes && (!dst_dev || !src_host)) return fail(ctx, XC_EBADARG, "xc_memcpy_h2d: NULL pointer");
+    XC_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return XC_OK;
+}
+
+int xc_memcpy_d2h(xc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes)
+{
+    XC_CTX(ctx);
+    if (bytes && (!dst_host || !src_dev)) return fail(ctx, XC_EBADARG, "xc_memcpy_d2h: NULL pointer");
+    XC_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return XC_OK;
+}
+
+int xc_memset(xc_ctx* ctx, void* dptr, int value, size_t bytes)
+{
+    XC_CTX(ctx);
+    if (bytes && !dptr) return fail(ctx, XC_EBADARG, "xc_memset: NULL pointer");
+    XC_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return XC_OK;
+}
+
+int xc_event_create(xc_ctx* ctx, void** out_event)
+{
+    XC_CTX(ctx);
+    if (!out_event) return fail(ctx, XC_EBADARG, "xc_event_create: out is NULL");
+    hipEvent_t ev;
+    XC_HIP(ctx, hipEventCreate(&ev));
+    *out_event = (void*)ev;
+    return XC_OK;
+}
+
+int xc_event_destroy(xc_ctx* ctx, void* event)
+{
+    XC_CTX(ctx);
+    if (event) XC_HIP(ctx, hipEventDestroy((hipEvent_t)event));
+    return XC_OK;
+}
+
+int xc_event_record(xc_ctx* ctx, void* event)
+{
+    XC_CTX(ctx);
+    if (!event) return fail(ctx, XC_EBADARG, "xc_event_record: NULL event");
+    XC_HIP(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+    return XC_OK;
+}
+
+int xc_event_elapsed_ms(xc_ctx* ctx, void* start, void* stop, float* out_ms)
+{
+    XC_CTX(ctx);
+    if (!start || !stop || !out_ms) return fail(ctx, XC_EBADARG, "xc_event_elapsed_ms: NULL argument");
+    XC_HIP(ctx, hipEventSynchronize((hipEvent_t)stop));
+    XC_HIP(ctx, hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return XC_OK;
+}
+
+int xc_set_kernel_timing(xc_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
+    ctx->timing = enable ? 1 : 0; ctx->ev_valid = 0;
+    return XC_OK;
+}
+
+int xc_last_hist_ms(xc_ctx* ctx, float* out_ms)
+{
+    XC_CTX(ctx);
+    if (!out_ms) return fail(ctx, XC_EBADARG, "xc_last_hist_ms: out is NULL");
+    if (!ctx->ev_valid) return fail(ctx, XC_EBADARG, "xc_last_hist_ms: no timed histogram launch (call xc_set_kernel_timing(ctx,1) first)");
+    XC_HIP(ctx, hipEventSynchronize(ctx->ev_hist1));
+    XC_HIP(ctx, hipEventElapsedTime(out_ms, ctx->ev_hist0, ctx->ev_hist1));
+    return XC_OK;
+}
+
+// ------------------------------------------------------------------------------------ K1
+int xc_minmax_dev(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* out_minmax)
+{
+    XC_CTX(ctx);
+    if (!q || !out_minmax || nslab < 1 || ncell < 1) return fail(ctx, XC_EBADARG, "xc_minmax: bad arguments");
+    XC_TRY(ensure_scratch(ctx, al((size_t)nslab * kMinmaxBlocks * 2 * sizeof(double))));
+    double* part = (double*)ctx->scratch;
+    XC_TRY(launch_minmax_partial(ctx, q, q_dtype, nslab, ncell, part));
+    return launch_minmax_final(ctx, part, nslab, out_minmax);
+}
+
+int xc_minmax(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* out_minmax)
+{
+    XC_CTX(ctx);
+    if (!q || !out_minmax || nslab < 1 || ncell < 1) return fail(ctx, XC_EBADARG, "xc_minmax: bad arguments");
+    if (q_dtype != XC_F32 && q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_minmax: q_dtype must be XC_F32 or XC_F64");
+    const size_t qb = (size_t)nslab * ncell * esize(q_dtype), ob = (size_t)nslab * 2 * sizeof(double);
+    XC_TRY(ensure_arena(ctx, al(qb) + al(ob)));
+    Stage st(ctx);
+    void* dq = st.take(qb); double* dout = (double*)st.take(ob);
+    XC_TRY(h2d(ctx, dq, q, qb));
+    XC_TRY(xc_minmax_dev(ctx, dq, q_dtype, nslab, ncell, dout));
+    XC_TRY(d2h(ctx, out_minmax, dout, ob));
+    return xc_sync(ctx);
+}
+
+// ------------------------------------------------------------------------------------ levels
+int xc_levels_dev(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
+                  int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status)
+{
+    XC_CTX(ctx);
+    return launch_levels(ctx, minmax, q_dtype, nslab, N, increase, ctr_dtype, right_edge, ctr, edges, status);
+}
+
+int xc_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
+              int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status)
+{
+    XC_CTX(ctx);
+    if (!minmax || !ctr || !edges || !status || N < 2 || nslab < 1) return fail(ctx, XC_EBADARG, "xc_levels: bad arguments (need N >= 2)");
+    const size_t mb = (size_t)nslab * 2 * 8, cb = (size_t)nslab * N * 8, eb = (size_t)nslab * (N + 1) * 8, sb = (size_t)nslab * 4;
+    XC_TRY(ensure_arena(ctx, al(mb) + al(cb) + al(eb) + al(sb)));
+    Stage st(ctx);
+    double* dm = (double*)st.take(mb); double* dc = (double*)st.take(cb);
+    double* de = (double*)st.take(eb); int32_t* ds = (int32_t*)st.take(sb);
+    XC_TRY(h2d(ctx, dm, minmax, mb));
+    XC_TRY(launch_levels(ctx, dm, q_dtype, nslab, N, increase, ctr_dtype, right_edge, dc, de, ds));
+    XC_TRY(d2h(ctx, ctr, dc, cb)); XC_TRY(d2h(ctx, edges, de, eb)); XC_TRY(d2h(ctx, status, ds, sb));
+    return xc_sync(ctx);
+}
+
+// ------------------------------------------------------------------------------------ K3 + K5
+static int check_hist_desc(xc_ctx* ctx, const xc_hist_desc* d)
+{
+    if (!d) return fail(ctx, XC_EBADARG, "xc_hist: desc is NULL");
+    if (!d->q || !d->edges) return fail(ctx, XC_EBADARG, "xc_hist: q / edges is NULL");
+    if (d->q_dtype != XC_F32 && d->q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_hist: q_dtype must be XC_F32 or XC_F64");
+    if (d->nslab < 1 || d->ny < 1 || d->nx < 1) return fail(ctx, XC_EBADARG, "xc_hist: nslab, ny, nx must be >= 1");
+    if (d->nedge < 2) return fail(ctx, XC_EBADARG, "xc_hist: need at least 2 edges");
+    if (d->dA_rank < XC_DA_NONE || d->dA_rank > XC_DA_SLAB) return fail(ctx, XC_EBADARG, "xc_hist: bad dA_rank");
+    if (d->dA_rank != XC_DA_NONE && !d->dA) return fail(ctx, XC_EBADARG, "xc_hist: dA is NULL");
+    if (d->nint < 0 || d->nint > XC_MAX_INTEGRANDS) return fail(ctx, XC_EBADARG, "xc_hist: nint must be 0..2");
+    for (int i = 0; i < d->nint; ++i) {
+        if (!d->integrand[i]) return fail(ctx, XC_EBADARG, "xc_hist: integrand is NULL");
+        if (d->integrand_dtype[i] != XC_F32 && d->integrand_dtype[i] != XC_F64) return fail(ctx, XC_EBADARG, "xc_hist: bad integrand dtype");
+    }
+    if (d->grad && (!d->rdx || !d->rdy)) return fail(ctx, XC_EBADARG, "xc_hist: grad needs rdx and rdy");
+    if (!d->pdf && !d->counts && !d->cdf) return fail(ctx, XC_EBADARG, "xc_hist: no output requested");
+    return XC_OK;
+}
+
+int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
+{
+    XC_CTX(ctx);
+    XC_TRY(check_hist_desc(ctx, d));
+    const int nbin = (int)(d->nedge - 1), nch = 1 + d->nint + (d->grad ? 1 : 0);
+    HistGeom g;
+    XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, nbin, nch, d->q, &g));
+    const size_t ph = al((size_t)d->nslab * g.bps * nch * nbin * sizeof(double));
+    const size_t pc = al((size_t)d->nslab * g.bps * nbin * sizeof(unsigned));
+    XC_TRY(ensure_scratch(ctx, ph + pc));
+    HistArgs a; memset(&a, 0, sizeof(a));
+    a.q = d->q; a.dA = d->dA;
+    for (int i = 0; i < d->nint; ++i) { a.integ[i] = d->integrand[i]; a.integ_f32[i] = d->integrand_dtype[i] == XC_F32; }
+    a.edges = d->edges; a.levels_mode = 0; a.nbin = nbin; a.edges_per_slab = d->edges_per_slab;
+    a.last_closed = d->last_closed; a.q_f32 = d->q_dtype == XC_F32;
+    a.dA_rank = d->dA_rank; a.prod_f32 = d->prod_f32;
+    a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
+    a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
+    a.part_h = (double*)ctx->scratch; a.part_c = (unsigned*)((char*)ctx->scratch + ph);
+    if (ctx->timing) XC_HIP(ctx, hipEventRecord(ctx->ev_hist0, ctx->stream));
+    XC_TRY(launch_hist(ctx, d->q_dtype, d->nint, d->grad, g, d->nslab, a));
+    if (ctx->timing) { XC_HIP(ctx, hipEventRecord(ctx->ev_hist1, ctx->stream)); ctx->ev_valid = 1; }
+    FinalArgs f; memset(&f, 0, sizeof(f));
+    f.part_h = a.part_h; f.part_c = a.part_c; f.bps = g.bps; f.nch = nch; f.nbin = nbin;
+    f.lt = d->lt; f.reverse = d->reverse; f.pdf = d->pdf; f.counts = d->counts; f.cdf = d->cdf;
+    return launch_finalize(ctx, d->nslab, f);
+}
+
+int xc_hist(xc_ctx* ctx, const xc_hist_desc* hd)
+{
+    XC_CTX(ctx);
+    XC_TRY(check_hist_desc(ctx, hd));
+    const int64_t S = hd->nslab, ny = hd->ny, nx = hd->nx, ne = hd->nedge;
+    const int nbin = (int)(ne - 1), nch = 1 + hd->nint + (hd->grad ? 1 : 0);
+    const int64_t nes = hd->edges_per_slab ? S : 1;
+    // reference: 'non monotonic bins' (core.py:1233-1251); np.digitize needs monotone edges.
+    // NaN edges are let through (an all-NaN slab yields NaN levels and an empty histogram).
+    for (int64_t s = 0; s < nes; ++s)
+        for (int64_t k = 1; k < ne; ++k) {
+            const double e0 = hd->edges[s * ne + k - 1], e1 = hd->edges[s * ne + k];
+            if (e1 <= e0) return fail(ctx, XC_EEDGES, "non monotonic bins");
+        }
+    const size_t cells = (size_t)S * ny * nx;
+    const size_t qb = cells * esize(hd->q_dtype), eb = (size_t)nes * ne * 8;
+    size_t dab = 0;
+    if (hd->dA_rank == XC_DA_ROW) dab = (size_t)ny * 8;
+    else if (hd->dA_rank == XC_DA_PLANE) dab = (size_t)ny * nx * 8;
+    else if (hd->dA_rank == XC_DA_SLAB) dab = cells * 8;
+    size_t ib[XC_MAX_INTEGRANDS] = {0, 0};
+    for (int i = 0; i < hd->nint; ++i) ib[i] = cells * esize(hd->integrand_dtype[i]);
+    const size_t rb = hd->grad ? (size_t)ny * 8 : 0;
+    const size_t pb = (size_t)S * nch * nbin * 8, cb = (size_t)S * nbin * 8;
+    XC_TRY(ensure_arena(ctx, al(qb) + al(eb) + al(dab) + al(ib[0]) + al(ib[1]) + 2 * al(rb) + 2 * al(pb) + al(cb)));
+    Stage st(ctx);
+    xc_hist_desc d = *hd;
+    void* dq = st.take(qb); XC_TRY(h2d(ctx, dq, hd->q, qb)); d.q = dq;
+    double* de = (double*)st.take(eb); XC_TRY(h2d(ctx, de, hd->edges, eb)); d.edges = de;
+    if (dab) { double* p = (double*)st.take(dab); XC_TRY(h2d(ctx, p, hd->dA, dab)); d.dA = p; }
+    for (int i = 0; i < hd->nint; ++i) { void* p = st.take(ib[i]); XC_TRY(h2d(ctx, p, hd->integrand[i], ib[i])); d.integrand[i] = p; }
+    if (hd->grad) {
+        double* p = (double*)st.take(rb); XC_TRY(h2d(ctx, p, hd->rdx, rb)); d.rdx = p;
+        p = (double*)st.take(rb); XC_TRY(h2d(ctx, p, hd->rdy, rb)); d.rdy = p;
+    }
+    d.pdf = hd->pdf ? (double*)st.take(pb) : nullptr;
+    d.cdf = hd->cdf ? (double*)st.take(pb) : nullptr;
+    d.counts = hd->counts ? (uint64_t*)st.take(cb) : nullptr;
+    XC_TRY(xc_hist_dev(ctx, &d));
+    if (hd->pdf) XC_TRY(d2h(ctx, hd->pdf, d.pdf, pb));
+    if (hd->cdf) XC_TRY(d2h(ctx, hd->cdf, d.cdf, pb));
+    if (hd->counts) XC_TRY(d2h(ctx, hd->counts, d.counts, cb));
+    return xc_sync(ctx);
+}
+
+// ------------------------------------------------------------------------------------ K2
+int xc_rowsum_dev(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
+                  int64_t ny, int64_t nx, double* out_rows)
+{
+    XC_CTX(ctx);
+    return launch_rowsum(ctx, mask, mask_dtype, dA, dA_rank, ny, nx, out_rows);
+}
+
+int xc_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
+              int64_t ny, int64_t nx, double* out_rows)
+{
+    XC_CTX(ctx);
+    if (!out_rows || ny < 1 || nx < 1) return fail(ctx, XC_EBADARG, "xc_rowsum: bad arguments");
+    if (mask && mask_dtype != XC_F32 && mask_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_rowsum: bad mask dtype");
+    const size_t mb = mask ? (size_t)ny * nx * esize(mask_dtype) : 0;
+    const size_t dab = dA_rank == XC_DA_ROW ? (size_t)ny * 8 : dA_rank == XC_DA_PLANE ? (size_t)ny * nx * 8 : 0;
+    if (dab && !dA) return fail(ctx, XC_EBADARG, "xc_rowsum: dA is NULL");
+    XC_TRY(ensure_arena(ctx, al(mb) + al(dab) + al((size_t)ny * 8)));
+    Stage st(ctx);
+    void* dm = nullptr; double* dd = nullptr;
+    if (mb) { dm = st.take(mb); XC_TRY(h2d(ctx, dm, mask, mb)); }
+    if (dab) { dd = (double*)st.take(dab); XC_TRY(h2d(ctx, dd, dA, dab)); }
+    double* dout = (double*)st.take((size_t)ny * 8);
+    XC_TRY(launch_rowsum(ctx, dm, mask_dtype, dd, dA_rank, ny, nx, dout));
+    XC_TRY(d2h(ctx, out_rows, dout, (size_t)ny * 8));
+    return xc_sync(ctx);
+}
+
+// ------------------------------------------------------------------------------------ K4
+int xc_grad2_dev(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                 const double* rdx, const double* rdy, int periodic_x, double* out)
+{
+    XC_CTX(ctx);
+    return launch_grad2(ctx, q, q_dtype, nslab, ny, nx, rdx, rdy, periodic_x, out);
+}
+
+int xc_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+             const double* rdx, const double* rdy, int periodic_x, double* out)
+{
+    XC_CTX(ctx);
+    if (!q || !rdx || !rdy || !out || nslab < 1 || ny < 1 || nx < 1) return fail(ctx, XC_EBADARG, "xc_grad2: bad arguments");
+    if (q_dtype != XC_F32 && q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_grad2: bad dtype");
+    const size_t cells = (size_t)nslab * ny * nx, qb = cells * esize(q_dtype), ob = cells * 8, rb = (size_t)ny * 8;
+    XC_TRY(ensure_arena(ctx, al(qb) + al(ob) + 2 * al(rb)));
+    Stage st(ctx);
+    void* dq = st.take(qb); double* dx = (double*)st.take(rb); double* dy = (double*)st.take(rb); double* dout = (double*)st.take(ob);
+    XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, dx, rdx, rb)); XC_TRY(h2d(ctx, dy, rdy, rb));
+    XC_TRY(launch_grad2(ctx, dq, q_dtype, nslab, ny, nx, dx, dy, periodic_x, dout));
+    XC_TRY(d2h(ctx, out, dout, ob));
+    return xc_sync(ctx);
+}
+
+// ------------------------------------------------------------------------------------ K7
+int xc_lwa_dev(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
+               const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
+               int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+               const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks)
+{
+    XC_CTX(ctx);
+    return launch_lwa(ctx, q, q_dtype, Q, coord, dA, dA_rank, dA_max, M, M_rank, nslab, ny, nx,
+                      increase, part, mask_idx, nmask, out_lwa, out_masks);
+}
+
+int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
+           const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
+           int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+           const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks)
+{
+    XC_CTX(ctx);
+    if (!q || !Q || !coord || !dA || !out_lwa || nslab < 1 || ny < 2 || nx < 1) return fail(ctx, XC_EBADARG, "xc_lwa: bad arguments");
+    if (q_dtype != XC_F32 && q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_lwa: bad dtype");
+    if (nmask < 0 || (nmask > 0 && (!mask_idx || !out_masks))) return fail(ctx, XC_EBADARG, "xc_lwa: mask arguments");
+    for (int i = 0; i < nmask; ++i)
+        if (mask_idx[i] < 0 || mask_idx[i] >= ny) return fail(ctx, XC_EBADARG, "indices in mask_idx out of boundary");
+    const size_t cells = (size_t)nslab * ny * nx, plane = (size_t)ny * nx;
+    const size_t qb = cells * esize(q_dtype), Qb = (size_t)nslab * ny * 8, cb = (size_t)ny * 8;
+    const size_t dab = dA_rank == XC_DA_ROW ? cb : plane * 8;
+    const size_t Mb = M_rank == XC_DA_NONE ? 0 : (M_rank == XC_DA_ROW ? cb : plane * 8);
+    const size_t ob = cells * 8, mib = (size_t)nmask * 4, mob = (size_t)nmask * cells;
+    XC_TRY(ensure_arena(ctx, al(qb) + al(Qb) + al(cb) + al(dab) + al(Mb) + al(ob) + al(mib) + al(mob)));
+    Stage st(ctx);
+    void* dq = st.take(qb); double* dQ = (double*)st.take(Qb); double* dc = (double*)st.take(cb);
+    double* dd = (double*)st.take(dab); double* dM = Mb ? (double*)st.take(Mb) : nullptr;
+    double* dout = (double*)st.take(ob);
+    int32_t* dmi = nmask ? (int32_t*)st.take(mib) : nullptr; int8_t* dmo = nmask ? (int8_t*)st.take(mob) : nullptr;
+    XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, dQ, Q, Qb)); XC_TRY(h2d(ctx, dc, coord, cb)); XC_TRY(h2d(ctx, dd, dA, dab));
+    if (Mb) XC_TRY(h2d(ctx, dM, M, Mb));
+    if (nmask) XC_TRY(h2d(ctx, dmi, mask_idx, mib));
+    XC_TRY(launch_lwa(ctx, dq, q_dtype, dQ, dc, dd, dA_rank, dA_max, dM, M_rank, nslab, ny, nx, increase, part,
+                      dmi, nmask, dout, dmo));
+    XC_TRY(d2h(ctx, out_lwa, dout, ob));
+    if (nmask) XC_TRY(d2h(ctx, out_masks, dmo, mob));
+    return xc_sync(ctx);
+}
+
+// ------------------------------------------------------------------------------------ fused Keff pipeline
+int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
+{
+    XC_CTX(ctx);
+    if (!d) return fail(ctx, XC_EBADARG, "xc_keff: desc is NULL");
+    if (!d->q || !d->ctr || !d->area || !d->tbl || !d->tbl_coord) return fail(ctx, XC_EBADARG, "xc_keff: q/ctr/area/tbl/tbl_coord must be given");
+    if (d->q_dtype != XC_F32 && d->q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_keff: bad q_dtype");
+    if (d->ctr_dtype != XC_F32 && d->ctr_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_keff: bad ctr_dtype");
+    if (d->nslab < 1 || d->ny < 2 || d->nx < 1 || d->N < 2) return fail(ctx, XC_EBADARG, "xc_keff: need nslab>=1, ny>=2, nx>=1, N>=2");
+    if (d->dA_rank < XC_DA_NONE || d->dA_rank > XC_DA_SLAB || (d->dA_rank != XC_DA_NONE && !d->dA)) return fail(ctx, XC_EBADARG, "xc_keff: bad dA");
+    if (d->grad ? (!d->rdx || !d->rdy) : !d->grdS) return fail(ctx, XC_EBADARG, "xc_keff: need rdx/rdy (grad=1) or grdS (grad=0)");
+    if (d->npre < 0 || (d->npre > 0 && d->interp && !d->preY)) return fail(ctx, XC_EBADARG, "xc_keff: preY is NULL");
+    const int N = d->N, nch = 2;
+    HistGeom g;
+    XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, nch, d->q, &g));
+    const size_t mb = al((size_t)d->nslab * kMinmaxBlocks * 2 * sizeof(double));
+    const size_t ph = al((size_t)d->nslab * g.bps * nch * N * sizeof(double));
+    const size_t pc = al((size_t)d->nslab * g.bps * N * sizeof(unsigned));
+    XC_TRY(ensure_scratch(ctx, mb + ph + pc));
+    double* mmpart = (double*)ctx->scratch;
+    double* part_h = (double*)((char*)ctx->scratch + mb);
+    unsigned* part_c = (unsigned*)((char*)ctx->scratch + mb + ph);
+
+    if (d->status) XC_HIP(ctx, hipMemsetAsync(d->status, 0, (size_t)d->nslab * sizeof(int32_t), ctx->stream));
+    XC_TRY(launch_minmax_partial(ctx, d->q, d->q_dtype, d->nslab, d->ny * d->nx, mmpart));
+
+    HistArgs a; memset(&a, 0, sizeof(a));
+    a.q = d->q; a.dA = d->dA;
+    if (!d->grad) { a.integ[0] = d->grdS; a.integ_f32[0] = d->grdS_dtype == XC_F32; }
+    a.mmpart = mmpart; a.P = kMinmaxBlocks; a.levels_mode = 1; a.nbin = N;
+    a.last_closed = d->right_edge == XC_EDGE_NUMPY;
+    a.increase = d->increase; a.q_f32 = d->q_dtype == XC_F32; a.ctr_f32 = d->ctr_dtype == XC_F32;
+    a.right_edge = d->right_edge; a.inv_nm1 = 1.0 / (double)(N - 1);
+    a.dA_rank = d->dA_rank; a.prod_f32 = d->prod_f32;
+    a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
+    a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
+    a.part_h = part_h; a.part_c = part_c; a.ctr_out = d->ctr; a.status = d->status;
+    if (ctx->timing) XC_HIP(ctx, hipEventRecord(ctx->ev_hist0, ctx->stream));
+    XC_TRY(launch_hist(ctx, d->q_dtype, d->grad ? 0 : 1, d->grad, g, d->nslab, a));
+    if (ctx->timing) { XC_HIP(ctx, hipEventRecord(ctx->ev_hist1, ctx->stream)); ctx->ev_valid = 1; }
+
+    FinalArgs f; memset(&f, 0, sizeof(f));
+    f.part_h = part_h; f.part_c = part_c; f.bps = g.bps; f.nch = nch; f.nbin = N;
+    f.lt = d->lt; f.reverse = !d->increase;       // decreasing levels -> flip to level order (core.py:454-455)
+    f.counts = d->counts;
+    f.keff = 1; f.ctr_f32 = a.ctr_f32; f.ctr = d->ctr;
+    f.tbl = d->tbl; f.tbl_coord = d->tbl_coord; f.ntbl = (int)d->ny;
+    f.preY = d->preY; f.npre = d->interp ? d->npre : 0;
+    f.nkeff_mask = d->nkeff_mask; f.lmin_scale = d->lmin_scale;
+    f.o_area = d->area; f.o_intS = d->intgrdS; f.o_latEq = d->latEq; f.o_dqdA = d->dqdA; f.o_dSdA = d->dintSdA;
+    f.o_Leq2 = d->Leq2; f.o_Lmin = d->Lmin; f.o_nkeff = d->nkeff; f.o_interp = d->interp;
+    return launch_finalize(ctx, d->nslab, f);
+}
+
+// ------------------------------------------------------------------------------------ synthetic slabs
+int xc_synth_dev(xc_ctx* ctx, void* out, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                 const double* lat_deg, const double* lon_deg, uint64_t seed, int variant)
+{
+    XC_CTX(ctx);
+    return launch_synth(ctx, out, q_dtype, nslab, ny, nx, lat_deg, lon_deg, seed, variant);
+}
+
+}  // extern "C"

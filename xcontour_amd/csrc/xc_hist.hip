@@ -1,0 +1,487 @@
+// K3 -- one-pass, multi-channel weighted histogram of tracer slabs (gfx950).
+//
+// Replaces xhistogram.xarray.histogram(var, bins=[edges], dim=dims, weights=w)
+// (reference core.py:1284, 1307) for ALL weight channels of a Keff step at once,
+// with |grad q|^2 optionally computed in-kernel from a rolling 3-row register
+// window (no stand-alone gradient field is ever written).
+//
+// Layout / mapping (see DESIGN.md "K3"):
+//   * a slab is [ny][nx], X fastest.  It is cut into column strips of W = 64*VEC
+//     cells (VEC cells per lane, one 8/16-byte load per lane per row: fully
+//     coalesced 512 B / 1 KiB per wave-instruction).
+//   * the (strip, row) pairs of a slab are linearised strip-major and divided
+//     EVENLY over all waves of the slab's blocks: every wave sweeps ~the same
+//     number of rows top-to-bottom inside a strip, so y-neighbours live in
+//     registers and x-neighbours come from the adjacent lane (__shfl) plus one
+//     2-lane halo load per row.
+//   * bin search: uniform guess + fix-up against the explicit f64 edges in LDS
+//     (exactly np.digitize semantics, any ascending edges).
+//   * accumulation: rows whose 64*VEC cells all fall in one bin (the common case
+//     on smooth geophysical fields) accumulate in per-lane registers with no
+//     cross-lane traffic; other rows use LDS atomics on `ncopy` lane-privatised
+//     histogram copies.  Per-block partials are written with plain stores and
+//     reduced in fixed order by k_finalize: no global atomics.
+#include "xc_internal.h"
+
+namespace xc {
+
+namespace {
+
+constexpr int U = 2;   // rows per prefetch batch (double-buffered)
+
+__device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+__device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+template <typename T, int VEC> struct RowLoad;
+template <> struct RowLoad<double, 2> {
+    static __device__ __forceinline__ void ld(const double* p, double (&v)[2]) {
+        const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
+};
+template <> struct RowLoad<double, 1> {
+    static __device__ __forceinline__ void ld(const double* p, double (&v)[1]) { v[0] = *p; }
+};
+template <> struct RowLoad<float, 2> {
+    static __device__ __forceinline__ void ld(const float* p, double (&v)[2]) {
+        const float2 t = *reinterpret_cast<const float2*>(p); v[0] = (double)t.x; v[1] = (double)t.y; }
+};
+template <> struct RowLoad<float, 1> {
+    static __device__ __forceinline__ void ld(const float* p, double (&v)[1]) { v[0] = (double)*p; }
+};
+
+// ---- contour levels, bit-for-bit the arithmetic of cal_contours (core.py:228-246)
+// under np.vectorize: (stop-start) in the tracer dtype, everything else in f64,
+// cast to the contour dtype at the end.  __d*_rn / __f*_rn forbid FMA contraction.
+__device__ __forceinline__ double level_value(double mn, double mx, int k, int increase,
+                                              int q_f32, int ctr_f32, double inv_nm1)
+{
+    const double start = increase ? mn : mx, stop = increase ? mx : mn;
+    const double d = q_f32 ? (double)__fsub_rn((float)stop, (float)start) : __dsub_rn(stop, start);
+    const double steps = __dmul_rn(inv_nm1, d);
+    double c = __dadd_rn(__dmul_rn(steps, (double)k), start);
+    if (ctr_f32) c = (double)(float)c;
+    return c;
+}
+
+// dummy left edge of _histogram (core.py:1296-1305), in the contour dtype
+__device__ __forceinline__ double dummy_edge(double lo, double hi, int N, int ctr_f32)
+{
+    if (ctr_f32) {
+        const float step = __fdiv_rn(__fsub_rn((float)hi, (float)lo), (float)(N - 1));
+        return (double)__fsub_rn((float)lo, step);
+    }
+    const double step = __ddiv_rn(__dsub_rn(hi, lo), (double)(N - 1));
+    return __dsub_rn(lo, step);
+}
+
+__device__ __forceinline__ double bump_last_edge(double e, int ctr_f32)   // xhistogram's "+1e-8"
+{
+    return ctr_f32 ? (double)__fadd_rn((float)e, (float)1e-8) : __dadd_rn(e, 1e-8);
+}
+
+// np.digitize(v, edges) - 1 restricted to [0, N-1]; -1 when the cell is dropped.
+__device__ __forceinline__ int find_bin(double v, const double* __restrict__ s_edges, int N,
+                                        double e0, double eN, double inv, int last_closed)
+{
+    if (!(v >= e0)) return -1;                       // below range or NaN
+    if (last_closed ? !(v <= eN) : !(v < eN)) return -1;
+    int k = (int)((v - e0) * inv);
+    k = k < 0 ? 0 : (k > N - 1 ? N - 1 : k);
+    if (v < s_edges[k]) {
+        if (v >= s_edges[k - 1]) return k - 1;       // k >= 1 here because v >= e0
+        int lo = 0, hi = k - 1;                      // edges[lo] <= v < edges[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v >= s_edges[mid]) lo = mid; else hi = mid; }
+        return lo;
+    }
+    if (k < N - 1 && v >= s_edges[k + 1]) {
+        if (k + 1 == N - 1 || v < s_edges[k + 2]) return k + 1;
+        int lo = k + 2, hi = N;                      // edges[lo] <= v, v < edges[hi] (or v == eN closed)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v >= s_edges[mid]) lo = mid; else hi = mid; }
+        return lo > N - 1 ? N - 1 : lo;
+    }
+    return k;
+}
+
+__device__ __forceinline__ void lds_add(double* p, double v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add(unsigned* p, unsigned v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int VEC, int NINT>
+struct RowBuf {
+    double q[VEC];          // GRAD: row (center+1); else: the center row itself
+    double h;               // lane 0: left halo of that row, lane 63: right halo
+    double dA[VEC];
+    double in[NINT > 0 ? NINT : 1][VEC];
+};
+
+template <typename TQ, int VEC, int NINT, bool GRAD>
+__global__ __launch_bounds__(kHistThreads)
+void k_hist(const HistArgs a)
+{
+    constexpr int NCH = 1 + NINT + (GRAD ? 1 : 0);
+    constexpr int W = 64 * VEC;
+    extern __shared__ __align__(16) double smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const int slab = blockIdx.y;
+    const int N = a.nbin;
+    const int ncopy = a.ncopy;
+    const int epad = (N + 2) & ~1;
+    double*   s_red   = smem;                                   // 64 doubles
+    double*   s_edges = smem + 64;                              // N+1
+    double*   s_h     = s_edges + epad;                         // [NCH][N*ncopy]
+    unsigned* s_c     = reinterpret_cast<unsigned*>(s_h + (size_t)NCH * N * ncopy);   // [N*ncopy]
+    const int hsz = N * ncopy;
+
+    for (int i = tid; i < NCH * hsz; i += blockDim.x) s_h[i] = 0.0;
+    for (int i = tid; i < hsz; i += blockDim.x) s_c[i] = 0u;
+
+    // ------------------------------------------------------------------ edges -> LDS
+    if (a.levels_mode) {
+        // reduce the per-block partial min/max of K1 (fixed order: deterministic)
+        const double* mp = a.mmpart + (size_t)slab * a.P * 2;
+        double mn = dinf(), mx = -dinf();
+        for (int i = tid; i < a.P; i += blockDim.x) { mn = fmin(mn, mp[2 * i]); mx = fmax(mx, mp[2 * i + 1]); }
+        for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
+        if (lane == 0) { s_red[2 * wave] = mn; s_red[2 * wave + 1] = mx; }
+        __syncthreads();
+        mn = s_red[0]; mx = s_red[1];
+        for (int w = 1; w < nwave; ++w) { mn = fmin(mn, s_red[2 * w]); mx = fmax(mx, s_red[2 * w + 1]); }
+        if (mn == dinf() && mx == -dinf()) { mn = dnan(); mx = dnan(); }     // all-NaN slab
+        for (int k = tid; k < N; k += blockDim.x) {
+            const double c = level_value(mn, mx, k, a.increase, a.q_f32, a.ctr_f32, a.inv_nm1);
+            s_edges[a.increase ? k + 1 : N - k] = c;
+            if (blockIdx.x == 0 && a.ctr_out) a.ctr_out[(size_t)slab * N + k] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double lo = s_edges[1], hi = s_edges[N];
+            s_edges[0] = dummy_edge(lo, hi, N, a.ctr_f32);
+            if (a.right_edge == XC_EDGE_XHISTOGRAM) s_edges[N] = bump_last_edge(hi, a.ctr_f32);
+        }
+        if (blockIdx.x == 0 && a.status) {
+            // reference raises 'non monotonic bins' when two adjacent levels coincide (core.py:1233)
+            for (int k = tid + 1; k < N; k += blockDim.x)
+                if (s_edges[k] == s_edges[k + 1]) atomicOr(&a.status[slab], 1);
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && a.edges_out)
+            for (int k = tid; k <= N; k += blockDim.x) a.edges_out[(size_t)slab * (N + 1) + k] = s_edges[k];
+    } else {
+        const double* e = a.edges + (a.edges_per_slab ? (size_t)slab * (N + 1) : 0);
+        for (int k = tid; k <= N; k += blockDim.x) s_edges[k] = e[k];
+        __syncthreads();
+    }
+    const double e0 = s_edges[0], eN = s_edges[N];
+    const double inv = (double)N / (eN - e0);
+    const int last_closed = a.last_closed;
+
+    // ------------------------------------------------------------------ this wave's share of (strip,row) pairs
+    const int64_t ny = a.ny, nx = a.nx;
+    const int64_t total = (int64_t)a.nstrip * ny;
+    const int64_t nw = (int64_t)gridDim.x * nwave;
+    const int64_t wg = (int64_t)blockIdx.x * nwave + wave;
+    int64_t g0 = total * wg / nw;
+    const int64_t g1 = total * (wg + 1) / nw;
+
+    const size_t slab_off = (size_t)slab * ny * nx;
+    const TQ* __restrict__ qs = reinterpret_cast<const TQ*>(a.q) + slab_off;
+    const double* __restrict__ dAp = a.dA ? (a.dA_rank == XC_DA_SLAB ? a.dA + slab_off : a.dA) : nullptr;
+    const int dA_rank = a.dA_rank;
+    const int copy = lane & (ncopy - 1);
+
+    double   acc[NCH];
+    unsigned cnt = 0;
+    int      cur = -1;                   // wave-uniform: bin of the register accumulators
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = 0.0;
+
+    auto flush = [&]() {
+        if (cnt) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) lds_add(&s_h[c * hsz + cur * ncopy + copy], acc[c]);
+            lds_add(&s_c[cur * ncopy + copy], cnt);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] = 0.0;
+        cnt = 0;
+    };
+
+    while (g0 < g1) {
+        const int     s  = (int)(g0 / ny);
+        const int64_t y0 = g0 - (int64_t)s * ny;
+        const int64_t y1 = (y0 + (g1 - g0) < ny) ? y0 + (g1 - g0) : ny;
+        g0 += (y1 - y0);
+
+        const int64_t x0 = (int64_t)s * W;
+        const int64_t x  = x0 + (int64_t)lane * VEC;
+        const bool active = x < nx;
+        const int64_t xend = (x0 + W < nx) ? x0 + W : nx;
+        const int rlane = (int)((xend - x0) / VEC) - 1;               // lane holding the strip's last valid cell
+        const int64_t xl = (x0 == 0) ? (a.periodic_x ? nx - 1 : 0) : x0 - 1;
+        const int64_t xr = (xend == nx) ? (a.periodic_x ? 0 : nx - 1) : xend;
+        const int64_t xh = (lane == 0) ? xl : xr;
+        const bool halo_lane = (lane == 0) || (lane == 63);
+        // one-sided x differences at the walls of a non-periodic domain use spacing dx, not 2dx
+        double fx[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+            fx[c] = (!a.periodic_x && (x + c == 0 || x + c == nx - 1)) ? 2.0 : 1.0;
+
+        // loads of one row into a RowBuf: q row `yq`, weights of row `yw`
+        auto load_row = [&](RowBuf<VEC, NINT>& r, int64_t yq, int64_t yw) {
+            yq = yq < ny - 1 ? yq : ny - 1;
+            yw = yw < ny - 1 ? yw : ny - 1;
+            const TQ* qrow = qs + yq * nx;
+            if (active) RowLoad<TQ, VEC>::ld(qrow + x, r.q);
+            else {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) r.q[c] = dnan();
+            }
+            if (GRAD) r.h = halo_lane ? (double)qrow[xh] : 0.0;
+            if (dA_rank == XC_DA_NONE) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) r.dA[c] = 1.0;
+            } else if (dA_rank == XC_DA_ROW) {
+                const double v = dAp[yw];
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) r.dA[c] = v;
+            } else if (active) {
+                RowLoad<double, VEC>::ld(dAp + yw * nx + x, r.dA);
+            } else {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) r.dA[c] = 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NINT; ++i) {
+                if (!active) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) r.in[i][c] = 0.0;
+                } else if (a.integ_f32[i]) {
+                    RowLoad<float, VEC>::ld(reinterpret_cast<const float*>(a.integ[i]) + slab_off + yw * nx + x, r.in[i]);
+                } else {
+                    RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(a.integ[i]) + slab_off + yw * nx + x, r.in[i]);
+                }
+            }
+        };
+
+        // one centre row: bins, weights, accumulate
+        auto do_row = [&](const double (&qc)[VEC], const double (&qS)[VEC], const double (&qN)[VEC],
+                          double hc, const double (&dAv)[VEC], const double (&inv_)[NINT > 0 ? NINT : 1][VEC],
+                          int64_t y) {
+            int k[VEC];
+            double w[NCH][VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                k[c] = active ? find_bin(qc[c], s_edges, N, e0, eN, inv, last_closed) : -1;
+                const double dv = dAv[c];
+                w[0][c] = (dv != dv) ? 0.0 : dv;                                  // fillna(0), core.py:449
+#pragma unroll
+                for (int i = 0; i < NINT; ++i) {
+                    double p = a.prod_f32 ? (double)__fmul_rn((float)inv_[i][c], (float)dv)
+                                          : __dmul_rn(inv_[i][c], dv);            // integrand * dA, core.py:444
+                    w[1 + i][c] = (p != p) ? 0.0 : p;
+                }
+            }
+            if (GRAD) {
+                const double rdx = a.rdx[y], rdy = a.rdy[y];
+                const double hl = __shfl(hc, 0), hr = __shfl(hc, 63);
+                const double fromL = __shfl_up(qc[VEC - 1], 1);                  // lane-1's last cell
+                const double fromR = __shfl_down(qc[0], 1);                      // lane+1's first cell
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    const double qW = (c == 0) ? (lane == 0 ? hl : fromL) : qc[c > 0 ? c - 1 : 0];
+                    const double qE = (c == VEC - 1) ? (lane == rlane ? hr : fromR) : qc[c < VEC - 1 ? c + 1 : 0];
+                    const double gx = __dmul_rn(__dmul_rn(__dsub_rn(qE, qW), rdx), fx[c]);
+                    const double gy = __dmul_rn(__dsub_rn(qN[c], qS[c]), rdy);
+                    const double g2 = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
+                    const double p = __dmul_rn(g2, dAv[c]);
+                    w[NCH - 1][c] = (p != p) ? 0.0 : p;
+                }
+            }
+            // wave-uniform fast path: every valid cell of the row in one bin
+            const int rb = __builtin_amdgcn_readfirstlane(k[0]);
+            bool match = true;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) match = match && (k[c] == rb);
+            if (rb >= 0 && __all(match || !active)) {
+                if (rb != cur) { flush(); cur = rb; }
+                if (active) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) {
+#pragma unroll
+                        for (int ch = 0; ch < NCH; ++ch) acc[ch] += w[ch][c];
+                    }
+                    cnt += VEC;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+                    if (k[c] >= 0) {
+                        const int o = k[c] * ncopy + copy;
+#pragma unroll
+                        for (int ch = 0; ch < NCH; ++ch) lds_add(&s_h[ch * hsz + o], w[ch][c]);
+                        lds_add(&s_c[o], 1u);
+                    }
+                }
+            }
+        };
+
+        // rolling window (GRAD): qm = row y-1, qc = row y, hc = halo of row y
+        double qm[VEC], qcur[VEC], hcur = 0.0;
+        if (GRAD) {
+            RowBuf<VEC, NINT> t;
+            load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) qm[c] = t.q[c];
+            load_row(t, y0, y0);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) qcur[c] = t.q[c];
+            hcur = t.h;
+        }
+
+        // batch of U centre rows starting at yb; L holds (GRAD) q rows yb+1.. and weights rows yb..
+        auto load_batch = [&](RowBuf<VEC, NINT> (&L)[U], int64_t yb) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) load_row(L[i], GRAD ? yb + i + 1 : yb + i, yb + i);
+        };
+        auto process_batch = [&](RowBuf<VEC, NINT> (&L)[U], int64_t yb) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                if (yb + i < y1) {
+                    if (GRAD) {
+                        do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in, yb + i);
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) { qm[c] = qcur[c]; qcur[c] = L[i].q[c]; }
+                        hcur = L[i].h;
+                    } else {
+                        do_row(L[i].q, L[i].q, L[i].q, 0.0, L[i].dA, L[i].in, yb + i);
+                    }
+                }
+            }
+        };
+
+        RowBuf<VEC, NINT> A[U], B[U];
+        load_batch(A, y0);
+        for (int64_t yb = y0; yb < y1; yb += 2 * U) {
+            if (yb + U < y1) load_batch(B, yb + U);
+            process_batch(A, yb);
+            if (yb + U >= y1) break;
+            if (yb + 2 * U < y1) load_batch(A, yb + 2 * U);
+            process_batch(B, yb + U);
+        }
+    }
+    flush();
+    __syncthreads();
+
+    // ------------------------------------------------------------------ per-block partials (plain stores)
+    const size_t pb = (size_t)slab * gridDim.x + blockIdx.x;
+    double* ph = a.part_h + pb * NCH * N;
+    for (int i = tid; i < NCH * N; i += blockDim.x) {
+        const int ch = i / N, b = i - ch * N;
+        const double* src = &s_h[ch * hsz + b * ncopy];
+        double sum = 0.0;
+        for (int c = 0; c < ncopy; ++c) sum += src[c];
+        ph[i] = sum;
+    }
+    unsigned* pc = a.part_c + pb * N;
+    for (int b = tid; b < N; b += blockDim.x) {
+        unsigned sum = 0u;
+        for (int c = 0; c < ncopy; ++c) sum += s_c[b * ncopy + c];
+        pc[b] = sum;
+    }
+}
+
+template <typename TQ, int VEC, int NINT, bool GRAD>
+int launch_one(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
+{
+    auto kern = k_hist<TQ, VEC, NINT, GRAD>;
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+        XC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget + 4096));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)g.bps, (unsigned)nslab);
+    hipLaunchKernelGGL(kern, grid, dim3(kHistThreads), g.lds, ctx->stream, a);
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+template <typename TQ, int VEC>
+int launch_nint(xc_ctx* ctx, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a)
+{
+    if (grad) {
+        switch (nint) {
+            case 0: return launch_one<TQ, VEC, 0, true>(ctx, g, nslab, a);
+            case 1: return launch_one<TQ, VEC, 1, true>(ctx, g, nslab, a);
+            case 2: return launch_one<TQ, VEC, 2, true>(ctx, g, nslab, a);
+        }
+    } else {
+        switch (nint) {
+            case 0: return launch_one<TQ, VEC, 0, false>(ctx, g, nslab, a);
+            case 1: return launch_one<TQ, VEC, 1, false>(ctx, g, nslab, a);
+            case 2: return launch_one<TQ, VEC, 2, false>(ctx, g, nslab, a);
+        }
+    }
+    return fail(ctx, XC_EBADARG, "xc_hist: nint must be 0..2");
+}
+
+}  // namespace
+
+// Geometry: strips, blocks per slab, LDS copies.  Host-side checks live here so that
+// a kernel is never launched on shapes it does not assume (ny, nx >= 1; nx even for
+// VEC = 2; 16-byte aligned rows for the vector loads).
+int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int nbin, int nch,
+                  const void* q, HistGeom* g)
+{
+    if (nslab < 1 || ny < 1 || nx < 1) return fail(ctx, XC_EBADARG, "xc_hist: nslab, ny, nx must be >= 1");
+    if (nbin < 1) return fail(ctx, XC_EBADARG, "xc_hist: need at least 2 edges");
+    if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_hist: at most 65535 slabs per launch");
+    const size_t esz = (q_dtype == XC_F32) ? 4 : 8;
+    // VEC = 2 needs every row start (and dA / integrand rows, all f64 or f32) 2-element aligned
+    const bool even = (nx % 2) == 0 && (reinterpret_cast<uintptr_t>(q) % (2 * esz)) == 0;
+    g->vec = even ? 2 : 1;
+    const int W = 64 * g->vec;
+    g->nstrip = (int)((nx + W - 1) / W);
+    g->nch = nch;
+    // largest power-of-two copy count that fits the LDS budget
+    int ncopy = kMaxCopies;
+    const size_t fixed = (64 + ((nbin + 2) & ~1)) * sizeof(double);
+    while (ncopy > 1 && fixed + (size_t)nbin * ncopy * (nch * 8 + 4) > kLdsBudget) ncopy >>= 1;
+    if (fixed + (size_t)nbin * ncopy * (nch * 8 + 4) > kLdsBudget)
+        return fail(ctx, XC_EBADARG, "xc_hist: too many bins x channels for the LDS histogram");
+    g->ncopy = ncopy;
+    g->lds = fixed + (size_t)nbin * ncopy * (nch * 8 + 4);
+    g->lds = (g->lds + 15) & ~(size_t)15;
+    // blocks per slab: ~12 (strip,row) pairs per wave when few slabs, ~32 when many
+    const int64_t total = (int64_t)g->nstrip * ny;
+    const int waves = kHistThreads / 64;
+    const int cus = ctx->cus > 0 ? ctx->cus : 256;
+    int64_t bps = (total + waves * 32 - 1) / (waves * 32);
+    if (bps * nslab < cus) bps = (cus + nslab - 1) / nslab;
+    const int64_t maxb = (total + waves - 1) / waves;      // at least one pair per wave
+    if (bps > maxb) bps = maxb;
+    if (bps < 1) bps = 1;
+    g->bps = (int)bps;
+    g->part_h_doubles = (size_t)nch * nbin;
+    return XC_OK;
+}
+
+int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a)
+{
+    if (q_dtype == XC_F64) {
+        return g.vec == 2 ? launch_nint<double, 2>(ctx, nint, grad, g, nslab, a)
+                          : launch_nint<double, 1>(ctx, nint, grad, g, nslab, a);
+    } else if (q_dtype == XC_F32) {
+        return g.vec == 2 ? launch_nint<float, 2>(ctx, nint, grad, g, nslab, a)
+                          : launch_nint<float, 1>(ctx, nint, grad, g, nslab, a);
+    }
+    return fail(ctx, XC_EBADARG, "xc_hist: q_dtype must be XC_F32 or XC_F64");
+}
+
+}  // namespace xc

@@ -1,0 +1,123 @@
+// Internal declarations shared by the translation units of libxcontour_hip.so.
+// Not part of the C ABI (that is include/xcontour_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/xcontour_hip.h"
+
+struct xc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int cus = 0;
+    char name[256] = {0};
+    std::string err;
+    // grow-only device scratch owned by the context
+    void*  scratch = nullptr;   size_t scratch_bytes = 0;   // kernel workspaces (partials, minmax, edges)
+    void*  arena = nullptr;     size_t arena_bytes = 0;     // staging for the host-pointer entry points
+    // timing of the dominant kernel
+    int timing = 0;
+    hipEvent_t ev_hist0 = nullptr, ev_hist1 = nullptr;
+    int ev_valid = 0;
+};
+
+namespace xc {
+
+int fail(xc_ctx* ctx, int code, const std::string& msg);
+int hipfail(xc_ctx* ctx, hipError_t e, const char* what);
+
+#define XC_HIP(ctx, call)                                                     \
+    do {                                                                      \
+        hipError_t _e = (call);                                               \
+        if (_e != hipSuccess) return xc::hipfail((ctx), _e, #call);           \
+    } while (0)
+
+// grow-only scratch (never shrinks; pointer may change between calls, never within one)
+int ensure_scratch(xc_ctx* ctx, size_t bytes);
+int ensure_arena(xc_ctx* ctx, size_t bytes);
+
+// ---------------------------------------------------------------- launch geometry
+constexpr int kMinmaxBlocks = 1024;   // partial min/max pairs per slab
+constexpr int kHistThreads  = 1024;   // 16 waves: one block per CU (LDS-bound)
+constexpr int kMaxCopies    = 16;     // lane-privatised LDS histogram copies
+constexpr size_t kLdsBudget = 150 * 1024;
+
+struct HistGeom {
+    int vec;        // cells per lane per row load (1 or 2)
+    int nstrip;     // column strips of 64*vec cells
+    int bps;        // blocks per slab
+    int ncopy;      // LDS histogram copies (power of two)
+    int nch;        // weight channels
+    size_t lds;     // dynamic LDS bytes
+    size_t part_h_doubles;   // per-(slab,block) partial doubles = nch*nbin
+};
+
+// ---------------------------------------------------------------- kernel argument blocks
+struct HistArgs {
+    const void*   q;
+    const double* dA;
+    const void*   integ[XC_MAX_INTEGRANDS];
+    int           integ_f32[XC_MAX_INTEGRANDS];
+    const double* edges;        // explicit edges (levels_mode == 0)
+    const double* mmpart;       // [nslab][P][2] partial min/max (levels_mode == 1)
+    int           P;
+    int           levels_mode;
+    int           nbin;
+    int           edges_per_slab;
+    int           last_closed;
+    int           increase, q_f32, ctr_f32, right_edge;
+    double        inv_nm1;      // 1.0/(N-1) (levels mode)
+    int           dA_rank, prod_f32;
+    const double* rdx;
+    const double* rdy;
+    int           periodic_x;
+    int64_t       ny, nx;
+    int           nstrip, ncopy;
+    double*       part_h;       // [nslab][bps][nch][nbin]
+    unsigned*     part_c;       // [nslab][bps][nbin]
+    double*       ctr_out;      // [nslab][nbin]   (levels mode, may be null)
+    double*       edges_out;    // [nslab][nbin+1] (levels mode, may be null)
+    int32_t*      status;       // [nslab]         (levels mode, may be null)
+};
+
+struct FinalArgs {
+    const double*   part_h;
+    const unsigned* part_c;
+    int             bps, nch, nbin;
+    int             lt, reverse;
+    double*         pdf;      // [nslab][nch][nbin] or null
+    uint64_t*       counts;   // [nslab][nbin] or null
+    double*         cdf;      // [nslab][nch][nbin] or null
+    // Keff epilogue (enabled when keff != 0); channel 0 = area, channel 1 = intgrdS
+    int             keff;
+    int             ctr_f32;
+    const double*   ctr;      // [nslab][nbin] level order
+    const double*   tbl;      const double* tbl_coord;   int ntbl;
+    const double*   preY;     int npre;
+    double          nkeff_mask, lmin_scale;
+    double *o_area, *o_intS, *o_latEq, *o_dqdA, *o_dSdA, *o_Leq2, *o_Lmin, *o_nkeff, *o_interp;
+};
+
+// ---------------------------------------------------------------- launchers (defined in the .hip files)
+int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part);
+int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, double* out);
+int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
+                  int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status);
+int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int nbin, int nch,
+                  const void* q, HistGeom* g);
+int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a);
+int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a);
+int launch_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
+                  int64_t ny, int64_t nx, double* out_rows);
+int launch_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                 const double* rdx, const double* rdy, int periodic_x, double* out);
+int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
+               const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
+               int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+               const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks);
+int launch_synth(xc_ctx* ctx, void* out, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                 const double* lat_deg, const double* lon_deg, uint64_t seed, int variant);
+
+}  // namespace xc

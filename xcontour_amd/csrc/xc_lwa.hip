@@ -1,0 +1,138 @@
+// K7 -- local finite-amplitude wave activity / local APE (gfx950).
+//
+// Replaces the J-iteration python loop of Contour2D.cal_local_wave_activity
+// (reference core.py:752-791): for every target row j and column x
+//     lwa[j,x] = - sum_{y'} (q[y',x] - Q[j]) * mask3(j,y',x) * (dA[y',x]/dAmax) * M[y',x]
+// with mask3 in {-1,0,1} from the sign of qe and the side of row j (core.py:757-766)
+// and the part selection of core.py:773-784 (masked-out cells are NaN there and are
+// skipped by the sum, i.e. contribute nothing).
+//
+// Mapping: lanes run along X (coalesced row reads), each thread keeps JT target rows in
+// registers and streams the column once per JT targets; the y' loop is sequential, the
+// same order numpy's axis-0 nansum uses, so results are reproducible bit for bit.
+#include "xc_internal.h"
+
+namespace xc {
+namespace {
+
+constexpr int JT = 8;
+
+__device__ __forceinline__ int mask3(double qe, bool m, int increase)
+{
+    // core.py:759-766
+    const bool neg = increase ? (qe > 0.0) : (qe < 0.0);   // -> -1 on the far side
+    const bool pos = increase ? (qe < 0.0) : (qe > 0.0);   // -> +1 on the near side
+    return (pos && m) ? 1 : (m ? 0 : (neg ? -1 : 0));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
+           const double* __restrict__ dA, int dA_rank, double dA_max,
+           const double* __restrict__ M, int M_rank,
+           int64_t ny, int64_t nx, int increase, int coord_incre, int part, double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t x = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t j0 = ((int64_t)blockIdx.y * 4 + wave) * JT;
+    if (j0 >= ny) return;
+    const size_t so = (size_t)blockIdx.z * ny * nx;
+    const T* qs = q + so;
+    const double* Qs = Q + (size_t)blockIdx.z * ny;
+    const bool active = x < nx;
+
+    double Qj[JT], cj[JT], acc[JT];
+#pragma unroll
+    for (int t = 0; t < JT; ++t) {
+        const int64_t j = (j0 + t < ny) ? j0 + t : ny - 1;
+        Qj[t] = Qs[j]; cj[t] = coord[j]; acc[t] = 0.0;
+    }
+    // keep the sign of the selected part: 'upper' keeps mask>0 if increase else mask<0 (core.py:775-784)
+    const int keep = (part == 0) ? 0 : (((part == 1) == (increase != 0)) ? 1 : -1);
+
+    for (int64_t y = 0; y < ny; ++y) {
+        const double qv = active ? (double)qs[y * nx + x] : 0.0;
+        const double cy = coord[y];
+        const double dv = (dA_rank == XC_DA_ROW) ? dA[y] : (active ? dA[y * nx + x] : 0.0);
+        const double wei = __ddiv_rn(dv, dA_max);                                   // core.py:724
+        const double mv = (M_rank == XC_DA_NONE) ? dv
+                        : (M_rank == XC_DA_ROW) ? M[y] : (active ? M[y * nx + x] : 0.0);
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+            const double qe = __dsub_rn(qv, Qj[t]);                                 // core.py:754
+            const bool m = coord_incre ? (cy >= cj[t]) : (cy <= cj[t]);             // core.py:757
+            const int mk = mask3(qe, m, increase);
+            if (mk != 0 && (keep == 0 || (keep > 0) == (mk > 0))) {
+                const double term = __dmul_rn(__dmul_rn(__dmul_rn(qe, (double)mk), wei), mv);
+                if (term == term) acc[t] = __dadd_rn(acc[t], term);                 // nansum
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < JT; ++t)
+            if (j0 + t < ny) out[so + (size_t)(j0 + t) * nx + x] = -acc[t];        // core.py:789
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_lwa_masks(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
+                 int64_t ny, int64_t nx, int increase, int coord_incre,
+                 const int32_t* __restrict__ mask_idx, int nmask, int8_t* __restrict__ out)
+{
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    const int slab = blockIdx.z / nmask, im = blockIdx.z % nmask;
+    if (x >= nx) return;
+    const int64_t j = mask_idx[im];
+    const double qe = __dsub_rn((double)q[(size_t)slab * ny * nx + y * nx + x], Q[(size_t)slab * ny + j]);
+    const bool m = coord_incre ? (coord[y] >= coord[j]) : (coord[y] <= coord[j]);
+    out[(((size_t)slab * nmask + im) * ny + y) * nx + x] = (int8_t)mask3(qe, m, increase);
+}
+
+}  // namespace
+
+int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
+               const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
+               int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+               const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks)
+{
+    if (!q || !Q || !coord || !dA || !out_lwa || nslab < 1 || ny < 2 || nx < 1)
+        return fail(ctx, XC_EBADARG, "xc_lwa: bad arguments");
+    if (dA_rank != XC_DA_ROW && dA_rank != XC_DA_PLANE) return fail(ctx, XC_EBADARG, "xc_lwa: dA_rank must be ROW or PLANE");
+    if (M_rank != XC_DA_NONE && M_rank != XC_DA_ROW && M_rank != XC_DA_PLANE) return fail(ctx, XC_EBADARG, "xc_lwa: bad M_rank");
+    if (M_rank != XC_DA_NONE && !M) return fail(ctx, XC_EBADARG, "xc_lwa: M is NULL");
+    if (part < 0 || part > 2) return fail(ctx, XC_EBADARG, "xc_lwa: part must be 0 (all), 1 (upper) or 2 (lower)");
+    if (nmask < 0 || (nmask > 0 && (!mask_idx || !out_masks))) return fail(ctx, XC_EBADARG, "xc_lwa: mask arguments");
+    if (ny > 65535 || nslab * (nmask > 0 ? nmask : 1) > 65535) return fail(ctx, XC_EBADARG, "xc_lwa: ny / nslab too large");
+    // coordinate direction (core.py:736-738) is decided on the host by the caller's coord;
+    // here we need it on the host too: read the two end values.
+    double c2[2];
+    XC_HIP(ctx, hipMemcpyAsync(&c2[0], coord, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    XC_HIP(ctx, hipMemcpyAsync(&c2[1], coord + (ny - 1), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int coord_incre = !(c2[1] < c2[0]);
+    dim3 grid((unsigned)((nx + 63) / 64), (unsigned)((ny + 4 * JT - 1) / (4 * JT)), (unsigned)nslab);
+    if (q_dtype == XC_F64)
+        hipLaunchKernelGGL(k_lwa<double>, grid, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, dA, dA_rank,
+                           dA_max, M, M_rank, ny, nx, increase, coord_incre, part, out_lwa);
+    else if (q_dtype == XC_F32)
+        hipLaunchKernelGGL(k_lwa<float>, grid, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, dA, dA_rank,
+                           dA_max, M, M_rank, ny, nx, increase, coord_incre, part, out_lwa);
+    else return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
+    XC_HIP(ctx, hipGetLastError());
+    if (nmask > 0) {
+        dim3 g2((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)(nslab * nmask));
+        if (q_dtype == XC_F64)
+            hipLaunchKernelGGL(k_lwa_masks<double>, g2, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, ny, nx,
+                               increase, coord_incre, mask_idx, nmask, out_masks);
+        else
+            hipLaunchKernelGGL(k_lwa_masks<float>, g2, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, ny, nx,
+                               increase, coord_incre, mask_idx, nmask, out_masks);
+        XC_HIP(ctx, hipGetLastError());
+    }
+    return XC_OK;
+}
+
+}  // namespace xc

@@ -1,0 +1,442 @@
+// K1 min/max, stand-alone levels, K5/K6 finalize + Keff epilogue, K2 row sums,
+// K4 stand-alone |grad q|^2, synthetic slab generator.  gfx950 only.
+#include "xc_internal.h"
+
+namespace xc {
+
+namespace {
+
+__device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+__device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+// =====================================================================================
+// K1  NaN-skipping min / max    (tracer.min/max(dim=dimVs), core.py:224-225)
+// One streaming pass, 16-byte loads, 4 in flight per lane; per-block partial pairs are
+// written with plain stores and reduced in fixed order by the consumer (k_minmax_final
+// or the K3 prologue): deterministic, no atomics, no memset.
+// =====================================================================================
+template <typename T> struct V16;
+template <> struct V16<double> { using type = double2; static constexpr int n = 2; };
+template <> struct V16<float>  { using type = float4;  static constexpr int n = 4; };
+
+__device__ __forceinline__ void mm(double& mn, double& mx, double v) { mn = fmin(mn, v); mx = fmax(mx, v); }
+__device__ __forceinline__ void mmv(double& mn, double& mx, const double2& v) { mm(mn, mx, v.x); mm(mn, mx, v.y); }
+__device__ __forceinline__ void mmv(double& mn, double& mx, const float4& v)
+{
+    // reduce in f32 first (exact), then widen
+    const float lo = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
+    const float hi = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    // fminf/fmaxf return the non-NaN operand; all four NaN -> NaN, skipped by fmin/fmax below
+    mn = fmin(mn, (double)lo); mx = fmax(mx, (double)hi);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_minmax_partial(const T* __restrict__ q, int64_t ncell, double* __restrict__ part)
+{
+    using V = typename V16<T>::type;
+    constexpr int VN = V16<T>::n;
+    const int P = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
+    const T* qs = q + (size_t)blockIdx.y * ncell;
+    double mn = dinf(), mx = -dinf();
+
+    // leading scalars up to 16-byte alignment, vector body, trailing scalars
+    int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(qs) & 15)) & 15) / sizeof(T));
+    if (head > ncell) head = ncell;
+    const int64_t nvec = (ncell - head) / VN;
+    const V* qv = reinterpret_cast<const V*>(qs + head);
+    const int64_t per = (nvec + P - 1) / P;
+    const int64_t v0 = (int64_t)b * per;
+    const int64_t v1 = (v0 + per < nvec) ? v0 + per : nvec;
+    int64_t i = v0 + tid;
+    for (; i + 3 * 256 < v1; i += 4 * 256) {
+        const V a0 = qv[i], a1 = qv[i + 256], a2 = qv[i + 512], a3 = qv[i + 768];
+        mmv(mn, mx, a0); mmv(mn, mx, a1); mmv(mn, mx, a2); mmv(mn, mx, a3);
+    }
+    for (; i < v1; i += 256) { const V a0 = qv[i]; mmv(mn, mx, a0); }
+    if (b == 0) {
+        for (int64_t j = tid; j < head; j += 256) mm(mn, mx, (double)qs[j]);
+        for (int64_t j = head + nvec * VN + tid; j < ncell; j += 256) mm(mn, mx, (double)qs[j]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
+    __shared__ double s[8];
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane == 0) { s[2 * wave] = mn; s[2 * wave + 1] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) { mn = fmin(mn, s[2 * w]); mx = fmax(mx, s[2 * w + 1]); }
+        double* o = part + ((size_t)blockIdx.y * P + b) * 2;
+        o[0] = mn; o[1] = mx;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_minmax_final(const double* __restrict__ part, int P, double* __restrict__ out)
+{
+    const int tid = threadIdx.x;
+    const double* mp = part + (size_t)blockIdx.x * P * 2;
+    double mn = dinf(), mx = -dinf();
+    for (int i = tid; i < P; i += 256) { mn = fmin(mn, mp[2 * i]); mx = fmax(mx, mp[2 * i + 1]); }
+    for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
+    __shared__ double s[8];
+    if ((tid & 63) == 0) { s[2 * (tid >> 6)] = mn; s[2 * (tid >> 6) + 1] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) { mn = fmin(mn, s[2 * w]); mx = fmax(mx, s[2 * w + 1]); }
+        if (mn == dinf() && mx == -dinf()) { mn = dnan(); mx = dnan(); }
+        out[2 * blockIdx.x] = mn; out[2 * blockIdx.x + 1] = mx;
+    }
+}
+
+// =====================================================================================
+// stand-alone levels + edges (same arithmetic as the K3 prologue; core.py:228-246, 1296-1305)
+// =====================================================================================
+__global__ __launch_bounds__(256)
+void k_levels(const double* __restrict__ minmax, int N, int increase, int q_f32, int ctr_f32,
+              int right_edge, double inv_nm1, double* __restrict__ ctr, double* __restrict__ edges,
+              int32_t* __restrict__ status)
+{
+    const int slab = blockIdx.x, tid = threadIdx.x;
+    const double mn = minmax[2 * slab], mx = minmax[2 * slab + 1];
+    double* e = edges + (size_t)slab * (N + 1);
+    const double start = increase ? mn : mx, stop = increase ? mx : mn;
+    const double d = q_f32 ? (double)__fsub_rn((float)stop, (float)start) : __dsub_rn(stop, start);
+    const double steps = __dmul_rn(inv_nm1, d);
+    for (int k = tid; k < N; k += 256) {
+        double c = __dadd_rn(__dmul_rn(steps, (double)k), start);
+        if (ctr_f32) c = (double)(float)c;
+        ctr[(size_t)slab * N + k] = c;
+        e[increase ? k + 1 : N - k] = c;
+    }
+    __syncthreads();   // block-scope visibility of the global stores above (same CU)
+    if (tid == 0) {
+        status[slab] = 0;
+        const double lo = e[1], hi = e[N];
+        if (ctr_f32) {
+            const float step = __fdiv_rn(__fsub_rn((float)hi, (float)lo), (float)(N - 1));
+            e[0] = (double)__fsub_rn((float)lo, step);
+            if (right_edge == XC_EDGE_XHISTOGRAM) e[N] = (double)__fadd_rn((float)hi, (float)1e-8);
+        } else {
+            const double step = __ddiv_rn(__dsub_rn(hi, lo), (double)(N - 1));
+            e[0] = __dsub_rn(lo, step);
+            if (right_edge == XC_EDGE_XHISTOGRAM) e[N] = __dadd_rn(hi, 1e-8);
+        }
+        int bad = 0;
+        for (int k = 1; k < N; ++k) bad |= (ctr[(size_t)slab * N + k] == ctr[(size_t)slab * N + k - 1]);
+        status[slab] = bad;
+    }
+}
+
+// =====================================================================================
+// K5 + K6  finalize: fixed-order reduction of the per-block partial histograms, PDF ->
+// CDF (sequential np.cumsum order), optional lt flip / reversal, optional Keff epilogue.
+// One 256-thread block per slab; everything lives in LDS.
+// =====================================================================================
+// np.interp(x, xp, fp) for ascending xp (numpy's compiled arr_interp, no precomputed slopes)
+__device__ double interp_asc(double x, const double* __restrict__ xp, const double* __restrict__ fp,
+                             int n, int rev)
+{
+    // rev: logical arrays are xp[n-1-i], fp[n-1-i]
+    auto X = [&](int i) { return rev ? xp[n - 1 - i] : xp[i]; };
+    auto F = [&](int i) { return rev ? fp[n - 1 - i] : fp[i]; };
+    if (x != x) return x;
+    if (x > X(n - 1)) return F(n - 1);
+    if (x < X(0)) return F(0);
+    // j = largest index with X(j) <= x
+    int lo = 0, hi = n;            // X(lo) <= x, x < X(hi) (virtual)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (x >= X(mid)) lo = mid; else hi = mid; }
+    const int j = lo;
+    if (j == n - 1) return F(j);
+    const double xj = X(j), fj = F(j);
+    if (xj == x) return fj;
+    const double slope = __ddiv_rn(__dsub_rn(F(j + 1), fj), __dsub_rn(X(j + 1), xj));
+    double r = __dadd_rn(__dmul_rn(slope, __dsub_rn(x, xj)), fj);
+    if (r != r) {
+        r = __dadd_rn(__dmul_rn(slope, __dsub_rn(x, X(j + 1))), F(j + 1));
+        if (r != r && F(j + 1) == fj) r = fj;
+    }
+    return r;
+}
+
+// np.gradient(f, uniform unit spacing, edge_order=1) at index k, f64
+__device__ __forceinline__ double grad_f64(const double* f, int k, int N)
+{
+    if (N == 1) return 0.0;
+    if (k == 0) return __dsub_rn(f[1], f[0]);
+    if (k == N - 1) return __dsub_rn(f[N - 1], f[N - 2]);
+    return __ddiv_rn(__dsub_rn(f[k + 1], f[k - 1]), 2.0);
+}
+// the same on float32 data (the default contour dtype): arithmetic stays in f32
+__device__ __forceinline__ double grad_f32(const double* f, int k, int N)
+{
+    if (N == 1) return 0.0;
+    if (k == 0) return (double)__fsub_rn((float)f[1], (float)f[0]);
+    if (k == N - 1) return (double)__fsub_rn((float)f[N - 1], (float)f[N - 2]);
+    return (double)__fdiv_rn(__fsub_rn((float)f[k + 1], (float)f[k - 1]), 2.0f);
+}
+
+__global__ __launch_bounds__(256)
+void k_finalize(const FinalArgs a)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int slab = blockIdx.x, tid = threadIdx.x;
+    const int N = a.nbin, NCH = a.nch;
+    double* s_pdf = sm;                   // [NCH][N]
+    double* s_cdf = sm + (size_t)NCH * N; // [NCH][N] in LEVEL order (after optional reversal)
+    double* s_x   = s_cdf + (size_t)NCH * N;   // 7*N scratch for the epilogue
+
+    const double* ph = a.part_h + (size_t)slab * a.bps * NCH * N;
+    for (int i = tid; i < NCH * N; i += 256) {
+        double sum = 0.0;
+        for (int b = 0; b < a.bps; ++b) sum += ph[(size_t)b * NCH * N + i];
+        s_pdf[i] = sum;
+    }
+    if (a.counts) {
+        const unsigned* pc = a.part_c + (size_t)slab * a.bps * N;
+        for (int i = tid; i < N; i += 256) {
+            uint64_t sum = 0;
+            for (int b = 0; b < a.bps; ++b) sum += pc[(size_t)b * N + i];
+            a.counts[(size_t)slab * N + (a.reverse ? N - 1 - i : i)] = sum;
+        }
+    }
+    __syncthreads();
+    if (tid < NCH) {                      // np.cumsum order (core.py:1320)
+        const double* p = s_pdf + (size_t)tid * N;
+        double* c = s_cdf + (size_t)tid * N;
+        double run = 0.0;
+        for (int k = 0; k < N; ++k) { run = __dadd_rn(run, p[k]); c[k] = run; }
+        if (!a.lt) { const double tot = c[N - 1]; for (int k = 0; k < N; ++k) c[k] = __dsub_rn(tot, c[k]); }   // core.py:1322-1323
+        if (a.reverse)                    // core.py:454-455
+            for (int k = 0; k < N / 2; ++k) { const double t = c[k]; c[k] = c[N - 1 - k]; c[N - 1 - k] = t; }
+    }
+    __syncthreads();
+    for (int i = tid; i < NCH * N; i += 256) {
+        const int ch = i / N, k = i - ch * N;
+        if (a.pdf) a.pdf[(size_t)slab * NCH * N + (size_t)ch * N + (a.reverse ? N - 1 - k : k)] = s_pdf[i];
+        if (a.cdf) a.cdf[(size_t)slab * NCH * N + i] = s_cdf[i];
+    }
+    if (!a.keff) return;
+
+    // ---------------- Keff epilogue, one thread per contour
+    const double* area = s_cdf;           // channel 0
+    const double* intS = s_cdf + N;       // channel 1
+    double* s_ctr = s_x;            double* s_lat = s_x + N;       double* s_lmin = s_x + 2 * N;
+    double* s_dS  = s_x + 3 * N;    double* s_dq  = s_x + 4 * N;   double* s_leq = s_x + 5 * N;
+    double* s_nk  = s_x + 6 * N;
+    const int tinc = a.tbl[a.ntbl - 1] > a.tbl[0];          // Table.__init__, core.py:1122-1128
+    for (int k = tid; k < N; k += 256) {
+        s_ctr[k] = a.ctr[(size_t)slab * N + k];
+        const double le = interp_asc(area[k], a.tbl, a.tbl_coord, a.ntbl, !tinc);   // core.py:1136-1174
+        s_lat[k] = le;
+        s_lmin[k] = __dmul_rn(a.lmin_scale, cos(__dmul_rn(le, 0.017453292519943295)));   // utils.py:532
+    }
+    __syncthreads();
+    for (int k = tid; k < N; k += 256) {
+        const double dA = grad_f64(area, k, N);
+        const double dS = __ddiv_rn(grad_f64(intS, k, N), dA);                    // core.py:480-483
+        const double dq = __ddiv_rn(a.ctr_f32 ? grad_f32(s_ctr, k, N) : grad_f64(s_ctr, k, N), dA);
+        const double leq = __ddiv_rn(dS, __dmul_rn(dq, dq));                      // core.py:635
+        double nk = __ddiv_rn(__ddiv_rn(leq, s_lmin[k]), s_lmin[k]);              // core.py:963
+        if (!(nk < a.nkeff_mask)) nk = dnan();                                    // core.py:964
+        s_dS[k] = dS; s_dq[k] = dq; s_leq[k] = leq; s_nk[k] = nk;
+        const size_t o = (size_t)slab * N + k;
+        if (a.o_area)  a.o_area[o]  = area[k];
+        if (a.o_intS)  a.o_intS[o]  = intS[k];
+        if (a.o_latEq) a.o_latEq[o] = s_lat[k];
+        if (a.o_Lmin)  a.o_Lmin[o]  = s_lmin[k];
+        if (a.o_dSdA)  a.o_dSdA[o]  = dS;
+        if (a.o_dqdA)  a.o_dqdA[o]  = dq;
+        if (a.o_Leq2)  a.o_Leq2[o]  = leq;
+        if (a.o_nkeff) a.o_nkeff[o] = nk;
+    }
+    if (a.o_interp && a.npre > 0) {
+        __syncthreads();
+        // interp_to_coords (core.py:1050-1100): direction from latEq[0] < latEq[-1]
+        const int rev = !(s_lat[0] < s_lat[N - 1]);
+        const double* vars[9] = {s_ctr, area, intS, s_lat, s_dS, s_dq, s_leq, s_lmin, s_nk};
+        for (int i = tid; i < 9 * a.npre; i += 256) {
+            const int v = i / a.npre, p = i - v * a.npre;
+            a.o_interp[((size_t)slab * 9 + v) * a.npre + p] = interp_asc(a.preY[p], s_lat, vars[v], N, rev);
+        }
+    }
+}
+
+// =====================================================================================
+// K2  per-row sums of dA * [mask == 1]        (cal_area_eqCoord_table_hist, core.py:176-193)
+// one wave per row, 4 rows per block
+// =====================================================================================
+template <typename TM>
+__global__ __launch_bounds__(256)
+void k_rowsum(const TM* __restrict__ mask, const double* __restrict__ dA, int dA_rank,
+              int64_t ny, int64_t nx, double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= ny) return;
+    double sum = 0.0;
+    const double rowv = (dA_rank == XC_DA_ROW) ? dA[row] : 1.0;
+    for (int64_t x = lane; x < nx; x += 64) {
+        const bool in = mask ? (mask[row * nx + x] == (TM)1) : true;
+        const double w = (dA_rank == XC_DA_PLANE) ? dA[row * nx + x] : rowv;
+        if (in) sum += w;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) out[row] = sum;
+}
+
+// =====================================================================================
+// K4  stand-alone |grad q|^2 (oracle grad2_sphere; no reference call site)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_grad2(const T* __restrict__ q, int64_t ny, int64_t nx, const double* __restrict__ rdx,
+             const double* __restrict__ rdy, int periodic_x, double* __restrict__ out)
+{
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= nx) return;
+    const T* qs = q + (size_t)blockIdx.z * ny * nx;
+    const int64_t xw = (x == 0) ? (periodic_x ? nx - 1 : 0) : x - 1;
+    const int64_t xe = (x == nx - 1) ? (periodic_x ? 0 : nx - 1) : x + 1;
+    const int64_t ys = y > 0 ? y - 1 : 0, yn = y < ny - 1 ? y + 1 : ny - 1;
+    const double f = (!periodic_x && (x == 0 || x == nx - 1)) ? 2.0 : 1.0;
+    const double gx = __dmul_rn(__dmul_rn(__dsub_rn((double)qs[y * nx + xe], (double)qs[y * nx + xw]), rdx[y]), f);
+    const double gy = __dmul_rn(__dsub_rn((double)qs[yn * nx + x], (double)qs[ys * nx + x]), rdy[y]);
+    out[(size_t)blockIdx.z * ny * nx + y * nx + x] = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
+}
+
+// =====================================================================================
+// synthetic PV-like slabs, counter-based RNG (splitmix64 finaliser -> Box-Muller)
+// =====================================================================================
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01(uint64_t r) { return ((double)(r >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_synth(T* __restrict__ out, int64_t ny, int64_t nx, const double* __restrict__ lat,
+             const double* __restrict__ lon, uint64_t seed, int variant)
+{
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= nx) return;
+    const uint64_t sseed = seed + blockIdx.z;
+    const double d2r = 0.017453292519943295;
+    const double phi = lat[y] * d2r, lam = lon[x] * d2r;
+    const uint64_t cell = (uint64_t)(y * nx + x);
+    const uint64_t r1 = mix64(mix64(sseed) ^ (2 * cell)), r2 = mix64(mix64(sseed) ^ (2 * cell + 1));
+    const double eps = sqrt(-2.0 * log(u01(r1))) * cos(6.283185307179586 * u01(r2));
+    double v;
+    if (variant == 1) v = eps;
+    else if (variant == 2) v = sin(phi);
+    else {
+        double wavy = 0.0;
+        for (int k = 1; k <= 6; ++k) {
+            const uint64_t rk = mix64(mix64(sseed ^ 0xA5A5A5A5ull) + k);
+            const double ak = 0.5 + 0.5 * u01(rk), th = 6.283185307179586 * u01(mix64(rk));
+            wavy += ak * cos(k * lam + th);
+        }
+        const double c = cos(phi);
+        v = sin(phi) + 0.25 * wavy * c * c + 0.02 * eps;
+    }
+    out[(size_t)blockIdx.z * ny * nx + y * nx + x] = (T)v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ launchers
+int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part)
+{
+    if (!q || !part || nslab < 1 || ncell < 1) return fail(ctx, XC_EBADARG, "xc_minmax: bad arguments");
+    if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_minmax: at most 65535 slabs per launch");
+    dim3 grid(kMinmaxBlocks, (unsigned)nslab);
+    if (q_dtype == XC_F64)
+        hipLaunchKernelGGL(k_minmax_partial<double>, grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part);
+    else if (q_dtype == XC_F32)
+        hipLaunchKernelGGL(k_minmax_partial<float>, grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part);
+    else return fail(ctx, XC_EBADARG, "xc_minmax: q_dtype must be XC_F32 or XC_F64");
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, double* out)
+{
+    hipLaunchKernelGGL(k_minmax_final, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, part, kMinmaxBlocks, out);
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
+                  int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status)
+{
+    if (!minmax || !ctr || !edges || !status || N < 2 || nslab < 1)
+        return fail(ctx, XC_EBADARG, "xc_levels: bad arguments (need N >= 2)");
+    const double inv = 1.0 / (double)(N - 1);
+    hipLaunchKernelGGL(k_levels, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, minmax, N, increase,
+                       q_dtype == XC_F32, ctr_dtype == XC_F32, right_edge, inv, ctr, edges, status);
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a)
+{
+    const size_t lds = ((size_t)2 * a.nch * a.nbin + (a.keff ? 7 * (size_t)a.nbin : 0)) * sizeof(double);
+    if (lds > 60 * 1024) return fail(ctx, XC_EBADARG, "xc finalize: too many bins x channels");
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)nslab), dim3(256), lds, ctx->stream, a);
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+int launch_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
+                  int64_t ny, int64_t nx, double* out_rows)
+{
+    if (!out_rows || ny < 1 || nx < 1) return fail(ctx, XC_EBADARG, "xc_rowsum: bad arguments");
+    if (dA_rank != XC_DA_NONE && dA_rank != XC_DA_ROW && dA_rank != XC_DA_PLANE)
+        return fail(ctx, XC_EBADARG, "xc_rowsum: dA_rank must be NONE, ROW or PLANE");
+    if (dA_rank != XC_DA_NONE && !dA) return fail(ctx, XC_EBADARG, "xc_rowsum: dA is NULL");
+    dim3 grid((unsigned)((ny + 3) / 4));
+    if (!mask || mask_dtype == XC_F64)
+        hipLaunchKernelGGL(k_rowsum<double>, grid, dim3(256), 0, ctx->stream, (const double*)mask, dA, dA_rank, ny, nx, out_rows);
+    else if (mask_dtype == XC_F32)
+        hipLaunchKernelGGL(k_rowsum<float>, grid, dim3(256), 0, ctx->stream, (const float*)mask, dA, dA_rank, ny, nx, out_rows);
+    else return fail(ctx, XC_EBADARG, "xc_rowsum: mask_dtype must be XC_F32 or XC_F64");
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+int launch_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                 const double* rdx, const double* rdy, int periodic_x, double* out)
+{
+    if (!q || !rdx || !rdy || !out || nslab < 1 || ny < 1 || nx < 1 || ny > 65535 || nslab > 65535)
+        return fail(ctx, XC_EBADARG, "xc_grad2: bad arguments");
+    dim3 grid((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)nslab);
+    if (q_dtype == XC_F64)
+        hipLaunchKernelGGL(k_grad2<double>, grid, dim3(256), 0, ctx->stream, (const double*)q, ny, nx, rdx, rdy, periodic_x, out);
+    else if (q_dtype == XC_F32)
+        hipLaunchKernelGGL(k_grad2<float>, grid, dim3(256), 0, ctx->stream, (const float*)q, ny, nx, rdx, rdy, periodic_x, out);
+    else return fail(ctx, XC_EBADARG, "xc_grad2: q_dtype must be XC_F32 or XC_F64");
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+int launch_synth(xc_ctx* ctx, void* out, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                 const double* lat_deg, const double* lon_deg, uint64_t seed, int variant)
+{
+    if (!out || !lat_deg || !lon_deg || nslab < 1 || ny < 1 || nx < 1 || ny > 65535 || nslab > 65535)
+        return fail(ctx, XC_EBADARG, "xc_synth: bad arguments");
+    dim3 grid((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)nslab);
+    if (q_dtype == XC_F64)
+        hipLaunchKernelGGL(k_synth<double>, grid, dim3(256), 0, ctx->stream, (double*)out, ny, nx, lat_deg, lon_deg, seed, variant);
+    else if (q_dtype == XC_F32)
+        hipLaunchKernelGGL(k_synth<float>, grid, dim3(256), 0, ctx->stream, (float*)out, ny, nx, lat_deg, lon_deg, seed, variant);
+    else return fail(ctx, XC_EBADARG, "xc_synth: q_dtype must be XC_F32 or XC_F64");
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+}  // namespace xc

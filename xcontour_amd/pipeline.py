@@ -1,0 +1,165 @@
+# -*- coding: utf-8 -*-
+"""
+Batched, device-resident Keff pipeline (host side of `xc_keff_dev`).
+
+One `KeffPlan` = one batch of independent (time, level) slabs resident in HBM on
+one GPU plus every static input (dA, gradient metrics, A(Yeq) table, prescribed
+equivalent coordinates) and pre-allocated outputs.  `run()` enqueues the three
+kernels of the reference's call sequence (SURVEY 3.1 steps 2-10:
+core.py:205-249, 412-460, 1136-1174, 463-488, 619-637, 945-966, 1050-1100,
+utils.py:518-534) with no host round trip; `fetch()` copies the results back.
+
+Independent slabs shard across GPUs with no exchange during compute:
+`shard_slabs(S, rank, world)` is the static contiguous partition of SURVEY 8(e).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from .utils import Rearth, grad_metrics
+
+OUT_NAMES = ('ctr', 'area', 'intgrdS', 'latEq', 'dqdA', 'dintSdA', 'Leq2', 'Lmin', 'nkeff')
+INTERP_ORDER = ('ctr', 'area', 'intgrdS', 'latEq', 'dintSdA', 'dqdA', 'Leq2', 'Lmin', 'nkeff')
+
+
+def shard_slabs(nslab, rank, world):
+    """Contiguous block [lo, hi) of the flattened (time, level) slab index owned
+    by `rank` of `world`: ceil(S/G) slabs each, last ranks may be short."""
+    per = -(-int(nslab) // int(world))
+    lo = min(int(nslab), rank * per)
+    hi = min(int(nslab), lo + per)
+    return lo, hi
+
+
+class KeffPlan(object):
+    def __init__(self, ctx, nslab, ny, nx, N, q_dtype=np.float64, ctr_dtype=np.float64,
+                 dA=None, lat=None, lon=None, rdx=None, rdy=None, periodic_x=True,
+                 tbl=None, tbl_coord=None, preY=None, increase=True, lt=True,
+                 right_edge='numpy', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
+                 prod_f32=False, alloc_q=True):
+        """dA: None | (ny,) | (ny,nx) f64.  Gradient metrics either `rdx, rdy`
+        (per-row reciprocals) or derived from `lat, lon` (sphere).  If
+        `grdS_dtype` is given the squared gradient is an INPUT (set with
+        `set_grdS`) instead of being computed in-kernel."""
+        self.ctx = ctx
+        self.nslab, self.ny, self.nx, self.N = int(nslab), int(ny), int(nx), int(N)
+        self.q_dtype, self.ctr_dtype = np.dtype(q_dtype), np.dtype(ctr_dtype)
+        self.npre = 0 if preY is None else len(preY)
+        self._keep = []
+        d = nat.KeffDesc()
+        self.desc = d
+        cells = self.nslab * self.ny * self.nx
+        self.q_buf = ctx.alloc(cells * self.q_dtype.itemsize) if alloc_q else None
+        d.q = self.q_buf.ptr if alloc_q else None
+        d.q_dtype, d.ctr_dtype = nat.dtype_code(self.q_dtype), nat.dtype_code(self.ctr_dtype)
+        d.nslab, d.ny, d.nx, d.N = self.nslab, self.ny, self.nx, self.N
+        d.increase, d.lt = int(bool(increase)), int(bool(lt))
+        d.right_edge = nat.XC_EDGE_XHISTOGRAM if right_edge == 'xhistogram' else nat.XC_EDGE_NUMPY
+        if dA is None:
+            d.dA, d.dA_rank = None, nat.XC_DA_NONE
+        else:
+            dA = np.ascontiguousarray(dA, dtype=np.float64)
+            if dA.shape == (self.ny,):
+                d.dA_rank = nat.XC_DA_ROW
+            elif dA.shape == (self.ny, self.nx):
+                d.dA_rank = nat.XC_DA_PLANE
+            else:
+                raise Exception('dA must be (ny,) or (ny,nx)')
+            self.dA_buf = ctx.to_device(dA)
+            d.dA = self.dA_buf.ptr
+        if grdS_dtype is None:
+            if rdx is None:
+                rdx, rdy = grad_metrics(lat, lon, Rearth)
+            self.rdx_buf = ctx.to_device(np.asarray(rdx, dtype=np.float64))
+            self.rdy_buf = ctx.to_device(np.asarray(rdy, dtype=np.float64))
+            d.grad, d.rdx, d.rdy = 1, self.rdx_buf.ptr, self.rdy_buf.ptr
+            self.grdS_buf = None
+        else:
+            self.grdS_dtype = np.dtype(grdS_dtype)
+            self.grdS_buf = ctx.alloc(cells * self.grdS_dtype.itemsize)
+            d.grad, d.grdS, d.grdS_dtype = 0, self.grdS_buf.ptr, nat.dtype_code(self.grdS_dtype)
+        d.prod_f32 = int(bool(prod_f32))
+        d.periodic_x = int(bool(periodic_x))
+        self.tbl_buf = ctx.to_device(np.asarray(tbl, dtype=np.float64))
+        self.coord_buf = ctx.to_device(np.asarray(tbl_coord, dtype=np.float64))
+        d.tbl, d.tbl_coord = self.tbl_buf.ptr, self.coord_buf.ptr
+        d.npre = self.npre
+        if self.npre:
+            self.pre_buf = ctx.to_device(np.asarray(preY, dtype=np.float64))
+            d.preY = self.pre_buf.ptr
+        d.nkeff_mask = float(nkeff_mask)
+        d.lmin_scale = float(2.0 * np.pi * Rearth)
+        # outputs: one allocation, [9][nslab][N] f64 | counts | interp | status
+        nN = self.nslab * self.N
+        self._off = {}
+        off = 0
+        for name in OUT_NAMES:
+            self._off[name] = off
+            off += nN * 8
+        self._off['counts'] = off
+        off += nN * 8
+        self._off['interp'] = off
+        off += self.nslab * 9 * self.npre * 8
+        self._off['status'] = off
+        off += self.nslab * 4
+        self.out_buf = ctx.alloc(off)
+        for name in OUT_NAMES:
+            setattr(d, name, self.out_buf.ptr + self._off[name])
+        d.counts = self.out_buf.ptr + self._off['counts']
+        d.interp = (self.out_buf.ptr + self._off['interp']) if self.npre else None
+        d.status = self.out_buf.ptr + self._off['status']
+
+    # -- inputs
+    def set_q(self, q):
+        q = np.ascontiguousarray(q, dtype=self.q_dtype).reshape(self.nslab, self.ny, self.nx)
+        self.q_buf.upload(q)
+
+    def set_q_device(self, ptr):
+        """Use an existing device pointer ([nslab][ny][nx], q_dtype) as the tracer."""
+        self.desc.q = ptr
+
+    def set_grdS(self, g):
+        g = np.ascontiguousarray(g, dtype=self.grdS_dtype).reshape(self.nslab, self.ny, self.nx)
+        self.grdS_buf.upload(g)
+
+    def synth(self, lat, lon, seed, variant=0):
+        """Fill the tracer batch on device with the bench's synthetic PV-like slabs."""
+        lat_b = self.ctx.to_device(np.asarray(lat, dtype=np.float64))
+        lon_b = self.ctx.to_device(np.asarray(lon, dtype=np.float64))
+        self.ctx._check(self.ctx.lib.xc_synth_dev(self.ctx.handle, self.desc.q, self.desc.q_dtype,
+                                                  self.nslab, self.ny, self.nx, lat_b.ptr, lon_b.ptr,
+                                                  int(seed), int(variant)))
+        self.ctx.sync()
+        lat_b.free()
+        lon_b.free()
+
+    # -- compute
+    def run(self):
+        """Enqueue min/max -> histogram -> finalize+epilogue on the context's stream."""
+        self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
+
+    def fetch(self, check=True):
+        self.ctx.sync()
+        S, N = self.nslab, self.N
+        out = {}
+        for name in OUT_NAMES:
+            out[name] = self.out_buf.download((S, N), np.float64, self._off[name])
+        out['counts'] = self.out_buf.download((S, N), np.uint64, self._off['counts'])
+        if self.npre:
+            it = self.out_buf.download((S, 9, self.npre), np.float64, self._off['interp'])
+            for i, name in enumerate(INTERP_ORDER):
+                out[name + '_eq'] = it[:, i, :]
+        out['status'] = self.out_buf.download((S,), np.int32, self._off['status'])
+        if check and out['status'].any():
+            raise Exception('non monotonic bins')          # reference core.py:1233-1251
+        return out
+
+    def download_q(self):
+        return self.q_buf.download((self.nslab, self.ny, self.nx), self.q_dtype)
+
+    def free(self):
+        for name in ('q_buf', 'dA_buf', 'rdx_buf', 'rdy_buf', 'grdS_buf', 'tbl_buf', 'coord_buf', 'pre_buf', 'out_buf'):
+            b = getattr(self, name, None)
+            if b is not None:
+                b.free()
