@@ -43,6 +43,18 @@ static int grow(xc_ctx* ctx, void** p, size_t* have, size_t need)
 int ensure_scratch(xc_ctx* ctx, size_t bytes) { return grow(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes); }
 int ensure_arena(xc_ctx* ctx, size_t bytes)   { return grow(ctx, &ctx->arena, &ctx->arena_bytes, bytes); }
 
+int ensure_ones(xc_ctx* ctx, size_t n)
+{
+    if (n <= ctx->ones_n) return XC_OK;
+    if (ctx->ones) { XC_HIP(ctx, hipStreamSynchronize(ctx->stream)); XC_HIP(ctx, hipFree(ctx->ones)); ctx->ones = nullptr; ctx->ones_n = 0; }
+    size_t want = 4096; while (want < n) want *= 2;
+    XC_HIP(ctx, hipMalloc((void**)&ctx->ones, want * sizeof(double)));
+    std::vector<double> h(want, 1.0);
+    XC_HIP(ctx, hipMemcpy(ctx->ones, h.data(), want * sizeof(double), hipMemcpyHostToDevice));
+    ctx->ones_n = want;
+    return XC_OK;
+}
+
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t esize(int dtype) { return dtype == XC_F32 ? 4 : 8; }
 
@@ -120,6 +132,7 @@ int xc_destroy(xc_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->ones) (void)hipFree(ctx->ones);
     if (ctx->ev_hist0) (void)hipEventDestroy(ctx->ev_hist0);
     if (ctx->ev_hist1) (void)hipEventDestroy(ctx->ev_hist1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -319,13 +332,16 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, nbin, nch, d->q, &g));
     const size_t ph = al((size_t)d->nslab * g.bps * nch * nbin * sizeof(double));
     const size_t pc = al((size_t)d->nslab * g.bps * nbin * sizeof(unsigned));
-    XC_TRY(ensure_scratch(ctx, ph + pc));
+    const size_t rh = al((size_t)d->nslab * nch * nbin * sizeof(double));
+    const size_t rc = al((size_t)d->nslab * nbin * sizeof(unsigned long long));
+    XC_TRY(ensure_scratch(ctx, ph + pc + rh + rc));
     HistArgs a; memset(&a, 0, sizeof(a));
-    a.q = d->q; a.dA = d->dA;
+    a.q = d->q; a.dA = d->dA; a.dA_rank = d->dA_rank;
+    if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); a.dA = ctx->ones; a.dA_rank = XC_DA_ROW; }
     for (int i = 0; i < d->nint; ++i) { a.integ[i] = d->integrand[i]; a.integ_f32[i] = d->integrand_dtype[i] == XC_F32; }
     a.edges = d->edges; a.levels_mode = 0; a.nbin = nbin; a.edges_per_slab = d->edges_per_slab;
     a.last_closed = d->last_closed; a.q_f32 = d->q_dtype == XC_F32;
-    a.dA_rank = d->dA_rank; a.prod_f32 = d->prod_f32;
+    a.prod_f32 = d->prod_f32;
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
     a.part_h = (double*)ctx->scratch; a.part_c = (unsigned*)((char*)ctx->scratch + ph);
@@ -334,6 +350,7 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     if (ctx->timing) { XC_HIP(ctx, hipEventRecord(ctx->ev_hist1, ctx->stream)); ctx->ev_valid = 1; }
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = a.part_h; f.part_c = a.part_c; f.bps = g.bps; f.nch = nch; f.nbin = nbin;
+    f.red_h = (double*)((char*)ctx->scratch + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + ph + pc + rh);
     f.lt = d->lt; f.reverse = d->reverse; f.pdf = d->pdf; f.counts = d->counts; f.cdf = d->cdf;
     return launch_finalize(ctx, d->nslab, f);
 }
@@ -496,22 +513,24 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     const size_t mb = al((size_t)d->nslab * kMinmaxBlocks * 2 * sizeof(double));
     const size_t ph = al((size_t)d->nslab * g.bps * nch * N * sizeof(double));
     const size_t pc = al((size_t)d->nslab * g.bps * N * sizeof(unsigned));
-    XC_TRY(ensure_scratch(ctx, mb + ph + pc));
+    const size_t rh = al((size_t)d->nslab * nch * N * sizeof(double));
+    const size_t rc = al((size_t)d->nslab * N * sizeof(unsigned long long));
+    XC_TRY(ensure_scratch(ctx, mb + ph + pc + rh + rc));
     double* mmpart = (double*)ctx->scratch;
     double* part_h = (double*)((char*)ctx->scratch + mb);
     unsigned* part_c = (unsigned*)((char*)ctx->scratch + mb + ph);
 
-    if (d->status) XC_HIP(ctx, hipMemsetAsync(d->status, 0, (size_t)d->nslab * sizeof(int32_t), ctx->stream));
     XC_TRY(launch_minmax_partial(ctx, d->q, d->q_dtype, d->nslab, d->ny * d->nx, mmpart));
 
     HistArgs a; memset(&a, 0, sizeof(a));
-    a.q = d->q; a.dA = d->dA;
+    a.q = d->q; a.dA = d->dA; a.dA_rank = d->dA_rank;
+    if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); a.dA = ctx->ones; a.dA_rank = XC_DA_ROW; }
     if (!d->grad) { a.integ[0] = d->grdS; a.integ_f32[0] = d->grdS_dtype == XC_F32; }
     a.mmpart = mmpart; a.P = kMinmaxBlocks; a.levels_mode = 1; a.nbin = N;
     a.last_closed = d->right_edge == XC_EDGE_NUMPY;
     a.increase = d->increase; a.q_f32 = d->q_dtype == XC_F32; a.ctr_f32 = d->ctr_dtype == XC_F32;
     a.right_edge = d->right_edge; a.inv_nm1 = 1.0 / (double)(N - 1);
-    a.dA_rank = d->dA_rank; a.prod_f32 = d->prod_f32;
+    a.prod_f32 = d->prod_f32;
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
     a.part_h = part_h; a.part_c = part_c; a.ctr_out = d->ctr; a.status = d->status;
@@ -521,6 +540,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
 
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = part_h; f.part_c = part_c; f.bps = g.bps; f.nch = nch; f.nbin = N;
+    f.red_h = (double*)((char*)ctx->scratch + mb + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + mb + ph + pc + rh);
     f.lt = d->lt; f.reverse = !d->increase;       // decreasing levels -> flip to level order (core.py:454-455)
     f.counts = d->counts;
     f.keff = 1; f.ctr_f32 = a.ctr_f32; f.ctr = d->ctr;

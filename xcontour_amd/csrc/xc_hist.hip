@@ -29,6 +29,15 @@ namespace {
 
 constexpr int U = 2;   // rows per prefetch batch (double-buffered)
 
+// Diagnostic build only (-DXC_STAMPS): wave 0 / lane 0 of every block stores s_memrealtime
+// (100 MHz) at phase boundaries into a buffer nothing else reads.  Never in the shipped .so.
+#ifdef XC_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define XC_STAMP(i) do { if (g_stamps && tid == 0) g_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define XC_STAMP(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
 __device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
 
@@ -112,13 +121,14 @@ __device__ __forceinline__ void lds_add(unsigned* p, unsigned v)
 
 template <int VEC, int NINT>
 struct RowBuf {
-    double q[VEC];          // GRAD: row (center+1); else: the center row itself
-    double h;               // lane 0: left halo of that row, lane 63: right halo
+    double q[VEC];          // GRAD: row (centre+1); else: the centre row itself
+    double h;               // GRAD: lane 0 = left halo of that row, lane 63 = right halo
     double dA[VEC];
     double in[NINT > 0 ? NINT : 1][VEC];
 };
 
-template <typename TQ, int VEC, int NINT, bool GRAD>
+// DA2D: dA is a [ny][nx] plane (vector loads); otherwise one value per row (scalar).
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D>
 __global__ __launch_bounds__(kHistThreads)
 void k_hist(const HistArgs a)
 {
@@ -126,7 +136,9 @@ void k_hist(const HistArgs a)
     constexpr int W = 64 * VEC;
     extern __shared__ __align__(16) double smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction
+    const int nwave = blockDim.x >> 6;
     const int slab = blockIdx.y;
     const int N = a.nbin;
     const int ncopy = a.ncopy;
@@ -137,8 +149,99 @@ void k_hist(const HistArgs a)
     unsigned* s_c     = reinterpret_cast<unsigned*>(s_h + (size_t)NCH * N * ncopy);   // [N*ncopy]
     const int hsz = N * ncopy;
 
+    // ------------------------------------------------------------------ this wave's share of (strip,row) pairs
+    const int64_t ny = a.ny, nx = a.nx;
+    const int64_t total = (int64_t)a.nstrip * ny;
+    const int64_t nw = (int64_t)gridDim.x * nwave;
+    const int64_t wg = (int64_t)blockIdx.x * nwave + wave;
+    int64_t g0 = total * wg / nw;
+    const int64_t g1 = total * (wg + 1) / nw;
+
+    const size_t slab_off = (size_t)slab * ny * nx;
+    const TQ* __restrict__ qs = reinterpret_cast<const TQ*>(a.q) + slab_off;
+    const double* __restrict__ dAp = (DA2D && a.dA_rank == XC_DA_SLAB) ? a.dA + slab_off : a.dA;
+    const double* __restrict__ rdxp = a.rdx;
+    const double* __restrict__ rdyp = a.rdy;
+    const int copy = lane & (ncopy - 1);
+    const int periodic_x = a.periodic_x;
+
+    // segment state (wave-uniform scalars + per-lane column offsets)
+    int64_t y0 = 0, y1 = 0, xld = 0, xh = 0;
+    bool active = false;
+    int rlane = 63;
+    double fx[VEC];
+
+    auto begin_segment = [&]() {
+        const int     s  = (int)(g0 / ny);
+        y0 = g0 - (int64_t)s * ny;
+        y1 = (y0 + (g1 - g0) < ny) ? y0 + (g1 - g0) : ny;
+        g0 += (y1 - y0);
+        const int64_t x0 = (int64_t)s * W;
+        const int64_t x  = x0 + (int64_t)lane * VEC;
+        active = x < nx;
+        xld = active ? x : nx - VEC;                                   // clamped: loads are unconditional
+        const int64_t xend = (x0 + W < nx) ? x0 + W : nx;
+        rlane = (int)((xend - x0) / VEC) - 1;                          // lane holding the strip's last valid cell
+        const int64_t xl = (x0 == 0) ? (periodic_x ? nx - 1 : 0) : x0 - 1;
+        const int64_t xr = (xend == nx) ? (periodic_x ? 0 : nx - 1) : xend;
+        xh = (lane == 0) ? xl : ((lane == 63) ? xr : xld);             // halo column (lanes 0 / 63 matter)
+        // one-sided x differences at the walls of a non-periodic domain use spacing dx, not 2dx
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+            fx[c] = (!periodic_x && (x + c == 0 || x + c == nx - 1)) ? 2.0 : 1.0;
+    };
+
+    // branch-free loads of one row: q row `yq` (+ halo), weights of row `yw`
+    auto load_row = [&](RowBuf<VEC, NINT>& r, int64_t yq, int64_t yw) {
+        yq = yq < ny - 1 ? yq : ny - 1;
+        yw = yw < ny - 1 ? yw : ny - 1;
+        const TQ* qrow = qs + yq * nx;
+        RowLoad<TQ, VEC>::ld(qrow + xld, r.q);
+        if (GRAD) r.h = (double)qrow[xh];
+        if (DA2D) {
+            RowLoad<double, VEC>::ld(dAp + yw * nx + xld, r.dA);
+        } else {
+            const double v = dAp[yw];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) r.dA[c] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NINT; ++i) {
+            if (a.integ_f32[i])
+                RowLoad<float, VEC>::ld(reinterpret_cast<const float*>(a.integ[i]) + slab_off + yw * nx + xld, r.in[i]);
+            else
+                RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(a.integ[i]) + slab_off + yw * nx + xld, r.in[i]);
+        }
+    };
+    auto load_batch = [&](RowBuf<VEC, NINT> (&L)[U], int64_t yb) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) load_row(L[i], GRAD ? yb + i + 1 : yb + i, yb + i);
+    };
+
+    XC_STAMP(0);
+    // issue the first loads of this wave BEFORE the edge prologue so that their HBM latency
+    // overlaps the min/max reduction and the barriers below
+    RowBuf<VEC, NINT> A[U], B[U];
+    double qm[VEC], qcur[VEC], hcur = 0.0;
+    bool have = g0 < g1;
+    if (have) {
+        begin_segment();
+        if (GRAD) {
+            RowBuf<VEC, NINT> t;
+            load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) qm[c] = t.q[c];
+            load_row(t, y0, y0);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) qcur[c] = t.q[c];
+            hcur = t.h;
+        }
+        load_batch(A, y0);
+    }
+
     for (int i = tid; i < NCH * hsz; i += blockDim.x) s_h[i] = 0.0;
     for (int i = tid; i < hsz; i += blockDim.x) s_c[i] = 0u;
+    XC_STAMP(1);
 
     // ------------------------------------------------------------------ edges -> LDS
     if (a.levels_mode) {
@@ -165,8 +268,10 @@ void k_hist(const HistArgs a)
         }
         if (blockIdx.x == 0 && a.status) {
             // reference raises 'non monotonic bins' when two adjacent levels coincide (core.py:1233)
-            for (int k = tid + 1; k < N; k += blockDim.x)
-                if (s_edges[k] == s_edges[k + 1]) atomicOr(&a.status[slab], 1);
+            int bad = 0;
+            for (int k = tid + 1; k < N; k += blockDim.x) bad |= (s_edges[k] == s_edges[k + 1]);
+            bad = __syncthreads_or(bad);
+            if (tid == 0) a.status[slab] = bad ? 1 : 0;
         }
         __syncthreads();
         if (blockIdx.x == 0 && a.edges_out)
@@ -179,20 +284,7 @@ void k_hist(const HistArgs a)
     const double e0 = s_edges[0], eN = s_edges[N];
     const double inv = (double)N / (eN - e0);
     const int last_closed = a.last_closed;
-
-    // ------------------------------------------------------------------ this wave's share of (strip,row) pairs
-    const int64_t ny = a.ny, nx = a.nx;
-    const int64_t total = (int64_t)a.nstrip * ny;
-    const int64_t nw = (int64_t)gridDim.x * nwave;
-    const int64_t wg = (int64_t)blockIdx.x * nwave + wave;
-    int64_t g0 = total * wg / nw;
-    const int64_t g1 = total * (wg + 1) / nw;
-
-    const size_t slab_off = (size_t)slab * ny * nx;
-    const TQ* __restrict__ qs = reinterpret_cast<const TQ*>(a.q) + slab_off;
-    const double* __restrict__ dAp = a.dA ? (a.dA_rank == XC_DA_SLAB ? a.dA + slab_off : a.dA) : nullptr;
-    const int dA_rank = a.dA_rank;
-    const int copy = lane & (ncopy - 1);
+    XC_STAMP(2);
 
     double   acc[NCH];
     unsigned cnt = 0;
@@ -211,162 +303,87 @@ void k_hist(const HistArgs a)
         cnt = 0;
     };
 
-    while (g0 < g1) {
-        const int     s  = (int)(g0 / ny);
-        const int64_t y0 = g0 - (int64_t)s * ny;
-        const int64_t y1 = (y0 + (g1 - g0) < ny) ? y0 + (g1 - g0) : ny;
-        g0 += (y1 - y0);
-
-        const int64_t x0 = (int64_t)s * W;
-        const int64_t x  = x0 + (int64_t)lane * VEC;
-        const bool active = x < nx;
-        const int64_t xend = (x0 + W < nx) ? x0 + W : nx;
-        const int rlane = (int)((xend - x0) / VEC) - 1;               // lane holding the strip's last valid cell
-        const int64_t xl = (x0 == 0) ? (a.periodic_x ? nx - 1 : 0) : x0 - 1;
-        const int64_t xr = (xend == nx) ? (a.periodic_x ? 0 : nx - 1) : xend;
-        const int64_t xh = (lane == 0) ? xl : xr;
-        const bool halo_lane = (lane == 0) || (lane == 63);
-        // one-sided x differences at the walls of a non-periodic domain use spacing dx, not 2dx
-        double fx[VEC];
+    // one centre row: bins, weights, accumulate
+    auto do_row = [&](const double (&qc)[VEC], const double (&qS)[VEC], const double (&qN)[VEC],
+                      double hc, const double (&dAv)[VEC], const double (&inv_)[NINT > 0 ? NINT : 1][VEC],
+                      int64_t y) {
+        int k[VEC];
+        double w[NCH][VEC];
 #pragma unroll
-        for (int c = 0; c < VEC; ++c)
-            fx[c] = (!a.periodic_x && (x + c == 0 || x + c == nx - 1)) ? 2.0 : 1.0;
-
-        // loads of one row into a RowBuf: q row `yq`, weights of row `yw`
-        auto load_row = [&](RowBuf<VEC, NINT>& r, int64_t yq, int64_t yw) {
-            yq = yq < ny - 1 ? yq : ny - 1;
-            yw = yw < ny - 1 ? yw : ny - 1;
-            const TQ* qrow = qs + yq * nx;
-            if (active) RowLoad<TQ, VEC>::ld(qrow + x, r.q);
-            else {
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) r.q[c] = dnan();
-            }
-            if (GRAD) r.h = halo_lane ? (double)qrow[xh] : 0.0;
-            if (dA_rank == XC_DA_NONE) {
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) r.dA[c] = 1.0;
-            } else if (dA_rank == XC_DA_ROW) {
-                const double v = dAp[yw];
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) r.dA[c] = v;
-            } else if (active) {
-                RowLoad<double, VEC>::ld(dAp + yw * nx + x, r.dA);
-            } else {
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) r.dA[c] = 0.0;
-            }
+        for (int c = 0; c < VEC; ++c) {
+            const int kb = find_bin(qc[c], s_edges, N, e0, eN, inv, last_closed);
+            k[c] = active ? kb : -1;
+            const double dv = dAv[c];
+            w[0][c] = (dv != dv) ? 0.0 : dv;                                  // fillna(0), core.py:449
 #pragma unroll
             for (int i = 0; i < NINT; ++i) {
-                if (!active) {
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c) r.in[i][c] = 0.0;
-                } else if (a.integ_f32[i]) {
-                    RowLoad<float, VEC>::ld(reinterpret_cast<const float*>(a.integ[i]) + slab_off + yw * nx + x, r.in[i]);
-                } else {
-                    RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(a.integ[i]) + slab_off + yw * nx + x, r.in[i]);
-                }
+                double p = a.prod_f32 ? (double)__fmul_rn((float)inv_[i][c], (float)dv)
+                                      : __dmul_rn(inv_[i][c], dv);            // integrand * dA, core.py:444
+                w[1 + i][c] = (p != p) ? 0.0 : p;
             }
-        };
-
-        // one centre row: bins, weights, accumulate
-        auto do_row = [&](const double (&qc)[VEC], const double (&qS)[VEC], const double (&qN)[VEC],
-                          double hc, const double (&dAv)[VEC], const double (&inv_)[NINT > 0 ? NINT : 1][VEC],
-                          int64_t y) {
-            int k[VEC];
-            double w[NCH][VEC];
+        }
+        if (GRAD) {
+            const double rdx = rdxp[y], rdy = rdyp[y];
+            const double hl = __shfl(hc, 0), hr = __shfl(hc, 63);
+            const double fromL = __shfl_up(qc[VEC - 1], 1);                  // lane-1's last cell
+            const double fromR = __shfl_down(qc[0], 1);                      // lane+1's first cell
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
-                k[c] = active ? find_bin(qc[c], s_edges, N, e0, eN, inv, last_closed) : -1;
-                const double dv = dAv[c];
-                w[0][c] = (dv != dv) ? 0.0 : dv;                                  // fillna(0), core.py:449
-#pragma unroll
-                for (int i = 0; i < NINT; ++i) {
-                    double p = a.prod_f32 ? (double)__fmul_rn((float)inv_[i][c], (float)dv)
-                                          : __dmul_rn(inv_[i][c], dv);            // integrand * dA, core.py:444
-                    w[1 + i][c] = (p != p) ? 0.0 : p;
-                }
+                const double qW = (c == 0) ? (lane == 0 ? hl : fromL) : qc[c > 0 ? c - 1 : 0];
+                const double qE = (c == VEC - 1) ? (lane == rlane ? hr : fromR) : qc[c < VEC - 1 ? c + 1 : 0];
+                const double gx = __dmul_rn(__dmul_rn(__dsub_rn(qE, qW), rdx), fx[c]);
+                const double gy = __dmul_rn(__dsub_rn(qN[c], qS[c]), rdy);
+                const double g2 = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
+                const double p = __dmul_rn(g2, dAv[c]);
+                w[NCH - 1][c] = (p != p) ? 0.0 : p;
             }
-            if (GRAD) {
-                const double rdx = a.rdx[y], rdy = a.rdy[y];
-                const double hl = __shfl(hc, 0), hr = __shfl(hc, 63);
-                const double fromL = __shfl_up(qc[VEC - 1], 1);                  // lane-1's last cell
-                const double fromR = __shfl_down(qc[0], 1);                      // lane+1's first cell
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    const double qW = (c == 0) ? (lane == 0 ? hl : fromL) : qc[c > 0 ? c - 1 : 0];
-                    const double qE = (c == VEC - 1) ? (lane == rlane ? hr : fromR) : qc[c < VEC - 1 ? c + 1 : 0];
-                    const double gx = __dmul_rn(__dmul_rn(__dsub_rn(qE, qW), rdx), fx[c]);
-                    const double gy = __dmul_rn(__dsub_rn(qN[c], qS[c]), rdy);
-                    const double g2 = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
-                    const double p = __dmul_rn(g2, dAv[c]);
-                    w[NCH - 1][c] = (p != p) ? 0.0 : p;
-                }
-            }
-            // wave-uniform fast path: every valid cell of the row in one bin
-            const int rb = __builtin_amdgcn_readfirstlane(k[0]);
-            bool match = true;
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) match = match && (k[c] == rb);
-            if (rb >= 0 && __all(match || !active)) {
-                if (rb != cur) { flush(); cur = rb; }
-                if (active) {
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c) {
-#pragma unroll
-                        for (int ch = 0; ch < NCH; ++ch) acc[ch] += w[ch][c];
-                    }
-                    cnt += VEC;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) {
-                    if (k[c] >= 0) {
-                        const int o = k[c] * ncopy + copy;
-#pragma unroll
-                        for (int ch = 0; ch < NCH; ++ch) lds_add(&s_h[ch * hsz + o], w[ch][c]);
-                        lds_add(&s_c[o], 1u);
-                    }
-                }
-            }
-        };
-
-        // rolling window (GRAD): qm = row y-1, qc = row y, hc = halo of row y
-        double qm[VEC], qcur[VEC], hcur = 0.0;
-        if (GRAD) {
-            RowBuf<VEC, NINT> t;
-            load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) qm[c] = t.q[c];
-            load_row(t, y0, y0);
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) qcur[c] = t.q[c];
-            hcur = t.h;
         }
-
-        // batch of U centre rows starting at yb; L holds (GRAD) q rows yb+1.. and weights rows yb..
-        auto load_batch = [&](RowBuf<VEC, NINT> (&L)[U], int64_t yb) {
+        // wave-uniform fast path: every valid cell of the row in one bin
+        const int rb = __builtin_amdgcn_readfirstlane(k[0]);
+        bool match = true;
 #pragma unroll
-            for (int i = 0; i < U; ++i) load_row(L[i], GRAD ? yb + i + 1 : yb + i, yb + i);
-        };
-        auto process_batch = [&](RowBuf<VEC, NINT> (&L)[U], int64_t yb) {
+        for (int c = 0; c < VEC; ++c) match = match && (k[c] == rb);
+        if (rb >= 0 && __all(match || !active)) {
+            if (rb != cur) { flush(); cur = rb; }
+            if (active) {
 #pragma unroll
-            for (int i = 0; i < U; ++i) {
-                if (yb + i < y1) {
-                    if (GRAD) {
-                        do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in, yb + i);
+                for (int c = 0; c < VEC; ++c) {
 #pragma unroll
-                        for (int c = 0; c < VEC; ++c) { qm[c] = qcur[c]; qcur[c] = L[i].q[c]; }
-                        hcur = L[i].h;
-                    } else {
-                        do_row(L[i].q, L[i].q, L[i].q, 0.0, L[i].dA, L[i].in, yb + i);
-                    }
+                    for (int ch = 0; ch < NCH; ++ch) acc[ch] += w[ch][c];
+                }
+                cnt += VEC;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                if (k[c] >= 0) {
+                    const int o = k[c] * ncopy + copy;
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) lds_add(&s_h[ch * hsz + o], w[ch][c]);
+                    lds_add(&s_c[o], 1u);
                 }
             }
-        };
+        }
+    };
 
-        RowBuf<VEC, NINT> A[U], B[U];
-        load_batch(A, y0);
+    // batch of U centre rows starting at yb; L holds (GRAD) q rows yb+1.. and weights rows yb..
+    auto process_batch = [&](RowBuf<VEC, NINT> (&L)[U], int64_t yb) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            if (yb + i < y1) {
+                if (GRAD) {
+                    do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in, yb + i);
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) { qm[c] = qcur[c]; qcur[c] = L[i].q[c]; }
+                    hcur = L[i].h;
+                } else {
+                    do_row(L[i].q, L[i].q, L[i].q, 0.0, L[i].dA, L[i].in, yb + i);
+                }
+            }
+        }
+    };
+
+    while (have) {
         for (int64_t yb = y0; yb < y1; yb += 2 * U) {
             if (yb + U < y1) load_batch(B, yb + U);
             process_batch(A, yb);
@@ -374,32 +391,61 @@ void k_hist(const HistArgs a)
             if (yb + 2 * U < y1) load_batch(A, yb + 2 * U);
             process_batch(B, yb + U);
         }
+        have = g0 < g1;
+        if (have) {                                   // next segment (the range crossed a strip boundary)
+            begin_segment();
+            if (GRAD) {
+                RowBuf<VEC, NINT> t;
+                load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) qm[c] = t.q[c];
+                load_row(t, y0, y0);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) qcur[c] = t.q[c];
+                hcur = t.h;
+            }
+            load_batch(A, y0);
+        }
     }
+    XC_STAMP(3);
     flush();
     __syncthreads();
+    XC_STAMP(4);
 
     // ------------------------------------------------------------------ per-block partials (plain stores)
     const size_t pb = (size_t)slab * gridDim.x + blockIdx.x;
     double* ph = a.part_h + pb * NCH * N;
+    // sum the lane-privatised copies; every thread starts at a rotated copy index so that the
+    // 64 lanes of a wave hit distinct LDS banks (a fixed, thread-determined order)
     for (int i = tid; i < NCH * N; i += blockDim.x) {
         const int ch = i / N, b = i - ch * N;
         const double* src = &s_h[ch * hsz + b * ncopy];
         double sum = 0.0;
-        for (int c = 0; c < ncopy; ++c) sum += src[c];
+        for (int c = 0; c < ncopy; ++c) sum += src[(c + tid) & (ncopy - 1)];
         ph[i] = sum;
     }
     unsigned* pc = a.part_c + pb * N;
     for (int b = tid; b < N; b += blockDim.x) {
         unsigned sum = 0u;
-        for (int c = 0; c < ncopy; ++c) sum += s_c[b * ncopy + c];
+        for (int c = 0; c < ncopy; ++c) sum += s_c[b * ncopy + ((c + tid) & (ncopy - 1))];
         pc[b] = sum;
     }
+    XC_STAMP(5);
 }
 
-template <typename TQ, int VEC, int NINT, bool GRAD>
-int launch_one(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
+#ifdef XC_STAMPS
+}  // namespace
+extern "C" int xc_dbg_set_stamps(unsigned long long* p)
 {
-    auto kern = k_hist<TQ, VEC, NINT, GRAD>;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p));
+}
+namespace {
+#endif
+
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D>
+int launch_two(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
+{
+    auto kern = k_hist<TQ, VEC, NINT, GRAD, DA2D>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         XC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -410,6 +456,14 @@ int launch_one(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
     hipLaunchKernelGGL(kern, grid, dim3(kHistThreads), g.lds, ctx->stream, a);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
+}
+
+template <typename TQ, int VEC, int NINT, bool GRAD>
+int launch_one(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
+{
+    const bool da2d = a.dA_rank == XC_DA_PLANE || a.dA_rank == XC_DA_SLAB;
+    return da2d ? launch_two<TQ, VEC, NINT, GRAD, true>(ctx, g, nslab, a)
+                : launch_two<TQ, VEC, NINT, GRAD, false>(ctx, g, nslab, a);
 }
 
 template <typename TQ, int VEC>

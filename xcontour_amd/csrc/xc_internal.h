@@ -17,6 +17,7 @@ struct xc_ctx {
     // grow-only device scratch owned by the context
     void*  scratch = nullptr;   size_t scratch_bytes = 0;   // kernel workspaces (partials, minmax, edges)
     void*  arena = nullptr;     size_t arena_bytes = 0;     // staging for the host-pointer entry points
+    double* ones = nullptr;     size_t ones_n = 0;          // per-row weight 1.0 (dA_rank == XC_DA_NONE)
     // timing of the dominant kernel
     int timing = 0;
     hipEvent_t ev_hist0 = nullptr, ev_hist1 = nullptr;
@@ -37,6 +38,7 @@ int hipfail(xc_ctx* ctx, hipError_t e, const char* what);
 // grow-only scratch (never shrinks; pointer may change between calls, never within one)
 int ensure_scratch(xc_ctx* ctx, size_t bytes);
 int ensure_arena(xc_ctx* ctx, size_t bytes);
+int ensure_ones(xc_ctx* ctx, size_t n);
 
 // ---------------------------------------------------------------- launch geometry
 constexpr int kMinmaxBlocks = 1024;   // partial min/max pairs per slab
@@ -85,6 +87,8 @@ struct HistArgs {
 struct FinalArgs {
     const double*   part_h;
     const unsigned* part_c;
+    double*         red_h;    // [nslab][nch][nbin]  stage-1 output (scratch)
+    unsigned long long* red_c;// [nslab][nbin]
     int             bps, nch, nbin;
     int             lt, reverse;
     double*         pdf;      // [nslab][nch][nbin] or null
@@ -94,7 +98,7 @@ struct FinalArgs {
     int             keff;
     int             ctr_f32;
     const double*   ctr;      // [nslab][nbin] level order
-    const double*   tbl;      const double* tbl_coord;   int ntbl;
+    const double*   tbl;      const double* tbl_coord;   int ntbl;   int tbl_in_lds;
     const double*   preY;     int npre;
     double          nkeff_mask, lmin_scale;
     double *o_area, *o_intS, *o_latEq, *o_dqdA, *o_dSdA, *o_Leq2, *o_Lmin, *o_nkeff, *o_interp;

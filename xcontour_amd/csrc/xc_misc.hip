@@ -132,20 +132,29 @@ void k_levels(const double* __restrict__ minmax, int N, int increase, int q_f32,
 // CDF (sequential np.cumsum order), optional lt flip / reversal, optional Keff epilogue.
 // One 256-thread block per slab; everything lives in LDS.
 // =====================================================================================
-// np.interp(x, xp, fp) for ascending xp (numpy's compiled arr_interp, no precomputed slopes)
-__device__ double interp_asc(double x, const double* __restrict__ xp, const double* __restrict__ fp,
-                             int n, int rev)
+// np.interp(x, xp, fp) for ascending xp (numpy's compiled arr_interp, no precomputed slopes),
+// split into the bracket search and the evaluation so that several fp can share one search.
+// rev: the logical arrays are xp[n-1-i], fp[n-1-i] (the reference's decreasing case,
+// core.py:1428-1430).  Returns j = largest index with X(j) <= x, or -1 (left), -2 (right), -3 (NaN).
+__device__ __forceinline__ int interp_locate(double x, const double* __restrict__ xp, int n, int rev)
 {
-    // rev: logical arrays are xp[n-1-i], fp[n-1-i]
     auto X = [&](int i) { return rev ? xp[n - 1 - i] : xp[i]; };
-    auto F = [&](int i) { return rev ? fp[n - 1 - i] : fp[i]; };
-    if (x != x) return x;
-    if (x > X(n - 1)) return F(n - 1);
-    if (x < X(0)) return F(0);
-    // j = largest index with X(j) <= x
+    if (x != x) return -3;
+    if (x > X(n - 1)) return -2;
+    if (x < X(0)) return -1;
     int lo = 0, hi = n;            // X(lo) <= x, x < X(hi) (virtual)
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (x >= X(mid)) lo = mid; else hi = mid; }
-    const int j = lo;
+    return lo;
+}
+
+__device__ __forceinline__ double interp_eval(double x, int j, const double* __restrict__ xp,
+                                              const double* __restrict__ fp, int n, int rev)
+{
+    auto X = [&](int i) { return rev ? xp[n - 1 - i] : xp[i]; };
+    auto F = [&](int i) { return rev ? fp[n - 1 - i] : fp[i]; };
+    if (j == -3) return x;
+    if (j == -2) return F(n - 1);
+    if (j == -1) return F(0);
     if (j == n - 1) return F(j);
     const double xj = X(j), fj = F(j);
     if (xj == x) return fj;
@@ -175,42 +184,62 @@ __device__ __forceinline__ double grad_f32(const double* f, int k, int N)
     return (double)__fdiv_rn(__fsub_rn((float)f[k + 1], (float)f[k - 1]), 2.0f);
 }
 
+// Stage 1: sum the per-block partial histograms of K3 in a fixed order.  8 values per
+// 256-thread block, 32 lanes per value (each lane owns partials l, l+32, ...), then a
+// fixed xor-shuffle tree: deterministic, fully parallel (no serial latency chain).
 __global__ __launch_bounds__(256)
+void k_reduce_partials(const double* __restrict__ part_h, const unsigned* __restrict__ part_c,
+                       int bps, int nvh, int nbin, double* __restrict__ red_h,
+                       unsigned long long* __restrict__ red_c)
+{
+    const int slab = blockIdx.y, tid = threadIdx.x, l = tid & 31;
+    const int v = blockIdx.x * 8 + (tid >> 5);
+    if (v < nvh) {
+        const double* p = part_h + (size_t)slab * bps * nvh + v;
+        double sum = 0.0;
+        for (int b = l; b < bps; b += 32) sum += p[(size_t)b * nvh];
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (l == 0) red_h[(size_t)slab * nvh + v] = sum;
+    } else if (v < nvh + nbin) {
+        const int k = v - nvh;
+        const unsigned* p = part_c + (size_t)slab * bps * nbin + k;
+        unsigned long long sum = 0;
+        for (int b = l; b < bps; b += 32) sum += p[(size_t)b * nbin];
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (l == 0) red_c[(size_t)slab * nbin + k] = sum;
+    }
+}
+
+// Stage 2: one block per slab.
+__global__ __launch_bounds__(1024)
 void k_finalize(const FinalArgs a)
 {
     extern __shared__ __align__(16) double sm[];
-    const int slab = blockIdx.x, tid = threadIdx.x;
+    const int slab = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int N = a.nbin, NCH = a.nch;
     double* s_pdf = sm;                   // [NCH][N]
     double* s_cdf = sm + (size_t)NCH * N; // [NCH][N] in LEVEL order (after optional reversal)
     double* s_x   = s_cdf + (size_t)NCH * N;   // 7*N scratch for the epilogue
 
-    const double* ph = a.part_h + (size_t)slab * a.bps * NCH * N;
-    for (int i = tid; i < NCH * N; i += 256) {
-        double sum = 0.0;
-        for (int b = 0; b < a.bps; ++b) sum += ph[(size_t)b * NCH * N + i];
-        s_pdf[i] = sum;
-    }
+    const double* ph = a.red_h + (size_t)slab * NCH * N;
+    for (int i = tid; i < NCH * N; i += nthr) s_pdf[i] = ph[i];
     if (a.counts) {
-        const unsigned* pc = a.part_c + (size_t)slab * a.bps * N;
-        for (int i = tid; i < N; i += 256) {
-            uint64_t sum = 0;
-            for (int b = 0; b < a.bps; ++b) sum += pc[(size_t)b * N + i];
-            a.counts[(size_t)slab * N + (a.reverse ? N - 1 - i : i)] = sum;
-        }
+        const unsigned long long* pc = a.red_c + (size_t)slab * N;
+        for (int i = tid; i < N; i += nthr) a.counts[(size_t)slab * N + (a.reverse ? N - 1 - i : i)] = pc[i];
     }
     __syncthreads();
     if (tid < NCH) {                      // np.cumsum order (core.py:1320)
         const double* p = s_pdf + (size_t)tid * N;
         double* c = s_cdf + (size_t)tid * N;
         double run = 0.0;
+#pragma unroll 8
         for (int k = 0; k < N; ++k) { run = __dadd_rn(run, p[k]); c[k] = run; }
         if (!a.lt) { const double tot = c[N - 1]; for (int k = 0; k < N; ++k) c[k] = __dsub_rn(tot, c[k]); }   // core.py:1322-1323
         if (a.reverse)                    // core.py:454-455
             for (int k = 0; k < N / 2; ++k) { const double t = c[k]; c[k] = c[N - 1 - k]; c[N - 1 - k] = t; }
     }
     __syncthreads();
-    for (int i = tid; i < NCH * N; i += 256) {
+    for (int i = tid; i < NCH * N; i += nthr) {
         const int ch = i / N, k = i - ch * N;
         if (a.pdf) a.pdf[(size_t)slab * NCH * N + (size_t)ch * N + (a.reverse ? N - 1 - k : k)] = s_pdf[i];
         if (a.cdf) a.cdf[(size_t)slab * NCH * N + i] = s_cdf[i];
@@ -223,15 +252,25 @@ void k_finalize(const FinalArgs a)
     double* s_ctr = s_x;            double* s_lat = s_x + N;       double* s_lmin = s_x + 2 * N;
     double* s_dS  = s_x + 3 * N;    double* s_dq  = s_x + 4 * N;   double* s_leq = s_x + 5 * N;
     double* s_nk  = s_x + 6 * N;
-    const int tinc = a.tbl[a.ntbl - 1] > a.tbl[0];          // Table.__init__, core.py:1122-1128
-    for (int k = tid; k < N; k += 256) {
+    // stage the A(Yeq) table in LDS when it fits (coalesced reads instead of 11 dependent
+    // global round trips per contour)
+    const double* tblp = a.tbl; const double* crdp = a.tbl_coord;
+    if (a.tbl_in_lds) {
+        double* s_tbl = s_x + 7 * (size_t)N;
+        for (int i = tid; i < a.ntbl; i += nthr) { s_tbl[i] = a.tbl[i]; s_tbl[a.ntbl + i] = a.tbl_coord[i]; }
+        __syncthreads();
+        tblp = s_tbl; crdp = s_tbl + a.ntbl;
+    }
+    const int tinc = tblp[a.ntbl - 1] > tblp[0];            // Table.__init__, core.py:1122-1128
+    for (int k = tid; k < N; k += nthr) {
         s_ctr[k] = a.ctr[(size_t)slab * N + k];
-        const double le = interp_asc(area[k], a.tbl, a.tbl_coord, a.ntbl, !tinc);   // core.py:1136-1174
+        const int jt = interp_locate(area[k], tblp, a.ntbl, !tinc);
+        const double le = interp_eval(area[k], jt, tblp, crdp, a.ntbl, !tinc);       // core.py:1136-1174
         s_lat[k] = le;
         s_lmin[k] = __dmul_rn(a.lmin_scale, cos(__dmul_rn(le, 0.017453292519943295)));   // utils.py:532
     }
     __syncthreads();
-    for (int k = tid; k < N; k += 256) {
+    for (int k = tid; k < N; k += nthr) {
         const double dA = grad_f64(area, k, N);
         const double dS = __ddiv_rn(grad_f64(intS, k, N), dA);                    // core.py:480-483
         const double dq = __ddiv_rn(a.ctr_f32 ? grad_f32(s_ctr, k, N) : grad_f64(s_ctr, k, N), dA);
@@ -254,9 +293,12 @@ void k_finalize(const FinalArgs a)
         // interp_to_coords (core.py:1050-1100): direction from latEq[0] < latEq[-1]
         const int rev = !(s_lat[0] < s_lat[N - 1]);
         const double* vars[9] = {s_ctr, area, intS, s_lat, s_dS, s_dq, s_leq, s_lmin, s_nk};
-        for (int i = tid; i < 9 * a.npre; i += 256) {
-            const int v = i / a.npre, p = i - v * a.npre;
-            a.o_interp[((size_t)slab * 9 + v) * a.npre + p] = interp_asc(a.preY[p], s_lat, vars[v], N, rev);
+        for (int p = tid; p < a.npre; p += nthr) {
+            const double x = a.preY[p];
+            const int j = interp_locate(x, s_lat, N, rev);        // one search shared by the 9 variables
+#pragma unroll
+            for (int v = 0; v < 9; ++v)
+                a.o_interp[((size_t)slab * 9 + v) * a.npre + p] = interp_eval(x, j, s_lat, vars[v], N, rev);
         }
     }
 }
@@ -383,11 +425,23 @@ int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab,
     return XC_OK;
 }
 
-int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a)
+int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
 {
-    const size_t lds = ((size_t)2 * a.nch * a.nbin + (a.keff ? 7 * (size_t)a.nbin : 0)) * sizeof(double);
+    FinalArgs a = a_in;
+    size_t lds = ((size_t)2 * a.nch * a.nbin + (a.keff ? 7 * (size_t)a.nbin : 0)) * sizeof(double);
     if (lds > 60 * 1024) return fail(ctx, XC_EBADARG, "xc finalize: too many bins x channels");
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)nslab), dim3(256), lds, ctx->stream, a);
+    a.tbl_in_lds = 0;
+    if (a.keff && lds + (size_t)2 * a.ntbl * sizeof(double) <= 60 * 1024) {
+        a.tbl_in_lds = 1;
+        lds += (size_t)2 * a.ntbl * sizeof(double);
+    }
+    const int nvh = a.nch * a.nbin;
+    dim3 g1((unsigned)((nvh + a.nbin + 7) / 8), (unsigned)nslab);
+    hipLaunchKernelGGL(k_reduce_partials, g1, dim3(256), 0, ctx->stream, a.part_h, a.part_c, a.bps, nvh, a.nbin,
+                       a.red_h, a.red_c);
+    XC_HIP(ctx, hipGetLastError());
+    const int nthr = (a.keff && a.o_interp && a.npre > 256) ? 1024 : 256;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)nslab), dim3(nthr), lds, ctx->stream, a);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
 }
