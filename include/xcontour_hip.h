@@ -131,7 +131,7 @@ typedef struct xc_hist_desc {
     const double* rdx;          /* [ny] 1/(2 dx)  per row (grad only)            */
     const double* rdy;          /* [ny] 1/(y[jn]-y[js]) per row (grad only)      */
     int32_t       periodic_x;   int32_t lt;
-    int32_t       reverse;      int32_t _pad1;
+    int32_t       reverse;      int32_t negate;       /* negate: bin -q instead of q (right-closed bins on q) */
     double*       pdf;
     uint64_t*     counts;
     double*       cdf;
@@ -142,11 +142,12 @@ int xc_hist(xc_ctx* ctx, const xc_hist_desc* d);
 /* ------------------------------------------------------------------ K2  row sums for the A(Yeq) table
  * Replaces the degenerate histogram of cal_area_eqCoord_table_hist   core.py:176-193
  * rows[i] = sum_x dA[i,x] * [mask[i,x] == 1]; the prefix / end-point rules
- * are O(ny) host work.  mask may be NULL (all ones).                                 */
+ * are O(ny) host work.  mask may be NULL (all ones).
+ * multiply != 0: rows[i] = nansum_x mask[i,x] * dA[i,x]  (the xarray twin, core.py:109-133). */
 int xc_rowsum_dev(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
-                  int64_t ny, int64_t nx, double* out_rows);
+                  int64_t ny, int64_t nx, int multiply, double* out_rows);
 int xc_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
-              int64_t ny, int64_t nx, double* out_rows);
+              int64_t ny, int64_t nx, int multiply, double* out_rows);
 
 /* ------------------------------------------------------------------ K4  |grad q|^2 (stand-alone)
  * No reference call site (grdS is an input there); build-defined stencil.

@@ -1,0 +1,57 @@
+"""The C-ABI library builds, loads and exports every symbol include/xcontour_hip.h declares.
+No compute calls here (no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'xcontour_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(xc_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from xcontour_amd import _native as nat
+    assert os.path.exists(nat.LIB_PATH), 'build it: python -c "import __graft_entry__ as g; g.build()"'
+    lib = C.CDLL(nat.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), 'missing export %s' % s
+    # and the binding covers exactly the header
+    assert sorted(nat.PROTOTYPES) == syms
+
+
+def test_struct_layouts_match_header():
+    from xcontour_amd import _native as nat
+    # natural alignment, no packing: sizes follow from the field lists in the header
+    assert C.sizeof(nat.HistDesc) == 8 + 8 + 24 + 8 + 8 + 8 + 8 + 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 24
+    assert C.sizeof(nat.KeffDesc) % 8 == 0 and nat.KeffDesc.status.offset == C.sizeof(nat.KeffDesc) - 8
+    lib = nat.load()
+    assert lib.xc_version().startswith(b'xcontour_hip')
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU the product path must fail loudly, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from xcontour_amd import _native as nat
+    with pytest.raises(nat.XContourHipError) as e:
+        nat.Context(0)
+    assert e.value.code in (nat.XC_ENODEV, nat.XC_EHIP)
+    assert 'no CPU fallback' in str(e.value) or 'HIP' in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'xcontour_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(dp, f)).read()
+                assert 'xcontour_oracle' not in txt and 'import oracle' not in txt, f

@@ -1,0 +1,405 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle on the same inputs.
+Bar: bit-exact for bin counts / masks / levels; float64 sums within 1e-6 relative as
+BASELINE.json states (most checks use a far tighter bound, written next to each)."""
+import os
+
+import numpy as np
+import pytest
+
+import xcontour_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+RTOL = 1e-6          # north_star tolerance for float64 area / Keff / LWA values
+TIGHT = 1e-11        # what the kernels actually achieve on sums (summation order only)
+
+
+def rel(a, b, floor=1e-300):
+    """max |a-b| / max(|b|, floor); NaN / inf patterns must be identical.  `floor` is an
+    absolute scale for quantities that legitimately pass through zero (Lmin = 2 pi R cos(lat)
+    at the pole is ~1e-9 m on a 4e7 m scale: its relative error is meaningless there)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    m = np.isfinite(b)
+    assert np.array_equal(a[~m & ~np.isnan(b)], b[~m & ~np.isnan(b)])       # infs identical
+    if not m.any():
+        return 0.0
+    scale = np.maximum(np.abs(b[m]), floor)
+    return float(np.max(np.abs(a[m] - b[m]) / scale))
+
+
+LMIN_FLOOR = 2 * np.pi * 6371200.0 * 1e-6    # Lmin compared on the scale of 1e-6 of the equator length
+
+
+# ---------------------------------------------------------------- K1 / levels
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_minmax_and_levels_bit_exact(ctx, baro, dt):
+    q = baro[0].astype(dt)
+    rng = np.random.default_rng(3)
+    x = np.stack([q, q[::-1] * 2, rng.standard_normal(q.shape).astype(dt)])
+    x[2, 5, 7] = np.nan
+    mm = ctx.minmax(x)
+    for s in range(3):
+        assert mm[s, 0] == np.nanmin(x[s]) and mm[s, 1] == np.nanmax(x[s])
+    for N in (2, 20, 121, 201, 251):
+        for inc in (True, False):
+            for cd in (np.float32, np.float64):
+                for re_, rn in ((0, 'numpy'), (1, 'xhistogram')):
+                    ctr, edges, st = ctx.levels(mm, dt, N, inc, cd, re_)
+                    for s in range(3):
+                        ref = O.cal_contours(x[s], N, inc, cd)
+                        assert np.array_equal(ctr[s], ref.astype(np.float64))
+                        e, _ = O.hist_edges(ref)
+                        if rn == 'xhistogram':
+                            e = np.concatenate((e[:-1], e[-1:] + 1e-8))
+                        assert np.array_equal(edges[s], e.astype(np.float64))
+                        assert st[s] == 0
+
+
+def test_minmax_all_nan_and_odd_sizes(ctx):
+    x = np.full((2, 1, 77), np.nan)
+    x[1, 0, 3] = 2.5
+    mm = ctx.minmax(x)
+    assert np.isnan(mm[0]).all() and mm[1, 0] == 2.5 and mm[1, 1] == 2.5
+    for n in (1, 2, 3, 5, 1023, 4097):
+        y = np.arange(n, dtype=np.float32)[None] - 7
+        mm = ctx.minmax(y)
+        assert mm[0, 0] == -7 and mm[0, 1] == n - 8
+
+
+def test_constant_field_raises_like_reference(ctx):
+    import xcontour_amd as xa
+    q = xa.DataArray(np.ones((8, 16)), ('lat', 'lon'), {'lat': np.arange(8.), 'lon': np.arange(16.)}, 'q')
+    cm = xa.Contour2D(q, np.ones(8), {'X': 'lon', 'Y': 'lat'}, {'Y': 'lat'}, lt=True)
+    ctr = cm.cal_contours(5)
+    with pytest.raises(Exception, match='non monotonic bins'):
+        cm.cal_integral_within_contours_hist(ctr)
+
+
+# ---------------------------------------------------------------- K3 histogram
+@pytest.mark.parametrize('nx', [512, 131, 130, 64, 2, 1])
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_hist_random_shapes(ctx, nx, dt):
+    """ragged strips, odd nx (VEC=1), NaNs, per-slab edges, all weight ranks"""
+    rng = np.random.default_rng(nx)
+    ny, S = 37, 3
+    x = rng.standard_normal((S, ny, nx)).astype(dt)
+    x[0, 3, 0] = np.nan
+    x[1, :, nx // 2] = np.nan
+    ed = np.stack([np.sort(rng.uniform(-2.5, 2.5, 41)) for _ in range(S)])
+    for dA in (None, rng.random(ny), rng.random((ny, nx)), rng.random((S, ny, nx))):
+        out = ctx.hist(x, ed, dA=dA)
+        for s in range(S):
+            w = np.ones((ny, nx)) if dA is None else (dA[:, None] if dA.ndim == 1 else (dA if dA.ndim == 2 else dA[s]))
+            p, c = O.weighted_histogram(x[s], ed[s], np.broadcast_to(w, (ny, nx)))
+            assert np.array_equal(out['counts'][s].astype(np.int64), c)
+            assert np.allclose(out['pdf'][s, 0], p, rtol=1e-12, atol=1e-13)
+            assert np.allclose(out['cdf'][s, 0], np.cumsum(p), rtol=1e-12, atol=1e-13)
+
+
+def test_hist_ties_on_edges_and_last_bin(ctx):
+    """cells exactly on edges; closed vs half-open last bin; out-of-range both sides"""
+    ed = np.array([0., 1., 2., 3., 4.])
+    vals = np.array([-1., 0., 0.5, 1., 1., 2., 3., 3.999, 4., 4., 4.0000001, 5., np.nan, np.inf, -np.inf, 2.])
+    x = np.tile(vals, (4, 8))[None]                  # (1, 4, 128)
+    w = np.arange(x.size, dtype=np.float64).reshape(x.shape[1:]) + 1
+    for closed in (True, False):
+        out = ctx.hist(x, ed, dA=w, last_closed=closed)
+        e = ed if closed else ed.copy()
+        idx = np.digitize(x.ravel(), e)
+        if closed:
+            idx = np.where(x.ravel() == e[-1], 4, idx)
+        c = np.bincount(idx, minlength=6)[1:5]
+        p = np.bincount(idx, weights=w.ravel(), minlength=6)[1:5]
+        assert np.array_equal(out['counts'][0].astype(np.int64), c)
+        assert np.allclose(out['pdf'][0, 0], p, rtol=1e-13)
+
+
+def test_hist_nonuniform_levels_binary_search(ctx):
+    """strongly non-uniform edges defeat the uniform guess: the fix-up search must still be exact"""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 64, 256))
+    ed = np.concatenate(([-4.0], -3 + np.cumsum(np.abs(rng.standard_normal(300)) ** 3 * 0.02)))
+    out = ctx.hist(x, ed, dA=None)
+    for s in range(2):
+        _, c = O.weighted_histogram(x[s], ed)
+        assert np.array_equal(out['counts'][s].astype(np.int64), c)
+
+
+def test_hist_many_bins_reduced_copies(ctx):
+    """N large enough that the LDS copy count drops below 16"""
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((1, 50, 300))
+    w = rng.random((50, 300))
+    for nb in (401, 1001, 3000):
+        ed = np.linspace(-3, 3, nb + 1)
+        out = ctx.hist(x, ed, dA=w, integrands=[x], want=('pdf', 'counts'))
+        p, c = O.weighted_histogram(x[0], ed, w)
+        p1, _ = O.weighted_histogram(x[0], ed, w * x[0])
+        assert np.array_equal(out['counts'][0].astype(np.int64), c)
+        assert np.allclose(out['pdf'][0, 0], p, rtol=1e-12, atol=1e-14)
+        assert np.allclose(out['pdf'][0, 1], p1, rtol=1e-11, atol=1e-13)
+
+
+def test_hist_rejects_bad_edges(ctx):
+    from xcontour_amd import _native as nat
+    x = np.zeros((1, 4, 4))
+    with pytest.raises(nat.XContourHipError, match='non monotonic bins') as e:
+        ctx.hist(x, np.array([0., 1., 1., 2.]))
+    assert e.value.code == nat.XC_EEDGES
+    with pytest.raises(nat.XContourHipError):
+        ctx.hist(x, np.array([0., 2., 1., 3.]))
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_grad_in_kernel_matches_standalone_and_oracle(ctx, baro, dt):
+    q, lat, lon = baro
+    q = q.astype(dt)
+    dA = O.cell_area(lat, lon)
+    rdx, rdy = O.grad_metrics(lat, lon)
+    g2 = O.grad2_sphere(q, lat, lon)
+    gg = ctx.grad2(q[None], rdx, rdy, True)
+    assert np.array_equal(gg[0], g2)                              # same order of operations: bit-exact
+    ctr = O.cal_contours(q, 201, True, np.float32)
+    edges, _ = O.hist_edges(ctr)
+    out = ctx.hist(q[None], edges.astype(np.float64), dA=dA, grad=(rdx, rdy, True))
+    w = np.where(np.isnan(g2 * dA), 0, g2 * dA)
+    p1, c = O.weighted_histogram(q, edges, w)
+    assert np.array_equal(out['counts'][0].astype(np.int64), c)
+    assert rel(out['pdf'][0, 1], p1) < TIGHT
+    # non-periodic walls (X-Z planes): one-sided differences
+    q2 = q[:50, :300].copy()
+    rdx2, rdy2 = np.full(50, 1 / 4.0), 1.0 / (np.minimum(np.arange(50) + 1, 49) - np.maximum(np.arange(50) - 1, 0))
+    gx = np.gradient(q2.astype(np.float64), 2.0, axis=1, edge_order=1)
+    gy = np.gradient(q2.astype(np.float64), 1.0, axis=0, edge_order=1)
+    gg2 = ctx.grad2(q2[None], rdx2, rdy2, False)
+    assert rel(gg2[0], gx * gx + gy * gy) < 1e-12
+    out2 = ctx.hist(q2[None], edges.astype(np.float64), dA=None, grad=(rdx2, rdy2, False))
+    p2, _ = O.weighted_histogram(q2, edges, gg2[0])
+    assert rel(out2['pdf'][0, 1], p2) < TIGHT
+
+
+# ---------------------------------------------------------------- facade: the reference's own call sequences
+def _baro_da(xa, baro, flip=False):
+    q, lat, lon = baro
+    if flip:
+        q, lat = q[::-1].copy(), lat[::-1].copy()
+    tr = xa.DataArray(q, ('latitude', 'longitude'), {'latitude': lat, 'longitude': lon}, 'absolute_vorticity')
+    dA = xa.DataArray(O.cell_area(lat, lon), ('latitude', 'longitude'), {'latitude': lat, 'longitude': lon}, 'rA')
+    return tr, dA, q, lat, lon
+
+
+@pytest.mark.parametrize('increase', [True, False])
+@pytest.mark.parametrize('lt', [True, False])
+@pytest.mark.parametrize('flip', [False, True])
+def test_keff_call_sequence_8_cases(ctx, baro, increase, lt, flip):
+    """tests/test_hist.py computeKeff_hist / computeKeff for all (increase, lt) x coordinate direction"""
+    import xcontour_amd as xa
+    tr, dA, q, lat, lon = _baro_da(xa, baro, flip)
+    N = 251
+    g2 = O.grad2_sphere(q, lat, lon)
+    grdS = xa.DataArray(g2, tr.dims, tr.coords, 'grdS')
+    mask = xa.DataArray(np.ones_like(q), tr.dims, tr.coords, 'mask')
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'},
+                      increase=increase, lt=lt)
+    table = cm.cal_area_eqCoord_table_hist(mask)
+    ctr = cm.cal_contours(N)
+    area = cm.cal_integral_within_contours_hist(ctr).rename('intArea')
+    intgrdS = cm.cal_integral_within_contours_hist(ctr, integrand=grdS).rename('intgrdS')
+    Yeq = table.lookup_coordinates(area).rename('Yeq')
+    Lmin = xa.latitude_lengths_at(Yeq).rename('Lmin')
+    dgrdSdA = cm.cal_gradient_wrt_area(intgrdS, area)
+    dqdA = cm.cal_gradient_wrt_area(ctr, area)
+    Leq2 = cm.cal_sqared_equivalent_length(dgrdSdA, dqdA)
+    nkeff = cm.cal_normalized_Keff(Leq2, Lmin, mask=2e7)
+    # oracle, same sequence
+    o_tbl, o_cs = O.cal_area_eqCoord_table_hist(np.ones_like(q), dA.values, lat, increase, lt)
+    o_ctr = O.cal_contours(q, N, increase, np.float32)
+    o_area = O.cal_integral_within_contours_hist(q, o_ctr, dA.values, None, lt)
+    o_S = O.cal_integral_within_contours_hist(q, o_ctr, dA.values, g2, lt)
+    o_Yeq = O.lookup_coordinates(o_area, o_tbl, o_cs)
+    o_Lmin = O.latitude_lengths_at(o_Yeq)
+    o_dS = O.cal_gradient_wrt_area(o_S, o_area)
+    o_dq = O.cal_gradient_wrt_area(o_ctr, o_area)
+    o_Leq2 = O.cal_sqared_equivalent_length(o_dS, o_dq)
+    o_nk = O.cal_normalized_Keff(o_Leq2, o_Lmin, 2e7)
+    assert rel(table._table.values, o_tbl) < 1e-13 and np.array_equal(table._coord, o_cs)
+    assert ctr.values.dtype == np.float32 and np.array_equal(ctr.values, o_ctr)
+    assert rel(area.values, o_area) < TIGHT and rel(intgrdS.values, o_S) < TIGHT
+    assert rel(Yeq.values, o_Yeq) < 1e-9
+    assert rel(dqdA.values, o_dq) < 1e-8 and rel(dgrdSdA.values, o_dS) < 1e-8
+    assert rel(Leq2.values, o_Leq2) < RTOL and rel(nkeff.values, o_nk) < RTOL
+    assert area.name == 'intArea' and dqdA.name == 'dabsolute_vorticitydA' and Leq2.name == 'Leq2' and nkeff.name == 'nkeff'
+    assert area.dims == ('contour',) and area.coords['contour'].dtype == np.float32
+    # the xarray-style twin (strict comparisons) on the GPU vs the oracle's twin
+    t2 = cm.cal_area_eqCoord_table(mask)
+    o_t2, _ = O.cal_area_eqCoord_table(np.ones_like(q), dA.values, lat, increase, lt)
+    assert rel(t2._table.values, o_t2) < 1e-13
+    a2 = cm.cal_integral_within_contours(ctr)
+    o_a2 = O.cal_integral_within_contours(q, o_ctr, dA.values, None, lt)
+    assert rel(a2.values, o_a2) < TIGHT
+    s2 = cm.cal_integral_within_contours(ctr, integrand=grdS)
+    assert rel(s2.values, O.cal_integral_within_contours(q, o_ctr, dA.values, g2, lt)) < TIGHT
+    # interpolation to prescribed latitudes
+    preY = np.linspace(-90, 90, N)
+    ds = cm.interp_to_dataset(preY, Yeq, [ctr, area, Yeq, nkeff])
+    assert rel(ds['intArea'].values, O.interp_to_coords(preY, o_Yeq, o_area)) < 1e-9
+    assert ds['nkeff'].dims == ('new',)
+
+
+def test_golden_keff_fixtures(ctx, baro):
+    """the committed golden vectors (tests/golden/make_golden.py) through the fused pipeline"""
+    import xcontour_amd as xa
+    tr, dA, q, lat, lon = _baro_da(xa, baro)
+    mask = xa.DataArray(np.ones_like(q), tr.dims, tr.coords, 'mask')
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'},
+                      increase=True, lt=True)
+    table = cm.cal_area_eqCoord_table_hist(mask)
+    for N in (121, 201):
+        g = np.load(os.path.join(GOLD, 'baro_keff_N%d.npz' % N))
+        assert rel(table._table.values, g['tbl']) < 1e-13
+        ds = cm.keff(N, table, preY=lat, lat=lat, lon=lon)
+        assert np.array_equal(ds['ctr'].values, g['ctr'].astype(np.float64))
+        for k in ('area', 'intgrdS'):
+            assert rel(ds[k].values, g[k]) < TIGHT, k
+        for k in ('latEq', 'dqdA', 'dintSdA', 'Leq2', 'nkeff'):
+            assert rel(ds[k].values, g[k]) < RTOL, k
+        assert rel(ds['Lmin'].values, g['Lmin'], LMIN_FLOOR) < RTOL
+        for k in ('ctr', 'area', 'latEq', 'nkeff', 'Leq2'):
+            assert rel(ds[k + '_eq'].values, g[k + '_eq']) < RTOL, k
+
+
+@pytest.mark.parametrize('increase,lt,cd,re_', [(True, True, np.float64, 'numpy'), (False, True, np.float32, 'numpy'),
+                                                (True, False, np.float32, 'xhistogram'), (False, False, np.float64, 'numpy')])
+def test_fused_pipeline_batch_vs_oracle(ctx, increase, lt, cd, re_):
+    """xc_keff_dev on a batch of synthetic slabs with per-slab levels, counts bit-exact"""
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums
+    ny, nx, N, S = 181, 360, 101, 5
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 1.0
+    dA = cell_area(lat, lon)
+    ylt = lt if increase else (not lt)
+    tbl = table_from_rowsums(dA.sum(1), ylt)
+    plan = KeffPlan(ctx, S, ny, nx, N, np.float64, cd, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                    preY=lat, increase=increase, lt=lt, right_edge=re_)
+    plan.synth(lat, lon, 77, 0)
+    plan.run()
+    out = plan.fetch()
+    q = plan.download_q()
+    for s in range(S):
+        r = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=increase, lt=lt, dtype=cd, preLats=lat, right_edge=re_)
+        assert np.array_equal(out['counts'][s].astype(np.int64), r['counts'])
+        assert np.array_equal(out['ctr'][s], r['ctr'].astype(np.float64))
+        assert rel(out['area'][s], r['area']) < TIGHT and rel(out['intgrdS'][s], r['intgrdS']) < TIGHT
+        for k in ('latEq', 'dqdA', 'dintSdA', 'Leq2'):
+            assert rel(out[k][s], r[k]) < RTOL, k
+        assert rel(out['Lmin'][s], r['Lmin'], LMIN_FLOOR) < RTOL
+        ok = r['Lmin'] > LMIN_FLOOR                                    # nkeff = Leq2/Lmin^2 away from the pole
+        assert rel(out['nkeff'][s][ok], r['nkeff'][ok]) < RTOL
+        for k in ('ctr', 'area'):
+            assert rel(out[k + '_eq'][s], r[k + '_eq']) < RTOL, k
+    plan.free()
+
+
+def test_pipeline_supplied_grdS_f32(ctx, baro):
+    """PV.nc-like usage: float32 tracer, supplied float32 grdS, float32 dA -> f32 products (core.py:444)"""
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import table_from_rowsums
+    q, lat, lon = baro
+    dA32 = O.cell_area(lat, lon).astype(np.float32)
+    g32 = O.grad2_sphere(q, lat, lon).astype(np.float32)
+    tbl = table_from_rowsums(dA32.astype(np.float64).sum(1), True)
+    plan = KeffPlan(ctx, 1, 256, 512, 121, np.float32, np.float32, dA=dA32, tbl=tbl, tbl_coord=lat, increase=True,
+                    lt=True, grdS_dtype=np.float32, prod_f32=True)
+    plan.set_q(q); plan.set_grdS(g32); plan.run()
+    out = plan.fetch()
+    ctr = O.cal_contours(q, 121, True, np.float32)
+    S = O.cal_integral_within_contours_hist(q, ctr, dA32, g32, True)
+    assert rel(out['intgrdS'][0], S) < TIGHT
+    plan.free()
+
+
+# ---------------------------------------------------------------- K7 local wave activity
+def test_lwa_golden_and_call_sequence(ctx, baro):
+    """tests/test_LWA.py:35-78: sorted state, then LWA with mask_idx=[37,125,170,213]"""
+    import xcontour_amd as xa
+    tr, dA, q, lat, lon = _baro_da(xa, baro)
+    g = np.load(os.path.join(GOLD, 'baro_lwa_N121.npz'))
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True)
+    mask = xa.DataArray(np.ones_like(q), tr.dims, tr.coords, 'mask')
+    ctr = cm.cal_contours(121)
+    table = cm.cal_area_eqCoord_table_hist(mask)
+    area = cm.cal_integral_within_contours_hist(ctr).rename('intArea')
+    latEq = table.lookup_coordinates(area).rename('latEq')
+    ds_latEq = cm.interp_to_dataset(xa.DataArray(lat, ('latitude',), {'latitude': lat}), latEq, [ctr, area, latEq])
+    Q = ds_latEq['absolute_vorticity']
+    assert rel(Q.values, g['Q']) < 1e-9
+    Qg = xa.DataArray(g['Q'], ('latitude',), {'latitude': lat}, 'absolute_vorticity')
+    lwa, ctrs, masks = cm.cal_local_wave_activity(tr, Qg, mask_idx=[37, 125, 170, 213], part='all', metric=g['dy'])
+    assert lwa.name == 'LWA' and lwa.dims == tr.dims
+    assert np.array_equal(lwa.values, g['lwa_dy'])                 # same summation order: bit-exact
+    assert abs(lwa.values.max() - 28.921) < 1e-3
+    for i in range(4):
+        assert np.array_equal(masks[i].values, g['masks'][i])
+        assert ctrs[i].values == g['Q'][[37, 125, 170, 213][i]]
+    assert np.array_equal(cm.cal_local_wave_activity(tr, Qg).values, g['lwa_dA'])          # snapshot metric
+    assert np.array_equal(cm.cal_local_wave_activity(tr, Qg, part='upper', metric=g['dy']).values, g['lwa_upper'])
+    assert np.array_equal(cm.cal_local_APE(tr, Qg, part='lower', metric=g['dy']).values, g['lwa_lower'])
+    with pytest.raises(Exception, match='invalid part'):
+        cm.cal_local_wave_activity(tr, Qg, part='middle')
+    with pytest.raises(Exception, match='out of boundary'):
+        cm.cal_local_wave_activity(tr, Qg, mask_idx=[256])
+
+
+@pytest.mark.parametrize('increase', [True, False])
+@pytest.mark.parametrize('flip', [False, True])
+def test_lwa_directions_and_nans(ctx, increase, flip):
+    rng = np.random.default_rng(11)
+    ny, nx = 45, 70
+    coord = np.linspace(-200, 0, ny) if not flip else np.linspace(0, -200, ny)
+    q = rng.standard_normal((2, ny, nx)) + np.linspace(0, 3, ny)[None, :, None]
+    q[0, 4, 5] = np.nan
+    Q = np.sort(rng.standard_normal((2, ny)), axis=1)
+    dA = rng.random((ny, nx)) + 0.5
+    for part, pc in (('all', 0), ('upper', 1), ('lower', 2)):
+        out, _ = ctx.lwa(q, Q, coord, dA, dA.max(), M=None, increase=increase, part=pc)
+        for s in range(2):
+            ref = O.cal_local_wave_activity(q[s], Q[s], coord, dA, increase, part)
+            assert np.array_equal(out[s], ref)
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE cfg2)
+def test_cfg2_full_size_properties(ctx):
+    """3600x1801 f64, 201 contours: size-independent invariants + a CPU cross-check of the counts"""
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums
+    ny, nx, N = 1801, 3600, 201
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 0.1
+    dA = cell_area(lat, lon)
+    rows = ctx.rowsum(None, dA, ny, nx)
+    assert abs(rows.sum() / (4 * np.pi * O.Rearth ** 2) - 1) < 1e-12       # sphere area
+    tbl = table_from_rowsums(rows, True)
+    assert tbl[0] == 0 and abs(tbl[-1] / rows.sum() - 1) < 1e-13           # end point = total area (core.py:133-140)
+    plan = KeffPlan(ctx, 2, ny, nx, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                    increase=True, lt=True)
+    plan.synth(lat, lon, 20241008, 0)
+    plan.run()
+    out = plan.fetch()
+    q = plan.download_q()
+    for s in range(2):
+        assert out['counts'][s].sum() == ny * nx                            # every cell lands in exactly one bin
+        assert out['area'][s, 0] == 0 and (np.diff(out['area'][s]) >= 0).all()
+        assert abs(out['area'][s, -1] / rows.sum() - 1) < 1e-12             # cdf[-1] == total weight
+        assert (np.diff(out['intgrdS'][s]) >= 0).all()
+        assert (np.diff(out['latEq'][s]) >= 0).all()
+        ctr = O.cal_contours(q[s], N, True, np.float64)
+        assert np.array_equal(out['ctr'][s], ctr)
+        e, _ = O.hist_edges(ctr)
+        h, _ = np.histogram(q[s].ravel(), bins=e)
+        assert np.array_equal(out['counts'][s].astype(np.int64), h)         # bit-exact counts at full size
+    # idempotence: a second run of the same plan gives bit-identical counts and 1e-13-close sums
+    plan.run()
+    out2 = plan.fetch()
+    assert np.array_equal(out['counts'], out2['counts'])
+    assert rel(out2['area'], out['area']) < 1e-13
+    plan.free()

@@ -1,0 +1,124 @@
+"""Pin the oracle: SURVEY.md 8(c) known-answer vectors on the reference's bundled
+Data/barotropic_vorticity.nc, numpy's own histogram, and the committed golden npz."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import xcontour_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_fixture_bytes(baro):
+    q, lat, lon = baro
+    assert q.dtype == np.float32 and q.shape == (256, 512)
+    assert hashlib.sha256(q.tobytes()).hexdigest().startswith('c8d30d7acd84c77a')
+    assert hashlib.sha256(lat.tobytes()).hexdigest().startswith('49888387fcbea5e6')
+    assert q.min() == np.float32(-1.5368119e-4) and q.max() == np.float32(1.7907852e-4)
+
+
+@pytest.mark.parametrize('N,first5,last5,sha', [
+    (121, [0, 7058, 3160, 2646, 2468], [190, 222, 188, 194, 161], 'fe188fcc7af47e9d'),
+    (201, [0, 5396, 2364, 1886, 1670], [122, 110, 108, 122, 81], '5c785dbfe747de26'),
+])
+def test_survey_known_counts(baro, N, first5, last5, sha):
+    q, lat, lon = baro
+    dA = O.cell_area(lat, lon)
+    ctr = O.cal_contours(q, N, True, np.float32)
+    assert ctr.dtype == np.float32 and ctr[0] == q.min()
+    assert ctr[-1] == np.float32(0.0001790785) and ctr[-1] != q.max()
+    _, cnt = O.cal_integral_within_contours_hist(q, ctr, dA, None, True, return_counts=True)
+    assert cnt.sum() == 131071                                               # max cell excluded
+    assert list(cnt[:5]) == first5 and list(cnt[-5:]) == last5
+    assert hashlib.sha256(cnt.astype(np.int64).tobytes()).hexdigest().startswith(sha)
+    # numpy's own histogram has the same semantics
+    e, _ = O.hist_edges(ctr)
+    h, _ = np.histogram(q.ravel(), bins=e)
+    assert np.array_equal(h, cnt)
+    # the xhistogram (+1e-8) rule keeps the max cell
+    _, c2 = O.cal_integral_within_contours_hist(q, ctr, dA, None, True, 'xhistogram', True)
+    assert c2.sum() == 131072
+
+
+def test_survey_known_keff_and_lwa(baro):
+    q, lat, lon = baro
+    dA = O.cell_area(lat, lon)
+    assert abs(dA.sum() / (4 * np.pi * O.Rearth ** 2) - 1) < 1e-14
+    r = O.keff_pipeline(q, dA, lat, 121, lon=lon, preLats=lat)
+    assert abs(r['area'][-1] / 5.1009325369688875e14 - 1) < 1e-12
+    assert abs(r['area'][-1] / dA.sum() - 0.9999936) < 1e-7
+    nk = r['nkeff']
+    assert np.isfinite(nk).all()
+    assert abs(np.nanmin(nk) - 0.967) < 1e-3 and abs(np.nanmedian(nk) - 2.59) < 1e-2 and abs(np.nanmax(nk) - 168.2) < 0.1
+    assert abs(r['latEq'][1] + 79.78) < 1e-2 and abs(r['latEq'][-2] - 86.64) < 1e-2
+    assert (np.diff(r['area']) > 0).all()
+    Q = r['ctr_eq']
+    assert (np.diff(Q) >= 0).all()
+    dy = np.gradient(np.deg2rad(lat.astype(np.float64))) * O.Rearth
+    lwa = O.cal_local_wave_activity(q, Q, lat, dA, True, 'all', metric=dy)
+    assert lwa.min() >= -1e-12 and abs(lwa.max() - 28.921) < 1e-3
+    assert abs(lat[np.argmax(lwa.mean(1))] - 29.82) < 0.01
+    for j, v in zip((37, 125, 170, 213), (0.285, 3.224, 9.943, 7.817)):
+        assert abs(lwa[j].mean() - v) < 1e-3
+    r2 = O.keff_pipeline(q, dA, lat, 201, lon=lon)
+    nk = r2['nkeff']
+    assert abs(np.nanmin(nk) - 0.902) < 1e-3 and abs(np.nanmedian(nk) - 2.35) < 1e-2 and abs(np.nanmax(nk) - 98.1) < 0.1
+
+
+def test_hist_vs_strict_twin(baro):
+    """tests/test_hist.py:132-167 overlay: the two APIs agree except on the closed last bin."""
+    q, lat, lon = baro
+    dA = O.cell_area(lat, lon)
+    g2 = O.grad2_sphere(q, lat, lon)
+    for N in (121, 201):
+        ctr = O.cal_contours(q, N, True, np.float32)
+        for integ in (None, g2):
+            a = O.cal_integral_within_contours_hist(q, ctr, dA, integ, True)
+            b = O.cal_integral_within_contours(q, ctr, dA, integ, True)
+            assert np.max(np.abs(a[1:] - b[1:]) / b[1:]) < 1e-12
+
+
+def test_histogram_semantics_small():
+    """SURVEY A3."""
+    x = np.array([np.nan, -1, 0, .5, 1, 2.999, 3, 3 + 5e-9, 3.0001])
+    s, c = O.weighted_histogram(x, np.array([0., 1, 2, 3]))
+    assert list(c) == [2, 1, 2]          # last bin closed: 2.999, 3
+    s, c = O.weighted_histogram(x, np.array([0., 1, 2, 3]), right_edge='xhistogram')
+    assert list(c) == [2, 1, 3]          # [2, 3+1e-8): 2.999, 3, 3+5e-9
+    # float32 edges of magnitude >= 0.25 absorb the 1e-8: the last bin is then half-open
+    e32 = np.array([0., 1, 2, 3], dtype=np.float32)
+    s, c = O.weighted_histogram(x.astype(np.float32), e32, right_edge='xhistogram')
+    assert list(c) == [2, 1, 1]
+
+
+def test_table_rules():
+    """the degenerate histogram of the coordinate field."""
+    J, nx = 7, 5
+    rng = np.random.default_rng(1)
+    dA = rng.random((J, nx)) + 0.1
+    mask = np.ones((J, nx)); mask[2, 1] = 0; mask[5, :] = 0
+    r = np.where(mask == 1, dA, 0).sum(1)
+    for coord in (np.linspace(-60, 60, J), np.linspace(60, -60, J)):
+        ra = r if coord[-1] > coord[0] else r[::-1]
+        for inc in (True, False):
+            for lt in (True, False):
+                tbl, cs = O.cal_area_eqCoord_table_hist(mask, dA, coord, inc, lt)
+                ylt = lt if (inc == (coord[-1] > coord[0])) else (not lt)
+                assert (np.diff(cs) > 0).all()
+                if ylt:
+                    exp = np.concatenate(([0], np.cumsum(ra)[:-1])); exp[-1] = ra.sum()
+                else:
+                    exp = np.array([ra[j:].sum() for j in range(J)]); exp[-1] = 0
+                assert np.allclose(tbl, exp, rtol=1e-13, atol=1e-13)
+
+
+def test_golden_files_match_oracle(baro):
+    q, lat, lon = baro
+    dA = O.cell_area(lat, lon)
+    for N in (121, 201):
+        g = np.load(os.path.join(GOLD, 'baro_keff_N%d.npz' % N))
+        r = O.keff_pipeline(q, dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float32, preLats=lat)
+        for k in g.files:
+            assert np.array_equal(g[k], r[k], equal_nan=True), k

@@ -36,7 +36,7 @@ class HistDesc(C.Structure):
         ('integrand_dtype', _i32 * XC_MAX_INTEGRANDS),
         ('rdx', _vp), ('rdy', _vp),
         ('periodic_x', _i32), ('lt', _i32),
-        ('reverse', _i32), ('_pad1', _i32),
+        ('reverse', _i32), ('negate', _i32),
         ('pdf', _vp), ('counts', _vp), ('cdf', _vp),
     ]
 
@@ -83,8 +83,8 @@ PROTOTYPES = {
     'xc_levels': (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     'xc_hist_dev': (C.c_int, [_vp, C.POINTER(HistDesc)]),
     'xc_hist': (C.c_int, [_vp, C.POINTER(HistDesc)]),
-    'xc_rowsum_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _i64, _i64, _vp]),
-    'xc_rowsum': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _i64, _i64, _vp]),
+    'xc_rowsum_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _i64, _i64, C.c_int, _vp]),
+    'xc_rowsum': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _i64, _i64, C.c_int, _vp]),
     'xc_grad2_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp]),
     'xc_grad2': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp]),
     'xc_lwa_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _vp, C.c_int,
@@ -270,7 +270,7 @@ class Context(object):
         return ctr, edges, status
 
     def hist(self, q, edges, dA=None, integrands=(), grad=None, last_closed=True, lt=True,
-             reverse=False, prod_f32=False, want=('pdf', 'counts', 'cdf')):
+             reverse=False, prod_f32=False, negate=False, want=('pdf', 'counts', 'cdf')):
         """q: (nslab, ny, nx); edges: (nedge,) or (nslab, nedge) ascending f64.
         dA: None | (ny,) | (ny,nx) | (nslab,ny,nx) (converted to f64).
         grad: None or (rdx, rdy, periodic_x).  Returns dict of requested outputs."""
@@ -317,7 +317,7 @@ class Context(object):
             assert rdx.shape == (ny,) and rdy.shape == (ny,)
             keep += [rdx, rdy]
             d.grad, d.rdx, d.rdy, d.periodic_x = 1, _ptr(rdx), _ptr(rdy), 1 if grad[2] else 0
-        d.lt, d.reverse = 1 if lt else 0, 1 if reverse else 0
+        d.lt, d.reverse, d.negate = 1 if lt else 0, 1 if reverse else 0, 1 if negate else 0
         nch, nbin = 1 + d.nint + d.grad, d.nedge - 1
         out = {}
         if 'pdf' in want:
@@ -332,7 +332,7 @@ class Context(object):
         self._check(self.lib.xc_hist(self.handle, C.byref(d)))
         return out
 
-    def rowsum(self, mask, dA, ny, nx):
+    def rowsum(self, mask, dA, ny, nx, multiply=False):
         if mask is not None:
             mask = np.ascontiguousarray(mask)
             if mask.dtype not in (np.float32, np.float64):
@@ -345,7 +345,7 @@ class Context(object):
             assert dA.shape in ((ny,), (ny, nx))
         out = np.empty(ny, dtype=np.float64)
         self._check(self.lib.xc_rowsum(self.handle, _ptr(mask), dtype_code(mask.dtype) if mask is not None else XC_F64,
-                                       _ptr(dA), rank, ny, nx, _ptr(out)))
+                                       _ptr(dA), rank, ny, nx, 1 if multiply else 0, _ptr(out)))
         return out
 
     def grad2(self, q, rdx, rdy, periodic_x=True):

@@ -340,7 +340,7 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); a.dA = ctx->ones; a.dA_rank = XC_DA_ROW; }
     for (int i = 0; i < d->nint; ++i) { a.integ[i] = d->integrand[i]; a.integ_f32[i] = d->integrand_dtype[i] == XC_F32; }
     a.edges = d->edges; a.levels_mode = 0; a.nbin = nbin; a.edges_per_slab = d->edges_per_slab;
-    a.last_closed = d->last_closed; a.q_f32 = d->q_dtype == XC_F32;
+    a.last_closed = d->last_closed; a.negate = d->negate; a.q_f32 = d->q_dtype == XC_F32;
     a.prod_f32 = d->prod_f32;
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
@@ -402,14 +402,14 @@ int xc_hist(xc_ctx* ctx, const xc_hist_desc* hd)
 
 // ------------------------------------------------------------------------------------ K2
 int xc_rowsum_dev(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
-                  int64_t ny, int64_t nx, double* out_rows)
+                  int64_t ny, int64_t nx, int multiply, double* out_rows)
 {
     XC_CTX(ctx);
-    return launch_rowsum(ctx, mask, mask_dtype, dA, dA_rank, ny, nx, out_rows);
+    return launch_rowsum(ctx, mask, mask_dtype, dA, dA_rank, ny, nx, multiply, out_rows);
 }
 
 int xc_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
-              int64_t ny, int64_t nx, double* out_rows)
+              int64_t ny, int64_t nx, int multiply, double* out_rows)
 {
     XC_CTX(ctx);
     if (!out_rows || ny < 1 || nx < 1) return fail(ctx, XC_EBADARG, "xc_rowsum: bad arguments");
@@ -423,7 +423,7 @@ int xc_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, i
     if (mb) { dm = st.take(mb); XC_TRY(h2d(ctx, dm, mask, mb)); }
     if (dab) { dd = (double*)st.take(dab); XC_TRY(h2d(ctx, dd, dA, dab)); }
     double* dout = (double*)st.take((size_t)ny * 8);
-    XC_TRY(launch_rowsum(ctx, dm, mask_dtype, dd, dA_rank, ny, nx, dout));
+    XC_TRY(launch_rowsum(ctx, dm, mask_dtype, dd, dA_rank, ny, nx, multiply, dout));
     XC_TRY(d2h(ctx, out_rows, dout, (size_t)ny * 8));
     return xc_sync(ctx);
 }

@@ -284,6 +284,7 @@ void k_hist(const HistArgs a)
     const double e0 = s_edges[0], eN = s_edges[N];
     const double inv = (double)N / (eN - e0);
     const int last_closed = a.last_closed;
+    const int negate = a.negate;
     XC_STAMP(2);
 
     double   acc[NCH];
@@ -311,7 +312,7 @@ void k_hist(const HistArgs a)
         double w[NCH][VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-            const int kb = find_bin(qc[c], s_edges, N, e0, eN, inv, last_closed);
+            const int kb = find_bin(negate ? -qc[c] : qc[c], s_edges, N, e0, eN, inv, last_closed);
             k[c] = active ? kb : -1;
             const double dv = dAv[c];
             w[0][c] = (dv != dv) ? 0.0 : dv;                                  // fillna(0), core.py:449

@@ -69,6 +69,7 @@ struct HistArgs {
     int           nbin;
     int           edges_per_slab;
     int           last_closed;
+    int           negate;
     int           increase, q_f32, ctr_f32, right_edge;
     double        inv_nm1;      // 1.0/(N-1) (levels mode)
     int           dA_rank, prod_f32;
@@ -114,7 +115,7 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
 int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a);
 int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a);
 int launch_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
-                  int64_t ny, int64_t nx, double* out_rows);
+                  int64_t ny, int64_t nx, int multiply, double* out_rows);
 int launch_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
                  const double* rdx, const double* rdy, int periodic_x, double* out);
 int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,

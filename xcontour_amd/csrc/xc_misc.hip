@@ -310,7 +310,7 @@ void k_finalize(const FinalArgs a)
 template <typename TM>
 __global__ __launch_bounds__(256)
 void k_rowsum(const TM* __restrict__ mask, const double* __restrict__ dA, int dA_rank,
-              int64_t ny, int64_t nx, double* __restrict__ out)
+              int64_t ny, int64_t nx, int multiply, double* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -318,9 +318,14 @@ void k_rowsum(const TM* __restrict__ mask, const double* __restrict__ dA, int dA
     double sum = 0.0;
     const double rowv = (dA_rank == XC_DA_ROW) ? dA[row] : 1.0;
     for (int64_t x = lane; x < nx; x += 64) {
-        const bool in = mask ? (mask[row * nx + x] == (TM)1) : true;
         const double w = (dA_rank == XC_DA_PLANE) ? dA[row * nx + x] : rowv;
-        if (in) sum += w;
+        if (multiply) {                                   // (mask*dA).sum(skipna), core.py:130-133
+            const double t = mask ? (double)mask[row * nx + x] * w : w;
+            if (t == t) sum += t;
+        } else {
+            const bool in = mask ? (mask[row * nx + x] == (TM)1) : true;     // .where(mask==1), core.py:178
+            if (in) sum += w;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if (lane == 0) out[row] = sum;
@@ -429,9 +434,15 @@ int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
 {
     FinalArgs a = a_in;
     size_t lds = ((size_t)2 * a.nch * a.nbin + (a.keff ? 7 * (size_t)a.nbin : 0)) * sizeof(double);
-    if (lds > 60 * 1024) return fail(ctx, XC_EBADARG, "xc finalize: too many bins x channels");
+    if (lds > kLdsBudget) return fail(ctx, XC_EBADARG, "xc finalize: too many bins x channels");
+    static bool attr_set = false;
+    if (!attr_set) {
+        XC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_finalize),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget + 4096));
+        attr_set = true;
+    }
     a.tbl_in_lds = 0;
-    if (a.keff && lds + (size_t)2 * a.ntbl * sizeof(double) <= 60 * 1024) {
+    if (a.keff && lds + (size_t)2 * a.ntbl * sizeof(double) <= 64 * 1024) {
         a.tbl_in_lds = 1;
         lds += (size_t)2 * a.ntbl * sizeof(double);
     }
@@ -447,7 +458,7 @@ int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
 }
 
 int launch_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
-                  int64_t ny, int64_t nx, double* out_rows)
+                  int64_t ny, int64_t nx, int multiply, double* out_rows)
 {
     if (!out_rows || ny < 1 || nx < 1) return fail(ctx, XC_EBADARG, "xc_rowsum: bad arguments");
     if (dA_rank != XC_DA_NONE && dA_rank != XC_DA_ROW && dA_rank != XC_DA_PLANE)
@@ -455,9 +466,9 @@ int launch_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* d
     if (dA_rank != XC_DA_NONE && !dA) return fail(ctx, XC_EBADARG, "xc_rowsum: dA is NULL");
     dim3 grid((unsigned)((ny + 3) / 4));
     if (!mask || mask_dtype == XC_F64)
-        hipLaunchKernelGGL(k_rowsum<double>, grid, dim3(256), 0, ctx->stream, (const double*)mask, dA, dA_rank, ny, nx, out_rows);
+        hipLaunchKernelGGL(k_rowsum<double>, grid, dim3(256), 0, ctx->stream, (const double*)mask, dA, dA_rank, ny, nx, multiply, out_rows);
     else if (mask_dtype == XC_F32)
-        hipLaunchKernelGGL(k_rowsum<float>, grid, dim3(256), 0, ctx->stream, (const float*)mask, dA, dA_rank, ny, nx, out_rows);
+        hipLaunchKernelGGL(k_rowsum<float>, grid, dim3(256), 0, ctx->stream, (const float*)mask, dA, dA_rank, ny, nx, multiply, out_rows);
     else return fail(ctx, XC_EBADARG, "xc_rowsum: mask_dtype must be XC_F32 or XC_F64");
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
