@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the contour-coordinate hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic 3600 x 1801 float64 PV-like slabs, 2-D
+float64 cell areas, 201 contours, the FULL Keff pipeline per slab (min/max -> levels ->
+one histogram pass with in-kernel |grad q|^2 -> CDF -> A(Yeq) lookup -> d/dA -> Leq2 ->
+Lmin -> nkeff).  A "step" is one pass of that pipeline over one batch of `--batch`
+distinct slabs resident in HBM (the batch is larger than the 256 MiB Infinity Cache, so
+every step really reads the tracer from HBM).  Metric: lat-lon cells x contours per second,
+whole job.  N > 1: every rank owns its own batch of independent slabs (weak scaling), no
+data-path collective during compute, ONE RCCL all-gather of all per-slab result vectors at
+the end of the timed region.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel = the histogram pass, timed
+with HIP events on its own stream around every launch of the timed region) and, at N=1,
+`cpu_baseline` (the numpy oracle = a port of the reference's xarray/xhistogram call
+sequence, timed on this host's cores on a bounded sample of the same slabs).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+NY, NX, NCONT = 1801, 3600, 201
+SEED = 20241008
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_CELL = 16              # algorithmic: tracer f64 once + dA f64 once
+
+
+# ----------------------------------------------------------------------------- CPU baseline worker
+def _cpu_keff_worker(args):
+    """One slab through the oracle's Keff call sequence (runs in a spawned process)."""
+    path, idx = args
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import xcontour_oracle as O
+    q = np.load(path, mmap_mode='r')[idx]
+    lat = np.linspace(-90, 90, NY)
+    lon = np.arange(NX) * 0.1
+    dA = O.cell_area(lat, lon)
+    t = time.perf_counter()
+    r = O.keff_pipeline(np.asarray(q), dA, lat, NCONT, lon=lon, increase=True, lt=True, dtype=np.float64)
+    dt = time.perf_counter() - t
+    return dt, float(np.nansum(r['nkeff']))
+
+
+def cpu_baseline(q_host):
+    """Oracle on a bounded sample: single-thread time per slab, then all host cores in parallel."""
+    import multiprocessing as mp
+    import shutil
+    import tempfile
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, 32, q_host.shape[0]))
+    tmp = tempfile.mkdtemp(prefix='xc_bench_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    try:
+        path = os.path.join(tmp, 'q.npy')
+        np.save(path, q_host)
+        t1, _ = _cpu_keff_worker((path, 0))                       # single thread, in-process
+        ctx = mp.get_context('spawn')
+        n = q_host.shape[0]
+        with ctx.Pool(workers) as pool:
+            pool.map(_cpu_keff_worker, [(path, 0)] * workers)     # warm the workers (imports, page cache)
+            t = time.perf_counter()
+            pool.map(_cpu_keff_worker, [(path, i % n) for i in range(n)], chunksize=1)
+            wall = time.perf_counter() - t
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    work = NY * NX * NCONT
+    return {
+        'value': n * work / wall, 'unit': 'cells*contours/s', 'cores': workers, 'kind': 'port',
+        'sample': '%d slabs of %dx%d f64, %d contours, numpy oracle (port of the reference xarray/'
+                  'xhistogram Keff call sequence) in %d processes: %.2f s wall; single thread %.2f s/slab '
+                  '= %.3e cells*contours/s; host has %d logical cores'
+                  % (n, NX, NY, NCONT, workers, wall, t1, work / t1, cores),
+    }
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=8, help='slabs per step per GPU')
+    ap.add_argument('--group', type=int, default=0, help='slabs per launch set (0: whole batch)')
+    ap.add_argument('--variant', type=int, default=0, help='0 PV-like, 1 noise, 2 sin(lat)')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--cpu-slabs', type=int, default=0, help='CPU sample size (0: auto)')
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    if a.gpus != world and rank == 0 and world > 1:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
+
+    sys.path.insert(0, ROOT)
+    from xcontour_amd import _native as nat
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums, grad_metrics
+
+    ctx = nat.Context(local)
+    B, K, W = a.batch, a.steps, a.warmup
+    lat = np.linspace(-90, 90, NY)
+    lon = np.arange(NX) * 0.1
+    dA = cell_area(lat, lon)
+    rows = ctx.rowsum(None, dA, NY, NX)                           # K2: A(Yeq) table, once per mask
+    tbl = table_from_rowsums(rows, True)
+
+    # all K steps keep their per-slab result vectors on the device; one gather at the end
+    slot = KeffPlan.out_bytes(B, NCONT)
+    res = torch.empty(slot * K // 8, dtype=torch.float64, device='cuda')
+    wres = torch.empty(slot // 8, dtype=torch.float64, device='cuda')        # warm-up slot
+    plan = KeffPlan(ctx, B, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl,
+                    tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.data_ptr())
+    plan.synth(lat, lon, SEED + rank * B, a.variant)              # slab s of rank r: seed + r*B + s
+    group = a.group or None
+
+    plan.out_ptr = wres.data_ptr()
+    for _ in range(W):
+        plan.run(0, group)
+    plan.out_ptr = res.data_ptr()
+    ctx.sync()
+    torch.cuda.synchronize()
+    ev = [(ctx.event(), ctx.event()) for _ in range(K)]
+    gathered = torch.empty(res.numel() * world, dtype=torch.float64, device='cuda') if world > 1 else None
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        if group is None:
+            ctx.set_hist_events(ev[k][0], ev[k][1])               # events around the K3 launch only
+        plan.run(k, group)
+    ctx.sync()                                                    # the library's own HIP stream
+    if world > 1:
+        dist.all_gather_into_tensor(gathered, res)                # the one RCCL collective
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    el = t1 - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+
+    if rank == 0:
+        work_step = world * B * NY * NX * NCONT
+        line = {
+            'metric': 'lat-lon cells*contours/s, full Keff pipeline', 'value': work_step * K / el,
+            'unit': 'cells*contours/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': el / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'cfg2: synthetic %dx%d float64 PV-like slabs, 2-D f64 dA, %d contours, '
+                                   'full Keff (min/max + histogram with in-kernel |grad q|^2 + CDF + epilogue)'
+                                   % (NX, NY, NCONT),
+                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': a.group or B, 'variant': a.variant,
+                       'parallelism': 'independent slabs per GPU, one RCCL all-gather at the end' if world > 1 else 'single GPU',
+                       'device': ctx.device_name()},
+        }
+        if group is None:
+            ms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in ev])
+            alg = B * NY * NX * BYTES_PER_CELL
+            ach = alg / (ms.mean() * 1e-3) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, 'profiles', 'hist_traffic.json')
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+                except Exception:
+                    traffic = None
+            line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                                'kernel': 'k_hist<double,2,0,true,true>', 'launch_ms': float(ms.mean()),
+                                'algorithmic_bytes_per_launch': alg,
+                                'pipeline_frac': world and (B * NY * NX * BYTES_PER_CELL * K / el / 1e9 / world) / HBM_PEAK_GBS}
+        # parity spot check of the last step against nothing heavy: invariants only (oracle runs in cpu leg)
+        out = plan.fetch(slot=K - 1)
+        # every cell lands in exactly one bin, except that the slab's max cell may fall outside the
+        # rounded last level (the reference's own behaviour)
+        if not (NY * NX - out['counts'].sum(axis=1).astype(np.int64) <= 1).all():
+            raise RuntimeError('bench self-check failed: counts %r status %r' % (out['counts'].sum(axis=1), out['status']))
+        if world == 1 and not a.no_cpu:
+            cores = os.cpu_count() or 1
+            n = a.cpu_slabs or max(8, min(32, 2 * min(cores, 32)))
+            n = min(n, B) if n <= B else n
+            qh = plan.download_q()
+            if n > B:
+                qh = np.concatenate([qh] * (-(-n // B)))[:n]
+            else:
+                qh = qh[:n]
+            line['cpu_baseline'] = cpu_baseline(qh)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -207,6 +207,10 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
  * Enable with xc_set_kernel_timing(ctx, 1); xc_last_hist_ms waits for the launch.     */
 int xc_set_kernel_timing(xc_ctx* ctx, int enable);
 int xc_last_hist_ms(xc_ctx* ctx, float* out_ms);
+/* One-shot: record the caller's events (from xc_event_create) immediately before and after
+ * the NEXT histogram launch instead of the context's own pair -- lets a benchmark time every
+ * launch of a timed region without synchronising inside it.                              */
+int xc_set_hist_events(xc_ctx* ctx, void* start_event, void* stop_event);
 
 /* ------------------------------------------------------------------ synthetic slabs (bench / tests)
  * PV-like tracer q = sin(phi) + 0.25 sum_k a_k cos(k lambda + theta_k) cos^2(phi) + 0.02 eps

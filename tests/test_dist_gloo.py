@@ -1,0 +1,69 @@
+"""The N > 1 path on CPU: world_size-2 (and 3, ragged) gloo process groups run the slab
+sharding + the single end-of-job gather and must reproduce the 1-rank result bit for bit
+(slabs are independent)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _slab_result(s, N=11):
+    """stand-in for one slab's 9 result vectors: a deterministic function of the slab id only"""
+    rng = np.random.default_rng(1000 + s)
+    return rng.standard_normal((9, N))
+
+
+def _process(lo, hi):
+    return np.stack([_slab_result(s) for s in range(lo, hi)]) if hi > lo else np.empty((0, 9, 11))
+
+
+def _worker(rank, world, port, nslab, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from xcontour_amd.distributed import run_sharded
+    out = run_sharded(_process, nslab, rank, world)
+    dist.barrier()
+    q.put((rank, out.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('world,nslab', [(2, 8), (2, 7), (3, 5), (2, 1)])
+def test_sharded_gather_equals_single_rank(world, nslab):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nslab, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _process(0, nslab)
+    for r in range(world):
+        assert got[r].shape == ref.shape
+        assert np.array_equal(got[r], ref)          # every rank holds all slabs, in slab order
+
+
+def test_single_rank_passthrough():
+    sys.path.insert(0, ROOT)
+    from xcontour_amd.distributed import all_gather_slabs
+    t = torch.arange(12.).reshape(4, 3)
+    assert torch.equal(all_gather_slabs(t, 4, 0, 1), t)

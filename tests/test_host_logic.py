@@ -1,0 +1,135 @@
+"""Host-side logic that needs no GPU: labelled arrays, edge construction, table rules,
+O(N) contour-space algebra of the facade against the oracle, slab sharding."""
+import numpy as np
+import pytest
+
+import xcontour_oracle as O
+import xcontour_amd as xa
+from xcontour_amd import core
+from xcontour_amd.utils import table_from_rowsums, cell_area, grad_metrics
+from xcontour_amd.pipeline import shard_slabs
+
+
+def test_public_api_surface():
+    """reference xcontour/__init__.py:2-6 (hot-path subset) + method names of core.py"""
+    for n in ('Contour2D', 'Table', 'equivalent_latitudes', 'latitude_lengths_at'):
+        assert hasattr(xa, n)
+    for m in ('cal_area_eqCoord_table', 'cal_area_eqCoord_table_hist', 'cal_contours', 'cal_contours_at',
+              'cal_contours_at_hist', 'cal_integral_within_contours', 'cal_integral_within_contours_hist',
+              'cal_gradient_wrt_area', 'cal_contour_weigh_mean', 'cal_contour_weigh_mean_hist',
+              'cal_contour_mean', 'cal_contour_mean_hist', 'cal_sqared_equivalent_length',
+              'cal_local_wave_activity', 'cal_local_APE', 'cal_normalized_Keff', 'interp_to_dataset',
+              'interp_to_coords'):
+        assert callable(getattr(xa.Contour2D, m)), m
+    assert callable(xa.Table.lookup_coordinates) and callable(xa.Table.lookup_values)
+
+
+def test_constructor_errors_like_reference():
+    q = xa.DataArray(np.zeros((4, 6)), ('lat', 'lon'), {'lat': np.arange(4.), 'lon': np.arange(6.)}, 'q')
+    with pytest.raises(Exception, match='dimEq should be one dimension'):
+        xa.Contour2D(q, np.ones(4), {'X': 'lon', 'Y': 'lat'}, {'Y': 'lat', 'X': 'lon'})
+    with pytest.raises(Exception, match='dims should be a 2D plane'):
+        xa.Contour2D(q, np.ones(4), {'X': 'lon'}, {'Y': 'lat'})
+    cm = xa.Contour2D(q, np.ones(4), {'X': 'lon', 'Y': 'lat'}, {'Y': 'lat'})
+    assert cm.dimVs == ['lon', 'lat'] and cm.dimEqV == 'lat' and cm.lt is False and cm.dtype == np.float32
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_edges_from_levels_match_oracle(dt):
+    rng = np.random.default_rng(0)
+    for inc in (True, False):
+        b = np.sort(rng.standard_normal((3, 17)).astype(dt), axis=1)
+        if not inc:
+            b = b[:, ::-1]
+        e, binc, closed = core._edges_from_levels(b, 'numpy')
+        assert binc == inc and closed
+        for s in range(3):
+            eo, bo = O.hist_edges(b[s])
+            assert bo == inc and np.array_equal(e[s], eo.astype(np.float64))
+        e2, _, closed2 = core._edges_from_levels(b, 'xhistogram')
+        assert not closed2
+        eo, _ = O.hist_edges(b[0])
+        assert e2[0, -1] == np.float64((eo[-1:] + 1e-8)[0])
+    with pytest.raises(Exception, match='non monotonic bins'):
+        core._edges_from_levels(np.array([[0., 1., 1., 2.]]), 'numpy')
+
+
+def test_table_from_rowsums_matches_histogram_semantics():
+    rng = np.random.default_rng(2)
+    J, nx = 9, 4
+    dA = rng.random((J, nx)) + 0.1
+    coord = np.linspace(-80, 80, J)
+    for ylt in (True, False):
+        # oracle with increase=True on an increasing coordinate: ylt == lt
+        tbl, _ = O.cal_area_eqCoord_table_hist(np.ones((J, nx)), dA, coord, True, ylt)
+        assert np.allclose(table_from_rowsums(dA.sum(1), ylt), tbl, rtol=1e-14, atol=0)
+
+
+def test_contour_space_algebra_matches_oracle(baro):
+    """cal_gradient_wrt_area / Leq2 / nkeff / lookup / interp are host numpy in both"""
+    g = np.load(__import__('os').path.join(__import__('os').path.dirname(__file__), 'golden', 'baro_keff_N121.npz'))
+    q, lat, lon = baro
+    tr = xa.DataArray(q, ('latitude', 'longitude'), {'latitude': lat, 'longitude': lon}, 'absolute_vorticity')
+    cm = xa.Contour2D(tr, cell_area(lat, lon), {'X': 'longitude', 'Y': 'latitude'}, {'Y': 'latitude'}, increase=True, lt=True)
+    k = np.linspace(0, 120, 121, dtype=np.float32)
+    mk = lambda v, n: xa.DataArray(v, ('contour',), {'contour': k}, n)
+    ctr, area, S = mk(g['ctr'], 'absolute_vorticity'), mk(g['area'], 'intArea'), mk(g['intgrdS'], 'intgrdS')
+    tbl = xa.Table(xa.DataArray(g['tbl'], ('latitude',), {'latitude': g['tbl_coord']}, 'AeqCTbl'), 'latitude')
+    latEq = tbl.lookup_coordinates(area)
+    assert np.array_equal(latEq.values, g['latEq']) and latEq.dims == ('contour',)
+    dqdA = cm.cal_gradient_wrt_area(ctr, area)
+    dS = cm.cal_gradient_wrt_area(S, area)
+    assert dqdA.name == 'dabsolute_vorticitydA' and dS.name == 'dintgrdSdA'
+    assert np.array_equal(dqdA.values, g['dqdA']) and np.array_equal(dS.values, g['dintSdA'])
+    Leq2 = cm.cal_sqared_equivalent_length(dS, dqdA)
+    Lmin = xa.latitude_lengths_at(latEq)
+    nk = cm.cal_normalized_Keff(Leq2, Lmin)
+    assert np.array_equal(Leq2.values, g['Leq2']) and np.array_equal(Lmin.values, g['Lmin'])
+    assert np.array_equal(nk.values, g['nkeff'], equal_nan=True) and nk.name == 'nkeff'
+    ds = cm.interp_to_dataset(lat, latEq.rename('latEq'), [ctr, area, nk])
+    assert np.array_equal(ds['absolute_vorticity'].values, g['ctr_eq'])
+    assert np.array_equal(ds['nkeff'].values, g['nkeff_eq'], equal_nan=True)
+    assert ds['intArea'].dims == ('new',)
+    # lookup_values: the inverse direction (restated; the snapshot's attribute is undefined)
+    v = tbl.lookup_values(np.array([-30., 0., 45.]))
+    assert np.allclose(v, np.interp([-30., 0., 45.], g['tbl_coord'], g['tbl']))
+    # decreasing tables reverse (core.py:1428-1430)
+    t2 = xa.Table(xa.DataArray(g['tbl'][::-1].copy(), ('latitude',), {'latitude': g['tbl_coord']}, 'AeqCTbl'), 'latitude')
+    assert np.array_equal(t2.lookup_coordinates(area).values, O.lookup_coordinates(g['area'], g['tbl'][::-1], g['tbl_coord']))
+    # equivalent_latitudes (utils.py:491-515)
+    assert np.array_equal(xa.equivalent_latitudes(g['area']), O.equivalent_latitudes(g['area']))
+
+
+def test_table_direction_check():
+    t = xa.DataArray(np.array([[0., 1., 2.], [2., 1., 0.]]), ('time', 'lat'), {'lat': np.arange(3.)}, 'AeqCTbl')
+    with pytest.raises(Exception, match='not every time or level is increasing/decreasing'):
+        xa.Table(t, 'lat')
+
+
+def test_labeled_array_basics():
+    a = xa.DataArray(np.arange(24.).reshape(2, 3, 4), ('time', 'lat', 'lon'),
+                     {'time': np.arange(2), 'lat': np.arange(3.), 'lon': np.arange(4.)}, 'x')
+    assert a.rename('y').name == 'y' and a.rename({'lat': 'Y'}).dims == ('time', 'Y', 'lon')
+    assert a.isel({'time': 1}).shape == (3, 4) and a['lat'].values.tolist() == [0., 1., 2.]
+    assert a.transpose('lon', 'lat', 'time').shape == (4, 3, 2)
+    assert a.isel({'lat': slice(None, None, -1)}).coords['lat'].tolist() == [2., 1., 0.]
+    assert xa.DataArray(np.zeros((1, 3)), ('a', 'b')).squeeze().dims == ('b',)
+
+
+def test_shard_slabs_partition():
+    for S in (1, 7, 8, 18944, 37):
+        for G in (1, 2, 4, 8):
+            parts = [shard_slabs(S, r, G) for r in range(G)]
+            flat = [i for lo, hi in parts for i in range(lo, hi)]
+            assert flat == list(range(S))                       # contiguous, disjoint, complete
+            assert max(hi - lo for lo, hi in parts) == -(-S // G)
+
+
+def test_metrics_helpers():
+    lat = np.linspace(-90, 90, 181); lon = np.arange(360.)
+    dA = cell_area(lat, lon)
+    assert abs(dA.sum() / (4 * np.pi * xa.Rearth ** 2) - 1) < 1e-13
+    assert np.array_equal(dA, O.cell_area(lat, lon))
+    rdx, rdy = grad_metrics(lat, lon)
+    ox, oy = O.grad_metrics(lat, lon)
+    assert np.array_equal(rdx, ox) and np.array_equal(rdy, oy)

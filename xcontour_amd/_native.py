@@ -94,6 +94,7 @@ PROTOTYPES = {
     'xc_keff_dev': (C.c_int, [_vp, C.POINTER(KeffDesc)]),
     'xc_set_kernel_timing': (C.c_int, [_vp, C.c_int]),
     'xc_last_hist_ms': (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    'xc_set_hist_events': (C.c_int, [_vp, _vp, _vp]),
     'xc_synth_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _u64, C.c_int]),
 }
 
@@ -242,6 +243,9 @@ class Context(object):
 
     def set_kernel_timing(self, on):
         self._check(self.lib.xc_set_kernel_timing(self.handle, 1 if on else 0))
+
+    def set_hist_events(self, e0, e1):
+        self._check(self.lib.xc_set_hist_events(self.handle, e0, e1))
 
     def last_hist_ms(self):
         ms = C.c_float()

@@ -243,6 +243,31 @@ int xc_set_kernel_timing(xc_ctx* ctx, int enable)
     return XC_OK;
 }
 
+int xc_set_hist_events(xc_ctx* ctx, void* start_event, void* stop_event)
+{
+    if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
+    ctx->user_ev0 = (hipEvent_t)start_event; ctx->user_ev1 = (hipEvent_t)stop_event;
+    return XC_OK;
+}
+
+static int hist_ev_begin(xc_ctx* ctx)
+{
+    if (ctx->user_ev0) XC_HIP(ctx, hipEventRecord(ctx->user_ev0, ctx->stream));
+    else if (ctx->timing) XC_HIP(ctx, hipEventRecord(ctx->ev_hist0, ctx->stream));
+    return XC_OK;
+}
+
+static int hist_ev_end(xc_ctx* ctx)
+{
+    if (ctx->user_ev0) {
+        if (ctx->user_ev1) XC_HIP(ctx, hipEventRecord(ctx->user_ev1, ctx->stream));
+        ctx->user_ev0 = ctx->user_ev1 = nullptr;
+    } else if (ctx->timing) {
+        XC_HIP(ctx, hipEventRecord(ctx->ev_hist1, ctx->stream)); ctx->ev_valid = 1;
+    }
+    return XC_OK;
+}
+
 int xc_last_hist_ms(xc_ctx* ctx, float* out_ms)
 {
     XC_CTX(ctx);
@@ -345,9 +370,9 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
     a.part_h = (double*)ctx->scratch; a.part_c = (unsigned*)((char*)ctx->scratch + ph);
-    if (ctx->timing) XC_HIP(ctx, hipEventRecord(ctx->ev_hist0, ctx->stream));
+    XC_TRY(hist_ev_begin(ctx));
     XC_TRY(launch_hist(ctx, d->q_dtype, d->nint, d->grad, g, d->nslab, a));
-    if (ctx->timing) { XC_HIP(ctx, hipEventRecord(ctx->ev_hist1, ctx->stream)); ctx->ev_valid = 1; }
+    XC_TRY(hist_ev_end(ctx));
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = a.part_h; f.part_c = a.part_c; f.bps = g.bps; f.nch = nch; f.nbin = nbin;
     f.red_h = (double*)((char*)ctx->scratch + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + ph + pc + rh);
@@ -534,9 +559,9 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
     a.part_h = part_h; a.part_c = part_c; a.ctr_out = d->ctr; a.status = d->status;
-    if (ctx->timing) XC_HIP(ctx, hipEventRecord(ctx->ev_hist0, ctx->stream));
+    XC_TRY(hist_ev_begin(ctx));
     XC_TRY(launch_hist(ctx, d->q_dtype, d->grad ? 0 : 1, d->grad, g, d->nslab, a));
-    if (ctx->timing) { XC_HIP(ctx, hipEventRecord(ctx->ev_hist1, ctx->stream)); ctx->ev_valid = 1; }
+    XC_TRY(hist_ev_end(ctx));
 
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = part_h; f.part_c = part_c; f.bps = g.bps; f.nch = nch; f.nbin = N;

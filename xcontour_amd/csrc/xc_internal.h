@@ -22,6 +22,7 @@ struct xc_ctx {
     int timing = 0;
     hipEvent_t ev_hist0 = nullptr, ev_hist1 = nullptr;
     int ev_valid = 0;
+    hipEvent_t user_ev0 = nullptr, user_ev1 = nullptr;     // one-shot caller events around the next K3 launch
 };
 
 namespace xc {

@@ -37,11 +37,14 @@ class KeffPlan(object):
                  dA=None, lat=None, lon=None, rdx=None, rdy=None, periodic_x=True,
                  tbl=None, tbl_coord=None, preY=None, increase=True, lt=True,
                  right_edge='numpy', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
-                 prod_f32=False, alloc_q=True):
+                 prod_f32=False, alloc_q=True, nslots=1, out_ptr=None):
         """dA: None | (ny,) | (ny,nx) f64.  Gradient metrics either `rdx, rdy`
         (per-row reciprocals) or derived from `lat, lon` (sphere).  If
         `grdS_dtype` is given the squared gradient is an INPUT (set with
-        `set_grdS`) instead of being computed in-kernel."""
+        `set_grdS`) instead of being computed in-kernel.
+        `nslots`: number of result slots (`run(slot=k)` writes slot k, so a long job keeps
+        every step's vectors on the device until one gather at the end); `out_ptr`: use a
+        caller-owned device allocation of `out_bytes(…) * nslots` bytes for them."""
         self.ctx = ctx
         self.nslab, self.ny, self.nx, self.N = int(nslab), int(ny), int(nx), int(N)
         self.q_dtype, self.ctr_dtype = np.dtype(q_dtype), np.dtype(ctr_dtype)
@@ -51,7 +54,8 @@ class KeffPlan(object):
         self.desc = d
         cells = self.nslab * self.ny * self.nx
         self.q_buf = ctx.alloc(cells * self.q_dtype.itemsize) if alloc_q else None
-        d.q = self.q_buf.ptr if alloc_q else None
+        self._q_ptr = self.q_buf.ptr if alloc_q else 0
+        d.q = self._q_ptr if alloc_q else None
         d.q_dtype, d.ctr_dtype = nat.dtype_code(self.q_dtype), nat.dtype_code(self.ctr_dtype)
         d.nslab, d.ny, d.nx, d.N = self.nslab, self.ny, self.nx, self.N
         d.increase, d.lt = int(bool(increase)), int(bool(lt))
@@ -103,12 +107,35 @@ class KeffPlan(object):
         off += self.nslab * 9 * self.npre * 8
         self._off['status'] = off
         off += self.nslab * 4
-        self.out_buf = ctx.alloc(off)
+        self.slot_bytes = (off + 255) & ~255
+        self.nslots = int(nslots)
+        if out_ptr is None:
+            self.out_buf = ctx.alloc(self.slot_bytes * self.nslots)
+            self.out_ptr = self.out_buf.ptr
+        else:
+            self.out_buf = None
+            self.out_ptr = int(out_ptr)
+        self._point(0, 0, self.nslab)
+
+    @staticmethod
+    def out_bytes(nslab, N, npre=0):
+        """bytes of one result slot (so that a caller can own the allocation)"""
+        off = 9 * nslab * N * 8 + nslab * N * 8 + nslab * 9 * npre * 8 + nslab * 4
+        return (off + 255) & ~255
+
+    def _point(self, slot, s0, n):
+        """aim the descriptor at slabs [s0, s0+n) and result slot `slot`"""
+        d = self.desc
+        base = self.out_ptr + slot * self.slot_bytes
         for name in OUT_NAMES:
-            setattr(d, name, self.out_buf.ptr + self._off[name])
-        d.counts = self.out_buf.ptr + self._off['counts']
-        d.interp = (self.out_buf.ptr + self._off['interp']) if self.npre else None
-        d.status = self.out_buf.ptr + self._off['status']
+            setattr(d, name, base + self._off[name] + s0 * self.N * 8)
+        d.counts = base + self._off['counts'] + s0 * self.N * 8
+        d.interp = (base + self._off['interp'] + s0 * 9 * self.npre * 8) if self.npre else None
+        d.status = base + self._off['status'] + s0 * 4
+        d.nslab = n
+        d.q = self._q_ptr + s0 * self.ny * self.nx * self.q_dtype.itemsize
+        if self.grdS_buf is not None:
+            d.grdS = self.grdS_buf.ptr + s0 * self.ny * self.nx * self.grdS_dtype.itemsize
 
     # -- inputs
     def set_q(self, q):
@@ -117,7 +144,8 @@ class KeffPlan(object):
 
     def set_q_device(self, ptr):
         """Use an existing device pointer ([nslab][ny][nx], q_dtype) as the tracer."""
-        self.desc.q = ptr
+        self._q_ptr = int(ptr)
+        self.desc.q = self._q_ptr
 
     def set_grdS(self, g):
         g = np.ascontiguousarray(g, dtype=self.grdS_dtype).reshape(self.nslab, self.ny, self.nx)
@@ -127,7 +155,7 @@ class KeffPlan(object):
         """Fill the tracer batch on device with the bench's synthetic PV-like slabs."""
         lat_b = self.ctx.to_device(np.asarray(lat, dtype=np.float64))
         lon_b = self.ctx.to_device(np.asarray(lon, dtype=np.float64))
-        self.ctx._check(self.ctx.lib.xc_synth_dev(self.ctx.handle, self.desc.q, self.desc.q_dtype,
+        self.ctx._check(self.ctx.lib.xc_synth_dev(self.ctx.handle, self._q_ptr, self.desc.q_dtype,
                                                   self.nslab, self.ny, self.nx, lat_b.ptr, lon_b.ptr,
                                                   int(seed), int(variant)))
         self.ctx.sync()
@@ -135,22 +163,35 @@ class KeffPlan(object):
         lon_b.free()
 
     # -- compute
-    def run(self):
-        """Enqueue min/max -> histogram -> finalize+epilogue on the context's stream."""
-        self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
+    def run(self, slot=0, group=None):
+        """Enqueue min/max -> histogram -> finalize+epilogue on the context's stream for all
+        slabs of the batch, `group` slabs per launch set (None: the whole batch at once;
+        small groups keep a slab's second read inside the 256 MiB Infinity Cache)."""
+        g = self.nslab if not group else int(group)
+        for s0 in range(0, self.nslab, g):
+            self._point(slot, s0, min(g, self.nslab - s0))
+            self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
 
-    def fetch(self, check=True):
-        self.ctx.sync()
+    def unpack(self, raw):
+        """one result slot (bytes as a uint8 ndarray) -> dict of arrays"""
         S, N = self.nslab, self.N
         out = {}
         for name in OUT_NAMES:
-            out[name] = self.out_buf.download((S, N), np.float64, self._off[name])
-        out['counts'] = self.out_buf.download((S, N), np.uint64, self._off['counts'])
+            out[name] = raw[self._off[name]:self._off[name] + S * N * 8].view(np.float64).reshape(S, N)
+        out['counts'] = raw[self._off['counts']:self._off['counts'] + S * N * 8].view(np.uint64).reshape(S, N)
         if self.npre:
-            it = self.out_buf.download((S, 9, self.npre), np.float64, self._off['interp'])
+            it = raw[self._off['interp']:self._off['interp'] + S * 9 * self.npre * 8].view(np.float64).reshape(S, 9, self.npre)
             for i, name in enumerate(INTERP_ORDER):
                 out[name + '_eq'] = it[:, i, :]
-        out['status'] = self.out_buf.download((S,), np.int32, self._off['status'])
+        out['status'] = raw[self._off['status']:self._off['status'] + S * 4].view(np.int32)
+        return out
+
+    def fetch(self, check=True, slot=0):
+        self.ctx.sync()
+        raw = np.empty(self.slot_bytes, dtype=np.uint8)
+        self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, raw.ctypes.data,
+                                                   self.out_ptr + slot * self.slot_bytes, self.slot_bytes))
+        out = self.unpack(raw)
         if check and out['status'].any():
             raise Exception('non monotonic bins')          # reference core.py:1233-1251
         return out
