@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libxcontour_hip.so')
+LIB_PATH = os.environ.get('XC_LIB_PATH') or os.path.join(_HERE, 'libxcontour_hip.so')   # XC_LIB_PATH: diagnostic builds only
 
 XC_OK, XC_EBADARG, XC_EEDGES, XC_EHIP, XC_ENOMEM, XC_ENODEV = 0, -1, -2, -3, -4, -5
 XC_F32, XC_F64 = 0, 1

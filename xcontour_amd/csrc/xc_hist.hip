@@ -22,6 +22,7 @@
 //     histogram copies.  Per-block partials are written with plain stores and
 //     reduced in fixed order by k_finalize: no global atomics.
 #include "xc_internal.h"
+#include <stdlib.h>
 
 namespace xc {
 
@@ -118,6 +119,28 @@ __device__ __forceinline__ void lds_add(unsigned* p, unsigned v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+
+// ---- cross-lane moves that stay off the LDS pipe (the LDS is the busiest unit of this kernel)
+__device__ __forceinline__ double lane_bcast(double v, int srclane)          // v_readlane_b32 x2
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), srclane);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), srclane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+template <int CTRL>                                                           // DPP wave_shr:1 / wave_shl:1
+__device__ __forceinline__ double lane_shift(double v)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), CTRL, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// copy slot of a lane.  (Rotating the slot by the bin index to spread LDS banks was measured
+// 10 % SLOWER on MI355X -- profiles/r01_notes.md -- so the slot is simply lane % ncopy.)
+#define XC_ROT(copy, k, ncopy) (copy)
+constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i <- lane i+1
+constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1
 
 template <int VEC, int NINT>
 struct RowBuf {
@@ -312,7 +335,11 @@ void k_hist(const HistArgs a)
         double w[NCH][VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
+#ifdef XC_EXP_NOBIN
+            const int kb = (qc[c] == 12345.678) ? 1 : 0;        // experiment: no bin search
+#else
             const int kb = find_bin(negate ? -qc[c] : qc[c], s_edges, N, e0, eN, inv, last_closed);
+#endif
             k[c] = active ? kb : -1;
             const double dv = dAv[c];
             w[0][c] = (dv != dv) ? 0.0 : dv;                                  // fillna(0), core.py:449
@@ -323,11 +350,19 @@ void k_hist(const HistArgs a)
                 w[1 + i][c] = (p != p) ? 0.0 : p;
             }
         }
+#ifdef XC_EXP_NOGRAD
         if (GRAD) {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) w[NCH - 1][c] = qN[c] + qS[c] + hc;      // experiment: keep the loads alive
+        }
+        if (false) {
+#else
+        if (GRAD) {
+#endif
             const double rdx = rdxp[y], rdy = rdyp[y];
-            const double hl = __shfl(hc, 0), hr = __shfl(hc, 63);
-            const double fromL = __shfl_up(qc[VEC - 1], 1);                  // lane-1's last cell
-            const double fromR = __shfl_down(qc[0], 1);                      // lane+1's first cell
+            const double hl = lane_bcast(hc, 0), hr = lane_bcast(hc, 63);
+            const double fromL = lane_shift<DPP_WAVE_SHR1>(qc[VEC - 1]);     // lane-1's last cell
+            const double fromR = lane_shift<DPP_WAVE_SHL1>(qc[0]);           // lane+1's first cell
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
                 const double qW = (c == 0) ? (lane == 0 ? hl : fromL) : qc[c > 0 ? c - 1 : 0];
@@ -358,7 +393,7 @@ void k_hist(const HistArgs a)
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
                 if (k[c] >= 0) {
-                    const int o = k[c] * ncopy + copy;
+                    const int o = k[c] * ncopy + XC_ROT(copy, k[c], ncopy);
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) lds_add(&s_h[ch * hsz + o], w[ch][c]);
                     lds_add(&s_c[o], 1u);
@@ -454,7 +489,7 @@ int launch_two(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
         attr_set = true;
     }
     dim3 grid((unsigned)g.bps, (unsigned)nslab);
-    hipLaunchKernelGGL(kern, grid, dim3(kHistThreads), g.lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds, ctx->stream, a);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
 }
@@ -504,8 +539,16 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     const int W = 64 * g->vec;
     g->nstrip = (int)((nx + W - 1) / W);
     g->nch = nch;
+    // experiment knobs (environment, read once): XC_HIST_THREADS, XC_HIST_NCOPY, XC_HIST_ROWS
+    static int env_threads = -1, env_ncopy = -1, env_rows = -1;
+    if (env_threads < 0) {
+        const char* e = getenv("XC_HIST_THREADS"); env_threads = e ? atoi(e) : 0;
+        e = getenv("XC_HIST_NCOPY"); env_ncopy = e ? atoi(e) : 0;
+        e = getenv("XC_HIST_ROWS"); env_rows = e ? atoi(e) : 0;
+    }
+    g->threads = (env_threads >= 64 && env_threads <= kHistThreads && env_threads % 64 == 0) ? env_threads : kHistThreads;
     // largest power-of-two copy count that fits the LDS budget
-    int ncopy = kMaxCopies;
+    int ncopy = (env_ncopy >= 1 && env_ncopy <= kMaxCopies && (env_ncopy & (env_ncopy - 1)) == 0) ? env_ncopy : kMaxCopies;
     const size_t fixed = (64 + ((nbin + 2) & ~1)) * sizeof(double);
     while (ncopy > 1 && fixed + (size_t)nbin * ncopy * (nch * 8 + 4) > kLdsBudget) ncopy >>= 1;
     if (fixed + (size_t)nbin * ncopy * (nch * 8 + 4) > kLdsBudget)
@@ -515,9 +558,10 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     g->lds = (g->lds + 15) & ~(size_t)15;
     // blocks per slab: ~12 (strip,row) pairs per wave when few slabs, ~32 when many
     const int64_t total = (int64_t)g->nstrip * ny;
-    const int waves = kHistThreads / 64;
+    const int waves = g->threads / 64;
     const int cus = ctx->cus > 0 ? ctx->cus : 256;
-    int64_t bps = (total + waves * 32 - 1) / (waves * 32);
+    const int rows = env_rows > 0 ? env_rows : 64;     // (strip,row) pairs per wave when slabs are plentiful
+    int64_t bps = (total + waves * rows - 1) / (waves * rows);
     if (bps * nslab < cus) bps = (cus + nslab - 1) / nslab;
     const int64_t maxb = (total + waves - 1) / waves;      // at least one pair per wave
     if (bps > maxb) bps = maxb;

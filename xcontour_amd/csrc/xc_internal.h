@@ -48,6 +48,7 @@ constexpr int kMaxCopies    = 16;     // lane-privatised LDS histogram copies
 constexpr size_t kLdsBudget = 150 * 1024;
 
 struct HistGeom {
+    int threads;    // threads per block (multiple of 64, <= kHistThreads)
     int vec;        // cells per lane per row load (1 or 2)
     int nstrip;     // column strips of 64*vec cells
     int bps;        // blocks per slab
