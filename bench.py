@@ -92,6 +92,9 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='slabs per step per GPU')
     ap.add_argument('--group', type=int, default=0, help='slabs per launch set (0: whole batch)')
     ap.add_argument('--variant', type=int, default=0, help='0 PV-like, 1 noise, 2 sin(lat)')
+    ap.add_argument('--no-chain', action='store_true',
+                    help='run the stand-alone min/max pass every step instead of folding the next '
+                         "step's min/max into the histogram pass")
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-slabs', type=int, default=0, help='CPU sample size (0: auto)')
     a = ap.parse_args()
@@ -132,10 +135,11 @@ def main():
                     tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.data_ptr())
     plan.synth(lat, lon, SEED + rank * B, a.variant)              # slab s of rank r: seed + r*B + s
     group = a.group or None
+    chain = not a.no_chain
 
     plan.out_ptr = wres.data_ptr()
     for _ in range(W):
-        plan.run(0, group)
+        plan.run(0, group, chain)
     plan.out_ptr = res.data_ptr()
     ctx.sync()
     torch.cuda.synchronize()
@@ -149,7 +153,7 @@ def main():
     for k in range(K):
         if group is None:
             ctx.set_hist_events(ev[k][0], ev[k][1])               # events around the K3 launch only
-        plan.run(k, group)
+        plan.run(k, group, chain)
     ctx.sync()                                                    # the library's own HIP stream
     if world > 1:
         dist.all_gather_into_tensor(gathered, res)                # the one RCCL collective
@@ -174,6 +178,7 @@ def main():
                                    'full Keff (min/max + histogram with in-kernel |grad q|^2 + CDF + epilogue)'
                                    % (NX, NY, NCONT),
                        'slabs_per_step_per_gpu': B, 'slabs_per_launch': a.group or B, 'variant': a.variant,
+                       'minmax': 'folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass',
                        'parallelism': 'independent slabs per GPU, one RCCL all-gather at the end' if world > 1 else 'single GPU',
                        'device': ctx.device_name()},
         }
@@ -190,7 +195,7 @@ def main():
                     traffic = None
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                                'kernel': 'k_hist<double,2,0,true,true>', 'launch_ms': float(ms.mean()),
+                                'kernel': 'k_hist<double,2,0,true,true,%s>' % ('true' if chain else 'false'), 'launch_ms': float(ms.mean()),
                                 'algorithmic_bytes_per_launch': alg,
                                 'pipeline_frac': world and (B * NY * NX * BYTES_PER_CELL * K / el / 1e9 / world) / HBM_PEAK_GBS}
         # parity spot check of the last step against nothing heavy: invariants only (oracle runs in cpu leg)

@@ -199,6 +199,11 @@ typedef struct xc_keff_desc {
     uint64_t*     counts;       /* uint64[nslab][N] */
     double*       interp;       /* double[nslab][9][npre]: ctr, area, intgrdS, latEq, dintSdA, dqdA, Leq2, Lmin, nkeff on preY */
     int32_t*      status;       /* int32[nslab] 0 ok, 1 degenerate levels */
+    const void*   q_next;       /* optional: the batch the NEXT xc_keff_dev call will process (same dtype and
+                                   shape, may equal q).  Its per-slab min/max partials are accumulated inside this
+                                   call's histogram pass (+8 B/cell of loads, no extra kernel) and the next call on
+                                   that pointer skips its K1 pass.  The caller promises not to modify that batch in
+                                   between.  NULL: off. */
 } xc_keff_desc;
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
 

@@ -403,3 +403,33 @@ def test_cfg2_full_size_properties(ctx):
     assert np.array_equal(out['counts'], out2['counts'])
     assert rel(out2['area'], out['area']) < 1e-13
     plan.free()
+
+
+def test_chained_minmax_is_bit_identical(ctx):
+    """xc_keff_desc.q_next: min/max of the next launch set accumulated inside the histogram pass"""
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums
+    ny, nx, N, S = 181, 360, 101, 6
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 1.0
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(dA.sum(1), True)
+    plan = KeffPlan(ctx, S, ny, nx, N, np.float64, np.float32, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                    increase=True, lt=True, nslots=4)
+    plan.synth(lat, lon, 5, 0)
+    plan.run(0)                          # stand-alone K1
+    ref = plan.fetch(slot=0)
+    for group in (None, 2, 3):
+        plan.run(1, group, chain=True)   # first sets use K1, later ones the chained partials
+        plan.run(2, group, chain=True)   # every set now runs on partials produced by a histogram pass
+        for slot in (1, 2):
+            out = plan.fetch(slot=slot)
+            assert np.array_equal(out['ctr'], ref['ctr'])
+            assert np.array_equal(out['counts'], ref['counts'])
+            assert rel(out['area'], ref['area']) < 1e-13
+    # a different batch behind the same pointer without chaining must not reuse anything
+    plan.synth(lat, lon, 99, 0)
+    plan.run(3)
+    out = plan.fetch(slot=3)
+    q = plan.download_q()
+    assert np.array_equal(out['ctr'][0], O.cal_contours(q[0], N, True, np.float32).astype(np.float64))
+    plan.free()

@@ -54,7 +54,7 @@ class KeffDesc(C.Structure):
         ('nkeff_mask', _f64), ('lmin_scale', _f64),
         ('ctr', _vp), ('area', _vp), ('intgrdS', _vp), ('latEq', _vp),
         ('dqdA', _vp), ('dintSdA', _vp), ('Leq2', _vp), ('Lmin', _vp), ('nkeff', _vp),
-        ('counts', _vp), ('interp', _vp), ('status', _vp),
+        ('counts', _vp), ('interp', _vp), ('status', _vp), ('q_next', _vp),
     ]
 
 

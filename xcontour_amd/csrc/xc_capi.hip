@@ -133,6 +133,7 @@ int xc_destroy(xc_ctx* ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->ones) (void)hipFree(ctx->ones);
+    for (int i = 0; i < 2; ++i) if (ctx->mmnext[i]) (void)hipFree(ctx->mmnext[i]);
     if (ctx->ev_hist0) (void)hipEventDestroy(ctx->ev_hist0);
     if (ctx->ev_hist1) (void)hipEventDestroy(ctx->ev_hist1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -544,14 +545,29 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     double* mmpart = (double*)ctx->scratch;
     double* part_h = (double*)((char*)ctx->scratch + mb);
     unsigned* part_c = (unsigned*)((char*)ctx->scratch + mb + ph);
+    int mmP = kMinmaxBlocks;
 
-    XC_TRY(launch_minmax_partial(ctx, d->q, d->q_dtype, d->nslab, d->ny * d->nx, mmpart));
+    // min/max partials: either produced by the previous call's histogram pass (q_next) or by K1 now
+    if (ctx->mm_valid && ctx->mm_q == d->q && ctx->mm_nslab == d->nslab && ctx->mm_ny == d->ny &&
+        ctx->mm_nx == d->nx && ctx->mm_dtype == d->q_dtype) {
+        mmpart = ctx->mmnext[ctx->mm_cur]; mmP = ctx->mm_P;
+    } else {
+        XC_TRY(launch_minmax_partial(ctx, d->q, d->q_dtype, d->nslab, d->ny * d->nx, mmpart));
+    }
+    ctx->mm_valid = 0;
+    double* mm_next = nullptr;
+    if (d->q_next) {
+        const int nb = 1 - ctx->mm_cur;
+        XC_TRY(grow(ctx, (void**)&ctx->mmnext[nb], &ctx->mmnext_bytes[nb], al((size_t)d->nslab * g.bps * 2 * sizeof(double))));
+        mm_next = ctx->mmnext[nb];
+    }
 
     HistArgs a; memset(&a, 0, sizeof(a));
     a.q = d->q; a.dA = d->dA; a.dA_rank = d->dA_rank;
     if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); a.dA = ctx->ones; a.dA_rank = XC_DA_ROW; }
     if (!d->grad) { a.integ[0] = d->grdS; a.integ_f32[0] = d->grdS_dtype == XC_F32; }
-    a.mmpart = mmpart; a.P = kMinmaxBlocks; a.levels_mode = 1; a.nbin = N;
+    a.q_next = d->q_next; a.mm_next = mm_next;
+    a.mmpart = mmpart; a.P = mmP; a.levels_mode = 1; a.nbin = N;
     a.last_closed = d->right_edge == XC_EDGE_NUMPY;
     a.increase = d->increase; a.q_f32 = d->q_dtype == XC_F32; a.ctr_f32 = d->ctr_dtype == XC_F32;
     a.right_edge = d->right_edge; a.inv_nm1 = 1.0 / (double)(N - 1);
@@ -562,6 +578,10 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     XC_TRY(hist_ev_begin(ctx));
     XC_TRY(launch_hist(ctx, d->q_dtype, d->grad ? 0 : 1, d->grad, g, d->nslab, a));
     XC_TRY(hist_ev_end(ctx));
+    if (d->q_next) {
+        ctx->mm_cur = 1 - ctx->mm_cur; ctx->mm_valid = 1; ctx->mm_P = g.bps; ctx->mm_q = d->q_next;
+        ctx->mm_nslab = d->nslab; ctx->mm_ny = d->ny; ctx->mm_nx = d->nx; ctx->mm_dtype = d->q_dtype;
+    }
 
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = part_h; f.part_c = part_c; f.bps = g.bps; f.nch = nch; f.nbin = N;

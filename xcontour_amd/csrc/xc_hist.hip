@@ -89,13 +89,13 @@ __device__ __forceinline__ double bump_last_edge(double e, int ctr_f32)   // xhi
 }
 
 // np.digitize(v, edges) - 1 restricted to [0, N-1]; -1 when the cell is dropped.
-__device__ __forceinline__ int find_bin(double v, const double* __restrict__ s_edges, int N,
-                                        double e0, double eN, double inv, int last_closed)
+// Rare path: the uniform guess missed its bracket (bin boundary rounding, non-uniform user
+// levels), or the value is NaN / out of range / on the closed last edge.
+__device__ __noinline__ int find_bin_slow(double v, const double* __restrict__ s_edges, int N, int k,
+                                          double e0, double eN, int last_closed)
 {
     if (!(v >= e0)) return -1;                       // below range or NaN
     if (last_closed ? !(v <= eN) : !(v < eN)) return -1;
-    int k = (int)((v - e0) * inv);
-    k = k < 0 ? 0 : (k > N - 1 ? N - 1 : k);
     if (v < s_edges[k]) {
         if (v >= s_edges[k - 1]) return k - 1;       // k >= 1 here because v >= e0
         int lo = 0, hi = k - 1;                      // edges[lo] <= v < edges[hi]
@@ -108,7 +108,19 @@ __device__ __forceinline__ int find_bin(double v, const double* __restrict__ s_e
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v >= s_edges[mid]) lo = mid; else hi = mid; }
         return lo > N - 1 ? N - 1 : lo;
     }
-    return k;
+    return k;                                        // v == eN on the closed last edge
+}
+
+// Common path: uniform guess, one bracket test against the explicit edges (2 LDS reads).
+// A bracket hit proves e0 <= e[k] <= v < e[k+1] <= eN, so no separate range / NaN test is needed.
+__device__ __forceinline__ int find_bin(double v, const double* __restrict__ s_edges, int N,
+                                        double e0, double eN, double inv, int last_closed)
+{
+    int k = (int)((v - e0) * inv);                   // NaN -> 0
+    k = k < 0 ? 0 : (k > N - 1 ? N - 1 : k);
+    const double lo = s_edges[k], hi = s_edges[k + 1];
+    if (v >= lo && v < hi) return k;
+    return find_bin_slow(v, s_edges, N, k, e0, eN, last_closed);
 }
 
 __device__ __forceinline__ void lds_add(double* p, double v)
@@ -148,10 +160,12 @@ struct RowBuf {
     double h;               // GRAD: lane 0 = left halo of that row, lane 63 = right halo
     double dA[VEC];
     double in[NINT > 0 ? NINT : 1][VEC];
+    double qn[VEC];         // NEXT: the same cells of the next batch (min/max by-product)
 };
 
 // DA2D: dA is a [ny][nx] plane (vector loads); otherwise one value per row (scalar).
-template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D>
+// NEXT: also stream the same cells of a.q_next and emit its per-block min/max partials.
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT>
 __global__ __launch_bounds__(kHistThreads)
 void k_hist(const HistArgs a)
 {
@@ -182,6 +196,8 @@ void k_hist(const HistArgs a)
 
     const size_t slab_off = (size_t)slab * ny * nx;
     const TQ* __restrict__ qs = reinterpret_cast<const TQ*>(a.q) + slab_off;
+    const TQ* __restrict__ qnx = NEXT ? reinterpret_cast<const TQ*>(a.q_next) + slab_off : nullptr;
+    double nmn = dinf(), nmx = -dinf();
     const double* __restrict__ dAp = (DA2D && a.dA_rank == XC_DA_SLAB) ? a.dA + slab_off : a.dA;
     const double* __restrict__ rdxp = a.rdx;
     const double* __restrict__ rdyp = a.rdy;
@@ -221,6 +237,7 @@ void k_hist(const HistArgs a)
         const TQ* qrow = qs + yq * nx;
         RowLoad<TQ, VEC>::ld(qrow + xld, r.q);
         if (GRAD) r.h = (double)qrow[xh];
+        if (NEXT) RowLoad<TQ, VEC>::ld(qnx + yw * nx + xld, r.qn);
         if (DA2D) {
             RowLoad<double, VEC>::ld(dAp + yw * nx + xld, r.dA);
         } else {
@@ -367,7 +384,8 @@ void k_hist(const HistArgs a)
             for (int c = 0; c < VEC; ++c) {
                 const double qW = (c == 0) ? (lane == 0 ? hl : fromL) : qc[c > 0 ? c - 1 : 0];
                 const double qE = (c == VEC - 1) ? (lane == rlane ? hr : fromR) : qc[c < VEC - 1 ? c + 1 : 0];
-                const double gx = __dmul_rn(__dmul_rn(__dsub_rn(qE, qW), rdx), fx[c]);
+                double gx = __dmul_rn(__dsub_rn(qE, qW), rdx);
+                if (!periodic_x) gx = __dmul_rn(gx, fx[c]);               // wave-uniform branch
                 const double gy = __dmul_rn(__dsub_rn(qN[c], qS[c]), rdy);
                 const double g2 = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
                 const double p = __dmul_rn(g2, dAv[c]);
@@ -407,6 +425,10 @@ void k_hist(const HistArgs a)
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             if (yb + i < y1) {
+                if (NEXT && active) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) { nmn = fmin(nmn, L[i].qn[c]); nmx = fmax(nmx, L[i].qn[c]); }
+                }
                 if (GRAD) {
                     do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in, yb + i);
 #pragma unroll
@@ -445,7 +467,16 @@ void k_hist(const HistArgs a)
     }
     XC_STAMP(3);
     flush();
+    if (NEXT) {
+        for (int o = 32; o > 0; o >>= 1) { nmn = fmin(nmn, __shfl_xor(nmn, o)); nmx = fmax(nmx, __shfl_xor(nmx, o)); }
+        if (lane == 0) { s_red[2 * wave] = nmn; s_red[2 * wave + 1] = nmx; }
+    }
     __syncthreads();
+    if (NEXT && tid == 0) {
+        for (int w = 1; w < nwave; ++w) { nmn = fmin(nmn, s_red[2 * w]); nmx = fmax(nmx, s_red[2 * w + 1]); }
+        double* o = a.mm_next + ((size_t)slab * gridDim.x + blockIdx.x) * 2;
+        o[0] = nmn; o[1] = nmx;
+    }
     XC_STAMP(4);
 
     // ------------------------------------------------------------------ per-block partials (plain stores)
@@ -478,10 +509,10 @@ extern "C" int xc_dbg_set_stamps(unsigned long long* p)
 namespace {
 #endif
 
-template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D>
-int launch_two(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT>
+int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
 {
-    auto kern = k_hist<TQ, VEC, NINT, GRAD, DA2D>;
+    auto kern = k_hist<TQ, VEC, NINT, GRAD, DA2D, NEXT>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         XC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -492,6 +523,18 @@ int launch_two(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
     hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds, ctx->stream, a);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
+}
+
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D>
+int launch_two(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
+{
+    // the NEXT variant exists for the two channel layouts of the Keff pipeline only
+    constexpr bool kHasNext = (NINT == 0 && GRAD) || (NINT == 1 && !GRAD);
+    if (a.q_next) {
+        if constexpr (kHasNext) return launch_three<TQ, VEC, NINT, GRAD, DA2D, true>(ctx, g, nslab, a);
+        else return fail(ctx, XC_EBADARG, "xc_hist: q_next is only supported by the Keff pipeline layouts");
+    }
+    return launch_three<TQ, VEC, NINT, GRAD, DA2D, false>(ctx, g, nslab, a);
 }
 
 template <typename TQ, int VEC, int NINT, bool GRAD>

@@ -23,6 +23,10 @@ struct xc_ctx {
     hipEvent_t ev_hist0 = nullptr, ev_hist1 = nullptr;
     int ev_valid = 0;
     hipEvent_t user_ev0 = nullptr, user_ev1 = nullptr;     // one-shot caller events around the next K3 launch
+    // min/max partials of the NEXT batch, produced inside the K3 pass (xc_keff_desc.q_next)
+    double* mmnext[2] = {nullptr, nullptr};  size_t mmnext_bytes[2] = {0, 0};
+    int mm_cur = 0, mm_valid = 0, mm_P = 0, mm_dtype = 0;
+    const void* mm_q = nullptr;  int64_t mm_nslab = 0, mm_ny = 0, mm_nx = 0;
 };
 
 namespace xc {
@@ -61,6 +65,8 @@ struct HistGeom {
 // ---------------------------------------------------------------- kernel argument blocks
 struct HistArgs {
     const void*   q;
+    const void*   q_next;       // optional next batch (min/max partials by-product)
+    double*       mm_next;      // [nslab][bps][2]
     const double* dA;
     const void*   integ[XC_MAX_INTEGRANDS];
     int           integ_f32[XC_MAX_INTEGRANDS];

@@ -163,13 +163,22 @@ class KeffPlan(object):
         lon_b.free()
 
     # -- compute
-    def run(self, slot=0, group=None):
+    def run(self, slot=0, group=None, chain=False):
         """Enqueue min/max -> histogram -> finalize+epilogue on the context's stream for all
-        slabs of the batch, `group` slabs per launch set (None: the whole batch at once;
-        small groups keep a slab's second read inside the 256 MiB Infinity Cache)."""
+        slabs of the batch, `group` slabs per launch set (None: the whole batch at once).
+        `chain=True`: tell each launch set which slabs come NEXT (the following group, or this
+        batch again on the next call) so that their min/max is accumulated inside this
+        histogram pass and the separate K1 pass disappears (xc_keff_desc.q_next); only valid
+        while the tracer batch is not modified between calls."""
         g = self.nslab if not group else int(group)
-        for s0 in range(0, self.nslab, g):
-            self._point(slot, s0, min(g, self.nslab - s0))
+        starts = list(range(0, self.nslab, g))
+        esz = self.ny * self.nx * self.q_dtype.itemsize
+        for i, s0 in enumerate(starts):
+            n = min(g, self.nslab - s0)
+            self._point(slot, s0, n)
+            nxt = starts[(i + 1) % len(starts)]
+            ok = chain and min(g, self.nslab - nxt) == n          # same shape only
+            self.desc.q_next = (self._q_ptr + nxt * esz) if ok else None
             self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
 
     def unpack(self, raw):
