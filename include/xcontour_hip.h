@@ -174,6 +174,25 @@ int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const doubl
            int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
            const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks);
 
+/* ------------------------------------------------------------------ K8  exact adiabatic rearrangement (radix sort)
+ * No reference call site (the reference "sorts" by histogram CDF + table lookup);
+ * SURVEY 8-a9, pinned by oracle.sorted_profile.  One slab: drop NaN / mask != 1 cells, stable
+ * ascending radix sort of (q, dA) pairs, Acum = cumsum(dA_sorted),
+ *   Q[j] = q_sorted[min(searchsorted(Acum, targets[j], 'right'), nvalid-1)]   (increase, lt case)
+ *   bpe  = sum_i q_sorted[i] * z*(Acum[i] - dA_i/2) * dA_i,  z* = np.interp(., tbl, coord)
+ * negate != 0 sorts -q (decreasing tracers; outputs are values of -q).
+ * mask may be NULL; dA_rank NONE / ROW / PLANE; any of out_Q (double[J]), out_qsorted
+ * (double[ny*nx], invalid cells at the end), out_acum (double[ny*nx]), out_nvalid (uint32),
+ * out_bpe (double, needs tbl/coord) may be NULL.                                        */
+int xc_sort_profile_dev(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype,
+                        const double* dA, int dA_rank, int64_t ny, int64_t nx, int negate,
+                        const double* targets, int J, const double* tbl, const double* coord, int ntbl,
+                        double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
+int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype,
+                    const double* dA, int dA_rank, int64_t ny, int64_t nx, int negate,
+                    const double* targets, int J, const double* tbl, const double* coord, int ntbl,
+                    double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
+
 /* ------------------------------------------------------------------ fused, batched Keff pipeline
  * The reference's call sequence SURVEY 3.1 steps 2-10 for a batch of slabs resident
  * in HBM: min/max -> levels/edges -> one histogram pass (dA, |grad q|^2 dA or grdS dA)

@@ -481,6 +481,18 @@ def sorted_profile(q, dA, tbl_targets, mask=None):
     return xs[idx], xs, acum
 
 
+def bpe_integral(q, dA, tbl, coord, mask=None):
+    """Background-potential-energy-like integral of the exactly sorted state (a9,
+    build-defined): sum_i q_i * z*(A_i - dA_i/2) * dA_i over the sorted cells, with
+    z* = np.interp(A, tbl, coord) (reversed if the table decreases, like _interp1d)."""
+    _, xs, acum = sorted_profile(q, dA, [0.0], mask)
+    ws = np.diff(np.concatenate(([0.0], acum)))
+    tbl = np.asarray(tbl, dtype=np.float64)
+    coord = np.asarray(coord, dtype=np.float64)
+    z = interp1d(acum - 0.5 * ws, tbl, coord, table_increasing(tbl))
+    return float(np.sum(xs * z * ws))
+
+
 # ---------------------------------------------------------------------------
 # The reference's Keff call sequence (SURVEY 3.1; tests/test_Keff_atmos.py:75-92)
 # ---------------------------------------------------------------------------

@@ -433,3 +433,92 @@ def test_chained_minmax_is_bit_identical(ctx):
     q = plan.download_q()
     assert np.array_equal(out['ctr'][0], O.cal_contours(q[0], N, True, np.float32).astype(np.float64))
     plan.free()
+
+
+# ---------------------------------------------------------------- K8 exact adiabatic sort
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_radix_sort_profile_vs_oracle(ctx, baro, dt):
+    q, lat, lon = baro
+    q = q.astype(dt)
+    dA = O.cell_area(lat, lon)
+    tbl, cs = O.cal_area_eqCoord_table_hist(np.ones_like(q), dA, lat, True, True)
+    out = ctx.sort_profile(q, dA=dA, targets=tbl, tbl=tbl, coord=cs, want_sorted=True, want_acum=True)
+    Qo, xs, acum = O.sorted_profile(q, dA, tbl)
+    n = out['nvalid']
+    assert n == q.size
+    assert np.array_equal(out['q_sorted'][:n], xs.astype(np.float64))          # the sort itself: exact
+    assert rel(out['acum'][:n], acum) < 1e-12                                  # parallel scan vs np.cumsum
+    # Q_exact: identical except where a target sits within rounding of an Acum value
+    same = out['Q'] == Qo
+    assert same.mean() > 0.9          # ties between table values and Acum at row boundaries are rounding-sensitive
+    io = np.minimum(np.searchsorted(acum, tbl, side='right'), n - 1)[~same]     # oracle's sorted index
+    lo, hi = xs[np.maximum(io - 2, 0)], xs[np.minimum(io + 2, n - 1)]
+    assert ((out['Q'][~same] >= lo) & (out['Q'][~same] <= hi)).all()                # at most 2 sorted cells away
+    assert abs(out['bpe'] / O.bpe_integral(q, dA, tbl, cs) - 1) < 1e-10
+    # relation to the reference's histogram profile: within one contour spacing
+    g = np.load(os.path.join(GOLD, 'baro_keff_N121.npz'))
+    step = (q.max() - q.min()) / 120
+    assert np.max(np.abs(out['Q'][1:-1] - g['ctr_eq'][1:-1])) < 1.5 * step
+
+
+def test_radix_sort_nan_mask_negatives_and_ties(ctx):
+    rng = np.random.default_rng(21)
+    ny, nx = 61, 130                                   # not a multiple of the 1024-element wave tile
+    q = np.round(rng.standard_normal((ny, nx)) * 3, 1)        # many ties, negatives, zeros
+    q[3, 4] = np.nan; q[10, :] = np.nan; q[20, 5] = -np.inf; q[21, 6] = np.inf
+    mask = np.ones((ny, nx)); mask[:, 7] = 0
+    w = rng.random(ny) + 0.1
+    out = ctx.sort_profile(q, dA=w, mask=mask, targets=np.linspace(0, w.sum() * nx, 50), want_sorted=True, want_acum=True)
+    Qo, xs, acum = O.sorted_profile(q, w, np.linspace(0, w.sum() * nx, 50), mask)
+    n = out['nvalid']
+    assert n == len(xs)
+    assert np.array_equal(out['q_sorted'][:n], xs)
+    # stability: equal keys keep their original order, so the payload sequence matches numpy's stable sort
+    assert rel(out['acum'][:n], acum) < 1e-12
+    io = np.minimum(np.searchsorted(acum, np.linspace(0, w.sum() * nx, 50), side='right'), n - 1)
+    assert ((out['Q'] >= xs[np.maximum(io - 2, 0)]) & (out['Q'] <= xs[np.minimum(io + 2, n - 1)])).all()
+    # no weights, no mask
+    out2 = ctx.sort_profile(q, want_sorted=True)
+    ok = ~np.isnan(q)
+    assert out2['nvalid'] == ok.sum() and np.array_equal(out2['q_sorted'][:ok.sum()], np.sort(q[ok]))
+
+
+def test_radix_sort_full_size_sortedness(ctx):
+    """cfg2-sized slab: sortedness + permutation invariants (size-independent properties)"""
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((1801, 3600))
+    out = ctx.sort_profile(q, want_sorted=True, want_acum=True)
+    s = out['q_sorted']
+    assert out['nvalid'] == q.size
+    assert (np.diff(s) >= 0).all()
+    assert abs(s.sum() - q.sum()) < 1e-6 and s[0] == q.min() and s[-1] == q.max()
+    assert out['acum'][-1] == q.size                     # unit weights: cumulative count
+
+
+@pytest.mark.parametrize('increase', [True, False])
+@pytest.mark.parametrize('lt', [True, False])
+def test_facade_sorted_profile_brackets_histogram_profile(ctx, baro, increase, lt):
+    """Contour2D.cal_sorted_profile (exact) vs the reference's N-contour profile (SURVEY a9 relation)"""
+    import xcontour_amd as xa
+    q, lat, lon = baro
+    if not increase:
+        q = -q                                            # tracer decreasing with latitude
+    c = {'latitude': lat, 'longitude': lon}
+    tr = xa.DataArray(q, ('latitude', 'longitude'), c, 'pv')
+    dA = xa.DataArray(O.cell_area(lat, lon), ('latitude', 'longitude'), c, 'rA')
+    mask = xa.DataArray(np.ones_like(q), ('latitude', 'longitude'), c, 'mask')
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'},
+                      increase=increase, lt=lt)
+    table = cm.cal_area_eqCoord_table_hist(mask)
+    Q, qs = cm.cal_sorted_profile(table, return_sorted=True)
+    assert Q.dims == ('latitude',) and len(qs) == q.size
+    # histogram route of the reference (tests/test_LWA.py:60-72) with many contours
+    N = 401
+    ctr = cm.cal_contours(N)
+    area = cm.cal_integral_within_contours_hist(ctr)
+    latEq = table.lookup_coordinates(area)
+    Qh = cm.interp_to_coords(lat, latEq, ctr)
+    step = (q.max() - q.min()) / (N - 1)
+    assert np.max(np.abs(Q.values[2:-2] - Qh.values[2:-2])) < 2.5 * step
+    d = np.diff(Q.values)
+    assert (d >= 0).all() if increase else (d <= 0).all()

@@ -524,6 +524,40 @@ class Contour2D(object):
         name = lb.unwrap(tracer)[3]
         return lb.wrap(g, tdims, coords, 'grdS' + (name or ''), tracer)
 
+    def cal_sorted_profile(self, table, tracer=None, mask=None, return_sorted=False):
+        """
+        EXACT adiabatically sorted reference state Q(Yeq) (the reference only has the
+        N-contour histogram approximation `interp_to_coords(..., ctr)`, core.py:1050-1100, which
+        converges to this as N grows).  The valid cells of the slab are radix-sorted on the GPU
+        together with their areas; Q at equivalent coordinate y_j is the sorted value at the
+        cumulative area the table assigns to y_j.  `increase=False` sorts -q.
+        Returns Q on the table's coordinate (and the sorted values if `return_sorted`).
+        """
+        if tracer is None:
+            tracer = self.tracer
+        q, lead, lshape, coords = self._plane(tracer)
+        q = self._float(q)
+        if q.shape[0] != 1:
+            raise Exception('cal_sorted_profile works on one 2D plane at a time')
+        ny, nx = q.shape[1:]
+        dA, _ = self._dA_array(ny, nx, 1)
+        if dA.ndim == 3:
+            dA = dA[0]
+        m = None if mask is None else self._float(self._plane(mask)[0][0])
+        tv = np.asarray(lb.unwrap(table._table)[0], dtype=np.float64)
+        # cumulative area on the small-coordinate side of y_j, whatever (increase, lt) built the table
+        below = tv if table._incVl == table._incCd else tv[0] + tv[-1] - tv
+        cs = table._coord
+        if not table._incCd:                                   # ascending coordinate order for the lookup
+            below, cs = below[::-1], cs[::-1]
+        res = self.ctx.sort_profile(q[0], dA=dA, mask=m, targets=below, want_sorted=return_sorted,
+                                    negate=not self.increase)
+        sgn = 1.0 if self.increase else -1.0
+        Q = lb.wrap(sgn * res['Q'], (self.dimEqV,), {self.dimEqV: cs}, lb.unwrap(tracer)[3], tracer)
+        if return_sorted:
+            return Q, sgn * res['q_sorted'][:res['nvalid']]
+        return Q
+
     def keff(self, N, table, grdS=None, preY=None, lat=None, lon=None, rdx=None, rdy=None,
              periodic_x=True, nkeff_mask=1e5):
         """

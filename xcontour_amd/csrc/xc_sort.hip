@@ -1,0 +1,346 @@
+// K8 -- exact adiabatic rearrangement: device radix sort of (tracer, dA) pairs, cumulative
+// area of the sorted state, sorted profile Q(A) and background-potential-energy integral.
+//
+// No reference call site (the reference realises "sorting" as histogram CDF + table lookup,
+// SURVEY F6); this is SURVEY 8-a9, build-defined and pinned by oracle.sorted_profile:
+//   drop NaN / masked cells; stable ascending sort of (q, dA); Acum = cumsum(dA_sorted);
+//   Q_exact(A_j) = q_sorted[min(searchsorted(Acum, A_j, 'right'), n-1)].
+//
+// Hand-written LSD radix sort, 8-bit digits, 64-bit order-preserving keys, f64 payload:
+// one WAVE owns one tile of 1024 consecutive elements; stable ranks come from wave ballots
+// (8 ballots give the peer mask of a lane's digit), per-wave digit counters live in LDS,
+// the (digit-major) tile histogram is scanned by two small kernels.  Bandwidth-bound:
+// per pass 8 B/elem (histogram) + 32 B/elem (scatter read + write).
+#include "xc_internal.h"
+
+namespace xc {
+namespace {
+
+constexpr int TILE_ROUNDS = 16;
+constexpr int TILE = 64 * TILE_ROUNDS;      // elements per wave tile
+constexpr unsigned long long KEY_INVALID = ~0ull;
+
+__device__ __forceinline__ unsigned long long f64_to_key(double v)
+{
+    // order-preserving map of IEEE doubles to unsigned integers; -0.0 is folded onto +0.0 so that
+    // equal values keep their original order exactly like numpy's stable sort
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v == 0.0 ? 0.0 : v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_to_f64(unsigned long long k)
+{
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+template <typename TQ, typename TM>
+__global__ __launch_bounds__(256)
+void k_sort_keys(const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA, int dA_rank,
+                 int64_t nx, int64_t n, int negate, unsigned long long* __restrict__ keys, double* __restrict__ vals,
+                 unsigned* __restrict__ nvalid)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool ok = false;
+    if (i < n) {
+        const double v = negate ? -(double)q[i] : (double)q[i];
+        ok = (v == v) && (!mask || mask[i] == (TM)1);
+        const double w = (dA_rank == XC_DA_ROW) ? dA[i / nx] : (dA_rank == XC_DA_PLANE ? dA[i] : 1.0);
+        keys[i] = ok ? f64_to_key(v) : KEY_INVALID;        // invalid cells sort to the end
+        vals[i] = ok ? w : 0.0;
+    }
+    const unsigned long long b = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(nvalid, (unsigned)__popcll(b));
+}
+
+// peer mask of lanes holding the same 8-bit digit (only lanes in `valid`)
+__device__ __forceinline__ unsigned long long digit_peers(unsigned d, unsigned long long valid)
+{
+    unsigned long long m = valid;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const unsigned long long bal = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256)
+void k_radix_hist(const unsigned long long* __restrict__ keys, int64_t n, int shift, int ntiles,
+                  unsigned* __restrict__ hist)
+{
+    __shared__ unsigned s_cnt[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = 0;
+    if (t < ntiles) {
+        const int64_t base = t * TILE;
+        for (int r = 0; r < TILE_ROUNDS; ++r) {
+            const int64_t i = base + r * 64 + lane;
+            const bool valid = i < n;
+            const unsigned d = valid ? (unsigned)((keys[i] >> shift) & 255ull) : 0u;
+            const unsigned long long peers = digit_peers(d, __ballot(valid));
+            if (valid && (peers & ((1ull << lane) - 1ull)) == 0) s_cnt[wave][d] += (unsigned)__popcll(peers);
+        }
+        for (int d = lane; d < 256; d += 64) hist[(size_t)d * ntiles + t] = s_cnt[wave][d];
+    }
+}
+
+// exclusive scan of each digit's row over the tiles (one block per digit); row total out
+__global__ __launch_bounds__(256)
+void k_radix_scan_rows(unsigned* __restrict__ hist, int ntiles, unsigned* __restrict__ totals)
+{
+    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_carry;
+    unsigned* row = hist + (size_t)blockIdx.x * ntiles;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int b = 0; b < ntiles; b += 256) {
+        const int i = b + tid;
+        const unsigned v = i < ntiles ? row[i] : 0u;
+        unsigned x = v;                                        // inclusive wave scan
+        for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        unsigned off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        if (i < ntiles) row[i] = off + x - v;
+        __syncthreads();
+        if (tid == 255) s_carry = off + x;
+        __syncthreads();
+    }
+    if (tid == 0) totals[blockIdx.x] = s_carry;
+}
+
+__global__ __launch_bounds__(256)
+void k_radix_scan_totals(const unsigned* __restrict__ totals, unsigned* __restrict__ bases)
+{
+    __shared__ unsigned s[256];
+    s[threadIdx.x] = totals[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned run = 0; for (int d = 0; d < 256; ++d) { const unsigned v = s[d]; s[d] = run; run += v; } }
+    __syncthreads();
+    bases[threadIdx.x] = s[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256)
+void k_radix_scatter(const unsigned long long* __restrict__ kin, const double* __restrict__ vin,
+                     unsigned long long* __restrict__ kout, double* __restrict__ vout, int64_t n, int shift,
+                     int ntiles, const unsigned* __restrict__ hist, const unsigned* __restrict__ bases)
+{
+    __shared__ unsigned s_pos[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t >= ntiles) return;
+    for (int d = lane; d < 256; d += 64) s_pos[wave][d] = bases[d] + hist[(size_t)d * ntiles + t];
+    const int64_t base = t * TILE;
+    for (int r = 0; r < TILE_ROUNDS; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        const bool valid = i < n;
+        const unsigned long long key = valid ? kin[i] : 0ull;
+        const double val = valid ? vin[i] : 0.0;
+        const unsigned d = valid ? (unsigned)((key >> shift) & 255ull) : 0u;
+        const unsigned long long peers = digit_peers(d, __ballot(valid));
+        const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+        unsigned pos = 0;
+        if (valid) pos = s_pos[wave][d] + rank;                 // all peers read the same counter first ...
+        if (valid && rank == 0) s_pos[wave][d] += (unsigned)__popcll(peers);   // ... then the leader advances it
+        if (valid) { kout[pos] = key; vout[pos] = val; }
+    }
+}
+
+// ---- inclusive f64 scan (cumulative area of the sorted state): block-local scan + block sums
+__global__ __launch_bounds__(256)
+void k_scan_local(const double* __restrict__ in, double* __restrict__ out, int64_t n, double* __restrict__ bsum)
+{
+    __shared__ double s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * 2048;
+    double v[8], run = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int64_t i = base + (int64_t)tid * 8 + k; v[k] = i < n ? in[i] : 0.0; run += v[k]; v[k] = run; }
+    double x = run;
+    for (int o = 1; o < 64; o <<= 1) { const double y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    double off = x - run;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int64_t i = base + (int64_t)tid * 8 + k; if (i < n) out[i] = off + v[k]; }
+    if (tid == 255) bsum[blockIdx.x] = off + run;
+}
+
+__global__ __launch_bounds__(1024)
+void k_scan_bsums(double* __restrict__ bsum, int nb)        // exclusive scan in place, one block
+{
+    __shared__ double s_w[16];
+    __shared__ double s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0.0;
+    __syncthreads();
+    for (int b = 0; b < nb; b += 1024) {
+        const int i = b + tid;
+        const double v = i < nb ? bsum[i] : 0.0;
+        double x = v;
+        for (int o = 1; o < 64; o <<= 1) { const double y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        double off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        if (i < nb) bsum[i] = off + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = off + x;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_scan_add(double* __restrict__ out, int64_t n, const double* __restrict__ bsum)
+{
+    const double off = bsum[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * 2048;
+    for (int k = 0; k < 8; ++k) { const int64_t i = base + k * 256 + threadIdx.x; if (i < n) out[i] += off; }
+}
+
+__global__ __launch_bounds__(256)
+void k_unkey(const unsigned long long* __restrict__ keys, int64_t n, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = key_to_f64(keys[i]);
+}
+
+// Q_exact(A_j) = q_sorted[min(searchsorted(acum[:nvalid], A_j, 'right'), nvalid-1)]
+__global__ __launch_bounds__(256)
+void k_profile(const unsigned long long* __restrict__ keys, const double* __restrict__ acum,
+               const unsigned* __restrict__ nvalid, const double* __restrict__ targets, int J,
+               double* __restrict__ Q)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= J) return;
+    const int64_t n = *nvalid;
+    if (n == 0) { Q[j] = __longlong_as_double(0x7ff8000000000000LL); return; }
+    const double a = targets[j];
+    int64_t lo = 0, hi = n;                        // first index with acum[idx] > a
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (acum[mid] <= a) lo = mid + 1; else hi = mid; }
+    if (lo > n - 1) lo = n - 1;
+    Q[j] = key_to_f64(keys[lo]);
+}
+
+// BPE-like integral: sum_i q_i * z*(A_i - dA_i/2) * dA_i with z* = np.interp(A, tbl, coord)
+__global__ __launch_bounds__(256)
+void k_bpe(const unsigned long long* __restrict__ keys, const double* __restrict__ vals,
+           const double* __restrict__ acum, const unsigned* __restrict__ nvalid,
+           const double* __restrict__ tbl, const double* __restrict__ coord, int ntbl, double* __restrict__ part)
+{
+    const int64_t n = *nvalid;
+    const bool tinc = tbl[ntbl - 1] > tbl[0];
+    double sum = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double a = acum[i] - 0.5 * vals[i];
+        auto X = [&](int k) { return tinc ? tbl[k] : tbl[ntbl - 1 - k]; };
+        auto F = [&](int k) { return tinc ? coord[k] : coord[ntbl - 1 - k]; };
+        double z;
+        if (a >= X(ntbl - 1)) z = F(ntbl - 1);
+        else if (a <= X(0)) z = F(0);
+        else {
+            int lo = 0, hi = ntbl - 1;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a >= X(mid)) lo = mid; else hi = mid; }
+            z = F(lo) + (F(lo + 1) - F(lo)) * (a - X(lo)) / (X(lo + 1) - X(lo));
+        }
+        sum += key_to_f64(keys[i]) * z * vals[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void k_sum_parts(const double* __restrict__ part, int n, double* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { double s = 0.0; for (int i = 0; i < n; ++i) s += part[i]; *out = s; }
+}
+
+}  // namespace
+
+// Workspace layout (device): keys A/B, vals A/B, hist, totals, bases, nvalid, bsums, bpe parts
+size_t sort_workspace_bytes(int64_t n)
+{
+    const int64_t ntiles = (n + TILE - 1) / TILE;
+    const int64_t nb = (n + 2047) / 2048;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return 4 * al((size_t)n * 8) + al((size_t)256 * ntiles * 4) + al(256 * 4) * 2 + al(64) + al((size_t)nb * 8) + al(1024 * 8);
+}
+
+int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype,
+                        const double* dA, int dA_rank, int64_t ny, int64_t nx, int negate,
+                        const double* targets, int J, const double* tbl, const double* coord, int ntbl,
+                        void* workspace, double* out_Q, double* out_qsorted, double* out_acum,
+                        unsigned* out_nvalid, double* out_bpe)
+{
+    const int64_t n = ny * nx;
+    if (!q || !workspace || n < 1 || n > 0x7fffffff) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad arguments");
+    if (dA_rank != XC_DA_NONE && dA_rank != XC_DA_ROW && dA_rank != XC_DA_PLANE) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA_rank must be NONE, ROW or PLANE");
+    if (dA_rank != XC_DA_NONE && !dA) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA is NULL");
+    const int64_t ntiles = (n + TILE - 1) / TILE;
+    const int nb = (int)((n + 2047) / 2048);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    char* w = (char*)workspace;
+    unsigned long long* kA = (unsigned long long*)w; w += al((size_t)n * 8);
+    unsigned long long* kB = (unsigned long long*)w; w += al((size_t)n * 8);
+    double* vA = (double*)w; w += al((size_t)n * 8);
+    double* vB = (double*)w; w += al((size_t)n * 8);
+    unsigned* hist = (unsigned*)w; w += al((size_t)256 * ntiles * 4);
+    unsigned* totals = (unsigned*)w; w += al(256 * 4);
+    unsigned* bases = (unsigned*)w; w += al(256 * 4);
+    unsigned* nvalid = (unsigned*)w; w += al(64);
+    double* bsum = (double*)w; w += al((size_t)nb * 8);
+    double* parts = (double*)w;
+
+    XC_HIP(ctx, hipMemsetAsync(nvalid, 0, sizeof(unsigned), ctx->stream));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+#define XC_KEYS(TQ, TM) hipLaunchKernelGGL((k_sort_keys<TQ, TM>), dim3(gb), dim3(256), 0, ctx->stream, (const TQ*)q, \
+        (const TM*)mask, dA, dA_rank, nx, n, negate, kA, vA, nvalid)
+    const bool m32 = mask && mask_dtype == XC_F32;
+    if (q_dtype == XC_F64) { if (m32) XC_KEYS(double, float); else XC_KEYS(double, double); }
+    else if (q_dtype == XC_F32) { if (m32) XC_KEYS(float, float); else XC_KEYS(float, double); }
+    else return fail(ctx, XC_EBADARG, "xc_sort_profile: q_dtype must be XC_F32 or XC_F64");
+#undef XC_KEYS
+    XC_HIP(ctx, hipGetLastError());
+    const unsigned gt = (unsigned)((ntiles + 3) / 4);
+    unsigned long long *kin = kA, *kout = kB;
+    double *vin = vA, *vout = vB;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(k_radix_hist, dim3(gt), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist);
+        hipLaunchKernelGGL(k_radix_scan_rows, dim3(256), dim3(256), 0, ctx->stream, hist, (int)ntiles, totals);
+        hipLaunchKernelGGL(k_radix_scan_totals, dim3(1), dim3(256), 0, ctx->stream, totals, bases);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(gt), dim3(256), 0, ctx->stream, kin, vin, kout, vout, n, shift,
+                           (int)ntiles, hist, bases);
+        XC_HIP(ctx, hipGetLastError());
+        unsigned long long* tk = kin; kin = kout; kout = tk;
+        double* tv = vin; vin = vout; vout = tv;
+    }
+    // 8 passes: sorted data are back in kA / vA (= kin / vin)
+    double* acum = vout;                                   // reuse the idle payload buffer
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, ctx->stream, acum, n, bsum);
+    XC_HIP(ctx, hipGetLastError());
+    if (out_Q && J > 0) {
+        if (!targets) return fail(ctx, XC_EBADARG, "xc_sort_profile: targets is NULL");
+        hipLaunchKernelGGL(k_profile, dim3((J + 255) / 256), dim3(256), 0, ctx->stream, kin, acum, nvalid, targets, J, out_Q);
+    }
+    if (out_bpe) {
+        if (!tbl || !coord || ntbl < 2) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
+        hipLaunchKernelGGL(k_bpe, dim3(1024), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts);
+        hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(64), 0, ctx->stream, parts, 1024, out_bpe);
+    }
+    if (out_qsorted) hipLaunchKernelGGL(k_unkey, dim3(gb), dim3(256), 0, ctx->stream, kin, n, out_qsorted);
+    if (out_acum) XC_HIP(ctx, hipMemcpyAsync(out_acum, acum, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (out_nvalid) XC_HIP(ctx, hipMemcpyAsync(out_nvalid, nvalid, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+}  // namespace xc
