@@ -105,12 +105,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError('bench.py needs an MI355X (no CPU fallback)')
+    local = local if local < ndev else 0          # a launcher may expose one device per rank
+    torch.cuda.set_device(local)
     if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    else:
-        torch.cuda.set_device(0)
     if a.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
 

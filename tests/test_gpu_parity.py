@@ -522,3 +522,54 @@ def test_facade_sorted_profile_brackets_histogram_profile(ctx, baro, increase, l
     assert np.max(np.abs(Q.values[2:-2] - Qh.values[2:-2])) < 2.5 * step
     d = np.diff(Q.values)
     assert (d >= 0).all() if increase else (d <= 0).all()
+
+
+# ---------------------------------------------------------------- BASELINE cfg5 stand-in: X-Z plane, LAPE
+def test_cfg5_xz_plane_lape_and_bpe(ctx):
+    """tests/test_LAPE.py call sequence on a synthetic X-Z section (internalwave.nc is missing):
+    non-periodic X, decreasing Z coordinate, topography mask, increase=False, lt=False."""
+    import xcontour_amd as xa
+    nz, nxx = 100, 448
+    Z = -(np.arange(nz) + 0.5) * 2.0                                   # 0 ... -200 m, decreasing
+    X = (np.arange(nxx) + 0.5) * 20.0
+    xx, zz = np.meshgrid(X, Z)
+    T = 20 + 5 * np.tanh((zz + 60 + 15 * np.sin(2 * np.pi * xx / 3000.0)) / 20.0)
+    depth = 200 - 80 * np.exp(-((X - 6000) / 1500.0) ** 2)              # a ridge
+    maskC = (zz > -depth[None, :]).astype(np.float64)
+    b = 2e-4 * (np.where(maskC == 1, T, np.nan) - 20) * 9.81            # buoyancy, NaN in topography
+    c = {'Z': Z, 'XC': X}
+    bb = xa.DataArray(b, ('Z', 'XC'), c, 'buoyancy')
+    yA = xa.DataArray(np.full((nz, nxx), 40.0), ('Z', 'XC'), c, 'yA')
+    mk = xa.DataArray(maskC, ('Z', 'XC'), c, 'maskC')
+    cm = xa.Contour2D(bb, yA, dims={'X': 'XC', 'Z': 'Z'}, dimEq={'Z': 'Z'}, increase=False, lt=False)
+    N = 121
+    ctr = cm.cal_contours(N)
+    table = cm.cal_area_eqCoord_table_hist(mk)
+    area = cm.cal_integral_within_contours_hist(ctr)
+    ZEq = table.lookup_coordinates(area)
+    ds = cm.interp_to_dataset(xa.DataArray(Z.astype(np.float32), ('Z',), {'Z': Z}), ZEq.rename('ZEq'), [ctr, area])
+    # oracle, same sequence
+    o_ctr = O.cal_contours(b, N, False, np.float32)
+    o_tbl, o_cs = O.cal_area_eqCoord_table_hist(maskC, yA.values, Z, False, False)
+    o_area = O.cal_integral_within_contours_hist(b, o_ctr, yA.values, None, False)
+    o_ZEq = O.lookup_coordinates(o_area, o_tbl, o_cs)
+    o_Q = O.interp_to_coords(Z.astype(np.float32), o_ZEq, o_ctr)
+    assert np.array_equal(ctr.values, o_ctr)
+    assert rel(table._table.values, o_tbl) < 1e-13 and np.array_equal(table._coord, o_cs)
+    assert rel(area.values, o_area) < TIGHT and rel(ZEq.values, o_ZEq) < 1e-9
+    assert rel(ds['buoyancy'].values, o_Q) < 1e-9
+    lape, ctrs, masks = cm.cal_local_APE(bb, ds['buoyancy'], mask_idx=[8, 28, 51, 81])
+    o_lape, o_c, o_m = O.cal_local_wave_activity(b, o_Q, Z, yA.values, False, 'all', [8, 28, 51, 81])
+    assert lape.name == 'LAPE' and np.array_equal(lape.values, o_lape)
+    assert all(np.array_equal(masks[i].values, o_m[i]) for i in range(4))
+    # in-kernel gradient on a non-periodic Cartesian plane + exact sort + BPE integral
+    from xcontour_amd.utils import cartesian_metrics
+    rdx, rdy = cartesian_metrics(Z, 20.0)
+    g = cm.cal_squared_gradient(rdx=rdx, rdy=rdy, periodic_x=False)
+    gx = np.gradient(b, 20.0, axis=1, edge_order=1); gz = np.gradient(b, Z, axis=0, edge_order=1)
+    ok = np.isfinite(g.values) & np.isfinite(gx * gx + gz * gz)
+    assert rel(g.values[ok], (gx * gx + gz * gz)[ok]) < 1e-9
+    Qx = cm.cal_sorted_profile(table, mask=mk)
+    assert (np.diff(Qx.values[np.isfinite(Qx.values)]) >= 0).all()      # buoyancy increases with ascending Z
+    out = ctx.sort_profile(b, dA=yA.values, mask=maskC, tbl=o_tbl, coord=o_cs, negate=False)
+    assert abs(out['bpe'] / O.bpe_integral(b, yA.values, o_tbl, o_cs, maskC) - 1) < 1e-10

@@ -530,7 +530,8 @@ class Contour2D(object):
         N-contour histogram approximation `interp_to_coords(..., ctr)`, core.py:1050-1100, which
         converges to this as N grows).  The valid cells of the slab are radix-sorted on the GPU
         together with their areas; Q at equivalent coordinate y_j is the sorted value at the
-        cumulative area the table assigns to y_j.  `increase=False` sorts -q.
+        cumulative area the table assigns to y_j (a tracer decreasing with the coordinate value is
+        handled by sorting -q).
         Returns Q on the table's coordinate (and the sorted values if `return_sorted`).
         """
         if tracer is None:
@@ -550,9 +551,13 @@ class Contour2D(object):
         cs = table._coord
         if not table._incCd:                                   # ascending coordinate order for the lookup
             below, cs = below[::-1], cs[::-1]
+        # `increase` refers to the INDEX of the equivalent dim (core.py:44-46): the sorted tracer
+        # grows with the coordinate VALUE iff increase == (coordinate grows with index)
+        eq = self._eq_coord(tracer)
+        up = bool(self.increase) == bool(eq[-1] > eq[0])
         res = self.ctx.sort_profile(q[0], dA=dA, mask=m, targets=below, want_sorted=return_sorted,
-                                    negate=not self.increase)
-        sgn = 1.0 if self.increase else -1.0
+                                    negate=not up)
+        sgn = 1.0 if up else -1.0
         Q = lb.wrap(sgn * res['Q'], (self.dimEqV,), {self.dimEqV: cs}, lb.unwrap(tracer)[3], tracer)
         if return_sorted:
             return Q, sgn * res['q_sorted'][:res['nvalid']]
