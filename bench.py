@@ -10,8 +10,9 @@ Workload (BASELINE.json configs[1]): synthetic 3600 x 1801 float64 PV-like slabs
 float64 cell areas, 201 contours, the FULL Keff pipeline per slab (min/max -> levels ->
 one histogram pass with in-kernel |grad q|^2 -> CDF -> A(Yeq) lookup -> d/dA -> Leq2 ->
 Lmin -> nkeff).  A "step" is one pass of that pipeline over one batch of `--batch`
-distinct slabs resident in HBM (the batch is larger than the 256 MiB Infinity Cache, so
-every step really reads the tracer from HBM).  Metric: lat-lon cells x contours per second,
+distinct slabs resident in HBM; two such batches alternate (each larger than the 256 MiB
+Infinity Cache, so every step really reads its tracer from HBM, and the batch whose min/max is
+folded into a histogram pass is different data).  Metric: lat-lon cells x contours per second,
 whole job.  N > 1: every rank owns its own batch of independent slabs (weak scaling), no
 data-path collective during compute, ONE RCCL all-gather of all per-slab result vectors at
 the end of the timed region.
@@ -89,7 +90,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=8, help='slabs per step per GPU')
+    ap.add_argument('--batch', type=int, default=32, help='slabs per step per GPU')
     ap.add_argument('--group', type=int, default=0, help='slabs per launch set (0: whole batch)')
     ap.add_argument('--variant', type=int, default=0, help='0 PV-like, 1 noise, 2 sin(lat)')
     ap.add_argument('--no-chain', action='store_true',
@@ -129,19 +130,31 @@ def main():
     rows = ctx.rowsum(None, dA, NY, NX)                           # K2: A(Yeq) table, once per mask
     tbl = table_from_rowsums(rows, True)
 
-    # all K steps keep their per-slab result vectors on the device; one gather at the end
-    slot = KeffPlan.out_bytes(B, NCONT)
+    # Two resident batches (A, B) of `B` distinct slabs each; steps alternate between them like a
+    # time loop over a long record, so the batch whose min/max rides along in a histogram pass
+    # (q_next) is genuinely different data.  All K steps keep their per-slab result vectors on
+    # the device; one gather at the end.
+    NB = 2
+    slot = KeffPlan.out_bytes(NB * B, NCONT)
     res = torch.empty(slot * K // 8, dtype=torch.float64, device='cuda')
     wres = torch.empty(slot // 8, dtype=torch.float64, device='cuda')        # warm-up slot
-    plan = KeffPlan(ctx, B, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl,
+    plan = KeffPlan(ctx, NB * B, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl,
                     tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.data_ptr())
-    plan.synth(lat, lon, SEED + rank * B, a.variant)              # slab s of rank r: seed + r*B + s
-    group = a.group or None
+    plan.synth(lat, lon, SEED + rank * NB * B, a.variant)         # slab s of rank r: seed + r*2B + s
+    group = a.group or B
     chain = not a.no_chain
 
+    def step(k, slot_idx):
+        s0 = (k % NB) * B                                         # this step's batch
+        nxt = ((k + 1) % NB) * B                                  # the batch of the next step
+        for g0 in range(s0, s0 + B, group):
+            n = min(group, s0 + B - g0)
+            g1 = g0 + group if g0 + group < s0 + B else nxt       # what runs after this launch set
+            plan.run_range(slot_idx, g0, n, g1 if (chain and min(group, B) == n) else None)
+
     plan.out_ptr = wres.data_ptr()
-    for _ in range(W):
-        plan.run(0, group, chain)
+    for k in range(-W, 0):                                        # ends on batch B; its pass carries batch A's min/max
+        step(k, 0)
     plan.out_ptr = res.data_ptr()
     ctx.sync()
     torch.cuda.synchronize()
@@ -153,9 +166,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(K):
-        if group is None:
+        if group == B:
             ctx.set_hist_events(ev[k][0], ev[k][1])               # events around the K3 launch only
-        plan.run(k, group, chain)
+        step(k, k)
     ctx.sync()                                                    # the library's own HIP stream
     if world > 1:
         dist.all_gather_into_tensor(gathered, res)                # the one RCCL collective
@@ -179,12 +192,12 @@ def main():
             'config': {'workload': 'cfg2: synthetic %dx%d float64 PV-like slabs, 2-D f64 dA, %d contours, '
                                    'full Keff (min/max + histogram with in-kernel |grad q|^2 + CDF + epilogue)'
                                    % (NX, NY, NCONT),
-                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': a.group or B, 'variant': a.variant,
+                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant,
                        'minmax': 'folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass',
                        'parallelism': 'independent slabs per GPU, one RCCL all-gather at the end' if world > 1 else 'single GPU',
                        'device': ctx.device_name()},
         }
-        if group is None:
+        if group == B:
             ms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in ev])
             alg = B * NY * NX * BYTES_PER_CELL
             ach = alg / (ms.mean() * 1e-3) / 1e9
@@ -202,6 +215,8 @@ def main():
                                 'pipeline_frac': world and (B * NY * NX * BYTES_PER_CELL * K / el / 1e9 / world) / HBM_PEAK_GBS}
         # parity spot check of the last step against nothing heavy: invariants only (oracle runs in cpu leg)
         out = plan.fetch(slot=K - 1)
+        last = slice(((K - 1) % NB) * B, ((K - 1) % NB) * B + B)  # the batch the last step processed
+        out = {k_: v[last] for k_, v in out.items()}
         # every cell lands in exactly one bin, except that the slab's max cell may fall outside the
         # rounded last level (the reference's own behaviour)
         if not (NY * NX - out['counts'].sum(axis=1).astype(np.int64) <= 1).all():
@@ -210,7 +225,7 @@ def main():
             cores = os.cpu_count() or 1
             n = a.cpu_slabs or max(8, min(32, 2 * min(cores, 32)))
             n = min(n, B) if n <= B else n
-            qh = plan.download_q()
+            qh = plan.download_q()[:B]
             if n > B:
                 qh = np.concatenate([qh] * (-(-n // B)))[:n]
             else:

@@ -606,6 +606,13 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     const int rows = env_rows > 0 ? env_rows : 64;     // (strip,row) pairs per wave when slabs are plentiful
     int64_t bps = (total + waves * rows - 1) / (waves * rows);
     if (bps * nslab < cus) bps = (cus + nslab - 1) / nslab;
+    // one block per CU is resident (LDS): make the grid a whole number of CU-wide rounds so that
+    // the last round is not partly empty (408 blocks on 256 CUs ran at 80 % efficiency)
+    {
+        const int64_t tot = bps * nslab, rounds = (tot + cus - 1) / cus;
+        const int64_t b2 = (rounds * cus) / nslab;
+        if (b2 >= bps) bps = b2;
+    }
     const int64_t maxb = (total + waves - 1) / waves;      // at least one pair per wave
     if (bps > maxb) bps = maxb;
     if (bps < 1) bps = 1;

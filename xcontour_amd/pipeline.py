@@ -181,6 +181,14 @@ class KeffPlan(object):
             self.desc.q_next = (self._q_ptr + nxt * esz) if ok else None
             self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
 
+    def run_range(self, slot, s0, n, next_s0=None):
+        """One launch set over slabs [s0, s0+n) into result slot `slot`; `next_s0`: first slab of
+        the launch set that will run next (its min/max rides along, xc_keff_desc.q_next)."""
+        self._point(slot, s0, n)
+        esz = self.ny * self.nx * self.q_dtype.itemsize
+        self.desc.q_next = (self._q_ptr + next_s0 * esz) if next_s0 is not None else None
+        self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
+
     def unpack(self, raw):
         """one result slot (bytes as a uint8 ndarray) -> dict of arrays"""
         S, N = self.nslab, self.N
