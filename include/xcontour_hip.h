@@ -163,15 +163,17 @@ int xc_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny,
  * coord: double[ny] equivalent-coordinate values; Q: double[nslab][ny];
  * dA / M: float64, rank XC_DA_ROW or XC_DA_PLANE (M_rank may be XC_DA_NONE -> M = dA,
  * the snapshot text core.py:789).  part: 0 all, 1 upper, 2 lower.
+ * variant 0: cal_local_wave_activity (qe = q - Q[j]); 1: cal_local_wave_activity2 core.py:802-905
+ * (qe = q[row j] - Q, opposite sign convention).
  * out_lwa: double[nslab][ny][nx].  mask_idx: int32[nmask] rows whose mask3 is returned
  * in out_masks int8[nslab][nmask][ny][nx] (values -1/0/1); nmask may be 0.           */
 int xc_lwa_dev(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
                const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
-               int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+               int64_t nslab, int64_t ny, int64_t nx, int increase, int part, int variant,
                const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks);
 int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
            const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
-           int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+           int64_t nslab, int64_t ny, int64_t nx, int increase, int part, int variant,
            const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks);
 
 /* ------------------------------------------------------------------ K8  exact adiabatic rearrangement (radix sort)

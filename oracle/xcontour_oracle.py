@@ -392,6 +392,57 @@ def cal_local_wave_activity(q, Q, coord, dA, increase=True, part='all',
     return lwa
 
 
+def cal_local_wave_activity2(q, Q, coord, dA, increase=True, part='all', mask_idx=None, metric=None):
+    """core.py:802-905: qe = q[row j] - Q (dims (x, eq)), masks with the opposite sign
+    convention, same part selection and weights.  Returns lwa (J, nx) [, contours, masks (ny, nx)]."""
+    q = np.asarray(q)
+    Q = np.asarray(Q)
+    coord = np.asarray(coord)
+    dA2 = np.asarray(dA)
+    if dA2.ndim == 1:
+        dA2 = dA2[:, None]
+    wei = np.broadcast_to(dA2 / np.nanmax(dA2), q.shape)
+    M = dA2 if metric is None else np.asarray(metric)
+    if M.ndim == 1:
+        M = M[:, None]
+    M = np.broadcast_to(M, q.shape)
+    part = part.lower()
+    if part not in ['all', 'upper', 'lower']:
+        raise Exception("invalid part, should be in ['all', 'upper', 'lower']")
+    coord_incre = not (coord[-1] < coord[0])
+    J = len(coord)
+    returnmask = mask_idx is not None
+    if returnmask and max(mask_idx) >= J:
+        raise Exception('indices in mask_idx out of boundary')
+    mask_idx = list(mask_idx) if returnmask else []
+    lwa = np.empty((J, q.shape[1]), dtype=np.float64)
+    contours, masks = [], []
+    for j in range(J):
+        qe = q[j][None, :] - Q[:, None]                      # (eq, x) layout of core.py:860
+        m = (coord >= coord[j]) if coord_incre else (coord <= coord[j])
+        m = m[:, None]
+        if not increase:                                     # core.py:865-872
+            mask1 = np.where(qe > 0, -1, 0)
+            mask2 = np.where(m, 0, mask1)
+            mask3 = np.where(np.logical_and(qe < 0, m), 1, mask2)
+        else:
+            mask1 = np.where(qe < 0, -1, 0)
+            mask2 = np.where(m, 0, mask1)
+            mask3 = np.where(np.logical_and(qe > 0, m), 1, mask2)
+        if j in mask_idx:
+            contours.append(Q[j])
+            masks.append(mask3.astype(np.int64))
+        if part == 'all':
+            mf = mask3.astype(np.float64)
+        else:
+            pos = (part == 'upper') == bool(increase)
+            mf = np.where(mask3 > 0 if pos else mask3 < 0, mask3, np.nan)
+        lwa[j] = -np.nansum(qe * mf * wei * M, axis=0)       # core.py:895
+    if returnmask:
+        return lwa, contours, masks
+    return lwa
+
+
 # ---------------------------------------------------------------------------
 # Build-defined pieces (no reference call site: SURVEY F6, F7)
 # ---------------------------------------------------------------------------

@@ -573,3 +573,47 @@ def test_cfg5_xz_plane_lape_and_bpe(ctx):
     assert (np.diff(Qx.values[np.isfinite(Qx.values)]) >= 0).all()      # buoyancy increases with ascending Z
     out = ctx.sort_profile(b, dA=yA.values, mask=maskC, tbl=o_tbl, coord=o_cs, negate=False)
     assert abs(out['bpe'] / O.bpe_integral(b, yA.values, o_tbl, o_cs, maskC) - 1) < 1e-10
+
+
+@pytest.mark.parametrize('increase', [True, False])
+def test_lwa2_variant(ctx, baro, increase):
+    """cal_local_wave_activity2 (core.py:802-905; tests/test_LWA.py:79): SURVEY 8(f2)"""
+    import xcontour_amd as xa
+    tr, dA, q, lat, lon = _baro_da(xa, baro)
+    g = np.load(os.path.join(GOLD, 'baro_lwa_N121.npz'))
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=increase, lt=True)
+    Qv = g['Q'] if increase else g['Q'][::-1].copy()
+    Qg = xa.DataArray(Qv, ('latitude',), {'latitude': lat}, 'absolute_vorticity')
+    for part in ('all', 'upper', 'lower'):
+        out = cm.cal_local_wave_activity2(tr, Qg, part=part, metric=g['dy'])
+        ref = O.cal_local_wave_activity2(q, Qv, lat, dA.values, increase, part, metric=g['dy'])
+        assert np.array_equal(out.values, ref), part
+    out, ctrs, masks = cm.cal_local_wave_activity2(tr, Qg, mask_idx=[37, 125], metric=g['dy'])
+    ref, _, rm = O.cal_local_wave_activity2(q, Qv, lat, dA.values, increase, 'all', [37, 125], metric=g['dy'])
+    assert all(np.array_equal(masks[i].values, rm[i]) for i in range(2))
+
+
+def test_contour_mean_family(ctx, baro):
+    """cal_contour_weigh_mean(_hist) / cal_contour_mean(_hist) (core.py:491-616): SURVEY 8(f1)"""
+    import xcontour_amd as xa
+    tr, dA, q, lat, lon = _baro_da(xa, baro)
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True)
+    g2 = O.grad2_sphere(q, lat, lon)
+    grdm = xa.DataArray(np.sqrt(g2), tr.dims, tr.coords, 'grdm')
+    integ = xa.DataArray(np.cos(np.deg2rad(lat))[:, None] * np.ones_like(q, dtype=np.float64), tr.dims, tr.coords, 'coslat')
+    ctr = cm.cal_contours(61)
+    o_ctr = O.cal_contours(q, 61, True, np.float32)
+    o_area = O.cal_integral_within_contours_hist(q, o_ctr, dA.values, None, True)
+    for hist in (True, False):
+        fn_w = cm.cal_contour_weigh_mean_hist if hist else cm.cal_contour_weigh_mean
+        fn_m = cm.cal_contour_mean_hist if hist else cm.cal_contour_mean
+        integral = O.cal_integral_within_contours_hist if hist else O.cal_integral_within_contours
+        oa = o_area if hist else O.cal_integral_within_contours(q, o_ctr, dA.values, None, True)
+        lw = fn_w(ctr, integ)
+        o_lw = O.cal_gradient_wrt_area(integral(q, o_ctr, dA.values, integ.values, True), oa)
+        assert lw.name == 'lwmcoslat' and rel(lw.values, o_lw) < 1e-7
+        mean = fn_m(ctr, integ, grdm)
+        up = O.cal_gradient_wrt_area(integral(q, o_ctr, dA.values, integ.values * grdm.values, True), oa)
+        lo = O.cal_gradient_wrt_area(integral(q, o_ctr, dA.values, grdm.values, True), oa)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            assert mean.name == 'cmcoslat' and rel(mean.values, up / lo) < 1e-6

@@ -88,9 +88,9 @@ PROTOTYPES = {
     'xc_grad2_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp]),
     'xc_grad2': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, C.c_int, _vp]),
     'xc_lwa_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _vp, C.c_int,
-                             _i64, _i64, _i64, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+                             _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     'xc_lwa': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _vp, C.c_int,
-                         _i64, _i64, _i64, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+                         _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     'xc_sort_profile_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int,
                                       _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'xc_sort_profile': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int,
@@ -367,7 +367,7 @@ class Context(object):
                                       _ptr(rdx), _ptr(rdy), 1 if periodic_x else 0, _ptr(out)))
         return out
 
-    def lwa(self, q, Q, coord, dA, dA_max, M=None, increase=True, part=0, mask_idx=None):
+    def lwa(self, q, Q, coord, dA, dA_max, M=None, increase=True, part=0, mask_idx=None, variant=0):
         q = np.ascontiguousarray(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
@@ -387,7 +387,7 @@ class Context(object):
         mo = np.empty((nslab, nmask, ny, nx), dtype=np.int8) if nmask else None
         self._check(self.lib.xc_lwa(self.handle, _ptr(q), dtype_code(q.dtype), _ptr(Q), _ptr(coord),
                                     _ptr(dA), dr, float(dA_max), _ptr(M), mr, nslab, ny, nx,
-                                    1 if increase else 0, int(part), _ptr(mi), nmask, _ptr(out), _ptr(mo)))
+                                    1 if increase else 0, int(part), int(variant), _ptr(mi), nmask, _ptr(out), _ptr(mo)))
         return out, mo
 
 

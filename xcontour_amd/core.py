@@ -458,11 +458,16 @@ class Contour2D(object):
         """
         return self._lwa(q, Q, mask_idx, part, metric, 'LWA')
 
+    def cal_local_wave_activity2(self, q, Q, mask_idx=None, part='all', metric=None):
+        """The impulse-Casimir flavoured variant (reference core.py:802-905): qe = q[row j] - Q
+        with the opposite sign convention; same GPU kernel family."""
+        return self._lwa(q, Q, mask_idx, part, metric, 'LWA', variant=1)
+
     def cal_local_APE(self, q, Q, mask_idx=None, part='all', metric=None):
         """Local available potential energy density (reference core.py:908-942)."""
         return self._lwa(q, Q, mask_idx, part, metric, 'LAPE')
 
-    def _lwa(self, q, Q, mask_idx, part, metric, name):
+    def _lwa(self, q, Q, mask_idx, part, metric, name, variant=0):
         part = part.lower()
         if part not in ['all', 'upper', 'lower']:
             raise Exception('invalid part, should be in [\'all\', \'upper\', \'lower\']')
@@ -488,7 +493,7 @@ class Contour2D(object):
             M = np.asarray(lb.unwrap(metric)[0] if lb.is_labeled(metric) else metric, dtype=np.float64).squeeze()
         pcode = {'all': 0, 'upper': 1, 'lower': 2}[part]
         lwa, masks = self.ctx.lwa(qv, Qv, eq.astype(np.float64), dA, dmax, M=M, increase=self.increase,
-                                  part=pcode, mask_idx=mask_idx)
+                                  part=pcode, mask_idx=mask_idx, variant=variant)
         qdims = lb.unwrap(q)[1]
         full = tuple(lead) + (self.dimEqV, self._xdim)
         out = lwa.reshape(tuple(lshape) + (ny, nx))

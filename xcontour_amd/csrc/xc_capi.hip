@@ -481,17 +481,17 @@ int xc_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny,
 // ------------------------------------------------------------------------------------ K7
 int xc_lwa_dev(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
                const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
-               int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+               int64_t nslab, int64_t ny, int64_t nx, int increase, int part, int variant,
                const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks)
 {
     XC_CTX(ctx);
     return launch_lwa(ctx, q, q_dtype, Q, coord, dA, dA_rank, dA_max, M, M_rank, nslab, ny, nx,
-                      increase, part, mask_idx, nmask, out_lwa, out_masks);
+                      increase, part, variant, mask_idx, nmask, out_lwa, out_masks);
 }
 
 int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
            const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
-           int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+           int64_t nslab, int64_t ny, int64_t nx, int increase, int part, int variant,
            const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks)
 {
     XC_CTX(ctx);
@@ -514,7 +514,7 @@ int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const doubl
     XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, dQ, Q, Qb)); XC_TRY(h2d(ctx, dc, coord, cb)); XC_TRY(h2d(ctx, dd, dA, dab));
     if (Mb) XC_TRY(h2d(ctx, dM, M, Mb));
     if (nmask) XC_TRY(h2d(ctx, dmi, mask_idx, mib));
-    XC_TRY(launch_lwa(ctx, dq, q_dtype, dQ, dc, dd, dA_rank, dA_max, dM, M_rank, nslab, ny, nx, increase, part,
+    XC_TRY(launch_lwa(ctx, dq, q_dtype, dQ, dc, dd, dA_rank, dA_max, dM, M_rank, nslab, ny, nx, increase, part, variant,
                       dmi, nmask, dout, dmo));
     XC_TRY(d2h(ctx, out_lwa, dout, ob));
     if (nmask) XC_TRY(d2h(ctx, out_masks, dmo, mob));

@@ -128,7 +128,7 @@ int launch_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t
                  const double* rdx, const double* rdy, int periodic_x, double* out);
 int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
                const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
-               int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+               int64_t nslab, int64_t ny, int64_t nx, int increase, int part, int variant,
                const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks);
 size_t sort_workspace_bytes(int64_t n);
 int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype,

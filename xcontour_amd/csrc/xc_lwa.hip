@@ -25,7 +25,8 @@ __device__ __forceinline__ int mask3(double qe, bool m, int increase)
     return (pos && m) ? 1 : (m ? 0 : (neg ? -1 : 0));
 }
 
-template <typename T>
+// V2: cal_local_wave_activity2 (core.py:802-905): qe = q[row j] - Q[all rows], opposite sign convention.
+template <typename T, bool V2>
 __global__ __launch_bounds__(256)
 void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
            const double* __restrict__ dA, int dA_rank, double dA_max,
@@ -45,13 +46,15 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
 #pragma unroll
     for (int t = 0; t < JT; ++t) {
         const int64_t j = (j0 + t < ny) ? j0 + t : ny - 1;
-        Qj[t] = Qs[j]; cj[t] = coord[j]; acc[t] = 0.0;
+        Qj[t] = V2 ? (active ? (double)qs[j * nx + x] : 0.0) : Qs[j];      // V2: the tracer on target row j
+        cj[t] = coord[j]; acc[t] = 0.0;
     }
+    const int inc_eff = V2 ? !increase : increase;                          // core.py:865-872 vs 759-766
     // keep the sign of the selected part: 'upper' keeps mask>0 if increase else mask<0 (core.py:775-784)
     const int keep = (part == 0) ? 0 : (((part == 1) == (increase != 0)) ? 1 : -1);
 
     for (int64_t y = 0; y < ny; ++y) {
-        const double qv = active ? (double)qs[y * nx + x] : 0.0;
+        const double qv = V2 ? Qs[y] : (active ? (double)qs[y * nx + x] : 0.0);
         const double cy = coord[y];
         const double dv = (dA_rank == XC_DA_ROW) ? dA[y] : (active ? dA[y * nx + x] : 0.0);
         const double wei = __ddiv_rn(dv, dA_max);                                   // core.py:724
@@ -59,9 +62,9 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
                         : (M_rank == XC_DA_ROW) ? M[y] : (active ? M[y * nx + x] : 0.0);
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
-            const double qe = __dsub_rn(qv, Qj[t]);                                 // core.py:754
+            const double qe = V2 ? __dsub_rn(Qj[t], qv) : __dsub_rn(qv, Qj[t]);     // core.py:860 / 754
             const bool m = coord_incre ? (cy >= cj[t]) : (cy <= cj[t]);             // core.py:757
-            const int mk = mask3(qe, m, increase);
+            const int mk = mask3(qe, m, inc_eff);
             if (mk != 0 && (keep == 0 || (keep > 0) == (mk > 0))) {
                 const double term = __dmul_rn(__dmul_rn(__dmul_rn(qe, (double)mk), wei), mv);
                 if (term == term) acc[t] = __dadd_rn(acc[t], term);                 // nansum
@@ -78,7 +81,7 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_lwa_masks(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
-                 int64_t ny, int64_t nx, int increase, int coord_incre,
+                 int64_t ny, int64_t nx, int increase, int coord_incre, int v2,
                  const int32_t* __restrict__ mask_idx, int nmask, int8_t* __restrict__ out)
 {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -86,16 +89,17 @@ void k_lwa_masks(const T* __restrict__ q, const double* __restrict__ Q, const do
     const int slab = blockIdx.z / nmask, im = blockIdx.z % nmask;
     if (x >= nx) return;
     const int64_t j = mask_idx[im];
-    const double qe = __dsub_rn((double)q[(size_t)slab * ny * nx + y * nx + x], Q[(size_t)slab * ny + j]);
+    const double qe = v2 ? __dsub_rn((double)q[(size_t)slab * ny * nx + j * nx + x], Q[(size_t)slab * ny + y])
+                         : __dsub_rn((double)q[(size_t)slab * ny * nx + y * nx + x], Q[(size_t)slab * ny + j]);
     const bool m = coord_incre ? (coord[y] >= coord[j]) : (coord[y] <= coord[j]);
-    out[(((size_t)slab * nmask + im) * ny + y) * nx + x] = (int8_t)mask3(qe, m, increase);
+    out[(((size_t)slab * nmask + im) * ny + y) * nx + x] = (int8_t)mask3(qe, m, v2 ? !increase : increase);
 }
 
 }  // namespace
 
 int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
                const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
-               int64_t nslab, int64_t ny, int64_t nx, int increase, int part,
+               int64_t nslab, int64_t ny, int64_t nx, int increase, int part, int variant,
                const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks)
 {
     if (!q || !Q || !coord || !dA || !out_lwa || nslab < 1 || ny < 2 || nx < 1)
@@ -114,22 +118,22 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int coord_incre = !(c2[1] < c2[0]);
     dim3 grid((unsigned)((nx + 63) / 64), (unsigned)((ny + 4 * JT - 1) / (4 * JT)), (unsigned)nslab);
-    if (q_dtype == XC_F64)
-        hipLaunchKernelGGL(k_lwa<double>, grid, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, dA, dA_rank,
-                           dA_max, M, M_rank, ny, nx, increase, coord_incre, part, out_lwa);
-    else if (q_dtype == XC_F32)
-        hipLaunchKernelGGL(k_lwa<float>, grid, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, dA, dA_rank,
-                           dA_max, M, M_rank, ny, nx, increase, coord_incre, part, out_lwa);
+#define XC_LWA(T, V) hipLaunchKernelGGL((k_lwa<T, V>), grid, dim3(256), 0, ctx->stream, (const T*)q, Q, coord, dA, dA_rank, \
+                           dA_max, M, M_rank, ny, nx, increase, coord_incre, part, out_lwa)
+    if (variant != 0 && variant != 1) return fail(ctx, XC_EBADARG, "xc_lwa: variant must be 0 or 1");
+    if (q_dtype == XC_F64) { if (variant) XC_LWA(double, true); else XC_LWA(double, false); }
+    else if (q_dtype == XC_F32) { if (variant) XC_LWA(float, true); else XC_LWA(float, false); }
     else return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
+#undef XC_LWA
     XC_HIP(ctx, hipGetLastError());
     if (nmask > 0) {
         dim3 g2((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)(nslab * nmask));
         if (q_dtype == XC_F64)
             hipLaunchKernelGGL(k_lwa_masks<double>, g2, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, ny, nx,
-                               increase, coord_incre, mask_idx, nmask, out_masks);
+                               increase, coord_incre, variant, mask_idx, nmask, out_masks);
         else
             hipLaunchKernelGGL(k_lwa_masks<float>, g2, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, ny, nx,
-                               increase, coord_incre, mask_idx, nmask, out_masks);
+                               increase, coord_incre, variant, mask_idx, nmask, out_masks);
         XC_HIP(ctx, hipGetLastError());
     }
     return XC_OK;
