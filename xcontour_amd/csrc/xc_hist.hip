@@ -30,11 +30,24 @@ namespace {
 
 constexpr int U = 2;   // rows per prefetch batch (double-buffered)
 
+// Grid mapping.  Default: the SLAB is the fastest-varying block index, so blocks that work on the
+// same rows of different slabs are dispatched together and (blocks b, b+8 share an XCD) meet in one
+// XCD's L2, where the shared dA plane is then fetched once for several slabs.
+#ifdef XC_GRID_BLOCK_FASTEST
+#define XC_SLAB ((int)blockIdx.y)
+#define XC_BLK  ((int)blockIdx.x)
+#define XC_NBLK ((int)gridDim.x)
+#else
+#define XC_SLAB ((int)blockIdx.x)
+#define XC_BLK  ((int)blockIdx.y)
+#define XC_NBLK ((int)gridDim.y)
+#endif
+
 // Diagnostic build only (-DXC_STAMPS): wave 0 / lane 0 of every block stores s_memrealtime
 // (100 MHz) at phase boundaries into a buffer nothing else reads.  Never in the shipped .so.
 #ifdef XC_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;
-#define XC_STAMP(i) do { if (g_stamps && tid == 0) g_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#define XC_STAMP(i) do { if (g_stamps && tid == 0) g_stamps[(XC_SLAB * XC_NBLK + XC_BLK) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define XC_STAMP(i) do {} while (0)
 #endif
@@ -176,7 +189,7 @@ void k_hist(const HistArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction
     const int nwave = blockDim.x >> 6;
-    const int slab = blockIdx.y;
+    const int slab = XC_SLAB, bx = XC_BLK, nbx = XC_NBLK;
     const int N = a.nbin;
     const int ncopy = a.ncopy;
     const int epad = (N + 2) & ~1;
@@ -189,8 +202,8 @@ void k_hist(const HistArgs a)
     // ------------------------------------------------------------------ this wave's share of (strip,row) pairs
     const int64_t ny = a.ny, nx = a.nx;
     const int64_t total = (int64_t)a.nstrip * ny;
-    const int64_t nw = (int64_t)gridDim.x * nwave;
-    const int64_t wg = (int64_t)blockIdx.x * nwave + wave;
+    const int64_t nw = (int64_t)nbx * nwave;
+    const int64_t wg = (int64_t)bx * nwave + wave;
     int64_t g0 = total * wg / nw;
     const int64_t g1 = total * (wg + 1) / nw;
 
@@ -298,7 +311,7 @@ void k_hist(const HistArgs a)
         for (int k = tid; k < N; k += blockDim.x) {
             const double c = level_value(mn, mx, k, a.increase, a.q_f32, a.ctr_f32, a.inv_nm1);
             s_edges[a.increase ? k + 1 : N - k] = c;
-            if (blockIdx.x == 0 && a.ctr_out) a.ctr_out[(size_t)slab * N + k] = c;
+            if (bx == 0 && a.ctr_out) a.ctr_out[(size_t)slab * N + k] = c;
         }
         __syncthreads();
         if (tid == 0) {
@@ -306,7 +319,7 @@ void k_hist(const HistArgs a)
             s_edges[0] = dummy_edge(lo, hi, N, a.ctr_f32);
             if (a.right_edge == XC_EDGE_XHISTOGRAM) s_edges[N] = bump_last_edge(hi, a.ctr_f32);
         }
-        if (blockIdx.x == 0 && a.status) {
+        if (bx == 0 && a.status) {
             // reference raises 'non monotonic bins' when two adjacent levels coincide (core.py:1233)
             int bad = 0;
             for (int k = tid + 1; k < N; k += blockDim.x) bad |= (s_edges[k] == s_edges[k + 1]);
@@ -314,7 +327,7 @@ void k_hist(const HistArgs a)
             if (tid == 0) a.status[slab] = bad ? 1 : 0;
         }
         __syncthreads();
-        if (blockIdx.x == 0 && a.edges_out)
+        if (bx == 0 && a.edges_out)
             for (int k = tid; k <= N; k += blockDim.x) a.edges_out[(size_t)slab * (N + 1) + k] = s_edges[k];
     } else {
         const double* e = a.edges + (a.edges_per_slab ? (size_t)slab * (N + 1) : 0);
@@ -474,13 +487,13 @@ void k_hist(const HistArgs a)
     __syncthreads();
     if (NEXT && tid == 0) {
         for (int w = 1; w < nwave; ++w) { nmn = fmin(nmn, s_red[2 * w]); nmx = fmax(nmx, s_red[2 * w + 1]); }
-        double* o = a.mm_next + ((size_t)slab * gridDim.x + blockIdx.x) * 2;
+        double* o = a.mm_next + ((size_t)slab * nbx + bx) * 2;
         o[0] = nmn; o[1] = nmx;
     }
     XC_STAMP(4);
 
     // ------------------------------------------------------------------ per-block partials (plain stores)
-    const size_t pb = (size_t)slab * gridDim.x + blockIdx.x;
+    const size_t pb = (size_t)slab * nbx + bx;
     double* ph = a.part_h + pb * NCH * N;
     // sum the lane-privatised copies; every thread starts at a rotated copy index so that the
     // 64 lanes of a wave hit distinct LDS banks (a fixed, thread-determined order)
@@ -519,7 +532,11 @@ int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget + 4096));
         attr_set = true;
     }
+#ifdef XC_GRID_BLOCK_FASTEST
     dim3 grid((unsigned)g.bps, (unsigned)nslab);
+#else
+    dim3 grid((unsigned)nslab, (unsigned)g.bps);
+#endif
     hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds, ctx->stream, a);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;

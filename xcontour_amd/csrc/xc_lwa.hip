@@ -15,7 +15,6 @@
 namespace xc {
 namespace {
 
-constexpr int JT = 8;
 
 __device__ __forceinline__ int mask3(double qe, bool m, int increase)
 {
@@ -26,13 +25,16 @@ __device__ __forceinline__ int mask3(double qe, bool m, int increase)
 }
 
 // V2: cal_local_wave_activity2 (core.py:802-905): qe = q[row j] - Q[all rows], opposite sign convention.
-template <typename T, bool V2>
+// JT target rows per thread: 1 for small problems (more waves in flight), 4 when the slab is large
+// (each thread re-streams its column once per JT targets).
+template <typename T, bool V2, int JT>
 __global__ __launch_bounds__(256)
 void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
            const double* __restrict__ dA, int dA_rank, double dA_max,
            const double* __restrict__ M, int M_rank,
-           int64_t ny, int64_t nx, int increase, int coord_incre, int part, double* __restrict__ out)
+           int64_t ny, int64_t nx, int increase, int part, double* __restrict__ out)
 {
+    const int coord_incre = !(coord[ny - 1] < coord[0]);                 // core.py:736-738
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t x = (int64_t)blockIdx.x * 64 + lane;
     const int64_t j0 = ((int64_t)blockIdx.y * 4 + wave) * JT;
@@ -53,21 +55,34 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
     // keep the sign of the selected part: 'upper' keeps mask>0 if increase else mask<0 (core.py:775-784)
     const int keep = (part == 0) ? 0 : (((part == 1) == (increase != 0)) ? 1 : -1);
 
-    for (int64_t y = 0; y < ny; ++y) {
-        const double qv = V2 ? Qs[y] : (active ? (double)qs[y * nx + x] : 0.0);
-        const double cy = coord[y];
-        const double dv = (dA_rank == XC_DA_ROW) ? dA[y] : (active ? dA[y * nx + x] : 0.0);
-        const double wei = __ddiv_rn(dv, dA_max);                                   // core.py:724
-        const double mv = (M_rank == XC_DA_NONE) ? dv
-                        : (M_rank == XC_DA_ROW) ? M[y] : (active ? M[y * nx + x] : 0.0);
+    // rows are consumed strictly in y' order (numpy's axis-0 nansum order), but the loads of RB rows
+    // are issued together so that their latency overlaps
+    constexpr int RB = 8;
+    const int64_t xl = active ? x : 0;
+    for (int64_t yb = 0; yb < ny; yb += RB) {
+        double qv_[RB], dv_[RB], mv_[RB], cy_[RB];
 #pragma unroll
-        for (int t = 0; t < JT; ++t) {
-            const double qe = V2 ? __dsub_rn(Qj[t], qv) : __dsub_rn(qv, Qj[t]);     // core.py:860 / 754
-            const bool m = coord_incre ? (cy >= cj[t]) : (cy <= cj[t]);             // core.py:757
-            const int mk = mask3(qe, m, inc_eff);
-            if (mk != 0 && (keep == 0 || (keep > 0) == (mk > 0))) {
-                const double term = __dmul_rn(__dmul_rn(__dmul_rn(qe, (double)mk), wei), mv);
-                if (term == term) acc[t] = __dadd_rn(acc[t], term);                 // nansum
+        for (int r = 0; r < RB; ++r) {
+            const int64_t y = (yb + r < ny) ? yb + r : ny - 1;
+            qv_[r] = V2 ? Qs[y] : (double)qs[y * nx + xl];
+            cy_[r] = coord[y];
+            dv_[r] = (dA_rank == XC_DA_ROW) ? dA[y] : dA[y * nx + xl];
+            mv_[r] = (M_rank == XC_DA_NONE) ? dv_[r] : (M_rank == XC_DA_ROW) ? M[y] : M[y * nx + xl];
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (yb + r >= ny) break;
+            const double qv = qv_[r], cy = cy_[r], mv = mv_[r];
+            const double wei = __ddiv_rn(dv_[r], dA_max);                               // core.py:724
+#pragma unroll
+            for (int t = 0; t < JT; ++t) {
+                const double qe = V2 ? __dsub_rn(Qj[t], qv) : __dsub_rn(qv, Qj[t]);     // core.py:860 / 754
+                const bool m = coord_incre ? (cy >= cj[t]) : (cy <= cj[t]);             // core.py:757
+                const int mk = mask3(qe, m, inc_eff);
+                if (mk != 0 && (keep == 0 || (keep > 0) == (mk > 0))) {
+                    const double term = __dmul_rn(__dmul_rn(__dmul_rn(qe, (double)mk), wei), mv);
+                    if (term == term) acc[t] = __dadd_rn(acc[t], term);                 // nansum
+                }
             }
         }
     }
@@ -81,13 +96,14 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_lwa_masks(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
-                 int64_t ny, int64_t nx, int increase, int coord_incre, int v2,
+                 int64_t ny, int64_t nx, int increase, int v2,
                  const int32_t* __restrict__ mask_idx, int nmask, int8_t* __restrict__ out)
 {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t y = blockIdx.y;
     const int slab = blockIdx.z / nmask, im = blockIdx.z % nmask;
     if (x >= nx) return;
+    const int coord_incre = !(coord[ny - 1] < coord[0]);
     const int64_t j = mask_idx[im];
     const double qe = v2 ? __dsub_rn((double)q[(size_t)slab * ny * nx + j * nx + x], Q[(size_t)slab * ny + y])
                          : __dsub_rn((double)q[(size_t)slab * ny * nx + y * nx + x], Q[(size_t)slab * ny + j]);
@@ -110,30 +126,28 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     if (part < 0 || part > 2) return fail(ctx, XC_EBADARG, "xc_lwa: part must be 0 (all), 1 (upper) or 2 (lower)");
     if (nmask < 0 || (nmask > 0 && (!mask_idx || !out_masks))) return fail(ctx, XC_EBADARG, "xc_lwa: mask arguments");
     if (ny > 65535 || nslab * (nmask > 0 ? nmask : 1) > 65535) return fail(ctx, XC_EBADARG, "xc_lwa: ny / nslab too large");
-    // coordinate direction (core.py:736-738) is decided on the host by the caller's coord;
-    // here we need it on the host too: read the two end values.
-    double c2[2];
-    XC_HIP(ctx, hipMemcpyAsync(&c2[0], coord, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    XC_HIP(ctx, hipMemcpyAsync(&c2[1], coord + (ny - 1), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int coord_incre = !(c2[1] < c2[0]);
-    dim3 grid((unsigned)((nx + 63) / 64), (unsigned)((ny + 4 * JT - 1) / (4 * JT)), (unsigned)nslab);
-#define XC_LWA(T, V) hipLaunchKernelGGL((k_lwa<T, V>), grid, dim3(256), 0, ctx->stream, (const T*)q, Q, coord, dA, dA_rank, \
-                           dA_max, M, M_rank, ny, nx, increase, coord_incre, part, out_lwa)
+    // small problems: one target row per thread so that the whole chip is busy
+    const bool small = (double)ny * (double)ny * (double)nx * (double)nslab < 4.0e9;
+    const int jt = small ? 1 : 4;
+    dim3 grid((unsigned)((nx + 63) / 64), (unsigned)((ny + 4 * jt - 1) / (4 * jt)), (unsigned)nslab);
+#define XC_LWA2(T, V, J) hipLaunchKernelGGL((k_lwa<T, V, J>), grid, dim3(256), 0, ctx->stream, (const T*)q, Q, coord, dA, dA_rank, \
+                           dA_max, M, M_rank, ny, nx, increase, part, out_lwa)
+#define XC_LWA(T, V) do { if (small) XC_LWA2(T, V, 1); else XC_LWA2(T, V, 4); } while (0)
     if (variant != 0 && variant != 1) return fail(ctx, XC_EBADARG, "xc_lwa: variant must be 0 or 1");
     if (q_dtype == XC_F64) { if (variant) XC_LWA(double, true); else XC_LWA(double, false); }
     else if (q_dtype == XC_F32) { if (variant) XC_LWA(float, true); else XC_LWA(float, false); }
     else return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
 #undef XC_LWA
+#undef XC_LWA2
     XC_HIP(ctx, hipGetLastError());
     if (nmask > 0) {
         dim3 g2((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)(nslab * nmask));
         if (q_dtype == XC_F64)
             hipLaunchKernelGGL(k_lwa_masks<double>, g2, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, ny, nx,
-                               increase, coord_incre, variant, mask_idx, nmask, out_masks);
+                               increase, variant, mask_idx, nmask, out_masks);
         else
             hipLaunchKernelGGL(k_lwa_masks<float>, g2, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, ny, nx,
-                               increase, coord_incre, variant, mask_idx, nmask, out_masks);
+                               increase, variant, mask_idx, nmask, out_masks);
         XC_HIP(ctx, hipGetLastError());
     }
     return XC_OK;
