@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 NY, NX, NCONT = 1801, 3600, 201
 SEED = 20241008
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-BYTES_PER_CELL = 16              # algorithmic: tracer f64 once + dA f64 once
+BYTES_PER_CELL = 16              # algorithmic: tracer f64 once + dA f64 once; 8 with --row-dA
 
 
 # ----------------------------------------------------------------------------- CPU baseline worker
@@ -96,6 +96,10 @@ def main():
     ap.add_argument('--no-chain', action='store_true',
                     help='run the stand-alone min/max pass every step instead of folding the next '
                          "step's min/max into the histogram pass")
+    ap.add_argument('--row-dA', action='store_true',
+                    help='let the plan detect that the lat-lon dA plane has constant rows and read it as a '
+                         'per-row vector (8 B/cell algorithmic instead of 16); off by default: the headline '
+                         'keeps the generic 2-D dA read')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-slabs', type=int, default=0, help='CPU sample size (0: auto)')
     a = ap.parse_args()
@@ -139,7 +143,7 @@ def main():
     res = torch.empty(slot * K // 8, dtype=torch.float64, device='cuda')
     wres = torch.empty(slot // 8, dtype=torch.float64, device='cuda')        # warm-up slot
     plan = KeffPlan(ctx, NB * B, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl,
-                    tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.data_ptr())
+                    tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.data_ptr(), detect_row_dA=a.row_dA)
     plan.synth(lat, lon, SEED + rank * NB * B, a.variant)         # slab s of rank r: seed + r*2B + s
     group = a.group or B
     chain = not a.no_chain
@@ -192,14 +196,14 @@ def main():
             'config': {'workload': 'cfg2: synthetic %dx%d float64 PV-like slabs, 2-D f64 dA, %d contours, '
                                    'full Keff (min/max + histogram with in-kernel |grad q|^2 + CDF + epilogue)'
                                    % (NX, NY, NCONT),
-                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant,
+                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant, 'dA': 'per-row vector (detected constant rows)' if a.row_dA else '2-D f64 plane',
                        'minmax': 'folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass',
                        'parallelism': 'independent slabs per GPU, one RCCL all-gather at the end' if world > 1 else 'single GPU',
                        'device': ctx.device_name()},
         }
         if group == B:
             ms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in ev])
-            alg = B * NY * NX * BYTES_PER_CELL
+            alg = B * NY * NX * (8 if a.row_dA else BYTES_PER_CELL)
             ach = alg / (ms.mean() * 1e-3) / 1e9
             traffic = None
             tf = os.path.join(ROOT, 'profiles', 'hist_traffic.json')
@@ -212,7 +216,7 @@ def main():
                                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                                 'kernel': 'k_hist<double,2,0,true,true,%s>' % ('true' if chain else 'false'), 'launch_ms': float(ms.mean()),
                                 'algorithmic_bytes_per_launch': alg,
-                                'pipeline_frac': world and (B * NY * NX * BYTES_PER_CELL * K / el / 1e9 / world) / HBM_PEAK_GBS}
+                                'pipeline_frac': (B * NY * NX * (8 if a.row_dA else BYTES_PER_CELL) * K / el / 1e9) / HBM_PEAK_GBS}
         # parity spot check of the last step against nothing heavy: invariants only (oracle runs in cpu leg)
         out = plan.fetch(slot=K - 1)
         last = slice(((K - 1) % NB) * B, ((K - 1) % NB) * B + B)  # the batch the last step processed

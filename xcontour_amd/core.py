@@ -594,7 +594,8 @@ class Contour2D(object):
                         periodic_x=periodic_x, tbl=tv, tbl_coord=tcoords[table._dimEq], preY=preY,
                         increase=self.increase, lt=self.lt, right_edge=self.right_edge,
                         nkeff_mask=nkeff_mask, grdS_dtype=None if g is None else g.dtype,
-                        prod_f32=bool(g is not None and g.dtype == np.float32 and dA_f32))
+                        prod_f32=bool(g is not None and g.dtype == np.float32 and dA_f32),
+                        detect_row_dA=True)
         try:
             plan.set_q(q)
             if g is not None:

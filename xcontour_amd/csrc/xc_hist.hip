@@ -55,6 +55,8 @@ __device__ unsigned long long* g_stamps = nullptr;
 __device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000LL); }
 __device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
 
+// Row loads take a wave-uniform row pointer plus a 32-bit per-lane byte offset so that the
+// compiler can use the saddr + voffset form (no 64-bit VALU address arithmetic per load).
 template <typename T, int VEC> struct RowLoad;
 template <> struct RowLoad<double, 2> {
     static __device__ __forceinline__ void ld(const double* p, double (&v)[2]) {
@@ -200,14 +202,15 @@ void k_hist(const HistArgs a)
     const int hsz = N * ncopy;
 
     // ------------------------------------------------------------------ this wave's share of (strip,row) pairs
-    const int64_t ny = a.ny, nx = a.nx;
+    const int ny = (int)a.ny, nx = (int)a.nx;                    // host guarantees < 2^31
     const int64_t total = (int64_t)a.nstrip * ny;
     const int64_t nw = (int64_t)nbx * nwave;
     const int64_t wg = (int64_t)bx * nwave + wave;
     int64_t g0 = total * wg / nw;
     const int64_t g1 = total * (wg + 1) / nw;
 
-    const size_t slab_off = (size_t)slab * ny * nx;
+    const size_t slab_off = (size_t)slab * (size_t)ny * (size_t)nx;
+    const size_t rowq = (size_t)nx * sizeof(TQ), rowd = (size_t)nx * sizeof(double);
     const TQ* __restrict__ qs = reinterpret_cast<const TQ*>(a.q) + slab_off;
     const TQ* __restrict__ qnx = NEXT ? reinterpret_cast<const TQ*>(a.q_next) + slab_off : nullptr;
     double nmn = dinf(), nmx = -dinf();
@@ -215,28 +218,33 @@ void k_hist(const HistArgs a)
     const double* __restrict__ rdxp = a.rdx;
     const double* __restrict__ rdyp = a.rdy;
     const int copy = lane & (ncopy - 1);
+    const int cshift = __builtin_ctz((unsigned)ncopy);            // ncopy is a power of two
     const int periodic_x = a.periodic_x;
 
-    // segment state (wave-uniform scalars + per-lane column offsets)
-    int64_t y0 = 0, y1 = 0, xld = 0, xh = 0;
+    // segment state (wave-uniform scalars + per-lane 32-bit byte offsets inside a row)
+    int y0 = 0, y1 = 0;
+    unsigned xo_q = 0, xo_h = 0, xo_d = 0, xo_f = 0;
     bool active = false;
     int rlane = 63;
     double fx[VEC];
 
     auto begin_segment = [&]() {
         const int     s  = (int)(g0 / ny);
-        y0 = g0 - (int64_t)s * ny;
-        y1 = (y0 + (g1 - g0) < ny) ? y0 + (g1 - g0) : ny;
+        y0 = (int)(g0 - (int64_t)s * ny);
+        const int64_t rem = g1 - g0;
+        y1 = (y0 + rem < ny) ? (int)(y0 + rem) : ny;
         g0 += (y1 - y0);
-        const int64_t x0 = (int64_t)s * W;
-        const int64_t x  = x0 + (int64_t)lane * VEC;
+        const int x0 = s * W;
+        const int x  = x0 + lane * VEC;
         active = x < nx;
-        xld = active ? x : nx - VEC;                                   // clamped: loads are unconditional
-        const int64_t xend = (x0 + W < nx) ? x0 + W : nx;
-        rlane = (int)((xend - x0) / VEC) - 1;                          // lane holding the strip's last valid cell
-        const int64_t xl = (x0 == 0) ? (periodic_x ? nx - 1 : 0) : x0 - 1;
-        const int64_t xr = (xend == nx) ? (periodic_x ? 0 : nx - 1) : xend;
-        xh = (lane == 0) ? xl : ((lane == 63) ? xr : xld);             // halo column (lanes 0 / 63 matter)
+        const int xld = active ? x : nx - VEC;                         // clamped: loads are unconditional
+        const int xend = (x0 + W < nx) ? x0 + W : nx;
+        rlane = (xend - x0) / VEC - 1;                                 // lane holding the strip's last valid cell
+        const int xl = (x0 == 0) ? (periodic_x ? nx - 1 : 0) : x0 - 1;
+        const int xr = (xend == nx) ? (periodic_x ? 0 : nx - 1) : xend;
+        const int xh = (lane == 0) ? xl : ((lane == 63) ? xr : xld);   // halo column (lanes 0 / 63 matter)
+        xo_q = (unsigned)xld * (unsigned)sizeof(TQ); xo_h = (unsigned)xh * (unsigned)sizeof(TQ);
+        xo_d = (unsigned)xld * 8u; xo_f = (unsigned)xld * 4u;
         // one-sided x differences at the walls of a non-periodic domain use spacing dx, not 2dx
 #pragma unroll
         for (int c = 0; c < VEC; ++c)
@@ -244,15 +252,18 @@ void k_hist(const HistArgs a)
     };
 
     // branch-free loads of one row: q row `yq` (+ halo), weights of row `yw`
-    auto load_row = [&](RowBuf<VEC, NINT>& r, int64_t yq, int64_t yw) {
+    const char* qbase = reinterpret_cast<const char*>(qs);
+    const char* nbase = reinterpret_cast<const char*>(qnx);
+    const char* dbase = reinterpret_cast<const char*>(dAp);
+    auto load_row = [&](RowBuf<VEC, NINT>& r, int yq, int yw) {
         yq = yq < ny - 1 ? yq : ny - 1;
         yw = yw < ny - 1 ? yw : ny - 1;
-        const TQ* qrow = qs + yq * nx;
-        RowLoad<TQ, VEC>::ld(qrow + xld, r.q);
-        if (GRAD) r.h = (double)qrow[xh];
-        if (NEXT) RowLoad<TQ, VEC>::ld(qnx + yw * nx + xld, r.qn);
+        const char* qrow = qbase + (size_t)yq * rowq;                          // wave-uniform
+        RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
+        if (GRAD) r.h = (double)*reinterpret_cast<const TQ*>(qrow + xo_h);
+        if (NEXT) RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
         if (DA2D) {
-            RowLoad<double, VEC>::ld(dAp + yw * nx + xld, r.dA);
+            RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(dbase + (size_t)yw * rowd + xo_d), r.dA);
         } else {
             const double v = dAp[yw];
 #pragma unroll
@@ -261,12 +272,14 @@ void k_hist(const HistArgs a)
 #pragma unroll
         for (int i = 0; i < NINT; ++i) {
             if (a.integ_f32[i])
-                RowLoad<float, VEC>::ld(reinterpret_cast<const float*>(a.integ[i]) + slab_off + yw * nx + xld, r.in[i]);
+                RowLoad<float, VEC>::ld(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.integ[i]) +
+                                        (slab_off + (size_t)yw * nx) * 4 + xo_f), r.in[i]);
             else
-                RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(a.integ[i]) + slab_off + yw * nx + xld, r.in[i]);
+                RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.integ[i]) +
+                                         (slab_off + (size_t)yw * nx) * 8 + xo_d), r.in[i]);
         }
     };
-    auto load_batch = [&](RowBuf<VEC, NINT> (&L)[U], int64_t yb) {
+    auto load_batch = [&](RowBuf<VEC, NINT> (&L)[U], int yb) {
 #pragma unroll
         for (int i = 0; i < U; ++i) load_row(L[i], GRAD ? yb + i + 1 : yb + i, yb + i);
     };
@@ -360,7 +373,7 @@ void k_hist(const HistArgs a)
     // one centre row: bins, weights, accumulate
     auto do_row = [&](const double (&qc)[VEC], const double (&qS)[VEC], const double (&qN)[VEC],
                       double hc, const double (&dAv)[VEC], const double (&inv_)[NINT > 0 ? NINT : 1][VEC],
-                      int64_t y) {
+                      int y) {
         int k[VEC];
         double w[NCH][VEC];
 #pragma unroll
@@ -424,7 +437,7 @@ void k_hist(const HistArgs a)
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
                 if (k[c] >= 0) {
-                    const int o = k[c] * ncopy + XC_ROT(copy, k[c], ncopy);
+                    const int o = (k[c] << cshift) + XC_ROT(copy, k[c], ncopy);
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) lds_add(&s_h[ch * hsz + o], w[ch][c]);
                     lds_add(&s_c[o], 1u);
@@ -434,13 +447,16 @@ void k_hist(const HistArgs a)
     };
 
     // batch of U centre rows starting at yb; L holds (GRAD) q rows yb+1.. and weights rows yb..
-    auto process_batch = [&](RowBuf<VEC, NINT> (&L)[U], int64_t yb) {
+    auto process_batch = [&](RowBuf<VEC, NINT> (&L)[U], int yb) {
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             if (yb + i < y1) {
                 if (NEXT && active) {
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) { nmn = fmin(nmn, L[i].qn[c]); nmx = fmax(nmx, L[i].qn[c]); }
+                    for (int c = 0; c < VEC; ++c) {              // NaN never wins a compare: NaN-skipping
+                        const double v = L[i].qn[c];
+                        nmn = (v < nmn) ? v : nmn; nmx = (v > nmx) ? v : nmx;
+                    }
                 }
                 if (GRAD) {
                     do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in, yb + i);
@@ -455,7 +471,7 @@ void k_hist(const HistArgs a)
     };
 
     while (have) {
-        for (int64_t yb = y0; yb < y1; yb += 2 * U) {
+        for (int yb = y0; yb < y1; yb += 2 * U) {
             if (yb + U < y1) load_batch(B, yb + U);
             process_batch(A, yb);
             if (yb + U >= y1) break;

@@ -37,14 +37,16 @@ class KeffPlan(object):
                  dA=None, lat=None, lon=None, rdx=None, rdy=None, periodic_x=True,
                  tbl=None, tbl_coord=None, preY=None, increase=True, lt=True,
                  right_edge='numpy', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
-                 prod_f32=False, alloc_q=True, nslots=1, out_ptr=None):
+                 prod_f32=False, alloc_q=True, nslots=1, out_ptr=None, detect_row_dA=False):
         """dA: None | (ny,) | (ny,nx) f64.  Gradient metrics either `rdx, rdy`
         (per-row reciprocals) or derived from `lat, lon` (sphere).  If
         `grdS_dtype` is given the squared gradient is an INPUT (set with
         `set_grdS`) instead of being computed in-kernel.
         `nslots`: number of result slots (`run(slot=k)` writes slot k, so a long job keeps
         every step's vectors on the device until one gather at the end); `out_ptr`: use a
-        caller-owned device allocation of `out_bytes(…) * nslots` bytes for them."""
+        caller-owned device allocation of `out_bytes(…) * nslots` bytes for them.
+        `detect_row_dA`: a 2-D dA whose rows are constant (every regular lat-lon `rA`) is passed
+        to the kernels as its first column (identical results, 8 B/cell less traffic)."""
         self.ctx = ctx
         self.nslab, self.ny, self.nx, self.N = int(nslab), int(ny), int(nx), int(N)
         self.q_dtype, self.ctr_dtype = np.dtype(q_dtype), np.dtype(ctr_dtype)
@@ -64,6 +66,8 @@ class KeffPlan(object):
             d.dA, d.dA_rank = None, nat.XC_DA_NONE
         else:
             dA = np.ascontiguousarray(dA, dtype=np.float64)
+            if detect_row_dA and dA.shape == (self.ny, self.nx) and np.array_equal(dA, np.repeat(dA[:, :1], self.nx, axis=1)):
+                dA = np.ascontiguousarray(dA[:, 0])
             if dA.shape == (self.ny,):
                 d.dA_rank = nat.XC_DA_ROW
             elif dA.shape == (self.ny, self.nx):
