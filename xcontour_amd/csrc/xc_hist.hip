@@ -133,8 +133,9 @@ __device__ __forceinline__ int find_bin(double v, const double* __restrict__ s_e
 {
     int k = (int)((v - e0) * inv);                   // NaN -> 0
     k = k < 0 ? 0 : (k > N - 1 ? N - 1 : k);
-    const double lo = s_edges[k], hi = s_edges[k + 1];
-    if (v >= lo && v < hi) return k;
+    const double lo = s_edges[k], hi = s_edges[k + 1];          // one ds_read2_b64
+    const bool hit = (v >= lo) & (v < hi);                      // bitwise: no short-circuit branch between the reads
+    if (hit) return k;
     return find_bin_slow(v, s_edges, N, k, e0, eN, last_closed);
 }
 
@@ -176,6 +177,7 @@ struct RowBuf {
     double dA[VEC];
     double in[NINT > 0 ? NINT : 1][VEC];
     double qn[VEC];         // NEXT: the same cells of the next batch (min/max by-product)
+    double rdx, rdy;        // GRAD: the centre row's reciprocal metrics (wave-uniform)
 };
 
 // DA2D: dA is a [ny][nx] plane (vector loads); otherwise one value per row (scalar).
@@ -262,6 +264,7 @@ void k_hist(const HistArgs a)
         RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
         if (GRAD) r.h = (double)*reinterpret_cast<const TQ*>(qrow + xo_h);
         if (NEXT) RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
+        if (GRAD) { r.rdx = rdxp[yw]; r.rdy = rdyp[yw]; }
         if (DA2D) {
             RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(dbase + (size_t)yw * rowd + xo_d), r.dA);
         } else {
@@ -373,7 +376,7 @@ void k_hist(const HistArgs a)
     // one centre row: bins, weights, accumulate
     auto do_row = [&](const double (&qc)[VEC], const double (&qS)[VEC], const double (&qN)[VEC],
                       double hc, const double (&dAv)[VEC], const double (&inv_)[NINT > 0 ? NINT : 1][VEC],
-                      int y) {
+                      double rdx, double rdy) {
         int k[VEC];
         double w[NCH][VEC];
 #pragma unroll
@@ -402,7 +405,6 @@ void k_hist(const HistArgs a)
 #else
         if (GRAD) {
 #endif
-            const double rdx = rdxp[y], rdy = rdyp[y];
             const double hl = lane_bcast(hc, 0), hr = lane_bcast(hc, 63);
             const double fromL = lane_shift<DPP_WAVE_SHR1>(qc[VEC - 1]);     // lane-1's last cell
             const double fromR = lane_shift<DPP_WAVE_SHL1>(qc[0]);           // lane+1's first cell
@@ -459,12 +461,12 @@ void k_hist(const HistArgs a)
                     }
                 }
                 if (GRAD) {
-                    do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in, yb + i);
+                    do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in, L[i].rdx, L[i].rdy);
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) { qm[c] = qcur[c]; qcur[c] = L[i].q[c]; }
                     hcur = L[i].h;
                 } else {
-                    do_row(L[i].q, L[i].q, L[i].q, 0.0, L[i].dA, L[i].in, yb + i);
+                    do_row(L[i].q, L[i].q, L[i].q, 0.0, L[i].dA, L[i].in, 0.0, 0.0);
                 }
             }
         }
