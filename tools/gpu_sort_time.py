@@ -1,0 +1,15 @@
+import sys, numpy as np
+sys.path.insert(0, ".")
+from xcontour_amd import _native as nat
+ctx = nat.Context(0)
+n = 1801*3600
+q = np.random.default_rng(0).standard_normal((1801, 3600))
+dq = ctx.to_device(q)
+e0, e1 = ctx.event(), ctx.event()
+nv = ctx.alloc(64)
+for rep in range(4):
+    ctx.record(e0)
+    ctx._check(ctx.lib.xc_sort_profile_dev(ctx.handle, dq.ptr, 1, None, 1, None, 0, 1801, 3600, 0, None, 0, None, None, 0, None, None, None, nv.ptr, None))
+    ctx.record(e1)
+    ms = ctx.elapsed_ms(e0, e1)
+    print("sort 6.48M (key f64, payload f64): %.3f ms -> %.2f Gpairs/s; pass traffic %.0f GB/s" % (ms, n/ms/1e6, 8*(8+32)*n/ms/1e6))

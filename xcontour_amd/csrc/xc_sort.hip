@@ -36,20 +36,26 @@ __device__ __forceinline__ double key_to_f64(unsigned long long k)
 template <typename TQ, typename TM>
 __global__ __launch_bounds__(256)
 void k_sort_keys(const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA, int dA_rank,
-                 int64_t nx, int64_t n, int negate, unsigned long long* __restrict__ keys, double* __restrict__ vals,
-                 unsigned* __restrict__ nvalid)
+                 int64_t nx, int64_t n, int negate, unsigned long long* __restrict__ keys, double* __restrict__ vals)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool ok = false;
     if (i < n) {
         const double v = negate ? -(double)q[i] : (double)q[i];
-        ok = (v == v) && (!mask || mask[i] == (TM)1);
+        const bool ok = (v == v) && (!mask || mask[i] == (TM)1);
         const double w = (dA_rank == XC_DA_ROW) ? dA[i / nx] : (dA_rank == XC_DA_PLANE ? dA[i] : 1.0);
         keys[i] = ok ? f64_to_key(v) : KEY_INVALID;        // invalid cells sort to the end
         vals[i] = ok ? w : 0.0;
     }
-    const unsigned long long b = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(nvalid, (unsigned)__popcll(b));
+}
+
+// number of valid cells = position of the first KEY_INVALID in the sorted keys (one thread:
+// a per-wave atomic counter in k_sort_keys serialised 100k atomics on one address = 1.1 ms)
+__global__ void k_count_valid(const unsigned long long* __restrict__ keys, int64_t n, unsigned* __restrict__ nvalid)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t lo = 0, hi = n;                        // first index with keys[idx] == KEY_INVALID
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < KEY_INVALID) lo = mid + 1; else hi = mid; }
+    *nvalid = (unsigned)lo;
 }
 
 // peer mask of lanes holding the same 8-bit digit (only lanes in `valid`)
@@ -74,10 +80,17 @@ void k_radix_hist(const unsigned long long* __restrict__ keys, int64_t n, int sh
     for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = 0;
     if (t < ntiles) {
         const int64_t base = t * TILE;
+        unsigned long long kreg[TILE_ROUNDS];                  // all loads of the tile in flight at once
+#pragma unroll
+        for (int r = 0; r < TILE_ROUNDS; ++r) {
+            const int64_t i = base + r * 64 + lane;
+            kreg[r] = i < n ? keys[i] : 0ull;
+        }
+#pragma unroll
         for (int r = 0; r < TILE_ROUNDS; ++r) {
             const int64_t i = base + r * 64 + lane;
             const bool valid = i < n;
-            const unsigned d = valid ? (unsigned)((keys[i] >> shift) & 255ull) : 0u;
+            const unsigned d = valid ? (unsigned)((kreg[r] >> shift) & 255ull) : 0u;
             const unsigned long long peers = digit_peers(d, __ballot(valid));
             if (valid && (peers & ((1ull << lane) - 1ull)) == 0) s_cnt[wave][d] += (unsigned)__popcll(peers);
         }
@@ -134,11 +147,20 @@ void k_radix_scatter(const unsigned long long* __restrict__ kin, const double* _
     if (t >= ntiles) return;
     for (int d = lane; d < 256; d += 64) s_pos[wave][d] = bases[d] + hist[(size_t)d * ntiles + t];
     const int64_t base = t * TILE;
+    unsigned long long kreg[TILE_ROUNDS];                      // the whole tile's loads in flight at once
+    double vreg[TILE_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < TILE_ROUNDS; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        kreg[r] = i < n ? kin[i] : 0ull;
+        vreg[r] = i < n ? vin[i] : 0.0;
+    }
+#pragma unroll
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
         const bool valid = i < n;
-        const unsigned long long key = valid ? kin[i] : 0ull;
-        const double val = valid ? vin[i] : 0.0;
+        const unsigned long long key = kreg[r];
+        const double val = vreg[r];
         const unsigned d = valid ? (unsigned)((key >> shift) & 255ull) : 0u;
         const unsigned long long peers = digit_peers(d, __ballot(valid));
         const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
@@ -297,10 +319,9 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
     double* bsum = (double*)w; w += al((size_t)nb * 8);
     double* parts = (double*)w;
 
-    XC_HIP(ctx, hipMemsetAsync(nvalid, 0, sizeof(unsigned), ctx->stream));
     const unsigned gb = (unsigned)((n + 255) / 256);
 #define XC_KEYS(TQ, TM) hipLaunchKernelGGL((k_sort_keys<TQ, TM>), dim3(gb), dim3(256), 0, ctx->stream, (const TQ*)q, \
-        (const TM*)mask, dA, dA_rank, nx, n, negate, kA, vA, nvalid)
+        (const TM*)mask, dA, dA_rank, nx, n, negate, kA, vA)
     const bool m32 = mask && mask_dtype == XC_F32;
     if (q_dtype == XC_F64) { if (m32) XC_KEYS(double, float); else XC_KEYS(double, double); }
     else if (q_dtype == XC_F32) { if (m32) XC_KEYS(float, float); else XC_KEYS(float, double); }
@@ -322,6 +343,7 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
         double* tv = vin; vin = vout; vout = tv;
     }
     // 8 passes: sorted data are back in kA / vA (= kin / vin)
+    hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(64), 0, ctx->stream, kin, n, nvalid);
     double* acum = vout;                                   // reuse the idle payload buffer
     hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb);
