@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_variant.sh NAME "-DFLAG1 -DFLAG2"  -> xcontour_amd/libxc_NAME.so (diagnostic builds only)
+# tools/build_variant.sh NAME "-DXC_STAMPS" (or any -D flag of xc_hist.hip)  -> xcontour_amd/libxc_NAME.so (diagnostic builds only)
 set -e
 cd /root/repo/xcontour_amd/csrc
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -Wno-unused-value"

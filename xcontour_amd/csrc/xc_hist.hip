@@ -30,18 +30,12 @@ namespace {
 
 constexpr int U = 2;   // rows per prefetch batch (double-buffered)
 
-// Grid mapping.  Default: the SLAB is the fastest-varying block index, so blocks that work on the
-// same rows of different slabs are dispatched together and (blocks b, b+8 share an XCD) meet in one
+// Grid mapping: the SLAB is the fastest-varying block index, so blocks that work on the same
+// rows of different slabs are dispatched together and (blocks b, b+8 share an XCD) meet in one
 // XCD's L2, where the shared dA plane is then fetched once for several slabs.
-#ifdef XC_GRID_BLOCK_FASTEST
-#define XC_SLAB ((int)blockIdx.y)
-#define XC_BLK  ((int)blockIdx.x)
-#define XC_NBLK ((int)gridDim.x)
-#else
 #define XC_SLAB ((int)blockIdx.x)
 #define XC_BLK  ((int)blockIdx.y)
 #define XC_NBLK ((int)gridDim.y)
-#endif
 
 // Diagnostic build only (-DXC_STAMPS): wave 0 / lane 0 of every block stores s_memrealtime
 // (100 MHz) at phase boundaries into a buffer nothing else reads.  Never in the shipped .so.
@@ -381,11 +375,7 @@ void k_hist(const HistArgs a)
         double w[NCH][VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-#ifdef XC_EXP_NOBIN
-            const int kb = (qc[c] == 12345.678) ? 1 : 0;        // experiment: no bin search
-#else
             const int kb = find_bin(negate ? -qc[c] : qc[c], s_edges, N, e0, eN, inv, last_closed);
-#endif
             k[c] = active ? kb : -1;
             const double dv = dAv[c];
             w[0][c] = (dv != dv) ? 0.0 : dv;                                  // fillna(0), core.py:449
@@ -396,15 +386,7 @@ void k_hist(const HistArgs a)
                 w[1 + i][c] = (p != p) ? 0.0 : p;
             }
         }
-#ifdef XC_EXP_NOGRAD
         if (GRAD) {
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) w[NCH - 1][c] = qN[c] + qS[c] + hc;      // experiment: keep the loads alive
-        }
-        if (false) {
-#else
-        if (GRAD) {
-#endif
             const double hl = lane_bcast(hc, 0), hr = lane_bcast(hc, 63);
             const double fromL = lane_shift<DPP_WAVE_SHR1>(qc[VEC - 1]);     // lane-1's last cell
             const double fromR = lane_shift<DPP_WAVE_SHL1>(qc[0]);           // lane+1's first cell
@@ -550,11 +532,7 @@ int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget + 4096));
         attr_set = true;
     }
-#ifdef XC_GRID_BLOCK_FASTEST
-    dim3 grid((unsigned)g.bps, (unsigned)nslab);
-#else
     dim3 grid((unsigned)nslab, (unsigned)g.bps);
-#endif
     hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds, ctx->stream, a);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;

@@ -37,7 +37,8 @@ class KeffPlan(object):
                  dA=None, lat=None, lon=None, rdx=None, rdy=None, periodic_x=True,
                  tbl=None, tbl_coord=None, preY=None, increase=True, lt=True,
                  right_edge='numpy', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
-                 prod_f32=False, alloc_q=True, nslots=1, out_ptr=None, detect_row_dA=False):
+                 prod_f32=False, alloc_q=True, nslots=1, out_ptr=None, detect_row_dA=False,
+                 out_slabs=None):
         """dA: None | (ny,) | (ny,nx) f64.  Gradient metrics either `rdx, rdy`
         (per-row reciprocals) or derived from `lat, lon` (sphere).  If
         `grdS_dtype` is given the squared gradient is an INPUT (set with
@@ -98,8 +99,10 @@ class KeffPlan(object):
             d.preY = self.pre_buf.ptr
         d.nkeff_mask = float(nkeff_mask)
         d.lmin_scale = float(2.0 * np.pi * Rearth)
-        # outputs: one allocation, [9][nslab][N] f64 | counts | interp | status
-        nN = self.nslab * self.N
+        # outputs: one allocation, [9][out_slabs][N] f64 | counts | interp | status
+        # (out_slabs < nslab: the tracer buffer holds several batches, a slot one batch)
+        self.out_slabs = self.nslab if out_slabs is None else int(out_slabs)
+        nN = self.out_slabs * self.N
         self._off = {}
         off = 0
         for name in OUT_NAMES:
@@ -108,9 +111,9 @@ class KeffPlan(object):
         self._off['counts'] = off
         off += nN * 8
         self._off['interp'] = off
-        off += self.nslab * 9 * self.npre * 8
+        off += self.out_slabs * 9 * self.npre * 8
         self._off['status'] = off
-        off += self.nslab * 4
+        off += self.out_slabs * 4
         self.slot_bytes = (off + 255) & ~255
         self.nslots = int(nslots)
         if out_ptr is None:
@@ -127,15 +130,17 @@ class KeffPlan(object):
         off = 9 * nslab * N * 8 + nslab * N * 8 + nslab * 9 * npre * 8 + nslab * 4
         return (off + 255) & ~255
 
-    def _point(self, slot, s0, n):
-        """aim the descriptor at slabs [s0, s0+n) and result slot `slot`"""
+    def _point(self, slot, s0, n, out_s0=None):
+        """aim the descriptor at slabs [s0, s0+n) and result slot `slot` (results land at slab
+        index `out_s0` of the slot, default s0)"""
         d = self.desc
+        o0 = s0 if out_s0 is None else out_s0
         base = self.out_ptr + slot * self.slot_bytes
         for name in OUT_NAMES:
-            setattr(d, name, base + self._off[name] + s0 * self.N * 8)
-        d.counts = base + self._off['counts'] + s0 * self.N * 8
-        d.interp = (base + self._off['interp'] + s0 * 9 * self.npre * 8) if self.npre else None
-        d.status = base + self._off['status'] + s0 * 4
+            setattr(d, name, base + self._off[name] + o0 * self.N * 8)
+        d.counts = base + self._off['counts'] + o0 * self.N * 8
+        d.interp = (base + self._off['interp'] + o0 * 9 * self.npre * 8) if self.npre else None
+        d.status = base + self._off['status'] + o0 * 4
         d.nslab = n
         d.q = self._q_ptr + s0 * self.ny * self.nx * self.q_dtype.itemsize
         if self.grdS_buf is not None:
@@ -185,17 +190,18 @@ class KeffPlan(object):
             self.desc.q_next = (self._q_ptr + nxt * esz) if ok else None
             self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
 
-    def run_range(self, slot, s0, n, next_s0=None):
+    def run_range(self, slot, s0, n, next_s0=None, out_s0=None):
         """One launch set over slabs [s0, s0+n) into result slot `slot`; `next_s0`: first slab of
-        the launch set that will run next (its min/max rides along, xc_keff_desc.q_next)."""
-        self._point(slot, s0, n)
+        the launch set that will run next (its min/max rides along, xc_keff_desc.q_next);
+        `out_s0`: slab index inside the slot where the results go (default s0)."""
+        self._point(slot, s0, n, out_s0)
         esz = self.ny * self.nx * self.q_dtype.itemsize
         self.desc.q_next = (self._q_ptr + next_s0 * esz) if next_s0 is not None else None
         self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
 
     def unpack(self, raw):
         """one result slot (bytes as a uint8 ndarray) -> dict of arrays"""
-        S, N = self.nslab, self.N
+        S, N = self.out_slabs, self.N
         out = {}
         for name in OUT_NAMES:
             out[name] = raw[self._off[name]:self._off[name] + S * N * 8].view(np.float64).reshape(S, N)
