@@ -617,3 +617,57 @@ def test_contour_mean_family(ctx, baro):
         lo = O.cal_gradient_wrt_area(integral(q, o_ctr, dA.values, grdm.values, True), oa)
         with np.errstate(divide='ignore', invalid='ignore'):
             assert mean.name == 'cmcoslat' and rel(mean.values, up / lo) < 1e-6
+
+
+# ---------------------------------------------------------------- BASELINE cfg1 stand-in: PV-like (level, lat, lon) f32 stack
+def test_cfg1_multilevel_facade(ctx):
+    """notebooks/1.Keff_atmos.ipynb / tests/test_Keff_atmos.py on a PV.nc-shaped stand-in (PV.nc is missing):
+    15 levels x 241 x 480 float32, contour sets that differ per level (the thing xhistogram cannot do,
+    core.py:1259-1294), supplied float32 grdS, results with a leading 'level' dim."""
+    import xcontour_amd as xa
+    nl, ny, nx, N = 15, 241, 480, 121
+    lat = np.linspace(-90, 90, ny).astype(np.float32); lon = (np.arange(nx) * 0.75).astype(np.float32)
+    lev = np.linspace(265, 850, nl).astype(np.float32)
+    rng = np.random.default_rng(8)
+    phi = np.deg2rad(lat.astype(np.float64))[None, :, None]; lam = np.deg2rad(lon.astype(np.float64))[None, None, :]
+    amp = (1 + np.arange(nl) / nl)[:, None, None]
+    pv = (amp * (np.sin(phi) + 0.2 * np.cos(3 * lam + amp) * np.cos(phi) ** 2) * 5e-6
+          + 1e-8 * rng.standard_normal((nl, ny, nx))).astype(np.float32)
+    pv[3, 100:104, 50:60] = np.nan
+    dA2 = O.cell_area(lat, lon)
+    g = np.stack([O.grad2_sphere(pv[l], lat, lon) for l in range(nl)]).astype(np.float32)
+    c3 = {'level': lev, 'latitude': lat, 'longitude': lon}
+    tr = xa.DataArray(pv, ('level', 'latitude', 'longitude'), c3, 'pv')
+    grdS = xa.DataArray(g, ('level', 'latitude', 'longitude'), c3, 'grdSpv')
+    dA = xa.DataArray(dA2, ('latitude', 'longitude'), {'latitude': lat, 'longitude': lon}, 'rA')
+    mask = xa.DataArray(np.ones((ny, nx), np.float32), ('latitude', 'longitude'), {'latitude': lat, 'longitude': lon}, 'mask')
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True)
+    ctr = cm.cal_contours(N)
+    assert ctr.dims == ('level', 'contour') and ctr.values.shape == (nl, N) and ctr.values.dtype == np.float32
+    table = cm.cal_area_eqCoord_table_hist(mask)
+    area = cm.cal_integral_within_contours_hist(ctr).rename('intArea')
+    intgrdS = cm.cal_integral_within_contours_hist(ctr, integrand=grdS).rename('intgrdS')
+    latEq = table.lookup_coordinates(area).rename('latEq')
+    Lmin = xa.latitude_lengths_at(latEq).rename('Lmin')
+    dintSdA = cm.cal_gradient_wrt_area(intgrdS, area).rename('dintSdA')
+    dqdA = cm.cal_gradient_wrt_area(ctr, area).rename('dqdA')
+    Leq2 = cm.cal_sqared_equivalent_length(dintSdA, dqdA).rename('Leq2')
+    nkeff = cm.cal_normalized_Keff(Leq2, Lmin).rename('nkeff')
+    preLats = np.linspace(-90, 90, 181).astype(np.float32)
+    ds = cm.interp_to_dataset(preLats, latEq, [ctr, area, nkeff])
+    assert area.dims == ('level', 'contour') and ds['nkeff'].dims == ('level', 'new') and ds['nkeff'].shape == (nl, 181)
+    a2 = cm.cal_integral_within_contours(ctr)                      # notebook 1 cell 5: the conditional API
+    for l in range(nl):
+        r = O.keff_pipeline(pv[l], dA2, lat, N, grdS=g[l], increase=True, lt=True, dtype=np.float32, preLats=preLats)
+        assert np.array_equal(ctr.values[l], r['ctr'])
+        assert rel(area.values[l], r['area']) < TIGHT and rel(intgrdS.values[l], r['intgrdS']) < 1e-6   # f32 products
+        assert rel(latEq.values[l], r['latEq']) < 1e-9
+        ok = r['Lmin'] > LMIN_FLOOR
+        assert rel(nkeff.values[l][ok], r['nkeff'][ok]) < RTOL
+        assert rel(ds['intArea'].values[l], r['area_eq']) < 1e-9
+        assert rel(a2.values[l], O.cal_integral_within_contours(pv[l], r['ctr'], dA2, None, True)) < TIGHT
+    # the fused pipeline on the whole stack (per-level contours, f32 tracer + f32 grdS)
+    dsk = cm.keff(N, table, grdS=grdS, preY=preLats)
+    assert dsk['nkeff'].dims == ('level', 'contour') and dsk['area_eq'].dims == ('level', 'new')
+    assert np.array_equal(dsk['ctr'].values, ctr.values.astype(np.float64))
+    assert rel(dsk['area'].values, area.values) < 1e-13
