@@ -75,12 +75,20 @@ def cpu_baseline(q_host):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     work = NY * NX * NCONT
+    model = 'unknown CPU'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         'value': n * work / wall, 'unit': 'cells*contours/s', 'cores': workers, 'kind': 'port',
         'sample': '%d slabs of %dx%d f64, %d contours, numpy oracle (port of the reference xarray/'
                   'xhistogram Keff call sequence) in %d processes: %.2f s wall; single thread %.2f s/slab '
-                  '= %.3e cells*contours/s; host has %d logical cores'
-                  % (n, NX, NY, NCONT, workers, wall, t1, work / t1, cores),
+                  '= %.3e cells*contours/s; host: %s, %d logical cores'
+                  % (n, NX, NY, NCONT, workers, wall, t1, work / t1, model, cores),
     }
 
 
@@ -101,6 +109,9 @@ def main():
                     help='let the plan detect that the lat-lon dA plane has constant rows and read it as a '
                          'per-row vector (8 B/cell algorithmic instead of 16); off by default: the headline '
                          'keeps the generic 2-D dA read')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="process-group backend; 'nccl' IS RCCL on ROCm (default).  'gloo' stages the one gather "
+                         'through the host: only for exercising the multi-rank path on a box with fewer GPUs than ranks')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-slabs', type=int, default=0, help='CPU sample size (0: auto)')
     a = ap.parse_args()
@@ -118,7 +129,10 @@ def main():
     local = local if local < ndev else 0          # a launcher may expose one device per rank
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
     if a.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
 
@@ -165,7 +179,8 @@ def main():
     ctx.sync()
     torch.cuda.synchronize()
     ev = [(ctx.event(), ctx.event()) for _ in range(K)]
-    gathered = torch.empty(res.numel() * world, dtype=torch.float64, device='cuda') if world > 1 else None
+    gdev = 'cuda' if a.backend == 'nccl' else 'cpu'
+    gathered = torch.empty(res.numel() * world, dtype=torch.float64, device=gdev) if world > 1 else None
 
     if world > 1:
         dist.barrier()
@@ -177,16 +192,21 @@ def main():
         step(k, k)
     ctx.sync()                                                    # the library's own HIP stream
     if world > 1:
-        dist.all_gather_into_tensor(gathered, res)                # the one RCCL collective
+        dist.all_gather_into_tensor(gathered, res if a.backend == 'nccl' else res.cpu())   # the one collective (RCCL)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
     el = t1 - t0
     if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([el], dtype=torch.float64, device=gdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+        if rank == 0:
+            # every rank's block arrived, in rank order, and rank r's slabs differ from rank 0's (seed + r*2B + s)
+            g = gathered.view(world, -1).view(torch.int64).cpu()      # bit patterns: results hold NaNs
+            mine = res.view(torch.int64).cpu()
+            assert torch.equal(g[0], mine) and all(not torch.equal(g[r], g[0]) for r in range(1, world))
 
     if rank == 0:
         work_step = world * B * NY * NX * NCONT
