@@ -109,6 +109,9 @@ def main():
                     help='let the plan detect that the lat-lon dA plane has constant rows and read it as a '
                          'per-row vector (8 B/cell algorithmic instead of 16); off by default: the headline '
                          'keeps the generic 2-D dA read')
+    ap.add_argument('--native-rccl', action='store_true',
+                    help="do the one end-of-job gather with the library's own RCCL communicator (xc_comm_*) on its "
+                         'own stream instead of torch.distributed (the id travels through the torch store)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="process-group backend; 'nccl' IS RCCL on ROCm (default).  'gloo' stages the one gather "
                          'through the host: only for exercising the multi-rank path on a box with fewer GPUs than ranks')
@@ -179,6 +182,10 @@ def main():
     ctx.sync()
     torch.cuda.synchronize()
     ev = [(ctx.event(), ctx.event()) for _ in range(K)]
+    if world > 1 and a.native_rccl:
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
     gdev = 'cuda' if a.backend == 'nccl' else 'cpu'
     gathered = torch.empty(res.numel() * world, dtype=torch.float64, device=gdev) if world > 1 else None
 
@@ -190,8 +197,10 @@ def main():
         if group == B:
             ctx.set_hist_events(ev[k][0], ev[k][1])               # events around the K3 launch only
         step(k, k)
+    if world > 1 and a.native_rccl:
+        ctx.comm_allgather(res.data_ptr(), gathered.data_ptr(), res.numel() * 8)         # the one collective, same stream
     ctx.sync()                                                    # the library's own HIP stream
-    if world > 1:
+    if world > 1 and not a.native_rccl:
         dist.all_gather_into_tensor(gathered, res if a.backend == 'nccl' else res.cpu())   # the one collective (RCCL)
     torch.cuda.synchronize()
     if world > 1:

@@ -238,6 +238,18 @@ int xc_last_hist_ms(xc_ctx* ctx, float* out_ms);
  * launch of a timed region without synchronising inside it.                              */
 int xc_set_hist_events(xc_ctx* ctx, void* start_event, void* stop_event);
 
+/* ------------------------------------------------------------------ X1  the one collective (RCCL over xGMI)
+ * No reference call site (the reference has no multi-process path).  Independent slabs are
+ * partitioned over one process per GPU; at the end of a job every rank contributes its block of
+ * per-slab result vectors to ONE all-gather.  Rank 0 creates the 128-byte id, the launcher
+ * distributes it (bench.py: torch.distributed store), every rank calls xc_comm_init.
+ * xc_comm_allgather_dev enqueues ncclAllGather on the context's stream: `send` holds
+ * bytes_per_rank bytes, `recv` nranks * bytes_per_rank (device pointers).                 */
+int xc_comm_unique_id(xc_ctx* ctx, void* out_id128);
+int xc_comm_init(xc_ctx* ctx, int nranks, int rank, const void* id128);
+int xc_comm_allgather_dev(xc_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
+int xc_comm_finalize(xc_ctx* ctx);
+
 /* ------------------------------------------------------------------ synthetic slabs (bench / tests)
  * PV-like tracer q = sin(phi) + 0.25 sum_k a_k cos(k lambda + theta_k) cos^2(phi) + 0.02 eps
  * generated on device from a counter-based RNG.  variant 0: PV-like,

@@ -671,3 +671,18 @@ def test_cfg1_multilevel_facade(ctx):
     assert dsk['nkeff'].dims == ('level', 'contour') and dsk['area_eq'].dims == ('level', 'new')
     assert np.array_equal(dsk['ctr'].values, ctr.values.astype(np.float64))
     assert rel(dsk['area'].values, area.values) < 1e-13
+
+
+def test_native_rccl_single_rank(ctx):
+    """xc_comm_*: RCCL communicator of one rank (all this box has); the N > 1 logic is covered on gloo"""
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(1, 0, uid)
+    x = np.arange(1000, dtype=np.float64)
+    a = ctx.to_device(x)
+    b = ctx.alloc(x.nbytes)
+    ctx.comm_allgather(a.ptr, b.ptr, x.nbytes)
+    ctx.sync()
+    assert np.array_equal(b.download((1000,), np.float64), x)
+    ctx.comm_finalize()
+    a.free(); b.free()

@@ -99,6 +99,10 @@ PROTOTYPES = {
     'xc_set_kernel_timing': (C.c_int, [_vp, C.c_int]),
     'xc_last_hist_ms': (C.c_int, [_vp, C.POINTER(C.c_float)]),
     'xc_set_hist_events': (C.c_int, [_vp, _vp, _vp]),
+    'xc_comm_unique_id': (C.c_int, [_vp, _vp]),
+    'xc_comm_init': (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    'xc_comm_allgather_dev': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    'xc_comm_finalize': (C.c_int, [_vp]),
     'xc_synth_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _u64, C.c_int]),
 }
 
@@ -255,6 +259,22 @@ class Context(object):
         ms = C.c_float()
         self._check(self.lib.xc_last_hist_ms(self.handle, C.byref(ms)))
         return ms.value
+
+    # -- the one collective (RCCL)
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.xc_comm_unique_id(self.handle, buf))
+        return bytes(buf.raw)
+
+    def comm_init(self, nranks, rank, uid):
+        assert len(uid) == 128
+        self._check(self.lib.xc_comm_init(self.handle, int(nranks), int(rank), C.create_string_buffer(uid, 128)))
+
+    def comm_allgather(self, send_ptr, recv_ptr, bytes_per_rank):
+        self._check(self.lib.xc_comm_allgather_dev(self.handle, send_ptr, recv_ptr, int(bytes_per_rank)))
+
+    def comm_finalize(self):
+        self._check(self.lib.xc_comm_finalize(self.handle))
 
     # -- host-pointer compute entry points (numpy in, numpy out)
     def minmax(self, q):

@@ -129,6 +129,7 @@ int xc_destroy(xc_ctx* ctx)
 {
     if (!ctx) return XC_OK;
     (void)hipSetDevice(ctx->device);
+    (void)xc_comm_finalize(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);

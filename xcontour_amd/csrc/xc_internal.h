@@ -22,6 +22,7 @@ struct xc_ctx {
     int timing = 0;
     hipEvent_t ev_hist0 = nullptr, ev_hist1 = nullptr;
     int ev_valid = 0;
+    void* comm = nullptr; int comm_nranks = 0, comm_rank = 0;   // RCCL communicator (xc_comm_*)
     hipEvent_t user_ev0 = nullptr, user_ev1 = nullptr;     // one-shot caller events around the next K3 launch
     // min/max partials of the NEXT batch, produced inside the K3 pass (xc_keff_desc.q_next)
     double* mmnext[2] = {nullptr, nullptr};  size_t mmnext_bytes[2] = {0, 0};
