@@ -686,3 +686,25 @@ def test_native_rccl_single_rank(ctx):
     assert np.array_equal(b.download((1000,), np.float64), x)
     ctx.comm_finalize()
     a.free(); b.free()
+
+
+def test_misaligned_device_pointers_fall_back(ctx):
+    """a slab that starts 8 bytes into a device buffer: the 16-byte vector loads must not be used"""
+    import ctypes as C
+    from xcontour_amd import _native as nat
+    rng = np.random.default_rng(4)
+    ny, nx = 33, 130
+    x = rng.standard_normal((1, ny, nx))
+    ed = np.linspace(-3, 3, 42)
+    buf = ctx.alloc(x.nbytes + 64)
+    ctx._check(ctx.lib.xc_memcpy_h2d(ctx.handle, buf.ptr + 8, x.ctypes.data, x.nbytes))
+    de = ctx.to_device(ed)
+    dc = ctx.alloc(41 * 8)
+    d = nat.HistDesc()
+    d.q, d.q_dtype, d.nslab, d.ny, d.nx = buf.ptr + 8, nat.XC_F64, 1, ny, nx
+    d.edges, d.nedge, d.last_closed, d.dA_rank, d.lt = de.ptr, 42, 1, nat.XC_DA_NONE, 1
+    d.counts = dc.ptr
+    ctx._check(ctx.lib.xc_hist_dev(ctx.handle, C.byref(d)))
+    cnt = dc.download((41,), np.uint64)
+    _, c = O.weighted_histogram(x[0], ed)
+    assert np.array_equal(cnt.astype(np.int64), c)

@@ -330,6 +330,27 @@ int xc_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int
     return xc_sync(ctx);
 }
 
+// The 2-cells-per-lane kernels issue 16-byte (f64) / 8-byte (f32) loads from EVERY streamed array:
+// OR the low address bits of all of them so that hist_geometry can fall back to 1 cell per lane
+// when any base is not suitably aligned (e.g. a slab offset inside a caller's buffer).
+static const void* vec_align_bits(const void* q, int q_dtype, const void* q_next, const double* dA, int dA_rank,
+                                  const void* const* integ, const int32_t* integ_dtype, int nint)
+{
+    uintptr_t bits = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(q_next);
+    // f64 arrays need 16-byte alignment; express it in q's units: for f32 q (8-byte requirement) an
+    // f64 array that is only 8-byte aligned must still force the fallback
+    auto need16 = [&](const void* p) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        if (a % 16 != 0) bits |= (q_dtype == XC_F32) ? 4 : 8;   // make (bits % (2*esz)) != 0
+    };
+    if (dA && (dA_rank == XC_DA_PLANE || dA_rank == XC_DA_SLAB)) need16(dA);
+    for (int i = 0; i < nint; ++i) {
+        if (integ_dtype[i] == XC_F64) need16(integ[i]);
+        else if (reinterpret_cast<uintptr_t>(integ[i]) % 8 != 0) bits |= (q_dtype == XC_F32) ? 4 : 8;
+    }
+    return reinterpret_cast<const void*>(bits);
+}
+
 // ------------------------------------------------------------------------------------ K3 + K5
 static int check_hist_desc(xc_ctx* ctx, const xc_hist_desc* d)
 {
@@ -356,7 +377,8 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     XC_TRY(check_hist_desc(ctx, d));
     const int nbin = (int)(d->nedge - 1), nch = 1 + d->nint + (d->grad ? 1 : 0);
     HistGeom g;
-    XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, nbin, nch, d->q, &g));
+    XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, nbin, nch,
+                         vec_align_bits(d->q, d->q_dtype, nullptr, d->dA, d->dA_rank, d->integrand, d->integrand_dtype, d->nint), &g));
     const size_t ph = al((size_t)d->nslab * g.bps * nch * nbin * sizeof(double));
     const size_t pc = al((size_t)d->nslab * g.bps * nbin * sizeof(unsigned));
     const size_t rh = al((size_t)d->nslab * nch * nbin * sizeof(double));
@@ -590,7 +612,11 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     if (d->npre < 0 || (d->npre > 0 && d->interp && !d->preY)) return fail(ctx, XC_EBADARG, "xc_keff: preY is NULL");
     const int N = d->N, nch = 2;
     HistGeom g;
-    XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, nch, d->q, &g));
+    {
+        const void* gi[1] = {d->grdS}; const int32_t gt[1] = {d->grdS_dtype};
+        XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, nch,
+                             vec_align_bits(d->q, d->q_dtype, d->q_next, d->dA, d->dA_rank, gi, gt, d->grad ? 0 : 1), &g));
+    }
     const size_t mb = al((size_t)d->nslab * kMinmaxBlocks * 2 * sizeof(double));
     const size_t ph = al((size_t)d->nslab * g.bps * nch * N * sizeof(double));
     const size_t pc = al((size_t)d->nslab * g.bps * N * sizeof(unsigned));

@@ -590,8 +590,11 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_hist: at most 65535 slabs per launch");
     const size_t esz = (q_dtype == XC_F32) ? 4 : 8;
     // VEC = 2 needs every row start (and dA / integrand rows, all f64 or f32) 2-element aligned
+    // (`q` here is the OR of every streamed pointer's low bits, see vec_align_bits)
     const bool even = (nx % 2) == 0 && (reinterpret_cast<uintptr_t>(q) % (2 * esz)) == 0;
     g->vec = even ? 2 : 1;
+    if (ny > 0x7fffffff || nx > 0x7fffffff || (int64_t)((nx + 127) / 128) * ny > 0x7fffffffLL)
+        return fail(ctx, XC_EBADARG, "xc_hist: slab too large (ny, nx and strips*ny must fit 31 bits)");
     const int W = 64 * g->vec;
     g->nstrip = (int)((nx + W - 1) / W);
     g->nch = nch;
