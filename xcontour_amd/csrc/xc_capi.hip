@@ -367,6 +367,7 @@ static int check_hist_desc(xc_ctx* ctx, const xc_hist_desc* d)
         if (d->integrand_dtype[i] != XC_F32 && d->integrand_dtype[i] != XC_F64) return fail(ctx, XC_EBADARG, "xc_hist: bad integrand dtype");
     }
     if (d->grad && (!d->rdx || !d->rdy)) return fail(ctx, XC_EBADARG, "xc_hist: grad needs rdx and rdy");
+    if (d->grad && d->negate) return fail(ctx, XC_EBADARG, "xc_hist: negate is not available together with grad");
     if (!d->pdf && !d->counts && !d->cdf) return fail(ctx, XC_EBADARG, "xc_hist: no output requested");
     return XC_OK;
 }

@@ -126,7 +126,7 @@ __device__ __forceinline__ int find_bin(double v, const double* __restrict__ s_e
                                         double e0, double eN, double inv, int last_closed)
 {
     int k = (int)((v - e0) * inv);                   // NaN -> 0
-    k = k < 0 ? 0 : (k > N - 1 ? N - 1 : k);
+    k = max(0, min(k, N - 1));                       // clamp to [0, N-1] (v_med3_i32)
     const double lo = s_edges[k], hi = s_edges[k + 1];          // one ds_read2_b64
     const bool hit = (v >= lo) & (v < hi);                      // bitwise: no short-circuit branch between the reads
     if (hit) return k;
@@ -143,24 +143,16 @@ __device__ __forceinline__ void lds_add(unsigned* p, unsigned v)
 }
 
 // ---- cross-lane moves that stay off the LDS pipe (the LDS is the busiest unit of this kernel)
-__device__ __forceinline__ double lane_bcast(double v, int srclane)          // v_readlane_b32 x2
+// DPP wave shift by one lane; the lane that has no source lane (lane 0 for shr, lane 63 for shl)
+// keeps `old`: with old = the halo register the strip-edge neighbour arrives without readlane / select
+template <int CTRL>
+__device__ __forceinline__ double lane_shift_keep(double v, double old)
 {
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), srclane);
-    const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), srclane);
+    const unsigned long long u = __double_as_longlong(v), o = __double_as_longlong(old);
+    const unsigned lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffu), (int)(u & 0xffffffffu), CTRL, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(u >> 32), CTRL, 0xf, 0xf, false);
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
-template <int CTRL>                                                           // DPP wave_shr:1 / wave_shl:1
-__device__ __forceinline__ double lane_shift(double v)
-{
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), CTRL, 0xf, 0xf, false);
-    const unsigned hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-// copy slot of a lane.  (Rotating the slot by the bin index to spread LDS banks was measured
-// 10 % SLOWER on MI355X -- profiles/r01_notes.md -- so the slot is simply lane % ncopy.)
-#define XC_ROT(copy, k, ncopy) (copy)
 constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i <- lane i+1
 constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1
 
@@ -233,9 +225,11 @@ void k_hist(const HistArgs a)
         const int x0 = s * W;
         const int x  = x0 + lane * VEC;
         active = x < nx;
-        const int xld = active ? x : nx - VEC;                         // clamped: loads are unconditional
         const int xend = (x0 + W < nx) ? x0 + W : nx;
         rlane = (xend - x0) / VEC - 1;                                 // lane holding the strip's last valid cell
+        // inactive lanes load from a clamped (valid) address; in a ragged last strip of a periodic
+        // domain the first inactive lane loads columns 0.. so that its cell 0 IS the right halo
+        const int xld = active ? x : ((periodic_x && lane == rlane + 1) ? 0 : nx - VEC);
         const int xl = (x0 == 0) ? (periodic_x ? nx - 1 : 0) : x0 - 1;
         const int xr = (xend == nx) ? (periodic_x ? 0 : nx - 1) : xend;
         const int xh = (lane == 0) ? xl : ((lane == 63) ? xr : xld);   // halo column (lanes 0 / 63 matter)
@@ -375,7 +369,7 @@ void k_hist(const HistArgs a)
         double w[NCH][VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-            const int kb = find_bin(negate ? -qc[c] : qc[c], s_edges, N, e0, eN, inv, last_closed);
+            const int kb = find_bin((!GRAD && negate) ? -qc[c] : qc[c], s_edges, N, e0, eN, inv, last_closed);
             k[c] = active ? kb : -1;
             const double dv = dAv[c];
             w[0][c] = (dv != dv) ? 0.0 : dv;                                  // fillna(0), core.py:449
@@ -387,15 +381,20 @@ void k_hist(const HistArgs a)
             }
         }
         if (GRAD) {
-            const double hl = lane_bcast(hc, 0), hr = lane_bcast(hc, 63);
-            const double fromL = lane_shift<DPP_WAVE_SHR1>(qc[VEC - 1]);     // lane-1's last cell
-            const double fromR = lane_shift<DPP_WAVE_SHL1>(qc[0]);           // lane+1's first cell
+            // x-neighbours: lane-1's last cell / lane+1's first cell; lane 0 keeps the left halo (hc of
+            // lane 0), lane 63 the right halo (hc of lane 63); a ragged strip's right halo sits in the
+            // first inactive lane's cell 0 (see begin_segment)
+            const double fromL = lane_shift_keep<DPP_WAVE_SHR1>(qc[VEC - 1], hc);
+            const double fromR = lane_shift_keep<DPP_WAVE_SHL1>(qc[0], hc);
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
-                const double qW = (c == 0) ? (lane == 0 ? hl : fromL) : qc[c > 0 ? c - 1 : 0];
-                const double qE = (c == VEC - 1) ? (lane == rlane ? hr : fromR) : qc[c < VEC - 1 ? c + 1 : 0];
+                double qW = (c == 0) ? fromL : qc[c > 0 ? c - 1 : 0];
+                double qE = (c == VEC - 1) ? fromR : qc[c < VEC - 1 ? c + 1 : 0];
+                if (!periodic_x) {                                        // wave-uniform branch: walls are one-sided
+                    if (fx[c] == 2.0) { if (lane == 0 && c == 0) qW = qc[c]; else qE = qc[c]; }
+                }
                 double gx = __dmul_rn(__dsub_rn(qE, qW), rdx);
-                if (!periodic_x) gx = __dmul_rn(gx, fx[c]);               // wave-uniform branch
+                if (!periodic_x) gx = __dmul_rn(gx, fx[c]);
                 const double gy = __dmul_rn(__dsub_rn(qN[c], qS[c]), rdy);
                 const double g2 = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
                 const double p = __dmul_rn(g2, dAv[c]);
