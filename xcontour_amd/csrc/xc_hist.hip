@@ -142,6 +142,10 @@ __device__ __forceinline__ void lds_add(unsigned* p, unsigned v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// copy slot of a lane.  (Rotating the slot by the bin index to spread LDS banks was measured
+// 10 % SLOWER on MI355X -- profiles/r01_notes.md -- so the slot is simply lane % ncopy.)
+#define XC_ROT(copy, k, ncopy) (copy)
+
 // ---- cross-lane moves that stay off the LDS pipe (the LDS is the busiest unit of this kernel)
 // DPP wave shift by one lane; the lane that has no source lane (lane 0 for shr, lane 63 for shl)
 // keeps `old`: with old = the halo register the strip-edge neighbour arrives without readlane / select
