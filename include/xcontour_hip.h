@@ -121,7 +121,7 @@ int xc_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab,
  * cdf double[nslab][nchan][nbin] = cumsum(pdf) (if !lt: cdf[-1]-cdf), reversed along
  * the bin axis iff reverse (decreasing levels, core.py:454-455).                     */
 typedef struct xc_hist_desc {
-    const void*   q;            int32_t q_dtype;  int32_t _pad0;
+    const void*   q;            int32_t q_dtype;  int32_t dA_pos_finite;  /* caller verified: dA finite and >= 0 (optional speed-up) */
     int64_t       nslab, ny, nx;
     const double* edges;        int64_t nedge;    int32_t edges_per_slab; int32_t last_closed;
     const double* dA;           int32_t dA_rank;  int32_t prod_f32;
@@ -225,6 +225,9 @@ typedef struct xc_keff_desc {
                                    call's histogram pass (+8 B/cell of loads, no extra kernel) and the next call on
                                    that pointer skips its K1 pass.  The caller promises not to modify that batch in
                                    between.  NULL: off. */
+    int32_t       dA_pos_finite;/* caller verified that every dA value is finite and >= 0: the kernel then skips the
+                                   fillna(0) selects on the dA channel (optional speed-up; 0 is always safe) */
+    int32_t       _pad2;
 } xc_keff_desc;
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
 

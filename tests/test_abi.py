@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     from xcontour_amd import _native as nat
     # natural alignment, no packing: sizes follow from the field lists in the header
     assert C.sizeof(nat.HistDesc) == 8 + 8 + 24 + 8 + 8 + 8 + 8 + 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 24
-    assert C.sizeof(nat.KeffDesc) % 8 == 0 and nat.KeffDesc.q_next.offset == C.sizeof(nat.KeffDesc) - 8
+    assert C.sizeof(nat.KeffDesc) % 8 == 0 and nat.KeffDesc.q_next.offset == C.sizeof(nat.KeffDesc) - 16
     lib = nat.load()
     assert lib.xc_version().startswith(b'xcontour_hip')
 

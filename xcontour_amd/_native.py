@@ -27,7 +27,7 @@ _vp, _i32, _i64, _u64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_
 class HistDesc(C.Structure):
     """struct xc_hist_desc (include/xcontour_hip.h)"""
     _fields_ = [
-        ('q', _vp), ('q_dtype', _i32), ('_pad0', _i32),
+        ('q', _vp), ('q_dtype', _i32), ('dA_pos_finite', _i32),
         ('nslab', _i64), ('ny', _i64), ('nx', _i64),
         ('edges', _vp), ('nedge', _i64), ('edges_per_slab', _i32), ('last_closed', _i32),
         ('dA', _vp), ('dA_rank', _i32), ('prod_f32', _i32),
@@ -55,6 +55,7 @@ class KeffDesc(C.Structure):
         ('ctr', _vp), ('area', _vp), ('intgrdS', _vp), ('latEq', _vp),
         ('dqdA', _vp), ('dintSdA', _vp), ('Leq2', _vp), ('Lmin', _vp), ('nkeff', _vp),
         ('counts', _vp), ('interp', _vp), ('status', _vp), ('q_next', _vp),
+        ('dA_pos_finite', _i32), ('_pad2', _i32),
     ]
 
 

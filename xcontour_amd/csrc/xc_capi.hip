@@ -391,6 +391,7 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     for (int i = 0; i < d->nint; ++i) { a.integ[i] = d->integrand[i]; a.integ_f32[i] = d->integrand_dtype[i] == XC_F32; }
     a.edges = d->edges; a.levels_mode = 0; a.nbin = nbin; a.edges_per_slab = d->edges_per_slab;
     a.last_closed = d->last_closed; a.negate = d->negate; a.q_f32 = d->q_dtype == XC_F32;
+    a.dA_pos_finite = (d->dA_rank == XC_DA_NONE) ? 1 : d->dA_pos_finite;
     a.prod_f32 = d->prod_f32;
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
@@ -649,6 +650,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); a.dA = ctx->ones; a.dA_rank = XC_DA_ROW; }
     if (!d->grad) { a.integ[0] = d->grdS; a.integ_f32[0] = d->grdS_dtype == XC_F32; }
     a.q_next = d->q_next; a.mm_next = mm_next;
+    a.dA_pos_finite = (d->dA_rank == XC_DA_NONE) ? 1 : d->dA_pos_finite;
     a.mmpart = mmpart; a.P = mmP; a.levels_mode = 1; a.nbin = N;
     a.last_closed = d->right_edge == XC_EDGE_NUMPY;
     a.increase = d->increase; a.q_f32 = d->q_dtype == XC_F32; a.ctr_f32 = d->ctr_dtype == XC_F32;

@@ -28,7 +28,10 @@ namespace xc {
 
 namespace {
 
-constexpr int U = 2;   // rows per prefetch batch (double-buffered)
+#ifndef XC_U
+#define XC_U 2
+#endif
+constexpr int U = XC_U;   // rows per prefetch batch (double-buffered)
 
 // Grid mapping: the SLAB is the fastest-varying block index, so blocks that work on the same
 // rows of different slabs are dispatched together and (blocks b, b+8 share an XCD) meet in one
@@ -126,7 +129,7 @@ __device__ __forceinline__ int find_bin(double v, const double* __restrict__ s_e
                                         double e0, double eN, double inv, int last_closed)
 {
     int k = (int)((v - e0) * inv);                   // NaN -> 0
-    k = max(0, min(k, N - 1));                       // clamp to [0, N-1] (v_med3_i32)
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(k) : "v"(k), "s"(N - 1));   // clamp to [0, N-1]
     const double lo = s_edges[k], hi = s_edges[k + 1];          // one ds_read2_b64
     const bool hit = (v >= lo) & (v < hi);                      // bitwise: no short-circuit branch between the reads
     if (hit) return k;
@@ -157,6 +160,14 @@ __device__ __forceinline__ double lane_shift_keep(double v, double old)
     const unsigned hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(u >> 32), CTRL, 0xf, 0xf, false);
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
+// value held by lane `idx` (wave-uniform index): two v_readlane_b32
+__device__ __forceinline__ double lane_get(double v, int idx)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), idx);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), idx);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i <- lane i+1
 constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i <- lane i-1
 
@@ -167,7 +178,6 @@ struct RowBuf {
     double dA[VEC];
     double in[NINT > 0 ? NINT : 1][VEC];
     double qn[VEC];         // NEXT: the same cells of the next batch (min/max by-product)
-    double rdx, rdy;        // GRAD: the centre row's reciprocal metrics (wave-uniform)
 };
 
 // DA2D: dA is a [ny][nx] plane (vector loads); otherwise one value per row (scalar).
@@ -216,7 +226,8 @@ void k_hist(const HistArgs a)
     // segment state (wave-uniform scalars + per-lane 32-bit byte offsets inside a row)
     int y0 = 0, y1 = 0;
     unsigned xo_q = 0, xo_h = 0, xo_d = 0, xo_f = 0;
-    bool active = false;
+    bool active = false, full_strip = true;
+    unsigned long long inactive_mask = 0ull;                      // lanes beyond the row end (ragged last strip)
     int rlane = 63;
     double fx[VEC];
 
@@ -231,6 +242,8 @@ void k_hist(const HistArgs a)
         active = x < nx;
         const int xend = (x0 + W < nx) ? x0 + W : nx;
         rlane = (xend - x0) / VEC - 1;                                 // lane holding the strip's last valid cell
+        full_strip = rlane == 63;
+        inactive_mask = full_strip ? 0ull : (~0ull << (rlane + 1));
         // inactive lanes load from a clamped (valid) address; in a ragged last strip of a periodic
         // domain the first inactive lane loads columns 0.. so that its cell 0 IS the right halo
         const int xld = active ? x : ((periodic_x && lane == rlane + 1) ? 0 : nx - VEC);
@@ -245,6 +258,16 @@ void k_hist(const HistArgs a)
             fx[c] = (!periodic_x && (x + c == 0 || x + c == nx - 1)) ? 2.0 : 1.0;
     };
 
+    // per-row gradient metrics, lane-distributed: lane i holds row ymet0 + i (64 rows per refill),
+    // read back with v_readlane -- 4 VGPRs per wave instead of 4 per buffered row
+    double rdxv = 0.0, rdyv = 0.0;
+    int ymet0 = 0;
+    auto load_metrics = [&](int yfirst) {
+        ymet0 = yfirst;
+        const int y = (yfirst + lane < ny) ? yfirst + lane : ny - 1;
+        rdxv = rdxp[y]; rdyv = rdyp[y];
+    };
+
     // branch-free loads of one row: q row `yq` (+ halo), weights of row `yw`
     const char* qbase = reinterpret_cast<const char*>(qs);
     const char* nbase = reinterpret_cast<const char*>(qnx);
@@ -256,7 +279,6 @@ void k_hist(const HistArgs a)
         RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
         if (GRAD) r.h = (double)*reinterpret_cast<const TQ*>(qrow + xo_h);
         if (NEXT) RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
-        if (GRAD) { r.rdx = rdxp[yw]; r.rdy = rdyp[yw]; }
         if (DA2D) {
             RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(dbase + (size_t)yw * rowd + xo_d), r.dA);
         } else {
@@ -288,6 +310,7 @@ void k_hist(const HistArgs a)
     if (have) {
         begin_segment();
         if (GRAD) {
+            load_metrics(y0);
             RowBuf<VEC, NINT> t;
             load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
 #pragma unroll
@@ -346,6 +369,7 @@ void k_hist(const HistArgs a)
     const double inv = (double)N / (eN - e0);
     const int last_closed = a.last_closed;
     const int negate = a.negate;
+    const bool wpos = a.dA_pos_finite != 0;
     XC_STAMP(2);
 
     double   acc[NCH];
@@ -374,9 +398,9 @@ void k_hist(const HistArgs a)
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
             const int kb = find_bin((!GRAD && negate) ? -qc[c] : qc[c], s_edges, N, e0, eN, inv, last_closed);
-            k[c] = active ? kb : -1;
+            k[c] = full_strip ? kb : (active ? kb : -1);                      // wave-uniform: selects only in a ragged strip
             const double dv = dAv[c];
-            w[0][c] = (dv != dv) ? 0.0 : dv;                                  // fillna(0), core.py:449
+            w[0][c] = wpos ? dv : ((dv != dv) ? 0.0 : dv);                    // fillna(0), core.py:449 (wpos: host checked dA finite)
 #pragma unroll
             for (int i = 0; i < NINT; ++i) {
                 double p = a.prod_f32 ? (double)__fmul_rn((float)inv_[i][c], (float)dv)
@@ -402,7 +426,8 @@ void k_hist(const HistArgs a)
                 const double gy = __dmul_rn(__dsub_rn(qN[c], qS[c]), rdy);
                 const double g2 = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
                 const double p = __dmul_rn(g2, dAv[c]);
-                w[NCH - 1][c] = (p != p) ? 0.0 : p;
+                // NaN -> 0; with finite non-negative dA the product is >= 0 or NaN, so one v_max_f64 does it
+                w[NCH - 1][c] = wpos ? fmax(p, 0.0) : ((p != p) ? 0.0 : p);
             }
         }
         // wave-uniform fast path: every valid cell of the row in one bin
@@ -410,7 +435,7 @@ void k_hist(const HistArgs a)
         bool match = true;
 #pragma unroll
         for (int c = 0; c < VEC; ++c) match = match && (k[c] == rb);
-        if (rb >= 0 && __all(match || !active)) {
+        if (rb >= 0 && (__ballot(match) | inactive_mask) == ~0ull) {
             if (rb != cur) { flush(); cur = rb; }
             if (active) {
 #pragma unroll
@@ -446,7 +471,9 @@ void k_hist(const HistArgs a)
                     }
                 }
                 if (GRAD) {
-                    do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in, L[i].rdx, L[i].rdy);
+                    if (yb + i - ymet0 >= 64) load_metrics(yb + i);               // wave-uniform, once per 64 rows
+                    do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in,
+                           lane_get(rdxv, yb + i - ymet0), lane_get(rdyv, yb + i - ymet0));
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) { qm[c] = qcur[c]; qcur[c] = L[i].q[c]; }
                     hcur = L[i].h;
@@ -469,6 +496,7 @@ void k_hist(const HistArgs a)
         if (have) {                                   // next segment (the range crossed a strip boundary)
             begin_segment();
             if (GRAD) {
+                load_metrics(y0);
                 RowBuf<VEC, NINT> t;
                 load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
 #pragma unroll

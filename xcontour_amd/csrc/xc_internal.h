@@ -82,6 +82,7 @@ struct HistArgs {
     int           increase, q_f32, ctr_f32, right_edge;
     double        inv_nm1;      // 1.0/(N-1) (levels mode)
     int           dA_rank, prod_f32;
+    int           dA_pos_finite;   // host verified: every dA value is finite and >= 0 (skips fillna selects)
     const double* rdx;
     const double* rdy;
     int           periodic_x;

@@ -77,6 +77,7 @@ class KeffPlan(object):
                 raise Exception('dA must be (ny,) or (ny,nx)')
             self.dA_buf = ctx.to_device(dA)
             d.dA = self.dA_buf.ptr
+            d.dA_pos_finite = int(bool(np.isfinite(dA).all() and (dA >= 0).all()))   # static metric: checked once
         if grdS_dtype is None:
             if rdx is None:
                 rdx, rdy = grad_metrics(lat, lon, Rearth)
