@@ -62,6 +62,13 @@ typedef struct xc_ctx xc_ctx;
 
 #define XC_MAX_INTEGRANDS 2
 
+/* X padding of xc_crossing: the `mode` of DataArray.pad / np.pad (core.py:674-676) */
+#define XC_PAD_EDGE      0
+#define XC_PAD_WRAP      1
+#define XC_PAD_NAN       2     /* mode='constant' (xarray fills floats with NaN)      */
+#define XC_PAD_REFLECT   3
+#define XC_PAD_SYMMETRIC 4
+
 /* ------------------------------------------------------------------ context */
 int         xc_create(int device_id, xc_ctx** out);
 int         xc_destroy(xc_ctx* ctx);
@@ -194,6 +201,32 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
                     const double* dA, int dA_rank, int64_t ny, int64_t nx, int negate,
                     const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                     double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
+
+/* ------------------------------------------------------------------ K9  box-counting contour crossing
+ * Replaces Contour2D.cal_contour_crossing (core.py:640-693) and the numba kernel
+ * _contour_crossing (core.py:1490-1566), for ALL contours of a slab in one pass.
+ * The slab is padded on the X side by pad_x columns (mode pad_mode; pass 0 when the grid
+ * has no 'X' dim, core.py:673-679); coarse shape Jn = round(ny/stride),
+ * In = round((nx+pad_x)/stride) (round half to even, core.py:1510-1511); box (j, i),
+ * j < Jn-1, covers corner rows j*s..j*s+s and corner columns i*s..i*s+s; contour c crosses
+ * it iff some non-NaN corner <= c and some non-NaN corner > c (core.py:1531-1557).
+ *   out_len[slab][k] = nansum over crossed boxes of sqrt(areaPad[j][i]) * stride
+ *                      (area taken at the COARSE indices, core.py:1560; f32 area: f32 sqrt)
+ *   out_cnt[slab][k] = number of crossed boxes (exact)
+ * full_width == 0 scans box columns i < min(Jn, In) - 1 -- the reference's loop bound is
+ * range(Jn-1) (core.py:1521), cut at In-1 where it would leave the array; full_width != 0
+ * scans all In-1 columns.  contours: double[ncont] or double[nslab][ncont]
+ * (contours_per_slab), ASCENDING, no NaN (the host entry point checks; callers with
+ * other orders sort and un-permute, as xcontour_amd/core.py does).  area: [ny][nx] or
+ * [nslab][ny][nx] (area_per_slab) of area_dtype.  Either output may be NULL.           */
+int xc_crossing_dev(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                    int pad_x, int pad_mode, const double* contours, int ncont, int contours_per_slab,
+                    const void* area, int area_dtype, int area_per_slab, int stride, int full_width,
+                    double* out_len, uint64_t* out_cnt);
+int xc_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                int pad_x, int pad_mode, const double* contours, int ncont, int contours_per_slab,
+                const void* area, int area_dtype, int area_per_slab, int stride, int full_width,
+                double* out_len, uint64_t* out_cnt);
 
 /* ------------------------------------------------------------------ fused, batched Keff pipeline
  * The reference's call sequence SURVEY 3.1 steps 2-10 for a batch of slabs resident

@@ -545,6 +545,110 @@ def bpe_integral(q, dA, tbl, coord, mask=None):
 
 
 # ---------------------------------------------------------------------------
+# Box-counting contour crossing (core.py:640-693 driver, 1490-1566 kernel)
+# ---------------------------------------------------------------------------
+PAD_MODES = ('edge', 'wrap', 'constant', 'reflect', 'symmetric')
+
+
+def pad_x(a, npad, mode='edge'):
+    """DataArray.pad({X: (0, npad)}, mode=mode) on the last axis (core.py:674-676);
+    xarray's 'constant' default fill for floats is NaN."""
+    a = np.asarray(a)
+    width = [(0, 0)] * (a.ndim - 1) + [(0, int(npad))]
+    if mode == 'constant':
+        return np.pad(a, width, mode='constant', constant_values=np.nan)
+    return np.pad(a, width, mode=mode)
+
+
+def crossing_shape(jo, io, stride):
+    """Coarse shape of core.py:1510-1511: np.round (half to even) of the padded sizes."""
+    return int(np.round(jo / stride)), int(np.round(io / stride))
+
+
+def contour_crossing_literal(dataPad, contour, areaPad, stride=1):
+    """The per-(slab, contour) kernel, loop for loop (core.py:1490-1566) -- small inputs only.
+
+    Box (j, i) covers the fine cells [j*s, j*s+s) x [i*s, i*s+s); each cell contributes its four
+    corners; `le` = some non-NaN corner <= contour, `gt` = some non-NaN corner > contour; a box
+    with both counts sqrt(areaPad[j, i]) * stride -- areaPad is indexed with the COARSE indices
+    (1560) -- and the column loop runs over range(Jn-1), not In-1 (1521): both kept.  Where
+    the reference would index outside the padded array (Jn > In; numba does not bounds-check)
+    the column range is cut at In-1."""
+    dataPad = np.asarray(dataPad)
+    areaPad = np.asarray(areaPad)
+    Jn, In = crossing_shape(dataPad.shape[0], dataPad.shape[1], stride)
+    re = np.zeros((Jn, In))
+    ncross = 0
+    for j in range(0, Jn - 1):
+        for i in range(0, min(Jn, In) - 1):
+            le = gt = False
+            for jj in range(j * stride, j * stride + stride):
+                for ii in range(i * stride, i * stride + stride):
+                    for v in (dataPad[jj, ii], dataPad[jj, ii + 1], dataPad[jj + 1, ii], dataPad[jj + 1, ii + 1]):
+                        if not np.isnan(v):
+                            if v <= contour:
+                                le = True
+                            else:
+                                gt = True
+            if le and gt:
+                ncross += 1
+                with np.errstate(invalid='ignore'):
+                    # numba types float32 * int64 as float64: f32 area -> sqrt rounded in f32, product in f64
+                    re[j, i] = np.float64(np.sqrt(areaPad[j, i])) * stride
+    return float(np.nansum(re)), ncross
+
+
+def _box_minmax(dataPad, stride, nbj, nbi):
+    """NaN-skipping min / max of the (s+1) x (s+1) corner block of every box."""
+    mn = np.full((nbj, nbi), np.nan)
+    mx = np.full((nbj, nbi), np.nan)
+    for dr in range(stride + 1):
+        for dc in range(stride + 1):
+            blk = dataPad[dr:dr + (nbj - 1) * stride + 1:stride, dc:dc + (nbi - 1) * stride + 1:stride].astype(np.float64)
+            mn = np.fmin(mn, blk)
+            mx = np.fmax(mx, blk)
+    return mn, mx
+
+
+def contour_crossing(dataPad, contours, areaPad, stride=1, full_width=False):
+    """All contours of one slab at once: a box is crossed by c iff min <= c < max over its
+    non-NaN corners.  Returns (lengths f64 (N,), box counts int64 (N,)); lengths[k] is what the
+    reference's `_contour_crossing(dataPad, contours[k], areaPad, stride)` returns.
+    `full_width=True` scans all In-1 box columns (the evident intent) instead of Jn-1."""
+    dataPad = np.asarray(dataPad)
+    areaPad = np.asarray(areaPad)
+    Jn, In = crossing_shape(dataPad.shape[0], dataPad.shape[1], stride)
+    nbj, nbi = Jn - 1, (In - 1) if full_width else (min(Jn, In) - 1)
+    contours = np.asarray(contours, dtype=np.float64).ravel()
+    if nbj < 1 or nbi < 1:
+        return np.zeros(len(contours)), np.zeros(len(contours), dtype=np.int64)
+    mn, mx = _box_minmax(dataPad, stride, nbj, nbi)
+    with np.errstate(invalid='ignore'):
+        w = np.sqrt(areaPad[:nbj, :nbi]).astype(np.float64) * stride
+    lengths = np.zeros(len(contours))
+    counts = np.zeros(len(contours), dtype=np.int64)
+    for k, c in enumerate(contours):
+        cross = (mn <= c) & (mx > c)
+        counts[k] = np.count_nonzero(cross)
+        lengths[k] = np.nansum(np.where(cross, w, 0.0))
+    return lengths, counts
+
+
+def cal_contour_crossing(tracer, ctr, dA, stride=1, mode='edge', has_x=True, dtype=np.float32,
+                         full_width=False):
+    """Contour2D.cal_contour_crossing (core.py:640-693) for one slab: pad X by max(stride)
+    (only when the grid has an 'X' dim, 673-679), then every stride on the SAME padded arrays;
+    output cast to `dtype` (output_dtypes=[self.dtype], 689).  Returns a list when `stride` is
+    iterable."""
+    strides = list(stride) if np.iterable(stride) else [stride]
+    npad = max(strides) if has_x else 0
+    dataPad = pad_x(tracer, npad, mode) if has_x else np.asarray(tracer)
+    areaPad = pad_x(np.broadcast_to(dA, np.shape(tracer)), npad, mode) if has_x else np.broadcast_to(dA, np.shape(tracer))
+    res = [contour_crossing(dataPad, ctr, areaPad, s, full_width)[0].astype(dtype) for s in strides]
+    return res if np.iterable(stride) else res[0]
+
+
+# ---------------------------------------------------------------------------
 # The reference's Keff call sequence (SURVEY 3.1; tests/test_Keff_atmos.py:75-92)
 # ---------------------------------------------------------------------------
 def keff_pipeline(q, dA, lat, N, grdS=None, lon=None, mask=None, increase=True,

@@ -708,3 +708,90 @@ def test_misaligned_device_pointers_fall_back(ctx):
     cnt = dc.download((41,), np.uint64)
     _, c = O.weighted_histogram(x[0], ed)
     assert np.array_equal(cnt.astype(np.int64), c)
+
+
+# ---------------------------------------------------------------- K9 box-counting contour crossing
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('stride,mode', [(1, 'edge'), (2, 'wrap'), (3, 'constant'), (2, 'reflect'), (5, 'symmetric')])
+def test_crossing_random_vs_oracle(ctx, dt, stride, mode):
+    """xc_crossing against the oracle: box counts exact, lengths to summation order; NaN cells,
+    NaN / negative areas, per-slab contours, padding modes, Jn < In and Jn > In shapes."""
+    rng = np.random.default_rng(stride * 10 + len(mode))
+    for (ny, nx) in [(37, 301), (300, 41), (64, 64)]:
+        q = rng.standard_normal((3, ny, nx)).astype(dt)
+        q[rng.random(q.shape) < 0.05] = np.nan
+        q[1, :4, :] = np.nan                                          # boxes with no valid corner
+        area = (rng.random((ny, nx)) * 9 + 1).astype(dt)
+        area[2, 3] = np.nan; area[5, 1] = -1.0
+        cs = np.sort(rng.standard_normal((3, 17)), axis=1)
+        cs[0, 3] = cs[0, 4]                                           # duplicated level
+        pad = stride + 2                                              # max(stride list) > stride
+        for full in (False, True):
+            lens, cnts = ctx.crossing(q, cs, area, stride=stride, pad_x=pad, pad_mode=mode, full_width=full)
+            for s in range(3):
+                ol, oc = O.contour_crossing(O.pad_x(q[s], pad, mode), cs[s], O.pad_x(area, pad, mode), stride, full)
+                assert np.array_equal(cnts[s].astype(np.int64), oc)
+                assert rel(lens[s], ol) < 1e-13
+    # shared contours, per-slab area, no padding (grids without an 'X' dim)
+    q = rng.standard_normal((2, 50, 70)).astype(dt)
+    a3 = rng.random((2, 50, 70)) + 0.5
+    c1 = np.linspace(-2, 2, 9)
+    lens, cnts = ctx.crossing(q, c1, a3, stride=stride, pad_x=0)
+    for s in range(2):
+        ol, oc = O.contour_crossing(q[s], c1, a3[s], stride)
+        assert np.array_equal(cnts[s].astype(np.int64), oc) and rel(lens[s], ol) < 1e-13
+
+
+def test_crossing_literal_loops_small(ctx):
+    """the pure-python loop restatement of core.py:1490-1566, contour by contour"""
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((1, 11, 23)).astype(np.float32)
+    q[0, 4, 5] = np.nan
+    area = (rng.random((11, 23)) + 1).astype(np.float32)              # f32 area: sqrt in f32
+    cs = np.linspace(-1.5, 1.5, 6)
+    for stride in (1, 2, 3):
+        lens, cnts = ctx.crossing(q, cs, area, stride=stride, pad_x=3, pad_mode='edge')
+        for k, c in enumerate(cs):
+            l, n = O.contour_crossing_literal(O.pad_x(q[0], 3, 'edge'), c, O.pad_x(area, 3, 'edge'), stride)
+            assert n == int(cnts[0, k]) and abs(lens[0, k] - l) <= 1e-13 * max(l, 1.0)
+
+
+def test_crossing_rejects_bad_input(ctx):
+    from xcontour_amd._native import XContourHipError
+    q = np.zeros((1, 8, 8)); a = np.ones((8, 8))
+    with pytest.raises(XContourHipError):
+        ctx.crossing(q, np.array([1.0, 0.0]), a)                      # not ascending
+    with pytest.raises(XContourHipError):
+        ctx.crossing(q, np.array([0.0, np.nan]), a)
+    with pytest.raises(XContourHipError):
+        ctx.crossing(q, np.array([0.0]), a, stride=0)
+    lens, cnts = ctx.crossing(q, np.array([0.0]), a, stride=8)        # Jn = 1: no boxes
+    assert lens[0, 0] == 0.0 and cnts[0, 0] == 0
+
+
+def test_facade_contour_crossing_golden(ctx, baro):
+    """Contour2D.cal_contour_crossing on the barotropic field: golden fixture + oracle, decreasing levels
+    (façade sorts / un-permutes), list of strides sharing one padding, box-count dimension sanity."""
+    import xcontour_amd as xa
+    tr, dA, q, lat, lon = _baro_da(xa, baro)
+    G = np.load(os.path.join(GOLD, 'baro_crossing_N41.npz'))
+    for increase in (True, False):
+        cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=increase, lt=True)
+        ctr = cm.cal_contours(41)
+        res = cm.cal_contour_crossing(ctr, stride=[1, 2, 4], mode='wrap')
+        assert isinstance(res, list) and len(res) == 3
+        for r, s in zip(res, (1, 2, 4)):
+            assert r.dims == ('contour',) and r.dtype == np.float32
+            want = O.cal_contour_crossing(q, ctr.values, dA.values, [1, 2, 4], 'wrap')[(1, 2, 4).index(s)]
+            assert rel(r.values, want) < 1e-6
+            if increase:
+                assert rel(r.values, G['len_s%d' % s]) < 1e-6
+    single = cm.cal_contour_crossing(ctr, stride=2, mode='wrap')
+    assert np.array_equal(single.values, res[1].values)
+    # counts: halving the resolution of a smooth contour roughly halves the number of crossed boxes
+    lens1, c1 = ctx.crossing(q[None], G['ctr'].astype(np.float64), dA.values, 1, 4, 'wrap')
+    lens4, c4 = ctx.crossing(q[None], G['ctr'].astype(np.float64), dA.values, 4, 4, 'wrap')
+    mid = slice(10, 30)
+    ratio = c1[0, mid].astype(float) / np.maximum(c4[0, mid].astype(float), 1)
+    assert np.all(ratio > 2.0) and np.all(ratio < 8.0)
+    assert np.array_equal(c1[0].astype(np.int64), G['cnt_sorted_s1'])

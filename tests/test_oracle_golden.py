@@ -122,3 +122,38 @@ def test_golden_files_match_oracle(baro):
         r = O.keff_pipeline(q, dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float32, preLats=lat)
         for k in g.files:
             assert np.array_equal(g[k], r[k], equal_nan=True), k
+
+
+def test_crossing_oracle_vectorised_equals_literal_loops():
+    """K9 oracle: the all-contours min/max formulation against the loop-for-loop restatement of
+    core.py:1490-1566 (small shapes, every pad mode, NaN cells and areas, Jn > In)."""
+    rng = np.random.default_rng(1)
+    for (ny, nx, s, mode) in [(9, 14, 1, 'edge'), (12, 20, 2, 'wrap'), (13, 17, 3, 'constant'), (20, 9, 2, 'edge'),
+                              (7, 30, 1, 'reflect'), (10, 12, 2, 'symmetric')]:
+        q = rng.standard_normal((ny, nx))
+        q[rng.random((ny, nx)) < 0.1] = np.nan
+        a = rng.random((ny, nx)) * 10
+        a[0, 0] = np.nan
+        dp, ap = O.pad_x(q, s + 1, mode), O.pad_x(a, s + 1, mode)
+        cs = np.linspace(-2, 2, 7)
+        L, C = O.contour_crossing(dp, cs, ap, s)
+        for k, c in enumerate(cs):
+            l, n = O.contour_crossing_literal(dp, c, ap, s)
+            assert n == C[k] and abs(l - L[k]) <= 1e-13 * max(abs(l), 1.0)
+    # coarse shape uses round-half-even (np.round): 7 / 2 = 3.5 -> 4, 5 / 2 = 2.5 -> 2
+    assert O.crossing_shape(7, 5, 2) == (4, 2)
+
+
+def test_crossing_golden_fixture():
+    G = np.load(os.path.join(GOLD, 'baro_crossing_N41.npz'))
+    q = np.load(os.path.join(GOLD, 'baro_q.npy'))
+    lat, lon = np.load(os.path.join(GOLD, 'baro_lat.npy')), np.load(os.path.join(GOLD, 'baro_lon.npy'))
+    dA = O.cell_area(lat, lon)
+    res = O.cal_contour_crossing(q, G['ctr'], dA, [1, 2, 4], 'wrap')
+    for r, s in zip(res, (1, 2, 4)):
+        assert r.dtype == np.float32 and np.array_equal(r, G['len_s%d' % s])
+    # the reference scans only Jn-1 = 255 of the In-1 = 515 box columns (core.py:1521): the literal
+    # result is smaller than the full-width one
+    full = O.cal_contour_crossing(q, G['ctr'], dA, 1, 'wrap', full_width=True)
+    assert np.all(full >= res[0]) and full.sum() > 1.5 * res[0].sum()
+    assert int(G['cnt_s1'][0]) == 15 and int(G['cnt_s1'][1]) == 291

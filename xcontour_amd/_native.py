@@ -20,6 +20,9 @@ XC_F32, XC_F64 = 0, 1
 XC_DA_NONE, XC_DA_ROW, XC_DA_PLANE, XC_DA_SLAB = 0, 1, 2, 3
 XC_EDGE_NUMPY, XC_EDGE_XHISTOGRAM = 0, 1
 XC_MAX_INTEGRANDS = 2
+XC_PAD_EDGE, XC_PAD_WRAP, XC_PAD_NAN, XC_PAD_REFLECT, XC_PAD_SYMMETRIC = 0, 1, 2, 3, 4
+PAD_MODES = {'edge': XC_PAD_EDGE, 'wrap': XC_PAD_WRAP, 'constant': XC_PAD_NAN, 'reflect': XC_PAD_REFLECT,
+             'symmetric': XC_PAD_SYMMETRIC}
 
 _vp, _i32, _i64, _u64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
 
@@ -92,6 +95,10 @@ PROTOTYPES = {
                              _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     'xc_lwa': (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _vp, C.c_int,
                          _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+    'xc_crossing_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, C.c_int, _vp, C.c_int, C.c_int,
+                                  _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    'xc_crossing': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, C.c_int, _vp, C.c_int, C.c_int,
+                              _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     'xc_sort_profile_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int,
                                       _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'xc_sort_profile': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int,
@@ -387,6 +394,33 @@ class Context(object):
         self._check(self.lib.xc_grad2(self.handle, _ptr(q), dtype_code(q.dtype), nslab, ny, nx,
                                       _ptr(rdx), _ptr(rdy), 1 if periodic_x else 0, _ptr(out)))
         return out
+
+    def crossing(self, q, contours, area, stride=1, pad_x=0, pad_mode='edge', full_width=False):
+        """Box-counting contour crossing (xc_crossing).  q (nslab, ny, nx) f32/f64; contours (N,) or
+        (nslab, N) ASCENDING f64; area (ny, nx) or (nslab, ny, nx) f32/f64.
+        Returns (lengths f64 (nslab, N), box counts uint64 (nslab, N))."""
+        q = np.ascontiguousarray(q)
+        assert q.ndim == 3
+        nslab, ny, nx = q.shape
+        contours = np.ascontiguousarray(contours, dtype=np.float64)
+        per_slab = contours.ndim == 2
+        if per_slab and contours.shape[0] != nslab:
+            raise XContourHipError(XC_EBADARG, 'contours must be (N,) or (nslab, N)')
+        area = np.ascontiguousarray(area)
+        if area.dtype not in (np.float32, np.float64):
+            area = area.astype(np.float64)
+        if area.shape not in ((ny, nx), (nslab, ny, nx)):
+            raise XContourHipError(XC_EBADARG, 'area must be (ny, nx) or (nslab, ny, nx)')
+        if pad_mode not in PAD_MODES:
+            raise XContourHipError(XC_EBADARG, 'pad mode must be one of %s' % sorted(PAD_MODES))
+        N = contours.shape[-1]
+        lens = np.empty((nslab, N), dtype=np.float64)
+        cnts = np.empty((nslab, N), dtype=np.uint64)
+        self._check(self.lib.xc_crossing(self.handle, _ptr(q), dtype_code(q.dtype), nslab, ny, nx, int(pad_x),
+                                         PAD_MODES[pad_mode], _ptr(contours), N, 1 if per_slab else 0,
+                                         _ptr(area), dtype_code(area.dtype), 1 if area.ndim == 3 else 0,
+                                         int(stride), 1 if full_width else 0, _ptr(lens), _ptr(cnts)))
+        return lens, cnts
 
     def lwa(self, q, Q, coord, dA, dA_max, M=None, increase=True, part=0, mask_idx=None, variant=0):
         q = np.ascontiguousarray(q)

@@ -449,6 +449,61 @@ class Contour2D(object):
         return lb.wrap(out, lead + (dimTmp,), coords, vname, var)
 
     # ------------------------------------------------------------------ local wave activity
+    def cal_contour_crossing(self, ctr, stride=1, mode='edge', full_width=False):
+        """
+        Whether (and over what length) contours cross grid boxes, 'box-counting' method
+        (reference core.py:640-693 and its numba kernel _contour_crossing, 1490-1566).
+
+        One GPU pass per stride serves all contours of all slabs (K9, xc_crossing): the
+        tracer is padded on the X side by max(stride) columns (`mode` as in
+        DataArray.pad: 'edge', 'wrap', 'constant' (NaN), 'reflect', 'symmetric'), boxes of
+        stride x stride cells are tested corner by corner and each crossed box counts
+        sqrt(area) * stride.  Like the reference, the area is read at the coarse box
+        indices and only the first Jn-1 box columns are scanned (core.py:1521, 1560);
+        `full_width=True` (an extension) scans all of them.  Returns an array over
+        (..., contour) in `self.dtype`, or a list of them when `stride` is iterable.
+        """
+        from collections.abc import Iterable
+        if isinstance(stride, Iterable):
+            strides, isiterable = [int(t) for t in stride], True
+        else:
+            strides, isiterable = [int(stride)], False
+        maxStride = max(strides)
+        if min(strides) < 1:
+            raise Exception('stride should be a positive integer')
+        if mode not in nat.PAD_MODES:
+            raise Exception('unsupported pad mode %r (one of %s)' % (mode, sorted(nat.PAD_MODES)))
+        dims = lb.unwrap(self.tracer)[1]
+        if [d for d in dims if d in self.dimVs] != [self.dimEqV, self._xdim]:
+            raise Exception('cal_contour_crossing expects the tracer stored as (..., %s, %s)' % (self.dimEqV, self._xdim))
+        has_x = 'X' in self.dims                                               # core.py:673-679
+        if has_x and self.dims['X'] != self._xdim:
+            raise Exception('the X dim should be the fastest-varying dim of the plane')
+        q, lead, lshape, coords = self._plane(self.tracer)
+        q = self._float(q)
+        nslab, ny, nx = q.shape
+        area, was_f32 = self._dA_array(ny, nx, nslab)
+        if area.ndim == 1:
+            area = np.broadcast_to(area[:, None], (ny, nx))
+        if was_f32:
+            area = area.astype(np.float32)             # the reference takes np.sqrt in the area's own dtype
+        b = np.array(self._contour_values(ctr, nslab, list(lead), list(lshape)), dtype=np.float64)
+        b[np.isnan(b)] = np.inf                        # a NaN level is never crossed; neither is +inf
+        order = np.argsort(b, axis=1, kind='stable')
+        bs = np.take_along_axis(b, order, axis=1)
+        ccoord = lb.unwrap(ctr)[2].get('contour') if lb.is_labeled(ctr) else None
+        if ccoord is None:
+            ccoord = np.arange(b.shape[1]).astype(self.dtype)
+        re = []
+        for strd in strides:
+            lens, _ = self.ctx.crossing(q, bs, area, stride=strd, pad_x=maxStride if has_x else 0,
+                                        pad_mode=mode, full_width=full_width)
+            out = np.empty_like(lens)
+            np.put_along_axis(out, order, lens, axis=1)
+            re.append(self._wrap_contour(out.astype(self.dtype), lead, lshape, coords, None, self.tracer, ccoord))
+        return re if isiterable else re[0]
+
+    # ------------------------------------------------------------------ local wave activity
     def cal_local_wave_activity(self, q, Q, mask_idx=None, part='all', metric=None):
         """
         Local finite-amplitude wave activity density (reference core.py:696-799;

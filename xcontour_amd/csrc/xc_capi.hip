@@ -503,6 +503,50 @@ int xc_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny,
     return xc_sync(ctx);
 }
 
+// ------------------------------------------------------------------------------------ K9
+int xc_crossing_dev(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                    int pad_x, int pad_mode, const double* contours, int ncont, int contours_per_slab,
+                    const void* area, int area_dtype, int area_per_slab, int stride, int full_width,
+                    double* out_len, uint64_t* out_cnt)
+{
+    XC_CTX(ctx);
+    return launch_crossing(ctx, q, q_dtype, nslab, ny, nx, pad_x, pad_mode, contours, ncont, contours_per_slab,
+                           area, area_dtype, area_per_slab, stride, full_width, out_len, out_cnt);
+}
+
+int xc_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                int pad_x, int pad_mode, const double* contours, int ncont, int contours_per_slab,
+                const void* area, int area_dtype, int area_per_slab, int stride, int full_width,
+                double* out_len, uint64_t* out_cnt)
+{
+    XC_CTX(ctx);
+    if (!q || !contours || !area || (!out_len && !out_cnt) || nslab < 1 || ny < 1 || nx < 1 || ncont < 1)
+        return fail(ctx, XC_EBADARG, "xc_crossing: bad arguments");
+    if ((q_dtype != XC_F32 && q_dtype != XC_F64) || (area_dtype != XC_F32 && area_dtype != XC_F64))
+        return fail(ctx, XC_EBADARG, "xc_crossing: bad dtype");
+    const int64_t nc = contours_per_slab ? nslab : 1;
+    for (int64_t s = 0; s < nc; ++s)
+        for (int k = 0; k < ncont; ++k) {
+            const double c = contours[s * ncont + k];
+            if (c != c || (k > 0 && c < contours[s * ncont + k - 1]))
+                return fail(ctx, XC_EEDGES, "xc_crossing: contours must be ascending without NaN");
+        }
+    const size_t cells = (size_t)nslab * ny * nx, qb = cells * esize(q_dtype);
+    const size_t ab = (area_per_slab ? cells : (size_t)ny * nx) * esize(area_dtype);
+    const size_t cb = (size_t)nc * ncont * 8, ob = (size_t)nslab * ncont * 8;
+    XC_TRY(ensure_arena(ctx, al(qb) + al(ab) + al(cb) + 2 * al(ob)));
+    Stage st(ctx);
+    void* dq = st.take(qb); void* da = st.take(ab); double* dc = (double*)st.take(cb);
+    double* dl = out_len ? (double*)st.take(ob) : nullptr;
+    uint64_t* dn = out_cnt ? (uint64_t*)st.take(ob) : nullptr;
+    XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, da, area, ab)); XC_TRY(h2d(ctx, dc, contours, cb));
+    XC_TRY(launch_crossing(ctx, dq, q_dtype, nslab, ny, nx, pad_x, pad_mode, dc, ncont, contours_per_slab,
+                           da, area_dtype, area_per_slab, stride, full_width, dl, dn));
+    if (out_len) XC_TRY(d2h(ctx, out_len, dl, ob));
+    if (out_cnt) XC_TRY(d2h(ctx, out_cnt, dn, ob));
+    return xc_sync(ctx);
+}
+
 // ------------------------------------------------------------------------------------ K7
 int xc_lwa_dev(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const double* coord,
                const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,

@@ -138,6 +138,10 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
                         const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                         void* workspace, double* out_Q, double* out_qsorted, double* out_acum,
                         unsigned* out_nvalid, double* out_bpe);
+int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
+                    int pad_x, int pad_mode, const double* contours, int N, int contours_per_slab,
+                    const void* area, int area_dtype, int area_per_slab, int stride, int full_width,
+                    double* out_len, uint64_t* out_cnt);
 int launch_synth(xc_ctx* ctx, void* out, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
                  const double* lat_deg, const double* lon_deg, uint64_t seed, int variant);
 
