@@ -19,6 +19,7 @@
 // (ds_add_f64 / ds_add_u32), one partial vector per block, reduced in fixed order afterwards.
 // HBM-bound: tracer (4|8 B) + area (4|8 B) per fine cell at stride 1, independent of N.
 #include "xc_internal.h"
+#include <stdlib.h>
 
 namespace xc {
 namespace {
@@ -56,35 +57,90 @@ __device__ __forceinline__ void row_segment(const T* __restrict__ row, int64_t c
     }
 }
 
-__device__ __forceinline__ int lower_bound(const double* __restrict__ c, int n, double v)
+// number of contours < v, i.e. the klo with cx[klo] < v <= cx[klo+1]; cx = [-inf, c_0 .. c_{N-1}, +inf]
+__device__ __forceinline__ int count_below(const double* __restrict__ cx, int N, double v)
 {
-    int lo = 0, hi = n;                               // first k with c[k] >= v
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c[mid] < v) lo = mid + 1; else hi = mid; }
+    int lo = 0, hi = N;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cx[mid + 1] < v) lo = mid + 1; else hi = mid; }
     return lo;
 }
 
-template <typename TQ>
+template <typename TA> __device__ __forceinline__ double sqrt_like_numpy(TA a);
+// f32 area: np.sqrt rounds in f32; an f64 root rounded once more to f32 IS the correctly rounded f32 root (53 >= 2*24+2)
+template <> __device__ __forceinline__ double sqrt_like_numpy<float>(float a) { return (double)(float)__dsqrt_rn((double)a); }
+template <> __device__ __forceinline__ double sqrt_like_numpy<double>(double a) { return __dsqrt_rn(a); }
+
+// One finished box: contours k with cx[k+1] in [mn, mx) are crossed.  `g` is the previous box's klo
+// (walking down a column the tracer changes slowly: one adjacent-pair LDS read confirms the guess).
+template <typename TA, bool CNT>
+__device__ __forceinline__ void box_done(const double* __restrict__ cx, int N, double mn, double mx, TA araw, bool nanfill,
+                                         double fs, double c_first, double inv_step, int& g,
+                                         double* __restrict__ my_len, unsigned* __restrict__ my_cnt)
+{
+    if (!(mn < mx)) return;                            // one value, or no valid corner at all
+    // equally spaced levels (what cal_contours produces, inv_step > 0): the position follows from arithmetic;
+    // otherwise start from the previous box's answer.  One adjacent-pair LDS read verifies, bisection is the fallback.
+    if (inv_step > 0.0) g = (int)fmin(fmax((mn - c_first) * inv_step + 1.0, 0.0), (double)N);
+    const double c_lo = cx[g], c_hi = cx[g + 1];
+    if (!((c_lo < mn) & (mn <= c_hi))) g = count_below(cx, N, mn);
+    int k = g;
+    double ck = cx[k + 1];
+    if (!(ck < mx)) return;
+    double w = __dmul_rn(sqrt_like_numpy<TA>(araw), fs);    // core.py:1560 (product in f64: numba types f32 * int64 as f64)
+    if (nanfill) w = __longlong_as_double(0x7ff8000000000000LL);
+    const bool add = (w == w);                         // np.nansum skips NaN (negative or NaN area)
+    do {                                               // the +inf sentinel ends the scan
+#ifndef XC_CROSS_NOATOM
+        if (add) atomicAdd(&my_len[k], w);
+        if (CNT) atomicAdd(&my_cnt[k], 1u);
+#else
+        if (add && w == 1.2345) my_len[k] = w;         // diagnostic build: the loop without its atomics
+#endif
+        ++k; ck = cx[k + 1];
+    } while (ck < mx);
+}
+
+// CNT: also count the crossed boxes (exact integer output).  S: compile-time stride (loads of a batch
+// of boxes are issued together), 0 = any stride at run time.  ncopy lane-privatised copies of the
+// per-contour sums: neighbouring lanes (neighbouring columns) cross the SAME contour, and same-address
+// LDS atomics serialise.
+template <typename TQ, typename TA, bool CNT, int S>
 __global__ __launch_bounds__(CROSS_TPB)
 void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                 const double* __restrict__ contours, int N, int contours_per_slab,
-                const void* __restrict__ area, int area_f32, int area_per_slab,
-                int s, int64_t nbj, int64_t nbi, int64_t ntj, int64_t nti, int bps,
+                const TA* __restrict__ area, int area_per_slab,
+                int s_rt, int64_t nbj, int64_t nbi, int64_t ntj, int64_t nti, int bps, int ncopy, int np,
                 double* __restrict__ part_len, unsigned* __restrict__ part_cnt)
 {
     extern __shared__ double sm[];
-    double* s_c = sm;                      // [N] ascending contours of this slab
-    double* s_len = sm + N;                // [N]
-    unsigned* s_cnt = (unsigned*)(sm + 2 * (size_t)N);   // [N]
+    double* s_cx = sm;                                   // [N + 2]  -inf, ascending contours of this slab, +inf
+    double* s_len = sm + (N + 2);                        // [ncopy][np]
+    unsigned* s_cnt = (unsigned*)(s_len + (size_t)ncopy * np);   // [ncopy][np]
     const int tid = threadIdx.x;
     const int64_t slab = blockIdx.y;
     const double* cs = contours + (contours_per_slab ? (size_t)slab * N : 0);
-    for (int k = tid; k < N; k += CROSS_TPB) { s_c[k] = cs[k]; s_len[k] = 0.0; s_cnt[k] = 0u; }
-    __syncthreads();
-
-    const TQ* qs = q + (size_t)slab * ny * nx;
-    const size_t aoff = area_per_slab ? (size_t)slab * ny * nx : 0;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    for (int k = tid; k < N; k += CROSS_TPB) s_cx[k + 1] = cs[k];
+    if (tid == 0) { s_cx[0] = -inf; s_cx[N + 1] = inf; }
+    for (int k = tid; k < ncopy * np; k += CROSS_TPB) { s_len[k] = 0.0; if (CNT) s_cnt[k] = 0u; }
+    __syncthreads();
+    double* my_len = s_len + (size_t)(tid & (ncopy - 1)) * np;
+    unsigned* my_cnt = s_cnt + (size_t)(tid & (ncopy - 1)) * np;
+
+    const int s = S > 0 ? S : s_rt;
+    const TQ* qs = q + (size_t)slab * ny * nx;
+    const TA* as = area + (area_per_slab ? (size_t)slab * ny * nx : 0);
     const double fs = (double)s;
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    const double c_first = s_cx[1];
+    double inv_step = (N > 1) ? (double)(N - 1) / (s_cx[N] - c_first) : 0.0;
+    if (!(inv_step > 0.0 && inv_step < inf)) inv_step = 0.0;
+    {   // equally spaced?  (block-uniform answer)
+        int ok = inv_step > 0.0;
+        for (int k = tid; k < N && ok; k += CROSS_TPB) ok = fabs((s_cx[k + 1] - c_first) * inv_step - (double)k) < 0.01;
+        if (!__syncthreads_and(ok)) inv_step = 0.0;
+    }
+    int g = 0;
 
     for (int64_t tile = blockIdx.x; tile < ntj * nti; tile += bps) {
         const int64_t tj = tile / nti, ti = tile - tj * nti;
@@ -92,41 +148,68 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
         if (i >= nbi) continue;                       // no block-wide barrier inside the loop
         const int64_t j0 = tj * CROSS_RB, j1 = (j0 + CROSS_RB < nbj) ? j0 + CROSS_RB : nbj;
         const int64_t c0 = i * s;
+        // column of the box area: the padded area array at the COARSE indices (core.py:1560)
+        int64_t ac = i;
+        bool nanfill = false;
+        if (ac >= nx) { ac = pad_source(ac, nx, pad_mode); nanfill = ac < 0; if (nanfill) ac = 0; }
         double cmn = inf, cmx = -inf;                 // the corner row shared with the previous box
         row_segment(qs + (size_t)(j0 * s) * nx, c0, s, nx, pad_mode, cmn, cmx);
-        for (int64_t j = j0; j < j1; ++j) {
-            double mn = cmn, mx = cmx;
-            for (int r = 1; r < s; ++r) row_segment(qs + (size_t)(j * s + r) * nx, c0, s, nx, pad_mode, mn, mx);
-            cmn = inf; cmx = -inf;
-            row_segment(qs + (size_t)(j * s + s) * nx, c0, s, nx, pad_mode, cmn, cmx);
-            mn = fmin(mn, cmn); mx = fmax(mx, cmx);
-            // area of the box: the padded area array at the COARSE indices (core.py:1560)
-            double a;
-            {
-                int64_t ac = i;
-                bool nanfill = false;
-                if (ac >= nx) { ac = pad_source(ac, nx, pad_mode); nanfill = ac < 0; if (nanfill) ac = 0; }
-                const size_t idx = aoff + (size_t)j * nx + ac;
-                // f32 area: np.sqrt rounds in f32; f64 sqrt then one rounding to f32 is the correctly rounded f32 root (53 >= 2*24+2)
-                a = area_f32 ? (double)(float)__dsqrt_rn((double)((const float*)area)[idx]) : __dsqrt_rn(((const double*)area)[idx]);
-                if (nanfill) a = __longlong_as_double(0x7ff8000000000000LL);
+        if constexpr (S == 0) {
+            for (int64_t j = j0; j < j1; ++j) {
+                double mn = cmn, mx = cmx;
+                for (int r = 1; r < s; ++r) row_segment(qs + (size_t)(j * s + r) * nx, c0, s, nx, pad_mode, mn, mx);
+                cmn = inf; cmx = -inf;
+                row_segment(qs + (size_t)(j * s + s) * nx, c0, s, nx, pad_mode, cmn, cmx);
+                mn = fmin(mn, cmn); mx = fmax(mx, cmx);
+                box_done<TA, CNT>(s_cx, N, mn, mx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, g, my_len, my_cnt);
             }
-            if (mn < mx) {
-                const int klo = lower_bound(s_c, N, mn);
-                if (klo < N && s_c[klo] < mx) {
-                    const int khi = lower_bound(s_c, N, mx);
-                    const double w = __dmul_rn(a, fs);
-                    for (int k = klo; k < khi; ++k) {
-                        if (w == w) atomicAdd(&s_len[k], w);
-                        atomicAdd(&s_cnt[k], 1u);
+        } else {
+            constexpr int B = S == 1 ? 8 : S == 2 ? 4 : S == 3 ? 2 : 1;     // boxes per load batch
+            int64_t src[S + 1]; bool pnan[S + 1];      // source columns of the S+1 corner columns (X padding resolved once)
+#pragma unroll
+            for (int d = 0; d <= S; ++d) {
+                int64_t c = c0 + d; pnan[d] = false;
+                if (c >= nx) { c = pad_source(c, nx, pad_mode); pnan[d] = c < 0; if (pnan[d]) c = 0; }
+                src[d] = c;
+            }
+            for (int64_t jb = j0; jb < j1; jb += B) {
+                TQ v[B][S][S + 1]; TA av[B];
+#pragma unroll
+                for (int b = 0; b < B; ++b) {          // all loads of the batch in flight together
+                    const int64_t jj = (jb + b < j1) ? jb + b : j1 - 1;
+                    av[b] = as[(size_t)jj * nx + ac];
+#pragma unroll
+                    for (int r = 0; r < S; ++r) {
+                        const TQ* row = qs + (size_t)(jj * S + r + 1) * nx;
+#pragma unroll
+                        for (int d = 0; d <= S; ++d) v[b][r][d] = row[src[d]];
                     }
+                }
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    if (jb + b >= j1) break;
+                    double mn = cmn, mx = cmx;
+#pragma unroll
+                    for (int r = 0; r < S - 1; ++r)
+#pragma unroll
+                        for (int d = 0; d <= S; ++d) { const double x = pnan[d] ? qnan : (double)v[b][r][d]; mn = fmin(mn, x); mx = fmax(mx, x); }
+                    cmn = inf; cmx = -inf;
+#pragma unroll
+                    for (int d = 0; d <= S; ++d) { const double x = pnan[d] ? qnan : (double)v[b][S - 1][d]; cmn = fmin(cmn, x); cmx = fmax(cmx, x); }
+                    mn = fmin(mn, cmn); mx = fmax(mx, cmx);
+                    box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, g, my_len, my_cnt);
                 }
             }
         }
     }
     __syncthreads();
     const size_t pb = ((size_t)slab * bps + blockIdx.x) * N;
-    for (int k = tid; k < N; k += CROSS_TPB) { part_len[pb + k] = s_len[k]; part_cnt[pb + k] = s_cnt[k]; }
+    for (int k = tid; k < N; k += CROSS_TPB) {
+        double l = 0.0; unsigned n = 0;
+        for (int c = 0; c < ncopy; ++c) { l += s_len[(size_t)c * np + k]; if (CNT) n += s_cnt[(size_t)c * np + k]; }
+        part_len[pb + k] = l;
+        if (CNT) part_cnt[pb + k] = n;
+    }
 }
 
 __global__ __launch_bounds__(256)
@@ -139,7 +222,7 @@ void k_crossing_reduce(const double* __restrict__ part_len, const unsigned* __re
     double len = 0.0; unsigned long long cnt = 0;
     for (int b = 0; b < bps; ++b) {
         len += part_len[(slab * bps + b) * N + k];
-        cnt += part_cnt[(slab * bps + b) * N + k];
+        if (out_cnt) cnt += part_cnt[(slab * bps + b) * N + k];
     }
     if (out_len) out_len[slab * N + k] = len;
     if (out_cnt) out_cnt[slab * N + k] = cnt;
@@ -162,7 +245,11 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
     if (stride < 1 || pad_x < 0) return fail(ctx, XC_EBADARG, "xc_crossing: stride must be >= 1 and pad_x >= 0");
     if (pad_mode < XC_PAD_EDGE || pad_mode > XC_PAD_SYMMETRIC) return fail(ctx, XC_EBADARG, "xc_crossing: unknown pad_mode");
     if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_crossing: nslab too large");
-    const size_t lds = (size_t)N * 20 + 8;
+    const int np = N | 1;                                 // odd row pitch: the copies of one contour fall in different banks
+    int ncopy = 8;
+    if (const char* e = getenv("XC_CROSS_NCOPY")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ncopy = v; }
+    while (ncopy > 1 && (size_t)(N + 2) * 8 + (size_t)ncopy * np * 12 > 48 * 1024) ncopy >>= 1;   // several blocks per CU
+    const size_t lds = (size_t)(N + 2) * 8 + (size_t)ncopy * np * 12;
     if (lds > kLdsBudget) return fail(ctx, XC_EBADARG, "xc_crossing: too many contours for one pass");
     const int64_t Jn = coarse(ny, stride), In = coarse(nx + pad_x, stride);
     const int64_t nbj = Jn - 1, nbi = full_width ? In - 1 : (Jn < In ? Jn : In) - 1;
@@ -183,13 +270,19 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
     double* part_len = (double*)ctx->scratch;
     unsigned* part_cnt = (unsigned*)((char*)ctx->scratch + ((pl + 255) & ~(size_t)255));
     const dim3 grid((unsigned)bps, (unsigned)nslab);
-#define XC_CROSS(T) do { \
-        if (lds > 64 * 1024) XC_HIP(ctx, hipFuncSetAttribute((const void*)k_crossing<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_crossing<T>), grid, dim3(CROSS_TPB), lds, ctx->stream, (const T*)q, ny, nx, pad_mode, contours, N, \
-                           contours_per_slab, area, area_dtype == XC_F32, area_per_slab, stride, nbj, nbi, ntj, nti, (int)bps, \
-                           part_len, part_cnt); } while (0)
-    if (q_dtype == XC_F64) XC_CROSS(double); else XC_CROSS(float);
-#undef XC_CROSS
+#define XC_CROSS4(TQ_, TA_, C_, S_) do { \
+        if (lds > 64 * 1024) XC_HIP(ctx, hipFuncSetAttribute((const void*)k_crossing<TQ_, TA_, C_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_crossing<TQ_, TA_, C_, S_>), grid, dim3(CROSS_TPB), lds, ctx->stream, (const TQ_*)q, ny, nx, pad_mode, contours, N, \
+                           contours_per_slab, (const TA_*)area, area_per_slab, stride, nbj, nbi, ntj, nti, (int)bps, \
+                           ncopy, np, part_len, part_cnt); } while (0)
+#define XC_CROSS3(TQ_, TA_, C_) do { switch (stride) { case 1: XC_CROSS4(TQ_, TA_, C_, 1); break; case 2: XC_CROSS4(TQ_, TA_, C_, 2); break; \
+        case 4: XC_CROSS4(TQ_, TA_, C_, 4); break; default: XC_CROSS4(TQ_, TA_, C_, 0); } } while (0)
+#define XC_CROSS2(TQ_, TA_) do { if (out_cnt) XC_CROSS3(TQ_, TA_, true); else XC_CROSS3(TQ_, TA_, false); } while (0)
+    if (q_dtype == XC_F64) { if (area_dtype == XC_F64) XC_CROSS2(double, double); else XC_CROSS2(double, float); }
+    else { if (area_dtype == XC_F64) XC_CROSS2(float, double); else XC_CROSS2(float, float); }
+#undef XC_CROSS2
+#undef XC_CROSS3
+#undef XC_CROSS4
     XC_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_crossing_reduce, dim3((unsigned)((N + 255) / 256), (unsigned)nslab), dim3(256), 0, ctx->stream,
                        part_len, part_cnt, (int)bps, N, out_len, (unsigned long long*)out_cnt);
