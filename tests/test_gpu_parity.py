@@ -617,6 +617,21 @@ def test_contour_mean_family(ctx, baro):
         lo = O.cal_gradient_wrt_area(integral(q, o_ctr, dA.values, grdm.values, True), oa)
         with np.errstate(divide='ignore', invalid='ignore'):
             assert mean.name == 'cmcoslat' and rel(mean.values, up / lo) < 1e-6
+    # the histogram variant runs area + both integrals as channels of ONE K3 pass
+    calls = []
+    real = type(cm.ctx).hist
+    try:
+        type(cm.ctx).hist = lambda self, *a, **k: (calls.append(len(k.get('integrands', ()))), real(self, *a, **k))[1]
+        fused = cm.cal_contour_mean_hist(ctr, integ, grdm)
+        assert calls == [2]
+        calls.clear()
+        lw_u = cm.cal_contour_weigh_mean_hist(ctr, xa.DataArray(integ.values * grdm.values, tr.dims, tr.coords, None))
+        lw_l = cm.cal_contour_weigh_mean_hist(ctr, grdm)
+        assert len(calls) == 4
+    finally:
+        type(cm.ctx).hist = real
+    with np.errstate(divide='ignore', invalid='ignore'):
+        assert rel(fused.values, lw_u.values / lw_l.values) < 1e-9
 
 
 # ---------------------------------------------------------------- BASELINE cfg1 stand-in: PV-like (level, lat, lon) f32 stack

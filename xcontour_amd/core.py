@@ -383,12 +383,52 @@ class Contour2D(object):
         iv, idims, icoords, iname = lb.unwrap(integrand)
         gv, gdims, _, _ = lb.unwrap(grdm)
         prod = lb.wrap(iv * _align(gv, gdims, idims), idims, icoords, None, integrand)
-        upper = fn(contour, prod, area=area)
-        lower = fn(contour, grdm, area=area)
+        fused = self._integrals_hist(contour, [prod, grdm]) if fn == self.cal_contour_weigh_mean_hist else None
+        if fused is not None:
+            # area, int(integrand*grdm) and int(grdm) as three weight channels of ONE histogram
+            # pass (the reference: four passes, core.py:523-552 called twice from 586-616)
+            a_cdf, (intU, intL) = fused
+            if area is None:
+                area = a_cdf
+            upper = self.cal_gradient_wrt_area(intU, area)
+            lower = self.cal_gradient_wrt_area(intL, area)
+        else:
+            upper = fn(contour, prod, area=area)
+            lower = fn(contour, grdm, area=area)
         uv, udims, ucoords, _ = lb.unwrap(upper)
         with np.errstate(divide='ignore', invalid='ignore'):
             lmA = uv / lb.unwrap(lower)[0]
         return lb.wrap(lmA, udims, ucoords, 'cm' if iname is None else 'cm' + iname, upper)
+
+    def _integrals_hist(self, contour, integrands):
+        """CDF of dA and of every integrand*dA within the contours in ONE K3 pass ->
+        (area, [integral_i]), each exactly what cal_integral_within_contours_hist returns; None when
+        the integrands cannot share a launch (more than XC_MAX_INTEGRANDS, or mixed f32/f64 products)."""
+        q, lead, lshape, coords = self._plane(self.tracer)
+        q = self._float(q)
+        nslab, ny, nx = q.shape
+        dA, dA_f32 = self._dA_array(ny, nx, nslab)
+        gs, flags = [], []
+        for it in integrands:
+            g = self._float(self._plane(it)[0])
+            if g.shape != q.shape:
+                g = np.ascontiguousarray(np.broadcast_to(g, q.shape))
+            gs.append(g)
+            flags.append(bool(g.dtype == np.float32 and dA_f32))           # f32*f32 stays f32 (core.py:444)
+        if len(gs) > nat.XC_MAX_INTEGRANDS or len(set(flags)) > 1:
+            return None
+        b = self._contour_values(contour, nslab, list(lead), list(lshape))
+        edges, binc, last_closed = _edges_from_levels(b, self.right_edge)
+        out = self.ctx.hist(q, edges, dA=dA, integrands=gs, last_closed=last_closed, lt=self.lt,
+                            reverse=not binc, prod_f32=flags[0], want=('cdf',))
+        binNum = np.arange(b.shape[1]).astype(np.float32)                  # core.py:1255-1257
+        name = 'histogram_%s' % lb.unwrap(self.tracer)[3]
+        res = [self._wrap_contour(np.ascontiguousarray(out['cdf'][:, c, :]), lead, lshape, coords, name, self.tracer, binNum)
+               for c in range(1 + len(gs))]
+        if self.check_mono:
+            for r in res:
+                _check_monotonicity(r, 'contour')
+        return res[0], res[1:]
 
     def cal_sqared_equivalent_length(self, dgrdSdA, dqdA):
         """Leq2 = d[int |grad q|^2]/dA / (dq/dA)^2 (reference core.py:619-637)."""
