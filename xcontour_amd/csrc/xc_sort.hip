@@ -7,9 +7,10 @@
 //   Q_exact(A_j) = q_sorted[min(searchsorted(Acum, A_j, 'right'), n-1)].
 //
 // Hand-written LSD radix sort, 8-bit digits, 64-bit order-preserving keys, f64 payload:
-// one WAVE owns one tile of 1024 consecutive elements; stable ranks come from wave ballots
-// (8 ballots give the peer mask of a lane's digit), per-wave digit counters live in LDS,
-// the (digit-major) tile histogram is scanned by two small kernels.  Bandwidth-bound:
+// one block owns one tile of 4096 consecutive elements (4 waves x 1024); stable ranks come from wave
+// ballots (8 ballots give the peer mask of a lane's digit) + per-wave digit counters in LDS; the tile is
+// reordered by digit in LDS before it is stored; the (digit-major) tile histogram is scanned by two
+// small kernels.  float32 tracers skip the three passes whose digits are all zero.  Bandwidth-bound:
 // per pass 8 B/elem (histogram) + 32 B/elem (scatter read + write).
 #include "xc_internal.h"
 
@@ -17,7 +18,8 @@ namespace xc {
 namespace {
 
 constexpr int TILE_ROUNDS = 16;
-constexpr int TILE = 64 * TILE_ROUNDS;      // elements per wave tile
+constexpr int TILE = 64 * TILE_ROUNDS;      // elements per wave
+constexpr int BTILE = 4 * TILE;             // elements per block tile
 constexpr unsigned long long KEY_INVALID = ~0ull;
 
 __device__ __forceinline__ unsigned long long f64_to_key(double v)
@@ -70,45 +72,58 @@ __device__ __forceinline__ unsigned long long digit_peers(unsigned d, unsigned l
     return m;
 }
 
+// tile = 4 waves x TILE elements (one block); digit-major tile histogram hist[d][tile].
+// Counting needs no ranks: one returnless ds_add_u32 per key on per-wave counters (the ballot ranking
+// of the scatter costs ~60 VALU instructions per 64 keys and made this kernel ALU-bound); a round
+// whose 64 digits are all equal -- sorted or constant data -- is added once by one lane.
 __global__ __launch_bounds__(256)
 void k_radix_hist(const unsigned long long* __restrict__ keys, int64_t n, int shift, int ntiles,
                   unsigned* __restrict__ hist)
 {
     __shared__ unsigned s_cnt[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t t = blockIdx.x;
     for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = 0;
-    if (t < ntiles) {
-        const int64_t base = t * TILE;
-        unsigned long long kreg[TILE_ROUNDS];                  // all loads of the tile in flight at once
+    // counting does not care about the order inside the tile: 16-byte loads, two keys per lane
+    const int64_t base = t * BTILE + (int64_t)wave * TILE;
+    unsigned long long kreg[TILE_ROUNDS];                  // all loads of the wave's part in flight at once
+    const bool full = base + TILE <= n;
+    if (full) {
+        const ulonglong2* k2 = (const ulonglong2*)(keys + base);      // workspace is 256-byte aligned, base a multiple of 1024
 #pragma unroll
-        for (int r = 0; r < TILE_ROUNDS; ++r) {
-            const int64_t i = base + r * 64 + lane;
-            kreg[r] = i < n ? keys[i] : 0ull;
-        }
+        for (int r = 0; r < TILE_ROUNDS / 2; ++r) { const ulonglong2 u = k2[r * 64 + lane]; kreg[2 * r] = u.x; kreg[2 * r + 1] = u.y; }
+    } else {
 #pragma unroll
-        for (int r = 0; r < TILE_ROUNDS; ++r) {
-            const int64_t i = base + r * 64 + lane;
-            const bool valid = i < n;
-            const unsigned d = valid ? (unsigned)((kreg[r] >> shift) & 255ull) : 0u;
-            const unsigned long long peers = digit_peers(d, __ballot(valid));
-            if (valid && (peers & ((1ull << lane) - 1ull)) == 0) s_cnt[wave][d] += (unsigned)__popcll(peers);
+        for (int r = 0; r < TILE_ROUNDS / 2; ++r) {
+            const int64_t i = base + (r * 64 + lane) * 2;
+            kreg[2 * r] = i < n ? keys[i] : 0ull; kreg[2 * r + 1] = i + 1 < n ? keys[i + 1] : 0ull;
         }
-        for (int d = lane; d < 256; d += 64) hist[(size_t)d * ntiles + t] = s_cnt[wave][d];
     }
+#pragma unroll
+    for (int r = 0; r < TILE_ROUNDS; ++r) {
+        const int64_t i = base + ((r >> 1) * 64 + lane) * 2 + (r & 1);
+        const bool valid = full || i < n;
+        const unsigned d = (unsigned)((kreg[r] >> shift) & 255ull);
+        const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+        if (full && __ballot(d != d0) == 0ull) { if (lane == 0) atomicAdd(&s_cnt[wave][d0], 64u); }
+        else if (valid) atomicAdd(&s_cnt[wave][d], 1u);
+    }
+    __syncthreads();
+    const int d = threadIdx.x;
+    hist[(size_t)d * ntiles + t] = s_cnt[0][d] + s_cnt[1][d] + s_cnt[2][d] + s_cnt[3][d];
 }
 
 // exclusive scan of each digit's row over the tiles (one block per digit); row total out
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void k_radix_scan_rows(unsigned* __restrict__ hist, int ntiles, unsigned* __restrict__ totals)
 {
-    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_w[16];
     __shared__ unsigned s_carry;
     unsigned* row = hist + (size_t)blockIdx.x * ntiles;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int b = 0; b < ntiles; b += 256) {
+    for (int b = 0; b < ntiles; b += 1024) {
         const int i = b + tid;
         const unsigned v = i < ntiles ? row[i] : 0u;
         unsigned x = v;                                        // inclusive wave scan
@@ -119,77 +134,158 @@ void k_radix_scan_rows(unsigned* __restrict__ hist, int ntiles, unsigned* __rest
         for (int w = 0; w < wave; ++w) off += s_w[w];
         if (i < ntiles) row[i] = off + x - v;
         __syncthreads();
-        if (tid == 255) s_carry = off + x;
+        if (tid == 1023) s_carry = off + x;
         __syncthreads();
     }
     if (tid == 0) totals[blockIdx.x] = s_carry;
 }
 
-__global__ __launch_bounds__(256)
-void k_radix_scan_totals(const unsigned* __restrict__ totals, unsigned* __restrict__ bases)
-{
-    __shared__ unsigned s[256];
-    s[threadIdx.x] = totals[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) { unsigned run = 0; for (int d = 0; d < 256; ++d) { const unsigned v = s[d]; s[d] = run; run += v; } }
-    __syncthreads();
-    bases[threadIdx.x] = s[threadIdx.x];
-}
-
+// Scatter of one block tile (4 waves x TILE elements).  The tile is first sorted by digit in LDS
+// (stable: wave-major, then round, then lane = element order), then written out position by position:
+// consecutive LDS positions with the same digit go to consecutive global addresses, so the stores
+// of a wave cover runs of ~BTILE/256 elements instead of 64 unrelated 8-byte targets.
 __global__ __launch_bounds__(256)
 void k_radix_scatter(const unsigned long long* __restrict__ kin, const double* __restrict__ vin,
                      unsigned long long* __restrict__ kout, double* __restrict__ vout, int64_t n, int shift,
-                     int ntiles, const unsigned* __restrict__ hist, const unsigned* __restrict__ bases)
+                     int ntiles, const unsigned* __restrict__ hist, const unsigned* __restrict__ totals)
 {
-    __shared__ unsigned s_pos[4][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
-    if (t >= ntiles) return;
-    for (int d = lane; d < 256; d += 64) s_pos[wave][d] = bases[d] + hist[(size_t)d * ntiles + t];
-    const int64_t base = t * TILE;
-    unsigned long long kreg[TILE_ROUNDS];                      // the whole tile's loads in flight at once
+    extern __shared__ unsigned long long s_dyn[];
+    unsigned long long* s_k = s_dyn;                           // [BTILE] staging: keys first, then the payload
+    double* s_v = (double*)s_dyn;
+    unsigned* s_cnt = (unsigned*)(s_dyn + BTILE);              // [4][256] per-wave digit counts -> start offsets
+    unsigned* s_gbase = s_cnt + 4 * 256;                       // [256] global position minus tile-local position
+    unsigned* s_wsum = s_gbase + 256;                          // [8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t t = blockIdx.x;
+    for (int d = lane; d < 256; d += 64) s_cnt[wave * 256 + d] = 0;
+    const int64_t tbase = t * BTILE;
+    const int64_t base = tbase + (int64_t)wave * TILE;
+    unsigned long long kreg[TILE_ROUNDS];                      // the whole part's loads in flight at once
     double vreg[TILE_ROUNDS];
+    unsigned short lrank[TILE_ROUNDS];
 #pragma unroll
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
         kreg[r] = i < n ? kin[i] : 0ull;
         vreg[r] = i < n ? vin[i] : 0.0;
     }
+    // rank of every element among the wave's elements with the same digit
 #pragma unroll
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
         const bool valid = i < n;
-        const unsigned long long key = kreg[r];
-        const double val = vreg[r];
-        const unsigned d = valid ? (unsigned)((key >> shift) & 255ull) : 0u;
+        const unsigned d = valid ? (unsigned)((kreg[r] >> shift) & 255ull) : 0u;
         const unsigned long long peers = digit_peers(d, __ballot(valid));
         const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
         unsigned pos = 0;
-        if (valid) pos = s_pos[wave][d] + rank;                 // all peers read the same counter first ...
-        if (valid && rank == 0) s_pos[wave][d] += (unsigned)__popcll(peers);   // ... then the leader advances it
-        if (valid) { kout[pos] = key; vout[pos] = val; }
+        if (valid) pos = s_cnt[wave * 256 + d] + rank;          // all peers read the same counter first ...
+        if (valid && rank == 0) s_cnt[wave * 256 + d] += (unsigned)__popcll(peers);   // ... then the leader advances it
+        lrank[r] = (unsigned short)pos;
+    }
+    __syncthreads();
+    {   // thread d: tile-local start of digit d (exclusive scan over digits), per-wave starts, global base
+        const int d = tid;
+        const unsigned c0 = s_cnt[d], c1 = s_cnt[256 + d], c2 = s_cnt[512 + d], c3 = s_cnt[768 + d];
+        const unsigned tot = c0 + c1 + c2 + c3, gtot = totals[d];
+        unsigned x = tot, gx = gtot;                       // two exclusive scans over the digits: tile-local and global
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned y = __shfl_up(x, o), gy = __shfl_up(gx, o);
+            if (lane >= o) { x += y; gx += gy; }
+        }
+        if (lane == 63) { s_wsum[wave] = x; s_wsum[4 + wave] = gx; }
+        __syncthreads();
+        unsigned start = x - tot, gbase = gx - gtot;
+        for (int w = 0; w < wave; ++w) { start += s_wsum[w]; gbase += s_wsum[4 + w]; }
+        s_cnt[d] = start; s_cnt[256 + d] = start + c0; s_cnt[512 + d] = start + c0 + c1; s_cnt[768 + d] = start + c0 + c1 + c2;
+        s_gbase[d] = gbase + hist[(size_t)d * ntiles + t] - start;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TILE_ROUNDS; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        const unsigned d = (unsigned)((kreg[r] >> shift) & 255ull);
+        lrank[r] = (unsigned short)(s_cnt[wave * 256 + d] + lrank[r]);      // tile-local position
+        if (i < n) s_k[lrank[r]] = kreg[r];
+    }
+    __syncthreads();
+    const int64_t left = n - tbase;
+    const int cnt = left < BTILE ? (int)left : BTILE;
+    unsigned gpos[TILE_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < TILE_ROUNDS; ++r) {
+        const int p = r * 256 + tid;
+        if (p < cnt) {
+            const unsigned long long key = s_k[p];
+            gpos[r] = s_gbase[(unsigned)((key >> shift) & 255ull)] + (unsigned)p;
+            kout[gpos[r]] = key;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TILE_ROUNDS; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        if (i < n) s_v[lrank[r]] = vreg[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TILE_ROUNDS; ++r) {
+        const int p = r * 256 + tid;
+        if (p < cnt) vout[gpos[r]] = s_v[p];
     }
 }
 
-// ---- inclusive f64 scan (cumulative area of the sorted state): block-local scan + block sums
+// ---- inclusive f64 scan (cumulative area of the sorted state): block sums, their exclusive scan, then
+// the block-local scan plus block offset.  Both passes run the same arithmetic, so the sums of pass 1
+// are exactly the last values pass 2 produces (read 2x, write 1x; the payload is never re-written).
+// A wave owns 512 consecutive values: 4 rounds of coalesced 16-byte accesses, one wave scan per round.
+template <bool FINAL>
 __global__ __launch_bounds__(256)
 void k_scan_local(const double* __restrict__ in, double* __restrict__ out, int64_t n, double* __restrict__ bsum)
 {
     __shared__ double s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t base = (int64_t)blockIdx.x * 2048;
-    double v[8], run = 0.0;
+    const int64_t wbase = (int64_t)blockIdx.x * 2048 + wave * 512;
+    double a[4], b[4];
+    if (wbase + 512 <= n) {
+        const double2* in2 = (const double2*)(in + wbase);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int64_t i = base + (int64_t)tid * 8 + k; v[k] = i < n ? in[i] : 0.0; run += v[k]; v[k] = run; }
-    double x = run;
-    for (int o = 1; o < 64; o <<= 1) { const double y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) s_w[wave] = x;
+        for (int r = 0; r < 4; ++r) { const double2 u = in2[r * 64 + lane]; a[r] = u.x; b[r] = u.y; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i = wbase + (r * 64 + lane) * 2;
+            a[r] = i < n ? in[i] : 0.0; b[r] = i + 1 < n ? in[i + 1] : 0.0;
+        }
+    }
+    double carry = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double pair = a[r] + b[r];
+        double x = pair;                                       // inclusive wave scan of the pair sums
+        for (int o = 1; o < 64; o <<= 1) { const double y = __shfl_up(x, o); if (lane >= o) x += y; }
+        const double before = carry + (x - pair);
+        a[r] = before + a[r]; b[r] = before + pair;
+        carry += __shfl(x, 63);
+    }
+    if (lane == 63) s_w[wave] = carry;
     __syncthreads();
-    double off = x - run;
+    double off = 0.0;
     for (int w = 0; w < wave; ++w) off += s_w[w];
+    if (FINAL) {
+        const double boff = bsum[blockIdx.x];
+        if (wbase + 512 <= n) {
+            double2* out2 = (double2*)(out + wbase);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int64_t i = base + (int64_t)tid * 8 + k; if (i < n) out[i] = off + v[k]; }
-    if (tid == 255) bsum[blockIdx.x] = off + run;
+            for (int r = 0; r < 4; ++r) out2[r * 64 + lane] = make_double2((off + a[r]) + boff, (off + b[r]) + boff);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = wbase + (r * 64 + lane) * 2;
+                if (i < n) out[i] = (off + a[r]) + boff;
+                if (i + 1 < n) out[i + 1] = (off + b[r]) + boff;
+            }
+        }
+    } else if (tid == 255) bsum[blockIdx.x] = off + carry;
 }
 
 __global__ __launch_bounds__(1024)
@@ -214,14 +310,6 @@ void k_scan_bsums(double* __restrict__ bsum, int nb)        // exclusive scan in
         if (tid == 1023) s_carry = off + x;
         __syncthreads();
     }
-}
-
-__global__ __launch_bounds__(256)
-void k_scan_add(double* __restrict__ out, int64_t n, const double* __restrict__ bsum)
-{
-    const double off = bsum[blockIdx.x];
-    const int64_t base = (int64_t)blockIdx.x * 2048;
-    for (int k = 0; k < 8; ++k) { const int64_t i = base + k * 256 + threadIdx.x; if (i < n) out[i] += off; }
 }
 
 __global__ __launch_bounds__(256)
@@ -285,10 +373,10 @@ __global__ void k_sum_parts(const double* __restrict__ part, int n, double* __re
 
 }  // namespace
 
-// Workspace layout (device): keys A/B, vals A/B, hist, totals, bases, nvalid, bsums, bpe parts
+// Workspace layout (device): keys A/B, vals A/B, hist, totals, spare, nvalid, bsums, bpe parts
 size_t sort_workspace_bytes(int64_t n)
 {
-    const int64_t ntiles = (n + TILE - 1) / TILE;
+    const int64_t ntiles = (n + BTILE - 1) / BTILE;
     const int64_t nb = (n + 2047) / 2048;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     return 4 * al((size_t)n * 8) + al((size_t)256 * ntiles * 4) + al(256 * 4) * 2 + al(64) + al((size_t)nb * 8) + al(1024 * 8);
@@ -304,7 +392,7 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
     if (!q || !workspace || n < 1 || n > 0x7fffffff) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad arguments");
     if (dA_rank != XC_DA_NONE && dA_rank != XC_DA_ROW && dA_rank != XC_DA_PLANE) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA_rank must be NONE, ROW or PLANE");
     if (dA_rank != XC_DA_NONE && !dA) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA is NULL");
-    const int64_t ntiles = (n + TILE - 1) / TILE;
+    const int64_t ntiles = (n + BTILE - 1) / BTILE;
     const int nb = (int)((n + 2047) / 2048);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     char* w = (char*)workspace;
@@ -314,7 +402,7 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
     double* vB = (double*)w; w += al((size_t)n * 8);
     unsigned* hist = (unsigned*)w; w += al((size_t)256 * ntiles * 4);
     unsigned* totals = (unsigned*)w; w += al(256 * 4);
-    unsigned* bases = (unsigned*)w; w += al(256 * 4);
+    w += al(256 * 4);                                      // (spare)
     unsigned* nvalid = (unsigned*)w; w += al(64);
     double* bsum = (double*)w; w += al((size_t)nb * 8);
     double* parts = (double*)w;
@@ -328,26 +416,28 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
     else return fail(ctx, XC_EBADARG, "xc_sort_profile: q_dtype must be XC_F32 or XC_F64");
 #undef XC_KEYS
     XC_HIP(ctx, hipGetLastError());
-    const unsigned gt = (unsigned)((ntiles + 3) / 4);
+    const unsigned gt = (unsigned)ntiles;
+    const size_t sc_lds = (size_t)BTILE * 8 + (4 * 256 + 256 + 8) * sizeof(unsigned);
+    XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds));
     unsigned long long *kin = kA, *kout = kB;
     double *vin = vA, *vout = vB;
-    for (int pass = 0; pass < 8; ++pass) {
+    // a float32 tracer widened to float64 has 29 zero mantissa bits: the digits of passes 0-2 are all zero
+    for (int pass = (q_dtype == XC_F32 ? 3 : 0); pass < 8; ++pass) {
         const int shift = pass * 8;
         hipLaunchKernelGGL(k_radix_hist, dim3(gt), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist);
-        hipLaunchKernelGGL(k_radix_scan_rows, dim3(256), dim3(256), 0, ctx->stream, hist, (int)ntiles, totals);
-        hipLaunchKernelGGL(k_radix_scan_totals, dim3(1), dim3(256), 0, ctx->stream, totals, bases);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(gt), dim3(256), 0, ctx->stream, kin, vin, kout, vout, n, shift,
-                           (int)ntiles, hist, bases);
+        hipLaunchKernelGGL(k_radix_scan_rows, dim3(256), dim3(1024), 0, ctx->stream, hist, (int)ntiles, totals);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(gt), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+                           (int)ntiles, hist, totals);
         XC_HIP(ctx, hipGetLastError());
         unsigned long long* tk = kin; kin = kout; kout = tk;
         double* tv = vin; vin = vout; vout = tv;
     }
-    // 8 passes: sorted data are back in kA / vA (= kin / vin)
+    // sorted data are in kin / vin (kA / vA after 8 passes, kB / vB after 5)
     hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(64), 0, ctx->stream, kin, n, nvalid);
     double* acum = vout;                                   // reuse the idle payload buffer
-    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
+    hipLaunchKernelGGL(k_scan_local<false>, dim3(nb), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, ctx->stream, acum, n, bsum);
+    hipLaunchKernelGGL(k_scan_local<true>, dim3(nb), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
     XC_HIP(ctx, hipGetLastError());
     if (out_Q && J > 0) {
         if (!targets) return fail(ctx, XC_EBADARG, "xc_sort_profile: targets is NULL");
