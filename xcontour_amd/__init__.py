@@ -11,7 +11,8 @@ There is no CPU fallback.
 from .core import Contour2D, Table
 from .utils import equivalent_latitudes, latitude_lengths_at, cell_area, grad_metrics, \
     cartesian_metrics, Rearth
-from .labeled import DataArray
+from .labeled import DataArray, Dataset
+from .ncio import open_dataset
 from .pipeline import KeffPlan, shard_slabs
 from ._native import Context, default_context, XContourHipError
 

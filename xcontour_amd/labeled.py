@@ -38,6 +38,7 @@ class DataArray(object):
                 raise ValueError('coordinate %r has wrong length' % k)
             self.coords[k] = v
         self.name = name
+        self.attrs = {}
 
     # -- numpy-ish
     @property
