@@ -810,3 +810,17 @@ def test_facade_contour_crossing_golden(ctx, baro):
     ratio = c1[0, mid].astype(float) / np.maximum(c4[0, mid].astype(float), 1)
     assert np.all(ratio > 2.0) and np.all(ratio < 8.0)
     assert np.array_equal(c1[0].astype(np.int64), G['cnt_sorted_s1'])
+
+
+def test_more_slabs_than_one_launch_takes(ctx):
+    """70 000 tiny slabs: the binding splits at the library's 65 535-slabs-per-launch limit"""
+    rng = np.random.default_rng(0)
+    S, ny, nx = 70000, 8, 16
+    q = rng.standard_normal((S, ny, nx)).astype(np.float32)
+    mm = ctx.minmax(q)
+    assert np.array_equal(mm[:, 0], q.reshape(S, -1).min(1)) and np.array_equal(mm[:, 1], q.reshape(S, -1).max(1))
+    ed = np.linspace(-3, 3, 12)
+    out = ctx.hist(q, ed, dA=np.ones((ny, nx)), want=('counts',))
+    assert out['counts'].shape == (S, 11)
+    for s in (0, 65534, 65535, S - 1):
+        assert np.array_equal(out['counts'][s].astype(np.int64), np.histogram(q[s], bins=ed)[0])

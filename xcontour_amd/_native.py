@@ -20,6 +20,7 @@ XC_F32, XC_F64 = 0, 1
 XC_DA_NONE, XC_DA_ROW, XC_DA_PLANE, XC_DA_SLAB = 0, 1, 2, 3
 XC_EDGE_NUMPY, XC_EDGE_XHISTOGRAM = 0, 1
 XC_MAX_INTEGRANDS = 2
+MAX_SLABS_PER_LAUNCH = 65535
 XC_PAD_EDGE, XC_PAD_WRAP, XC_PAD_NAN, XC_PAD_REFLECT, XC_PAD_SYMMETRIC = 0, 1, 2, 3, 4
 PAD_MODES = {'edge': XC_PAD_EDGE, 'wrap': XC_PAD_WRAP, 'constant': XC_PAD_NAN, 'reflect': XC_PAD_REFLECT,
              'symmetric': XC_PAD_SYMMETRIC}
@@ -289,6 +290,9 @@ class Context(object):
         """q: (nslab, ny, nx) or (nslab, ncell) f32/f64 -> (nslab, 2) f64"""
         q = np.ascontiguousarray(q)
         nslab = q.shape[0]
+        if nslab > MAX_SLABS_PER_LAUNCH:
+            return np.concatenate([self.minmax(q[s0:s0 + MAX_SLABS_PER_LAUNCH])
+                                   for s0 in range(0, nslab, MAX_SLABS_PER_LAUNCH)])
         out = np.empty((nslab, 2), dtype=np.float64)
         self._check(self.lib.xc_minmax(self.handle, _ptr(q), dtype_code(q.dtype), nslab,
                                        int(q.size // nslab), _ptr(out)))
@@ -313,6 +317,16 @@ class Context(object):
         q = np.ascontiguousarray(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
+        if nslab > MAX_SLABS_PER_LAUNCH:                     # the library launches at most 65535 slabs at once
+            parts = []
+            for s0 in range(0, nslab, MAX_SLABS_PER_LAUNCH):
+                sl = slice(s0, s0 + MAX_SLABS_PER_LAUNCH)
+                e = np.asarray(edges)
+                d3 = dA is not None and np.ndim(dA) == 3
+                parts.append(self.hist(q[sl], e[sl] if e.ndim == 2 else e, dA[sl] if d3 else dA,
+                                       [np.asarray(v)[sl] for v in integrands], grad, last_closed, lt, reverse,
+                                       prod_f32, negate, want))
+            return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
         edges = np.ascontiguousarray(edges, dtype=np.float64)
         d = HistDesc()
         keep = [q, edges]
