@@ -824,3 +824,30 @@ def test_more_slabs_than_one_launch_takes(ctx):
     assert out['counts'].shape == (S, 11)
     for s in (0, 65534, 65535, S - 1):
         assert np.array_equal(out['counts'][s].astype(np.int64), np.histogram(q[s], bins=ed)[0])
+
+
+def test_keff_plan_reuse_is_not_stale(ctx, baro):
+    """Contour2D.keff keeps its device plan between calls: a changed tracer must give new results, a changed dA
+    a new plan, an unchanged call the same values."""
+    import xcontour_amd as xa
+    tr, dA, q, lat, lon = _baro_da(xa, baro)
+    kw = dict(dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True)
+    cm = xa.Contour2D(tr, dA, **kw)
+    table = cm.cal_area_eqCoord_table_hist(xa.DataArray(np.ones_like(q), tr.dims, tr.coords, 'mask'))
+    a = cm.keff(61, table, lat=lat, lon=lon)
+    b = cm.keff(61, table, lat=lat, lon=lon)
+    assert len(cm._keff_plans) == 1 and np.array_equal(a['ctr'].values, b['ctr'].values)
+    for k in ('area', 'intgrdS'):                       # LDS float atomics: the summation order varies run to run
+        assert rel(a[k].values, b[k].values) < 1e-13
+    cm.tracer = xa.DataArray(q[::-1].copy() * 2, tr.dims, tr.coords, 'absolute_vorticity')     # same shapes: plan reused
+    c = cm.keff(61, table, lat=lat, lon=lon)
+    assert len(cm._keff_plans) == 1 and not np.array_equal(a['ctr'].values, c['ctr'].values)
+    fresh = xa.Contour2D(cm.tracer, dA, **kw).keff(61, table, lat=lat, lon=lon)
+    assert np.array_equal(c['ctr'].values, fresh['ctr'].values)
+    for k in ('area', 'intgrdS'):
+        assert rel(c[k].values, fresh[k].values) < 1e-13
+    cm.dA = xa.DataArray(dA.values * 2.0, dA.dims, dA.coords, 'rA')                             # other metric: new plan
+    d = cm.keff(61, table, lat=lat, lon=lon)
+    assert len(cm._keff_plans) == 2 and rel(d['area'].values, 2.0 * c['area'].values) < 1e-14
+    cm.close()
+    assert '_keff_plans' not in cm.__dict__

@@ -72,6 +72,17 @@ class Contour2D(object):
         self._xdim = [d for d in self.dimVs if d != self.dimEqV][0]
 
     # ------------------------------------------------------------------ plumbing
+    def close(self):
+        """Release the device buffers kept between keff() calls (also done when the object is collected)."""
+        for plan in self.__dict__.pop('_keff_plans', {}).values():
+            try:
+                plan.free()
+            except Exception:
+                pass
+
+    def __del__(self):
+        self.close()
+
     @property
     def ctx(self):
         return nat.default_context(self.device)
@@ -685,20 +696,38 @@ class Contour2D(object):
         elif rdx is None:
             rdx, rdy = grad_metrics(lat if lat is not None else coords[self.dimEqV],
                                     lon if lon is not None else coords[self._xdim])
-        plan = KeffPlan(self.ctx, nslab, ny, nx, N, q.dtype, self.dtype, dA=dA, rdx=rdx, rdy=rdy,
-                        periodic_x=periodic_x, tbl=tv, tbl_coord=tcoords[table._dimEq], preY=preY,
-                        increase=self.increase, lt=self.lt, right_edge=self.right_edge,
-                        nkeff_mask=nkeff_mask, grdS_dtype=None if g is None else g.dtype,
-                        prod_f32=bool(g is not None and g.dtype == np.float32 and dA_f32),
-                        detect_row_dA=True)
+        # The plan owns the device copies of everything static (dA, metrics, table, preY) and the work buffers:
+        # it is kept between calls, so a second keff() on the same grid only uploads the tracer.  Key = the
+        # configuration + the bytes of the small arrays + a fingerprint of dA (shape, ends and a strided sample:
+        # dA is the grid metric, not something callers edit in place between calls).
+        def small(a):
+            return None if a is None else np.ascontiguousarray(a, dtype=np.float64).tobytes()
+        flat = dA.reshape(-1)
+        key = (nslab, ny, nx, int(N), q.dtype.str, np.dtype(self.dtype).str, None if g is None else g.dtype.str,
+               bool(periodic_x), float(nkeff_mask), bool(self.increase), bool(self.lt), self.right_edge, self.device,
+               dA.shape, flat[::max(1, flat.size // 4096)].tobytes(), float(flat[0]), float(flat[-1]),
+               small(tv), small(tcoords[table._dimEq]), small(preY), small(rdx), small(rdy))
+        plans = self.__dict__.setdefault('_keff_plans', {})
+        plan = plans.pop(key, None)
+        if plan is None:
+            plan = KeffPlan(self.ctx, nslab, ny, nx, N, q.dtype, self.dtype, dA=dA, rdx=rdx, rdy=rdy,
+                            periodic_x=periodic_x, tbl=tv, tbl_coord=tcoords[table._dimEq], preY=preY,
+                            increase=self.increase, lt=self.lt, right_edge=self.right_edge,
+                            nkeff_mask=nkeff_mask, grdS_dtype=None if g is None else g.dtype,
+                            prod_f32=bool(g is not None and g.dtype == np.float32 and dA_f32),
+                            detect_row_dA=True)
         try:
             plan.set_q(q)
             if g is not None:
                 plan.set_grdS(g)
             plan.run()
             res = plan.fetch()
-        finally:
+        except Exception:
             plan.free()
+            raise
+        plans[key] = plan                                  # most recently used last
+        while len(plans) > 2:
+            plans.pop(next(iter(plans))).free()
         ccoord = np.linspace(0.0, N - 1.0, N, dtype=self.dtype)
         out = []
         for name in OUT_NAMES:

@@ -67,7 +67,7 @@ class KeffPlan(object):
             d.dA, d.dA_rank = None, nat.XC_DA_NONE
         else:
             dA = np.ascontiguousarray(dA, dtype=np.float64)
-            if detect_row_dA and dA.shape == (self.ny, self.nx) and np.array_equal(dA, np.repeat(dA[:, :1], self.nx, axis=1)):
+            if detect_row_dA and dA.shape == (self.ny, self.nx) and bool((dA == dA[:, :1]).all()):
                 dA = np.ascontiguousarray(dA[:, 0])
             if dA.shape == (self.ny,):
                 d.dA_rank = nat.XC_DA_ROW
