@@ -24,4 +24,11 @@ for s in (1, 2, 4):
     out['cnt_s%d' % s] = C
 out['cnt_sorted_s1'] = out['cnt_s1']            # levels ascend: sorted order == level order
 np.savez_compressed(os.path.join(HERE, 'baro_crossing_N41.npz'), **out)
+
+# the reference's own call (tests/test_fractal.py:30-75): N = 121, strides 1..32, mode='edge'
+ctr121 = O.cal_contours(q, 121, True, np.float32)
+strides = [1, 2, 4, 8, 16, 32]
+res = O.cal_contour_crossing(q, ctr121, dA, strides, 'edge')
+np.savez_compressed(os.path.join(HERE, 'baro_fractal_N121.npz'), ctr=ctr121, strides=np.array(strides),
+                    **{'bclens%d' % s: r for s, r in zip(strides, res)})
 print('wrote baro_crossing_N41.npz', out['cnt_s1'][:6], out['len_s1'][:4])

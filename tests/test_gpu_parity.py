@@ -851,3 +851,21 @@ def test_keff_plan_reuse_is_not_stale(ctx, baro):
     assert len(cm._keff_plans) == 2 and rel(d['area'].values, 2.0 * c['area'].values) < 1e-14
     cm.close()
     assert '_keff_plans' not in cm.__dict__
+
+
+def test_fractal_call_sequence(ctx, baro):
+    """tests/test_fractal.py:30-75: `analysis.cal_contour_crossing(ctr, stride=[1, 2, 4, 8, 16, 32], mode='edge')`
+    with N = 121 on the barotropic field (strides 8 / 16 / 32 run the run-time-stride kernel)."""
+    import xcontour_amd as xa
+    tr, dA, q, lat, lon = _baro_da(xa, baro)
+    G = np.load(os.path.join(GOLD, 'baro_fractal_N121.npz'))
+    analysis = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True)
+    ctr = analysis.cal_contours(121)
+    assert np.array_equal(ctr.values, G['ctr'])
+    strides = [1, 2, 4, 8, 16, 32]
+    bclens = analysis.cal_contour_crossing(ctr, stride=strides, mode='edge')
+    for b, s in zip(bclens, strides):
+        assert b.dtype == np.float32 and rel(b.values, G['bclens%d' % s]) < 1e-6
+    # box-counting: fewer, larger boxes are crossed as the stride grows, and the measured length shrinks slowly
+    tot = [float(b.values.sum()) for b in bclens]
+    assert all(t > 0 for t in tot) and tot[0] > tot[-1]

@@ -157,3 +157,14 @@ def test_crossing_golden_fixture():
     full = O.cal_contour_crossing(q, G['ctr'], dA, 1, 'wrap', full_width=True)
     assert np.all(full >= res[0]) and full.sum() > 1.5 * res[0].sum()
     assert int(G['cnt_s1'][0]) == 15 and int(G['cnt_s1'][1]) == 291
+
+
+def test_fractal_golden_fixture():
+    """tests/test_fractal.py's cal_contour_crossing call (N = 121, strides 1..32, mode='edge') through the oracle"""
+    G = np.load(os.path.join(GOLD, 'baro_fractal_N121.npz'))
+    q = np.load(os.path.join(GOLD, 'baro_q.npy'))
+    dA = O.cell_area(np.load(os.path.join(GOLD, 'baro_lat.npy')), np.load(os.path.join(GOLD, 'baro_lon.npy')))
+    ctr = O.cal_contours(q, 121, True, np.float32)
+    assert np.array_equal(ctr, G['ctr'])
+    for s, r in zip(G['strides'], O.cal_contour_crossing(q, ctr, dA, [int(t) for t in G['strides']], 'edge')):
+        assert np.array_equal(r, G['bclens%d' % s])
