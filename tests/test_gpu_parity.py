@@ -851,6 +851,14 @@ def test_keff_plan_reuse_is_not_stale(ctx, baro):
     assert len(cm._keff_plans) == 2 and rel(d['area'].values, 2.0 * c['area'].values) < 1e-14
     cm.close()
     assert '_keff_plans' not in cm.__dict__
+    # a stack larger than max_batch_bytes goes through in batches of whole slabs (5 slabs, 2 per batch)
+    st = np.stack([q * (1 + 0.1 * k) for k in range(5)])
+    c3 = dict(tr.coords); c3['level'] = np.arange(5.0)
+    cm5 = xa.Contour2D(xa.DataArray(st, ('level',) + tr.dims, c3, 'absolute_vorticity'), dA, **kw)
+    one = cm5.keff(61, table, lat=lat, lon=lon)
+    two = cm5.keff(61, table, lat=lat, lon=lon, max_batch_bytes=2 * q.nbytes)
+    assert one['ctr'].shape == (5, 61) and np.array_equal(one['ctr'].values, two['ctr'].values)
+    assert rel(two['area'].values, one['area'].values) < 1e-13 and rel(two['nkeff'].values, one['nkeff'].values) < 1e-8
 
 
 def test_fractal_call_sequence(ctx, baro):

@@ -675,12 +675,13 @@ class Contour2D(object):
         return Q
 
     def keff(self, N, table, grdS=None, preY=None, lat=None, lon=None, rdx=None, rdy=None,
-             periodic_x=True, nkeff_mask=1e5):
+             periodic_x=True, nkeff_mask=1e5, max_batch_bytes=8 << 30):
         """
         Fused Keff pipeline for every leading index at once:
         three kernel launches, no host round trip.  Returns a Dataset of
         ctr, area, intgrdS, latEq, dqdA, dintSdA, Leq2, Lmin, nkeff on 'contour'
-        (+ '<name>_eq' on `preY` if given).
+        (+ '<name>_eq' on `preY` if given).  Stacks whose tracer (+ grdS) exceeds `max_batch_bytes`
+        go through the device in equal batches of whole slabs.
         """
         from .pipeline import KeffPlan, OUT_NAMES
         q, lead, lshape, coords = self._plane(self.tracer)
@@ -702,26 +703,35 @@ class Contour2D(object):
         # dA is the grid metric, not something callers edit in place between calls).
         def small(a):
             return None if a is None else np.ascontiguousarray(a, dtype=np.float64).tobytes()
+        per_slab = ny * nx * (q.dtype.itemsize + (0 if g is None else g.dtype.itemsize))
+        batch = int(min(nslab, max(1, int(max_batch_bytes) // per_slab), 65535))
         flat = dA.reshape(-1)
-        key = (nslab, ny, nx, int(N), q.dtype.str, np.dtype(self.dtype).str, None if g is None else g.dtype.str,
+        key = (batch, ny, nx, int(N), q.dtype.str, np.dtype(self.dtype).str, None if g is None else g.dtype.str,
                bool(periodic_x), float(nkeff_mask), bool(self.increase), bool(self.lt), self.right_edge, self.device,
                dA.shape, flat[::max(1, flat.size // 4096)].tobytes(), float(flat[0]), float(flat[-1]),
                small(tv), small(tcoords[table._dimEq]), small(preY), small(rdx), small(rdy))
         plans = self.__dict__.setdefault('_keff_plans', {})
         plan = plans.pop(key, None)
         if plan is None:
-            plan = KeffPlan(self.ctx, nslab, ny, nx, N, q.dtype, self.dtype, dA=dA, rdx=rdx, rdy=rdy,
+            plan = KeffPlan(self.ctx, batch, ny, nx, N, q.dtype, self.dtype, dA=dA, rdx=rdx, rdy=rdy,
                             periodic_x=periodic_x, tbl=tv, tbl_coord=tcoords[table._dimEq], preY=preY,
                             increase=self.increase, lt=self.lt, right_edge=self.right_edge,
                             nkeff_mask=nkeff_mask, grdS_dtype=None if g is None else g.dtype,
                             prod_f32=bool(g is not None and g.dtype == np.float32 and dA_f32),
                             detect_row_dA=True)
         try:
-            plan.set_q(q)
-            if g is not None:
-                plan.set_grdS(g)
-            plan.run()
-            res = plan.fetch()
+            parts = []
+            for s0 in range(0, nslab, batch):
+                m = min(batch, nslab - s0)
+                plan.q_buf.upload(q[s0:s0 + m])
+                if g is not None:
+                    plan.grdS_buf.upload(g[s0:s0 + m])
+                plan.run_range(0, 0, m)
+                r = plan.fetch(check=False)
+                if r['status'][:m].any():
+                    raise Exception('non monotonic bins')          # reference core.py:1233-1251
+                parts.append({k: np.array(v[:m]) for k, v in r.items()})
+            res = parts[0] if len(parts) == 1 else {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
         except Exception:
             plan.free()
             raise
