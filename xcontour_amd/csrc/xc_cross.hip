@@ -26,6 +26,7 @@ namespace {
 
 constexpr int CROSS_RB = 32;     // box rows per tile
 constexpr int CROSS_TPB = 256;   // threads = box columns per tile
+constexpr int CROSS_W1 = 252;    // box columns per tile at stride 1 (4 waves x 63 boxes, see k_crossing)
 
 // source column of padded column c >= nx (np.pad semantics on the last axis); -1 = NaN fill
 __device__ __forceinline__ int64_t pad_source(int64_t c, int64_t nx, int mode)
@@ -55,6 +56,15 @@ __device__ __forceinline__ void row_segment(const T* __restrict__ row, int64_t c
         const double v = load_padded(row, c0 + d, nx, mode);
         mn = fmin(mn, v); mx = fmax(mx, v);          // fmin / fmax return the non-NaN operand
     }
+}
+
+// lane i <- lane i+1 (DPP wave_shl:1); lane 63 keeps its own value
+__device__ __forceinline__ double from_right_lane(double v)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_update_dpp((int)(u & 0xffffffffu), (int)(u & 0xffffffffu), 0x130, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp((int)(u >> 32), (int)(u >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
 // number of contours < v, i.e. the klo with cx[klo] < v <= cx[klo+1]; cx = [-inf, c_0 .. c_{N-1}, +inf]
@@ -144,6 +154,45 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
 
     for (int64_t tile = blockIdx.x; tile < ntj * nti; tile += bps) {
         const int64_t tj = tile / nti, ti = tile - tj * nti;
+        if constexpr (S == 1) {
+            // stride 1: a wave covers 63 boxes with 64 corner columns -- every lane loads ONE value per row and gets
+            // its right neighbour from the next lane (DPP), lane 63 only supplies the last corner column
+            constexpr int B = 8;
+            const int lane = tid & 63, wave = tid >> 6;
+            const int64_t i = ti * CROSS_W1 + wave * 63 + lane;
+            const int64_t j0 = tj * CROSS_RB, j1 = (j0 + CROSS_RB < nbj) ? j0 + CROSS_RB : nbj;
+            const bool box = lane < 63 && i < nbi;                    // lanes without a box still load and shift
+            int64_t c = i < nbi ? i : nbi;                            // corner column (padded index), <= nbi exists
+            bool pn = false;
+            if (c >= nx) { c = pad_source(c, nx, pad_mode); pn = c < 0; if (pn) c = 0; }
+            int64_t ac = i < nbi ? i : nbi - 1;
+            bool nanfill = false;
+            if (ac >= nx) { ac = pad_source(ac, nx, pad_mode); nanfill = ac < 0; if (nanfill) ac = 0; }
+            double cmn, cmx;
+            {
+                const double x = pn ? qnan : (double)qs[(size_t)j0 * nx + c], xr = from_right_lane(x);
+                cmn = fmin(fmin(inf, x), xr); cmx = fmax(fmax(-inf, x), xr);
+            }
+            for (int64_t jb = j0; jb < j1; jb += B) {
+                TQ v[B]; TA av[B];
+#pragma unroll
+                for (int b = 0; b < B; ++b) {                         // all loads of the batch in flight together
+                    const int64_t jj = (jb + b < j1) ? jb + b : j1 - 1;
+                    av[b] = as[(size_t)jj * nx + ac];
+                    v[b] = qs[(size_t)(jj + 1) * nx + c];
+                }
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    if (jb + b >= j1) break;                          // wave-uniform
+                    const double x = pn ? qnan : (double)v[b], xr = from_right_lane(x);
+                    const double rmn = fmin(fmin(inf, x), xr), rmx = fmax(fmax(-inf, x), xr);
+                    const double mn = fmin(cmn, rmn), mx = fmax(cmx, rmx);
+                    cmn = rmn; cmx = rmx;
+                    if (box) box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, g, my_len, my_cnt);
+                }
+            }
+            continue;
+        }
         const int64_t i = ti * CROSS_TPB + tid;
         if (i >= nbi) continue;                       // no block-wide barrier inside the loop
         const int64_t j0 = tj * CROSS_RB, j1 = (j0 + CROSS_RB < nbj) ? j0 + CROSS_RB : nbj;
@@ -260,7 +309,8 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
     }
     // the last corner row / column every box touches must exist in the padded slab
     if (nbj * stride > ny - 1 || nbi * stride > nx + pad_x - 1) return fail(ctx, XC_EBADARG, "xc_crossing: boxes leave the padded slab");
-    const int64_t ntj = (nbj + CROSS_RB - 1) / CROSS_RB, nti = (nbi + CROSS_TPB - 1) / CROSS_TPB;
+    const int64_t tw = stride == 1 ? CROSS_W1 : CROSS_TPB;
+    const int64_t ntj = (nbj + CROSS_RB - 1) / CROSS_RB, nti = (nbi + tw - 1) / tw;
     int64_t bps = 2048 / nslab; if (bps < 8) bps = 8; if (bps > ntj * nti) bps = ntj * nti;
     const size_t pl = (size_t)nslab * bps * N * 8, pc = (size_t)nslab * bps * N * 4;
     {
