@@ -877,3 +877,21 @@ def test_fractal_call_sequence(ctx, baro):
     # box-counting: fewer, larger boxes are crossed as the stride grows, and the measured length shrinks slowly
     tot = [float(b.values.sum()) for b in bclens]
     assert all(t > 0 for t in tot) and tot[0] > tot[-1]
+
+
+def test_sorted_profile_over_a_stack(ctx, baro):
+    """cal_sorted_profile loops the exact sort over the leading dims like every other method"""
+    import xcontour_amd as xa
+    tr, dA, q, lat, lon = _baro_da(xa, baro)
+    kw = dict(dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True)
+    table = xa.Contour2D(tr, dA, **kw).cal_area_eqCoord_table_hist(xa.DataArray(np.ones_like(q), tr.dims, tr.coords, 'mask'))
+    st = np.stack([q, q * 1.5 + 1e-5, q[:, ::-1].copy()])
+    c3 = dict(tr.coords); c3['time'] = np.arange(3.0)
+    cm = xa.Contour2D(xa.DataArray(st, ('time',) + tr.dims, c3, 'absolute_vorticity'), dA, **kw)
+    Q, sorted_ = cm.cal_sorted_profile(table, return_sorted=True)
+    assert Q.dims == ('time', 'latitude') and Q.shape == (3, 256) and len(sorted_) == 3
+    for k in range(3):
+        one = xa.Contour2D(xa.DataArray(st[k], tr.dims, tr.coords, 'absolute_vorticity'), dA, **kw).cal_sorted_profile(table)
+        assert np.array_equal(Q.values[k], one.values)
+        assert np.array_equal(sorted_[k], np.sort(st[k].ravel().astype(np.float64), kind='stable'))
+    assert np.array_equal(Q.values[0], Q.values[2])               # a zonal flip changes no area

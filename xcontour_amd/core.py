@@ -649,14 +649,14 @@ class Contour2D(object):
             tracer = self.tracer
         q, lead, lshape, coords = self._plane(tracer)
         q = self._float(q)
-        if q.shape[0] != 1:
-            raise Exception('cal_sorted_profile works on one 2D plane at a time')
-        ny, nx = q.shape[1:]
-        dA, _ = self._dA_array(ny, nx, 1)
-        if dA.ndim == 3:
-            dA = dA[0]
-        m = None if mask is None else self._float(self._plane(mask)[0][0])
+        nslab, ny, nx = q.shape
+        dA, _ = self._dA_array(ny, nx, nslab)
+        m = None if mask is None else self._float(self._plane(mask)[0])
+        if m is not None and m.shape[0] not in (1, nslab):
+            raise Exception('mask leading dims do not match the tracer')
         tv = np.asarray(lb.unwrap(table._table)[0], dtype=np.float64)
+        if tv.ndim != 1:
+            raise Exception('cal_sorted_profile needs a time-invariant table')
         # cumulative area on the small-coordinate side of y_j, whatever (increase, lt) built the table
         below = tv if table._incVl == table._incCd else tv[0] + tv[-1] - tv
         cs = table._coord
@@ -666,12 +666,20 @@ class Contour2D(object):
         # grows with the coordinate VALUE iff increase == (coordinate grows with index)
         eq = self._eq_coord(tracer)
         up = bool(self.increase) == bool(eq[-1] > eq[0])
-        res = self.ctx.sort_profile(q[0], dA=dA, mask=m, targets=below, want_sorted=return_sorted,
-                                    negate=not up)
         sgn = 1.0 if up else -1.0
-        Q = lb.wrap(sgn * res['Q'], (self.dimEqV,), {self.dimEqV: cs}, lb.unwrap(tracer)[3], tracer)
+        Qs, sorted_ = [], []
+        for k in range(nslab):                                 # one radix sort per (time, level) plane
+            res = self.ctx.sort_profile(q[k], dA=dA[k] if dA.ndim == 3 else dA, mask=None if m is None else m[min(k, m.shape[0] - 1)],
+                                        targets=below, want_sorted=return_sorted, negate=not up)
+            Qs.append(sgn * res['Q'])
+            if return_sorted:
+                sorted_.append(sgn * res['q_sorted'][:res['nvalid']])
+        c = {d: coords[d] for d in lead if d in coords}
+        c[self.dimEqV] = cs
+        Q = lb.wrap(np.stack(Qs).reshape(tuple(lshape) + (len(cs),)), tuple(lead) + (self.dimEqV,), c,
+                    lb.unwrap(tracer)[3], tracer)
         if return_sorted:
-            return Q, sgn * res['q_sorted'][:res['nvalid']]
+            return Q, (sorted_[0] if nslab == 1 and not lead else sorted_)
         return Q
 
     def keff(self, N, table, grdS=None, preY=None, lat=None, lon=None, rdx=None, rdy=None,
