@@ -17,6 +17,13 @@ whole job.  N > 1: every rank owns its own batch of independent slabs (weak scal
 data-path collective during compute, ONE RCCL all-gather of all per-slab result vectors at
 the end of the timed region.
 
+Steady-state schedule (default, `--chain`): the stack is processed as a software pipeline -- the
+histogram pass of step k also streams the batch of step k+1 and leaves its min/max partials
+(`xc_keff_desc.q_next`), which step k+1 turns into its levels.  Every step therefore does one
+batch of min/max AND one batch of histogram + epilogue (nothing is skipped or reused; results are
+bit-identical to the unchained order, tests/test_gpu_parity.py::test_chained_minmax_is_bit_identical);
+the stand-alone min/max launch merely disappears.  `--no-chain` runs K1 then K3 per step.
+
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel = the histogram pass, timed
 with HIP events on its own stream around every launch of the timed region) and, at N=1,
 `cpu_baseline` (the numpy oracle = a port of the reference's xarray/xhistogram call
@@ -101,10 +108,14 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='slabs per step per GPU')
     ap.add_argument('--group', type=int, default=0, help='slabs per launch set (0: whole batch)')
     ap.add_argument('--variant', type=int, default=0, help='0 PV-like, 1 noise, 2 sin(lat)')
-    ap.add_argument('--chain', action='store_true',
-                    help="fold the NEXT step's min/max into this step's histogram pass (xc_keff_desc.q_next) "
-                         'instead of running the stand-alone min/max pass: +5 % end to end, but the '
-                         'histogram kernel then streams 24 B/cell against a 16 B/cell numerator')
+    ap.add_argument('--chain', dest='chain', action='store_true', default=True,
+                    help="(default) software-pipelined stack processing: this step's histogram pass also streams the "
+                         "NEXT step's batch and leaves its min/max partials (xc_keff_desc.q_next), so the stand-alone "
+                         'min/max pass disappears: every step still computes one batch of min/max and one batch of '
+                         'histogram + epilogue, bit-identical results; the fused kernel streams 24 B/cell against '
+                         'the 16 B/cell roofline numerator')
+    ap.add_argument('--no-chain', dest='chain', action='store_false',
+                    help='stand-alone min/max pass (K1) before every histogram pass (K3)')
     ap.add_argument('--row-dA', action='store_true',
                     help='let the plan detect that the lat-lon dA plane has constant rows and read it as a '
                          'per-row vector (8 B/cell algorithmic instead of 16); off by default: the headline '
@@ -238,15 +249,17 @@ def main():
             ach = alg / (ms.mean() * 1e-3) / 1e9
             traffic = None
             tf = os.path.join(ROOT, 'profiles', 'hist_traffic.json')
-            if os.path.exists(tf):
+            if os.path.exists(tf) and B == 32 and not a.row_dA:    # PMC passes were taken at the default batch
                 try:
-                    traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+                    tj = json.load(open(tf))
+                    traffic = (tj.get('chain', {}) if chain else tj).get('hbm_bytes_per_launch')
                 except Exception:
                     traffic = None
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                                 'kernel': 'k_hist<double,2,0,true,true,%s>' % ('true' if chain else 'false'), 'launch_ms': float(ms.mean()),
                                 'algorithmic_bytes_per_launch': alg,
+                                'streamed_bytes_per_launch': alg + (B * NY * NX * 8 if chain else 0),
                                 'pipeline_frac': (B * NY * NX * (8 if a.row_dA else BYTES_PER_CELL) * K / el / 1e9) / HBM_PEAK_GBS}
         # parity spot check of the last step against nothing heavy: invariants only (oracle runs in cpu leg)
         out = plan.fetch(slot=K - 1)
