@@ -33,18 +33,19 @@ namespace {
 #endif
 constexpr int U = XC_U;   // rows per prefetch batch (double-buffered)
 
-// Grid mapping: the SLAB is the fastest-varying block index, so blocks that work on the same
-// rows of different slabs are dispatched together and (blocks b, b+8 share an XCD) meet in one
-// XCD's L2, where the shared dA plane is then fetched once for several slabs.
-#define XC_SLAB ((int)blockIdx.x)
-#define XC_BLK  ((int)blockIdx.y)
-#define XC_NBLK ((int)gridDim.y)
+// Grid mapping (1-D grid).  Workgroups go round-robin to the 8 XCDs (workgroup id % 8), each XCD has its own
+// L2, and every slab of a launch reads the SAME dA rows in its block `bx`.  XCD-aware order (default): XCD x
+// takes the row groups bx = x, x+8, ... and runs each for ALL slabs back to back -- with one 1024-thread block
+// per CU the 32 CUs of an XCD hold one row group of 32 slabs at a time, so that part of the dA plane is
+// fetched into that L2 once per launch instead of once per XCD per slab group.  Plain order (xcd_map == 0):
+// slab fastest, blocks of one row group spread over all XCDs.
+#define XC_NBLK (a.bps)
 
 // Diagnostic build only (-DXC_STAMPS): wave 0 / lane 0 of every block stores s_memrealtime
 // (100 MHz) at phase boundaries into a buffer nothing else reads.  Never in the shipped .so.
 #ifdef XC_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;
-#define XC_STAMP(i) do { if (g_stamps && tid == 0) g_stamps[(XC_SLAB * XC_NBLK + XC_BLK) * 8 + (i)] = wall_clock64(); } while (0)
+#define XC_STAMP(i) do { if (g_stamps && tid == 0) g_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define XC_STAMP(i) do {} while (0)
 #endif
@@ -193,7 +194,14 @@ void k_hist(const HistArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction
     const int nwave = blockDim.x >> 6;
-    const int slab = XC_SLAB, bx = XC_BLK, nbx = XC_NBLK;
+    int slab, bx;
+    {
+        const int L = (int)blockIdx.x;
+        if (a.xcd_map) { const int j = L >> 3; slab = j % a.nslab_grid; bx = (L & 7) + 8 * (j / a.nslab_grid); }
+        else { slab = L % a.nslab_grid; bx = L / a.nslab_grid; }
+        if (bx >= a.bps) return;                                  // padding blocks of the XCD-aware order
+    }
+    const int nbx = XC_NBLK;
     const int N = a.nbin;
     const int ncopy = a.ncopy;
     const int epad = (N + 2) & ~1;
@@ -563,8 +571,12 @@ int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget + 4096));
         attr_set = true;
     }
-    dim3 grid((unsigned)nslab, (unsigned)g.bps);
-    hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds, ctx->stream, a);
+    HistArgs b = a;
+    static const int xcd_env = [] { const char* e = getenv("XC_HIST_XCDMAP"); return e ? atoi(e) : 1; }();
+    b.bps = g.bps; b.nslab_grid = (int)nslab; b.xcd_map = xcd_env;
+    const int64_t nblk = b.xcd_map ? (int64_t)8 * ((g.bps + 7) / 8) * nslab : (int64_t)g.bps * nslab;
+    if (nblk > 0x7fffffff) return fail(ctx, XC_EBADARG, "xc_hist: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(g.threads), g.lds, ctx->stream, b);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
 }

@@ -88,6 +88,7 @@ struct HistArgs {
     int           periodic_x;
     int64_t       ny, nx;
     int           nstrip, ncopy;
+    int           bps, nslab_grid, xcd_map;   // launch geometry (set by launch_hist): blocks per slab, slabs, XCD-aware block order
     double*       part_h;       // [nslab][bps][nch][nbin]
     unsigned*     part_c;       // [nslab][bps][nbin]
     double*       ctr_out;      // [nslab][nbin]   (levels mode, may be null)
