@@ -895,3 +895,29 @@ def test_sorted_profile_over_a_stack(ctx, baro):
         assert np.array_equal(Q.values[k], one.values)
         assert np.array_equal(sorted_[k], np.sort(st[k].ravel().astype(np.float64), kind='stable'))
     assert np.array_equal(Q.values[0], Q.values[2])               # a zonal flip changes no area
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+def test_lwa_band_skipping_is_invisible(ctx, variant):
+    """K7 never loads rows whose extrema rule out a contribution: fields built to stress that test -- a sharp
+    front (narrow bands), a non-monotone Q, rows of NaN, +-inf cells, constant rows, f32 and f64, both variants,
+    every (increase, part), sizes that are not multiples of the 8-row batch or the 64-lane band search."""
+    rng = np.random.default_rng(3 + variant)
+    for (ny, nx, dt) in [(131, 70, np.float64), (67, 130, np.float32), (9, 5, np.float64)]:
+        coord = np.linspace(-80, 80, ny)
+        front = np.tanh((coord[:, None] - 10 * np.sin(np.linspace(0, 6.28, nx))[None, :]) / 4.0)
+        q = (front + 0.01 * rng.standard_normal((ny, nx))).astype(dt)[None]
+        q = np.concatenate([q, q[:, ::-1]], axis=0)                      # second slab: reversed in y
+        q[0, ny // 3, :] = np.nan                                        # a row of NaN
+        q[0, ny // 2, 2] = np.inf; q[1, 1, 1] = -np.inf
+        q[1, ny // 4, :] = 0.25                                          # a constant row
+        Q = np.stack([np.sort(q[0, :, 0].astype(np.float64)), rng.standard_normal(ny)])   # sorted / non-monotone
+        Q[0][np.isnan(Q[0])] = 0.0
+        dA = (rng.random((ny, nx)) + 0.5)
+        for increase in (True, False):
+            for part, pc in (('all', 0), ('upper', 1), ('lower', 2)):
+                out, _ = ctx.lwa(q, Q, coord, dA, dA.max(), M=None, increase=increase, part=pc, variant=variant)
+                fn = O.cal_local_wave_activity2 if variant else O.cal_local_wave_activity
+                for s in range(2):
+                    ref = fn(q[s], Q[s], coord, dA, increase, part)
+                    assert np.array_equal(out[s], ref, equal_nan=True), (ny, nx, increase, part, s)
