@@ -33,39 +33,46 @@ __device__ __forceinline__ int mask3(double qe, bool m, int increase)
 //    wave-uniform test -- without loading it.
 constexpr int LWA_RB = 8;     // rows per load batch of k_lwa; rowinfo is padded by as many rows
 
-// rowinfo[slab][ny + LWA_RB][4] = {row min, row max, coord, Q} -- everything the wave-uniform skip test of a
-// batch needs, contiguous so that it arrives with a few wide scalar loads; pad rows can never contribute.
+// Once per call, one block per (row, slab):
+//  * wei = dA.squeeze() / max(dA) (core.py:723-724) does not depend on the target row: one division per cell
+//    instead of one per (target row, cell);
+//  * rowinfo[slab][ny + LWA_RB][2] = {coord, Q} (padded, contiguous: wide scalar loads in k_lwa);
+//  * stripmm[slab][strip][ny][2]: NaN-skipping min / max of every 64-column strip of every tracer row.
+//    mask3(j, y', x) != 0 needs qe < 0 on the near side or qe > 0 on the far side of row j, so a strip row whose
+//    extrema exclude that (almost all rows away from the band where the tracer is displaced across Q[j])
+//    contributes nothing to the wave that owns the strip and is never loaded by it.
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_lwa_prep(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
                 const double* __restrict__ dA, int dA_rank, double dA_max,
-                int64_t ny, int64_t nx, double* __restrict__ wei, double* __restrict__ rowinfo)
+                int64_t ny, int64_t nx, int64_t nstrip, double* __restrict__ wei, double* __restrict__ rowinfo,
+                double* __restrict__ stripmm)
 {
     const int64_t y = blockIdx.x, slab = blockIdx.y;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
-    double* ri = rowinfo + ((size_t)slab * (ny + LWA_RB) + y) * 4;
-    if (y >= ny) {                                        // padding
-        if (threadIdx.x == 0) { ri[0] = inf; ri[1] = -inf; ri[2] = coord[ny - 1]; ri[3] = __longlong_as_double(0x7ff8000000000000LL); }
+    double* ri = rowinfo + ((size_t)slab * (ny + LWA_RB) + y) * 2;
+    if (y >= ny) {                                        // padding rows are never inside a band
+        if (threadIdx.x == 0) { ri[0] = coord[ny - 1]; ri[1] = __longlong_as_double(0x7ff8000000000000LL); }
         return;
     }
+    if (threadIdx.x == 0) { ri[0] = coord[y]; ri[1] = Q[(size_t)slab * ny + y]; }
     const T* row = q + ((size_t)slab * ny + y) * nx;
-    double mn = inf, mx = -inf;
-    for (int64_t x = threadIdx.x; x < nx; x += 256) {
-        const double v = (double)row[x];
-        mn = fmin(mn, v); mx = fmax(mx, v);
-        if (slab == 0 && dA_rank != XC_DA_ROW) wei[y * nx + x] = __ddiv_rn(dA[y * nx + x], dA_max);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t st = wave; st < nstrip; st += 4) {
+        const int64_t x = st * 64 + lane;
+        double mn = inf, mx = -inf;
+        if (x < nx) {
+            const double v = (double)row[x];
+            mn = fmin(mn, v); mx = fmax(mx, v);
+            if (slab == 0 && dA_rank != XC_DA_ROW) wei[y * nx + x] = __ddiv_rn(dA[y * nx + x], dA_max);
+        }
+        for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
+        if (lane == 0) {
+            double* sm = stripmm + (((size_t)slab * nstrip + st) * ny + y) * 2;
+            sm[0] = mn; sm[1] = mx;
+        }
     }
     if (slab == 0 && dA_rank == XC_DA_ROW && threadIdx.x == 0) wei[y] = __ddiv_rn(dA[y], dA_max);
-    for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
-    __shared__ double s_mn[4], s_mx[4];
-    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        ri[0] = fmin(fmin(s_mn[0], s_mn[1]), fmin(s_mn[2], s_mn[3]));
-        ri[1] = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3]));
-        ri[2] = coord[y];
-        ri[3] = Q[(size_t)slab * ny + y];
-    }
 }
 
 // V2: cal_local_wave_activity2 (core.py:802-905): qe = q[row j] - Q[all rows], opposite sign convention.
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(256)
 void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
            const double* __restrict__ wei_, int dA_rank,
            const double* __restrict__ M, int M_rank, const double* __restrict__ rowinfo,
+           const double* __restrict__ stripmm,
            int64_t ny, int64_t nx, int increase, int part, double* __restrict__ out)
 {
     const int coord_incre = !(coord[ny - 1] < coord[0]);                 // core.py:736-738
@@ -88,13 +96,14 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
     const double* Qs = Q + (size_t)blockIdx.z * ny;
     const bool active = x < nx;
 
-    const double* rinfo = rowinfo + (size_t)blockIdx.z * (ny + LWA_RB) * 4;
+    const double* rinfo = rowinfo + (size_t)blockIdx.z * (ny + LWA_RB) * 2;
+    const double* smm = stripmm + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * ny * 2;      // this wave's strip
     double Qj[JT], cj[JT], acc[JT];
-    double tlo[JT], thi[JT];            // wave-uniform: V1 the target level Q[j] (both), V2 min / max of the tracer row j
+    double tlo[JT], thi[JT];            // wave-uniform: V1 the target level Q[j] (both), V2 min / max of the strip of tracer row j
 #pragma unroll
     for (int t = 0; t < JT; ++t) {
         const int64_t j = (j0 + t < ny) ? j0 + t : ny - 1;
-        tlo[t] = V2 ? rinfo[4 * j] : Qs[j]; thi[t] = V2 ? rinfo[4 * j + 1] : Qs[j];
+        tlo[t] = V2 ? smm[2 * j] : Qs[j]; thi[t] = V2 ? smm[2 * j + 1] : Qs[j];
         Qj[t] = V2 ? (active ? (double)qs[j * nx + x] : 0.0) : Qs[j];      // V2: the tracer on target row j
         cj[t] = coord[j]; acc[t] = 0.0;
     }
@@ -110,10 +119,11 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
     // mask3(j, y', x) != 0 needs qe < 0 on the near side or qe > 0 on the far side of row j; the row extrema in
     // rowinfo bound qe, so rows outside [y0, y1) -- almost all rows away from where the tracer is displaced
     // across Q[j] -- are never loaded.  (Rows inside the band that cannot contribute still add nothing.)
+    // The extrema are those of THIS wave's 64-column strip, so a meandering front costs each wave only its own part.
     int64_t y0 = ny, y1 = 0;
     for (int64_t yy = 0; yy < ny; yy += 64) {
         const int64_t y = (yy + lane < ny) ? yy + lane : ny - 1;
-        const double rmin = rinfo[4 * y], rmax = rinfo[4 * y + 1], cyr = rinfo[4 * y + 2], Qy = rinfo[4 * y + 3];
+        const double rmin = smm[2 * y], rmax = smm[2 * y + 1], cyr = rinfo[2 * y], Qy = rinfo[2 * y + 1];
         bool nd = false;
 #pragma unroll
         for (int t = 0; t < JT; ++t) {
@@ -135,7 +145,7 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
         for (int r = 0; r < RB; ++r) {
             const int64_t y = (yb + r < ny) ? yb + r : ny - 1;
             qv_[r] = V2 ? Qs[y] : (double)qs[y * nx + xl];
-            cy_[r] = rinfo[4 * y + 2];
+            cy_[r] = rinfo[2 * y];
             wv_[r] = (dA_rank == XC_DA_ROW) ? wei_[y] : wei_[y * nx + xl];
             mv_[r] = (M_rank == XC_DA_ROW) ? M[y] : M[y * nx + xl];
         }
@@ -201,21 +211,23 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     // small problems: one target row per thread so that the whole chip is busy
     // scratch: wei (same rank as dA) and the per-row tracer extrema; M defaults to dA itself (core.py:789 as written)
     const int64_t nw = dA_rank == XC_DA_ROW ? ny : ny * nx;
-    { const int rc = ensure_scratch(ctx, (size_t)nw * 8 + (size_t)nslab * (ny + LWA_RB) * 32); if (rc != XC_OK) return rc; }
+    const int64_t nstrip = (nx + 63) / 64;
+    { const int rc = ensure_scratch(ctx, (size_t)nw * 8 + (size_t)nslab * (ny + LWA_RB) * 16 + (size_t)nslab * nstrip * ny * 16); if (rc != XC_OK) return rc; }
     double* wei = (double*)ctx->scratch;
     double* rowinfo = wei + nw;
+    double* stripmm = rowinfo + (size_t)nslab * (ny + LWA_RB) * 2;
     const dim3 gp((unsigned)(ny + LWA_RB), (unsigned)nslab);
     if (q_dtype == XC_F64)
-        hipLaunchKernelGGL(k_lwa_prep<double>, gp, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, wei, rowinfo);
+        hipLaunchKernelGGL(k_lwa_prep<double>, gp, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, nstrip, wei, rowinfo, stripmm);
     else if (q_dtype == XC_F32)
-        hipLaunchKernelGGL(k_lwa_prep<float>, gp, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, wei, rowinfo);
+        hipLaunchKernelGGL(k_lwa_prep<float>, gp, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, nstrip, wei, rowinfo, stripmm);
     else return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
     if (M_rank == XC_DA_NONE) { M = dA; M_rank = dA_rank; }
     const bool small = (double)ny * (double)ny * (double)nx * (double)nslab < 4.0e9;
     const int jt = small ? 1 : 4;
     dim3 grid((unsigned)((nx + 63) / 64), (unsigned)((ny + 4 * jt - 1) / (4 * jt)), (unsigned)nslab);
 #define XC_LWA2(T, V, J) hipLaunchKernelGGL((k_lwa<T, V, J>), grid, dim3(256), 0, ctx->stream, (const T*)q, Q, coord, wei, dA_rank, \
-                           M, M_rank, rowinfo, ny, nx, increase, part, out_lwa)
+                           M, M_rank, rowinfo, stripmm, ny, nx, increase, part, out_lwa)
 #define XC_LWA(T, V) do { if (small) XC_LWA2(T, V, 1); else XC_LWA2(T, V, 4); } while (0)
     if (variant != 0 && variant != 1) return fail(ctx, XC_EBADARG, "xc_lwa: variant must be 0 or 1");
     if (q_dtype == XC_F64) { if (variant) XC_LWA(double, true); else XC_LWA(double, false); }
