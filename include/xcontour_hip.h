@@ -202,6 +202,20 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
                     const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                     double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
 
+/* The same for a stack of nslab planes in ONE set of launches (segmented sort: every plane keeps its own
+ * tile histograms, digit bases and cumulative area).  q: [nslab][ny][nx]; mask: [ny][nx] shared or
+ * [nslab][ny][nx] (mask_per_slab); dA_rank NONE / ROW / PLANE (shared) or SLAB ([nslab][ny][nx]);
+ * targets / tbl / coord shared.  Outputs: out_Q double[nslab][J], out_qsorted / out_acum
+ * double[nslab][ny*nx], out_nvalid uint32[nslab], out_bpe double[nslab]; any may be NULL.        */
+int xc_sort_profile_batch_dev(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
+                              const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
+                              const double* targets, int J, const double* tbl, const double* coord, int ntbl,
+                              double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
+int xc_sort_profile_batch(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
+                          const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
+                          const double* targets, int J, const double* tbl, const double* coord, int ntbl,
+                          double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
+
 /* ------------------------------------------------------------------ K9  box-counting contour crossing
  * Replaces Contour2D.cal_contour_crossing (core.py:640-693) and the numba kernel
  * _contour_crossing (core.py:1490-1566), for ALL contours of a slab in one pass.

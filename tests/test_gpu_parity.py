@@ -921,3 +921,39 @@ def test_lwa_band_skipping_is_invisible(ctx, variant):
                 for s in range(2):
                     ref = fn(q[s], Q[s], coord, dA, increase, part)
                     assert np.array_equal(out[s], ref, equal_nan=True), (ny, nx, increase, part, s)
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_batched_sort_equals_per_slab_oracle(ctx, dt):
+    """xc_sort_profile_batch: a stack in one set of launches (segmented sort) -- per-slab masks, per-slab dA, NaNs,
+    a slab without a single valid cell, targets beyond the total area; every slab against the oracle."""
+    rng = np.random.default_rng(21)
+    S, ny, nx = 5, 37, 131                                   # 4847 cells: two tiles, the second one ragged
+    q = rng.standard_normal((S, ny, nx)).astype(dt)
+    q[rng.random(q.shape) < 0.03] = np.nan
+    q[1, :, :7] = 0.5                                        # ties
+    mask = (rng.random((S, ny, nx)) < 0.9).astype(np.float64)
+    mask[3] = 0.0                                            # nothing valid in slab 3
+    dA = rng.random((S, ny, nx)) + 0.1
+    tbl = np.linspace(0, dA[0].sum() * 1.2, 23)
+    coord = np.linspace(-1.0, 1.0, 23)
+    r = ctx.sort_profile(q, dA=dA, mask=mask, targets=tbl, tbl=tbl, coord=coord, want_sorted=True, want_acum=True)
+    assert r['Q'].shape == (S, 23) and r['nvalid'].shape == (S,)
+    for s in range(S):
+        ok = ~np.isnan(q[s]) & (mask[s] == 1)
+        assert int(r['nvalid'][s]) == int(ok.sum())
+        if ok.sum() == 0:
+            assert np.isnan(r['Q'][s]).all()
+            continue
+        Qo, xs, ac = O.sorted_profile(q[s], dA[s], tbl, mask[s])
+        n = len(xs)
+        assert np.array_equal(r['q_sorted'][s][:n], xs.astype(np.float64))
+        assert rel(r['acum'][s][:n], ac) < 1e-12
+        idx = np.minimum(np.searchsorted(r['acum'][s][:n], tbl, side='right'), n - 1)     # ties in Acum: +-1 cell
+        assert np.all(np.abs(np.searchsorted(xs, r['Q'][s]) - np.searchsorted(xs, xs[idx])) <= 2)
+        assert abs(r['bpe'][s] - O.bpe_integral(q[s], dA[s], tbl, coord, mask[s])) <= 1e-11 * abs(dA[s].sum())
+    # shared mask / shared dA variants agree with the per-slab call
+    r2 = ctx.sort_profile(q, dA=dA[0], mask=mask[0], targets=tbl)
+    for s in range(S):
+        one = ctx.sort_profile(q[s], dA=dA[0], mask=mask[0], targets=tbl)
+        assert np.array_equal(r2['Q'][s], one['Q'], equal_nan=True) and int(r2['nvalid'][s]) == one['nvalid']

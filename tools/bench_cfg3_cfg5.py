@@ -74,6 +74,29 @@ print(json.dumps({'config': 'cfg5 stand-in: X-Z section %dx%d f64, topography, e
                   'kernel': 'K8 radix sort (8 passes) + scan + profile + integral', 'gpu_ms': ms,
                   'cells_per_s': nz * nxx / ms * 1e3, 'cpu_oracle_s': tc, 'bpe_rel_err': abs(bg / bo - 1)}))
 
+# ---------------------------------------------------------------- cfg5 as a stack: 3 sections in one set of launches
+b3 = np.stack([b, b * 1.01, b[:, ::-1]])
+db3 = ctx.to_device(b3)
+dQ3 = ctx.alloc(3 * nz * 8); nv3 = ctx.alloc(64); dbpe3 = ctx.alloc(3 * 8)
+ms3 = timed(lambda: ctx._check(ctx.lib.xc_sort_profile_batch_dev(ctx.handle, db3.ptr, nat.XC_F64, dmk.ptr, nat.XC_F64, 0, dya.ptr,
+                                                                nat.XC_DA_PLANE, 3, nz, nxx, 0, dt_.ptr, nz, dt_.ptr, dcs.ptr, nz,
+                                                                dQ3.ptr, None, None, nv3.ptr, dbpe3.ptr)))
+print(json.dumps({'config': 'cfg5 stand-in x 3 time steps, one batched (segmented) sort', 'gpu_ms': ms3,
+                  'ms_per_section': ms3 / 3, 'one_section_alone_ms': ms}))
+
+# ---------------------------------------------------------------- 16 barotropic-sized f32 planes: loop vs batch
+qb16 = np.stack([q * (1 + 0.01 * k) for k in range(16)]).astype(np.float32)
+dqb = ctx.to_device(qb16)
+dAb = ctx.to_device(dA)
+tgt = ctx.to_device(np.cumsum(dA.sum(1)))
+Qo = ctx.alloc(16 * 256 * 8); nvb = ctx.alloc(64)
+msb = timed(lambda: ctx._check(ctx.lib.xc_sort_profile_batch_dev(ctx.handle, dqb.ptr, nat.XC_F32, None, nat.XC_F64, 0, dAb.ptr, nat.XC_DA_PLANE,
+                                                                16, 256, 512, 0, tgt.ptr, 256, None, None, 0, Qo.ptr, None, None, nvb.ptr, None)))
+ms1 = timed(lambda: ctx._check(ctx.lib.xc_sort_profile_dev(ctx.handle, dqb.ptr, nat.XC_F32, None, nat.XC_F64, dAb.ptr, nat.XC_DA_PLANE,
+                                                          256, 512, 0, tgt.ptr, 256, None, None, 0, Qo.ptr, None, None, nvb.ptr, None)))
+print(json.dumps({'config': '16 planes of 256x512 f32 (5 passes), exact sorted profile at 256 targets', 'batched_gpu_ms': msb,
+                  'ms_per_plane_batched': msb / 16, 'ms_per_plane_alone': ms1}))
+
 # ---------------------------------------------------------------- K8 on a cfg2-sized slab
 n = 1801 * 3600
 qq = np.random.default_rng(0).standard_normal((1801, 3600))

@@ -104,6 +104,10 @@ PROTOTYPES = {
                                       _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'xc_sort_profile': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _i64, _i64, C.c_int, _vp, C.c_int,
                                   _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'xc_sort_profile_batch_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i64, _i64, _i64, C.c_int,
+                                            _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'xc_sort_profile_batch': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i64, _i64, _i64, C.c_int,
+                                        _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'xc_keff_dev': (C.c_int, [_vp, C.POINTER(KeffDesc)]),
     'xc_set_kernel_timing': (C.c_int, [_vp, C.c_int]),
     'xc_last_hist_ms': (C.c_int, [_vp, C.POINTER(C.c_float)]),
@@ -463,50 +467,67 @@ class Context(object):
 
     def sort_profile(self, q, dA=None, mask=None, targets=None, tbl=None, coord=None,
                      want_sorted=False, want_acum=False, negate=False):
-        """Exact adiabatic rearrangement of one slab (xc_sort_profile).  Returns a dict with
-        'nvalid' and, as requested, 'Q' (at `targets`), 'q_sorted', 'acum', 'bpe' (needs tbl, coord)."""
+        """Exact adiabatic rearrangement (xc_sort_profile_batch).  q (ny, nx): one plane -> scalars / 1-D arrays
+        as before; q (nslab, ny, nx): a stack sorted by ONE set of launches -> leading slab dim on every
+        output ('nvalid' (nslab,), 'Q' (nslab, J), 'q_sorted' / 'acum' (nslab, ny*nx), 'bpe' (nslab,)).
+        dA: None | (ny,) | (ny, nx) | (nslab, ny, nx); mask: (ny, nx) or (nslab, ny, nx)."""
         q = np.ascontiguousarray(q)
-        assert q.ndim == 2
-        ny, nx = q.shape
+        single = q.ndim == 2
+        if single:
+            q = q[None]
+        assert q.ndim == 3
+        nslab, ny, nx = q.shape
         rank = XC_DA_NONE
         if dA is not None:
             dA = np.ascontiguousarray(dA, dtype=np.float64)
-            rank = XC_DA_ROW if dA.shape == (ny,) else XC_DA_PLANE
-            assert dA.shape in ((ny,), (ny, nx))
+            if dA.shape == (ny,):
+                rank = XC_DA_ROW
+            elif dA.shape == (ny, nx):
+                rank = XC_DA_PLANE
+            elif dA.shape == (nslab, ny, nx):
+                rank = XC_DA_SLAB
+            else:
+                raise XContourHipError(XC_EBADARG, 'dA must be (ny,), (ny, nx) or (nslab, ny, nx)')
+        per_slab = 0
         if mask is not None:
             mask = np.ascontiguousarray(mask)
             if mask.dtype not in (np.float32, np.float64):
                 mask = mask.astype(np.float64)
+            if mask.shape == (nslab, ny, nx) and not (single and mask.ndim == 2):
+                per_slab = 1
+            elif mask.shape != (ny, nx):
+                raise XContourHipError(XC_EBADARG, 'mask must be (ny, nx) or (nslab, ny, nx)')
         out = {}
         J = 0
         Q = None
         if targets is not None:
             targets = np.ascontiguousarray(targets, dtype=np.float64)
             J = len(targets)
-            Q = np.empty(J, dtype=np.float64)
-        qs = np.empty(ny * nx, dtype=np.float64) if want_sorted else None
-        ac = np.empty(ny * nx, dtype=np.float64) if want_acum else None
-        nv = np.zeros(1, dtype=np.uint32)
+            Q = np.empty((nslab, J), dtype=np.float64)
+        qs = np.empty((nslab, ny * nx), dtype=np.float64) if want_sorted else None
+        ac = np.empty((nslab, ny * nx), dtype=np.float64) if want_acum else None
+        nv = np.zeros(nslab, dtype=np.uint32)
         bpe = None
         ntbl = 0
         if tbl is not None:
             tbl = np.ascontiguousarray(tbl, dtype=np.float64)
             coord = np.ascontiguousarray(coord, dtype=np.float64)
             ntbl = len(tbl)
-            bpe = np.zeros(1, dtype=np.float64)
-        self._check(self.lib.xc_sort_profile(self.handle, _ptr(q), dtype_code(q.dtype), _ptr(mask),
-                                             dtype_code(mask.dtype) if mask is not None else XC_F64,
-                                             _ptr(dA), rank, ny, nx, 1 if negate else 0, _ptr(targets), J, _ptr(tbl), _ptr(coord), ntbl,
-                                             _ptr(Q), _ptr(qs), _ptr(ac), _ptr(nv), _ptr(bpe)))
-        out['nvalid'] = int(nv[0])
+            bpe = np.zeros(nslab, dtype=np.float64)
+        self._check(self.lib.xc_sort_profile_batch(self.handle, _ptr(q), dtype_code(q.dtype), _ptr(mask),
+                                                   dtype_code(mask.dtype) if mask is not None else XC_F64, per_slab,
+                                                   _ptr(dA), rank, nslab, ny, nx, 1 if negate else 0, _ptr(targets), J,
+                                                   _ptr(tbl), _ptr(coord), ntbl,
+                                                   _ptr(Q), _ptr(qs), _ptr(ac), _ptr(nv), _ptr(bpe)))
+        out['nvalid'] = int(nv[0]) if single else nv.astype(np.int64)
         if Q is not None:
-            out['Q'] = Q
+            out['Q'] = Q[0] if single else Q
         if qs is not None:
-            out['q_sorted'] = qs
+            out['q_sorted'] = qs[0] if single else qs
         if ac is not None:
-            out['acum'] = ac
+            out['acum'] = ac[0] if single else ac
         if bpe is not None:
-            out['bpe'] = float(bpe[0])
+            out['bpe'] = float(bpe[0]) if single else bpe
         return out
 
 

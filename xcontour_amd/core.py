@@ -667,16 +667,22 @@ class Contour2D(object):
         eq = self._eq_coord(tracer)
         up = bool(self.increase) == bool(eq[-1] > eq[0])
         sgn = 1.0 if up else -1.0
+        # the whole stack in ONE set of launches (segmented sort), in batches that keep the workspace
+        # (4 x 8 B per cell + outputs) below ~2 GiB
+        per = max(1, int((2 << 30) // (ny * nx * 8 * (6 if return_sorted else 5))))
         Qs, sorted_ = [], []
-        for k in range(nslab):                                 # one radix sort per (time, level) plane
-            res = self.ctx.sort_profile(q[k], dA=dA[k] if dA.ndim == 3 else dA, mask=None if m is None else m[min(k, m.shape[0] - 1)],
+        for k0 in range(0, nslab, per):
+            sl = slice(k0, min(nslab, k0 + per))
+            mk = None if m is None else (m[sl] if m.shape[0] == nslab and nslab > 1 else m[0])
+            res = self.ctx.sort_profile(q[sl], dA=dA[sl] if dA.ndim == 3 else dA, mask=mk,
                                         targets=below, want_sorted=return_sorted, negate=not up)
             Qs.append(sgn * res['Q'])
             if return_sorted:
-                sorted_.append(sgn * res['q_sorted'][:res['nvalid']])
+                sorted_ += [sgn * res['q_sorted'][i][:int(res['nvalid'][i])] for i in range(sl.stop - sl.start)]
+        Qs = [np.concatenate(Qs, axis=0)]
         c = {d: coords[d] for d in lead if d in coords}
         c[self.dimEqV] = cs
-        Q = lb.wrap(np.stack(Qs).reshape(tuple(lshape) + (len(cs),)), tuple(lead) + (self.dimEqV,), c,
+        Q = lb.wrap(Qs[0].reshape(tuple(lshape) + (len(cs),)), tuple(lead) + (self.dimEqV,), c,
                     lb.unwrap(tracer)[3], tracer)
         if return_sorted:
             return Q, (sorted_[0] if nslab == 1 and not lead else sorted_)

@@ -591,16 +591,67 @@ int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const doubl
 }
 
 // ------------------------------------------------------------------------------------ K8
+int xc_sort_profile_batch_dev(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
+                              const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
+                              const double* targets, int J, const double* tbl, const double* coord, int ntbl,
+                              double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe)
+{
+    XC_CTX(ctx);
+    if (ny < 1 || nx < 1 || nslab < 1) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad shape");
+    XC_TRY(ensure_scratch(ctx, sort_workspace_bytes(ny * nx, nslab)));
+    return launch_sort_profile(ctx, q, q_dtype, mask, mask_dtype, mask_per_slab, dA, dA_rank, nslab, ny, nx, negate,
+                               targets, J, tbl, coord, ntbl, ctx->scratch, out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
+}
+
+int xc_sort_profile_batch(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
+                          const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
+                          const double* targets, int J, const double* tbl, const double* coord, int ntbl,
+                          double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe)
+{
+    XC_CTX(ctx);
+    if (!q || ny < 1 || nx < 1 || nslab < 1 || J < 0) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad arguments");
+    if (q_dtype != XC_F32 && q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad dtype");
+    if (mask && mask_dtype != XC_F32 && mask_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad mask dtype");
+    const size_t S = (size_t)nslab, n = (size_t)ny * nx;
+    const size_t qb = S * n * esize(q_dtype), mb = mask ? (mask_per_slab ? S : 1) * n * esize(mask_dtype) : 0;
+    const size_t dab = dA_rank == XC_DA_ROW ? (size_t)ny * 8 : dA_rank == XC_DA_PLANE ? n * 8 : dA_rank == XC_DA_SLAB ? S * n * 8 : 0;
+    if (dab && !dA) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA is NULL");
+    const size_t tb = (size_t)J * 8, Qb = S * tb, tbb = (out_bpe ? (size_t)ntbl * 8 : 0);
+    XC_TRY(ensure_arena(ctx, al(qb) + al(mb) + al(dab) + al(tb) + al(Qb) + 2 * al(tbb) + 2 * al(S * n * 8) + al(S * 4) + al(S * 8)));
+    Stage st(ctx);
+    void* dq = st.take(qb); XC_TRY(h2d(ctx, dq, q, qb));
+    void* dm = nullptr; if (mb) { dm = st.take(mb); XC_TRY(h2d(ctx, dm, mask, mb)); }
+    double* dd = nullptr; if (dab) { dd = (double*)st.take(dab); XC_TRY(h2d(ctx, dd, dA, dab)); }
+    double* dt = nullptr; double* dQ = nullptr;
+    if (J > 0 && out_Q) { dt = (double*)st.take(tb); dQ = (double*)st.take(Qb); XC_TRY(h2d(ctx, dt, targets, tb)); }
+    double *dtbl = nullptr, *dcrd = nullptr;
+    if (out_bpe) {
+        if (!tbl || !coord || ntbl < 2) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
+        dtbl = (double*)st.take(tbb); dcrd = (double*)st.take(tbb);
+        XC_TRY(h2d(ctx, dtbl, tbl, tbb)); XC_TRY(h2d(ctx, dcrd, coord, tbb));
+    }
+    double* dqs = out_qsorted ? (double*)st.take(S * n * 8) : nullptr;
+    double* dac = out_acum ? (double*)st.take(S * n * 8) : nullptr;
+    uint32_t* dnv = (uint32_t*)st.take(S * 4);
+    double* dbpe = out_bpe ? (double*)st.take(S * 8) : nullptr;
+    XC_TRY(xc_sort_profile_batch_dev(ctx, dq, q_dtype, dm, mask_dtype, mask_per_slab, dd, dA_rank, nslab, ny, nx, negate,
+                                     dt, dQ ? J : 0, dtbl, dcrd, ntbl, dQ, dqs, dac, dnv, dbpe));
+    if (dQ) XC_TRY(d2h(ctx, out_Q, dQ, Qb));
+    if (dqs) XC_TRY(d2h(ctx, out_qsorted, dqs, S * n * 8));
+    if (dac) XC_TRY(d2h(ctx, out_acum, dac, S * n * 8));
+    if (out_nvalid) XC_TRY(d2h(ctx, out_nvalid, dnv, S * 4));
+    if (dbpe) XC_TRY(d2h(ctx, out_bpe, dbpe, S * 8));
+    return xc_sync(ctx);
+}
+
 int xc_sort_profile_dev(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype,
                         const double* dA, int dA_rank, int64_t ny, int64_t nx, int negate,
                         const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                         double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe)
 {
-    XC_CTX(ctx);
-    if (ny < 1 || nx < 1) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad shape");
-    XC_TRY(ensure_scratch(ctx, sort_workspace_bytes(ny * nx)));
-    return launch_sort_profile(ctx, q, q_dtype, mask, mask_dtype, dA, dA_rank, ny, nx, negate, targets, J, tbl, coord, ntbl,
-                               ctx->scratch, out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
+    if (dA_rank == XC_DA_SLAB) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA_rank must be NONE, ROW or PLANE");
+    return xc_sort_profile_batch_dev(ctx, q, q_dtype, mask, mask_dtype, 0, dA, dA_rank, 1, ny, nx, negate, targets, J, tbl, coord, ntbl,
+                                     out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
 }
 
 int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype,
@@ -608,40 +659,9 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
                     const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                     double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe)
 {
-    XC_CTX(ctx);
-    if (!q || ny < 1 || nx < 1 || J < 0) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad arguments");
-    if (q_dtype != XC_F32 && q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad dtype");
-    if (mask && mask_dtype != XC_F32 && mask_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad mask dtype");
-    const size_t n = (size_t)ny * nx;
-    const size_t qb = n * esize(q_dtype), mb = mask ? n * esize(mask_dtype) : 0;
-    const size_t dab = dA_rank == XC_DA_ROW ? (size_t)ny * 8 : dA_rank == XC_DA_PLANE ? n * 8 : 0;
-    if (dab && !dA) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA is NULL");
-    const size_t tb = (size_t)J * 8, tbb = (out_bpe ? (size_t)ntbl * 8 : 0);
-    XC_TRY(ensure_arena(ctx, al(qb) + al(mb) + al(dab) + 2 * al(tb) + 2 * al(tbb) + 2 * al(n * 8) + al(64) + al(8)));
-    Stage st(ctx);
-    void* dq = st.take(qb); XC_TRY(h2d(ctx, dq, q, qb));
-    void* dm = nullptr; if (mb) { dm = st.take(mb); XC_TRY(h2d(ctx, dm, mask, mb)); }
-    double* dd = nullptr; if (dab) { dd = (double*)st.take(dab); XC_TRY(h2d(ctx, dd, dA, dab)); }
-    double* dt = nullptr; double* dQ = nullptr;
-    if (J > 0 && out_Q) { dt = (double*)st.take(tb); dQ = (double*)st.take(tb); XC_TRY(h2d(ctx, dt, targets, tb)); }
-    double *dtbl = nullptr, *dcrd = nullptr;
-    if (out_bpe) {
-        if (!tbl || !coord || ntbl < 2) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
-        dtbl = (double*)st.take(tbb); dcrd = (double*)st.take(tbb);
-        XC_TRY(h2d(ctx, dtbl, tbl, tbb)); XC_TRY(h2d(ctx, dcrd, coord, tbb));
-    }
-    double* dqs = out_qsorted ? (double*)st.take(n * 8) : nullptr;
-    double* dac = out_acum ? (double*)st.take(n * 8) : nullptr;
-    uint32_t* dnv = (uint32_t*)st.take(64);
-    double* dbpe = out_bpe ? (double*)st.take(8) : nullptr;
-    XC_TRY(xc_sort_profile_dev(ctx, dq, q_dtype, dm, mask_dtype, dd, dA_rank, ny, nx, negate, dt, dQ ? J : 0, dtbl, dcrd, ntbl,
-                               dQ, dqs, dac, dnv, dbpe));
-    if (dQ) XC_TRY(d2h(ctx, out_Q, dQ, tb));
-    if (dqs) XC_TRY(d2h(ctx, out_qsorted, dqs, n * 8));
-    if (dac) XC_TRY(d2h(ctx, out_acum, dac, n * 8));
-    if (out_nvalid) XC_TRY(d2h(ctx, out_nvalid, dnv, 4));
-    if (dbpe) XC_TRY(d2h(ctx, out_bpe, dbpe, 8));
-    return xc_sync(ctx);
+    if (dA_rank == XC_DA_SLAB) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA_rank must be NONE, ROW or PLANE");
+    return xc_sort_profile_batch(ctx, q, q_dtype, mask, mask_dtype, 0, dA, dA_rank, 1, ny, nx, negate, targets, J, tbl, coord, ntbl,
+                                 out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
 }
 
 // ------------------------------------------------------------------------------------ fused Keff pipeline

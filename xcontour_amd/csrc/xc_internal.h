@@ -133,9 +133,9 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
                const double* dA, int dA_rank, double dA_max, const double* M, int M_rank,
                int64_t nslab, int64_t ny, int64_t nx, int increase, int part, int variant,
                const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks);
-size_t sort_workspace_bytes(int64_t n);
-int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype,
-                        const double* dA, int dA_rank, int64_t ny, int64_t nx, int negate,
+size_t sort_workspace_bytes(int64_t n, int64_t nslab);
+int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
+                        const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
                         const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                         void* workspace, double* out_Q, double* out_qsorted, double* out_acum,
                         unsigned* out_nvalid, double* out_bpe);

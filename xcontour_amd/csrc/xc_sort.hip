@@ -6,6 +6,9 @@
 //   drop NaN / masked cells; stable ascending sort of (q, dA); Acum = cumsum(dA_sorted);
 //   Q_exact(A_j) = q_sorted[min(searchsorted(Acum, A_j, 'right'), n-1)].
 //
+// Every kernel takes the slab from blockIdx.y (or blockIdx.x for the one-block-per-slab kernels): a stack of
+// planes is sorted by ONE set of launches (segmented sort: per-slab tile histograms, bases and scans).
+//
 // Hand-written LSD radix sort, 8-bit digits, 64-bit order-preserving keys, f64 payload:
 // one block owns one tile of 4096 consecutive elements (4 waves x 1024); stable ranks come from wave
 // ballots (8 ballots give the peer mask of a lane's digit) + per-wave digit counters in LDS; the tile is
@@ -38,8 +41,13 @@ __device__ __forceinline__ double key_to_f64(unsigned long long k)
 template <typename TQ, typename TM>
 __global__ __launch_bounds__(256)
 void k_sort_keys(const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA, int dA_rank,
-                 int64_t nx, int64_t n, int negate, unsigned long long* __restrict__ keys, double* __restrict__ vals)
+                 int64_t nx, int64_t n, int negate, unsigned long long* __restrict__ keys, double* __restrict__ vals,
+                 int64_t mask_stride, int64_t dA_stride)
 {
+    const size_t so = (size_t)blockIdx.y * n;
+    q += so; keys += so; vals += so;
+    if (mask) mask += (size_t)blockIdx.y * mask_stride;
+    if (dA) dA += (size_t)blockIdx.y * dA_stride;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         const double v = negate ? -(double)q[i] : (double)q[i];
@@ -54,7 +62,8 @@ void k_sort_keys(const TQ* __restrict__ q, const TM* __restrict__ mask, const do
 // a per-wave atomic counter in k_sort_keys serialised 100k atomics on one address = 1.1 ms)
 __global__ void k_count_valid(const unsigned long long* __restrict__ keys, int64_t n, unsigned* __restrict__ nvalid)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    keys += (size_t)blockIdx.x * n; nvalid += blockIdx.x;
     int64_t lo = 0, hi = n;                        // first index with keys[idx] == KEY_INVALID
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < KEY_INVALID) lo = mid + 1; else hi = mid; }
     *nvalid = (unsigned)lo;
@@ -83,6 +92,7 @@ void k_radix_hist(const unsigned long long* __restrict__ keys, int64_t n, int sh
     __shared__ unsigned s_cnt[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = blockIdx.x;
+    keys += (size_t)blockIdx.y * n; hist += (size_t)blockIdx.y * 256 * ntiles;
     for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = 0;
     // counting does not care about the order inside the tile: 16-byte loads, two keys per lane
     const int64_t base = t * BTILE + (int64_t)wave * TILE;
@@ -119,7 +129,8 @@ void k_radix_scan_rows(unsigned* __restrict__ hist, int ntiles, unsigned* __rest
 {
     __shared__ unsigned s_w[16];
     __shared__ unsigned s_carry;
-    unsigned* row = hist + (size_t)blockIdx.x * ntiles;
+    unsigned* row = hist + ((size_t)blockIdx.y * 256 + blockIdx.x) * ntiles;
+    totals += (size_t)blockIdx.y * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
@@ -157,6 +168,8 @@ void k_radix_scatter(const unsigned long long* __restrict__ kin, const double* _
     unsigned* s_wsum = s_gbase + 256;                          // [8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x;
+    { const size_t so = (size_t)blockIdx.y * n; kin += so; vin += so; kout += so; vout += so; }
+    hist += (size_t)blockIdx.y * 256 * ntiles; totals += (size_t)blockIdx.y * 256;
     for (int d = lane; d < 256; d += 64) s_cnt[wave * 256 + d] = 0;
     const int64_t tbase = t * BTILE;
     const int64_t base = tbase + (int64_t)wave * TILE;
@@ -244,6 +257,8 @@ void k_scan_local(const double* __restrict__ in, double* __restrict__ out, int64
 {
     __shared__ double s_w[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    in += (size_t)blockIdx.y * n; bsum += (size_t)blockIdx.y * gridDim.x;
+    if (FINAL) out += (size_t)blockIdx.y * n;
     const int64_t wbase = (int64_t)blockIdx.x * 2048 + wave * 512;
     double a[4], b[4];
     if (wbase + 512 <= n) {
@@ -294,6 +309,7 @@ void k_scan_bsums(double* __restrict__ bsum, int nb)        // exclusive scan in
     __shared__ double s_w[16];
     __shared__ double s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bsum += (size_t)blockIdx.x * nb;
     if (tid == 0) s_carry = 0.0;
     __syncthreads();
     for (int b = 0; b < nb; b += 1024) {
@@ -316,6 +332,7 @@ __global__ __launch_bounds__(256)
 void k_unkey(const unsigned long long* __restrict__ keys, int64_t n, double* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    keys += (size_t)blockIdx.y * n; out += (size_t)blockIdx.y * n;
     if (i < n) out[i] = key_to_f64(keys[i]);
 }
 
@@ -323,11 +340,12 @@ void k_unkey(const unsigned long long* __restrict__ keys, int64_t n, double* __r
 __global__ __launch_bounds__(256)
 void k_profile(const unsigned long long* __restrict__ keys, const double* __restrict__ acum,
                const unsigned* __restrict__ nvalid, const double* __restrict__ targets, int J,
-               double* __restrict__ Q)
+               double* __restrict__ Q, int64_t ncell)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= J) return;
-    const int64_t n = *nvalid;
+    keys += (size_t)blockIdx.y * ncell; acum += (size_t)blockIdx.y * ncell; Q += (size_t)blockIdx.y * J;
+    const int64_t n = nvalid[blockIdx.y];
     if (n == 0) { Q[j] = __longlong_as_double(0x7ff8000000000000LL); return; }
     const double a = targets[j];
     int64_t lo = 0, hi = n;                        // first index with acum[idx] > a
@@ -340,9 +358,12 @@ void k_profile(const unsigned long long* __restrict__ keys, const double* __rest
 __global__ __launch_bounds__(256)
 void k_bpe(const unsigned long long* __restrict__ keys, const double* __restrict__ vals,
            const double* __restrict__ acum, const unsigned* __restrict__ nvalid,
-           const double* __restrict__ tbl, const double* __restrict__ coord, int ntbl, double* __restrict__ part)
+           const double* __restrict__ tbl, const double* __restrict__ coord, int ntbl, double* __restrict__ part,
+           int64_t ncell)
 {
-    const int64_t n = *nvalid;
+    { const size_t so = (size_t)blockIdx.y * ncell; keys += so; vals += so; acum += so; }
+    part += (size_t)blockIdx.y * gridDim.x;
+    const int64_t n = nvalid[blockIdx.y];
     const bool tinc = tbl[ntbl - 1] > tbl[0];
     double sum = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -368,48 +389,54 @@ void k_bpe(const unsigned long long* __restrict__ keys, const double* __restrict
 
 __global__ void k_sum_parts(const double* __restrict__ part, int n, double* __restrict__ out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { double s = 0.0; for (int i = 0; i < n; ++i) s += part[i]; *out = s; }
+    if (threadIdx.x == 0) { part += (size_t)blockIdx.x * n; double s = 0.0; for (int i = 0; i < n; ++i) s += part[i]; out[blockIdx.x] = s; }
 }
 
 }  // namespace
 
-// Workspace layout (device): keys A/B, vals A/B, hist, totals, spare, nvalid, bsums, bpe parts
-size_t sort_workspace_bytes(int64_t n)
+// Workspace layout (device), every array with a leading slab dim: keys A/B, vals A/B, hist, totals, nvalid, bsums, bpe parts
+constexpr int BPE_BLOCKS = 256;
+size_t sort_workspace_bytes(int64_t n, int64_t nslab)
 {
     const int64_t ntiles = (n + BTILE - 1) / BTILE;
     const int64_t nb = (n + 2047) / 2048;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    return 4 * al((size_t)n * 8) + al((size_t)256 * ntiles * 4) + al(256 * 4) * 2 + al(64) + al((size_t)nb * 8) + al(1024 * 8);
+    const size_t S = (size_t)nslab;
+    return 4 * al(S * n * 8) + al(S * 256 * ntiles * 4) + al(S * 256 * 4) + al(S * 4) + al(S * nb * 8) + al(S * BPE_BLOCKS * 8);
 }
 
-int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype,
-                        const double* dA, int dA_rank, int64_t ny, int64_t nx, int negate,
+int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
+                        const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
                         const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                         void* workspace, double* out_Q, double* out_qsorted, double* out_acum,
                         unsigned* out_nvalid, double* out_bpe)
 {
     const int64_t n = ny * nx;
-    if (!q || !workspace || n < 1 || n > 0x7fffffff) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad arguments");
-    if (dA_rank != XC_DA_NONE && dA_rank != XC_DA_ROW && dA_rank != XC_DA_PLANE) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA_rank must be NONE, ROW or PLANE");
+    if (!q || !workspace || n < 1 || n > 0x7fffffff || nslab < 1 || nslab > 65535) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad arguments");
+    if (dA_rank < XC_DA_NONE || dA_rank > XC_DA_SLAB) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad dA_rank");
     if (dA_rank != XC_DA_NONE && !dA) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA is NULL");
     const int64_t ntiles = (n + BTILE - 1) / BTILE;
     const int nb = (int)((n + 2047) / 2048);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t S = (size_t)nslab;
     char* w = (char*)workspace;
-    unsigned long long* kA = (unsigned long long*)w; w += al((size_t)n * 8);
-    unsigned long long* kB = (unsigned long long*)w; w += al((size_t)n * 8);
-    double* vA = (double*)w; w += al((size_t)n * 8);
-    double* vB = (double*)w; w += al((size_t)n * 8);
-    unsigned* hist = (unsigned*)w; w += al((size_t)256 * ntiles * 4);
-    unsigned* totals = (unsigned*)w; w += al(256 * 4);
-    w += al(256 * 4);                                      // (spare)
-    unsigned* nvalid = (unsigned*)w; w += al(64);
-    double* bsum = (double*)w; w += al((size_t)nb * 8);
+    unsigned long long* kA = (unsigned long long*)w; w += al(S * n * 8);
+    unsigned long long* kB = (unsigned long long*)w; w += al(S * n * 8);
+    double* vA = (double*)w; w += al(S * n * 8);
+    double* vB = (double*)w; w += al(S * n * 8);
+    unsigned* hist = (unsigned*)w; w += al(S * 256 * ntiles * 4);
+    unsigned* totals = (unsigned*)w; w += al(S * 256 * 4);
+    unsigned* nvalid = (unsigned*)w; w += al(S * 4);
+    double* bsum = (double*)w; w += al(S * nb * 8);
     double* parts = (double*)w;
+    const unsigned ns = (unsigned)nslab;
 
     const unsigned gb = (unsigned)((n + 255) / 256);
-#define XC_KEYS(TQ, TM) hipLaunchKernelGGL((k_sort_keys<TQ, TM>), dim3(gb), dim3(256), 0, ctx->stream, (const TQ*)q, \
-        (const TM*)mask, dA, dA_rank, nx, n, negate, kA, vA)
+    // a per-slab dA plane is the PLANE case with a slab stride
+    const int krank = dA_rank == XC_DA_SLAB ? XC_DA_PLANE : dA_rank;
+    const int64_t dstride = dA_rank == XC_DA_SLAB ? n : 0, mstride = (mask && mask_per_slab) ? n : 0;
+#define XC_KEYS(TQ, TM) hipLaunchKernelGGL((k_sort_keys<TQ, TM>), dim3(gb, ns), dim3(256), 0, ctx->stream, (const TQ*)q, \
+        (const TM*)mask, dA, krank, nx, n, negate, kA, vA, mstride, dstride)
     const bool m32 = mask && mask_dtype == XC_F32;
     if (q_dtype == XC_F64) { if (m32) XC_KEYS(double, float); else XC_KEYS(double, double); }
     else if (q_dtype == XC_F32) { if (m32) XC_KEYS(float, float); else XC_KEYS(float, double); }
@@ -424,33 +451,33 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
     // a float32 tracer widened to float64 has 29 zero mantissa bits: the digits of passes 0-2 are all zero
     for (int pass = (q_dtype == XC_F32 ? 3 : 0); pass < 8; ++pass) {
         const int shift = pass * 8;
-        hipLaunchKernelGGL(k_radix_hist, dim3(gt), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist);
-        hipLaunchKernelGGL(k_radix_scan_rows, dim3(256), dim3(1024), 0, ctx->stream, hist, (int)ntiles, totals);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(gt), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+        hipLaunchKernelGGL(k_radix_hist, dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist);
+        hipLaunchKernelGGL(k_radix_scan_rows, dim3(256, ns), dim3(1024), 0, ctx->stream, hist, (int)ntiles, totals);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
                            (int)ntiles, hist, totals);
         XC_HIP(ctx, hipGetLastError());
         unsigned long long* tk = kin; kin = kout; kout = tk;
         double* tv = vin; vin = vout; vout = tv;
     }
     // sorted data are in kin / vin (kA / vA after 8 passes, kB / vB after 5)
-    hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(64), 0, ctx->stream, kin, n, nvalid);
+    hipLaunchKernelGGL(k_count_valid, dim3(ns), dim3(64), 0, ctx->stream, kin, n, nvalid);
     double* acum = vout;                                   // reuse the idle payload buffer
-    hipLaunchKernelGGL(k_scan_local<false>, dim3(nb), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb);
-    hipLaunchKernelGGL(k_scan_local<true>, dim3(nb), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
+    hipLaunchKernelGGL(k_scan_local<false>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(ns), dim3(1024), 0, ctx->stream, bsum, nb);
+    hipLaunchKernelGGL(k_scan_local<true>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
     XC_HIP(ctx, hipGetLastError());
     if (out_Q && J > 0) {
         if (!targets) return fail(ctx, XC_EBADARG, "xc_sort_profile: targets is NULL");
-        hipLaunchKernelGGL(k_profile, dim3((J + 255) / 256), dim3(256), 0, ctx->stream, kin, acum, nvalid, targets, J, out_Q);
+        hipLaunchKernelGGL(k_profile, dim3((J + 255) / 256, ns), dim3(256), 0, ctx->stream, kin, acum, nvalid, targets, J, out_Q, n);
     }
     if (out_bpe) {
         if (!tbl || !coord || ntbl < 2) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
-        hipLaunchKernelGGL(k_bpe, dim3(1024), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts);
-        hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(64), 0, ctx->stream, parts, 1024, out_bpe);
+        hipLaunchKernelGGL(k_bpe, dim3(BPE_BLOCKS, ns), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts, n);
+        hipLaunchKernelGGL(k_sum_parts, dim3(ns), dim3(64), 0, ctx->stream, parts, BPE_BLOCKS, out_bpe);
     }
-    if (out_qsorted) hipLaunchKernelGGL(k_unkey, dim3(gb), dim3(256), 0, ctx->stream, kin, n, out_qsorted);
-    if (out_acum) XC_HIP(ctx, hipMemcpyAsync(out_acum, acum, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    if (out_nvalid) XC_HIP(ctx, hipMemcpyAsync(out_nvalid, nvalid, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
+    if (out_qsorted) hipLaunchKernelGGL(k_unkey, dim3(gb, ns), dim3(256), 0, ctx->stream, kin, n, out_qsorted);
+    if (out_acum) XC_HIP(ctx, hipMemcpyAsync(out_acum, acum, S * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (out_nvalid) XC_HIP(ctx, hipMemcpyAsync(out_nvalid, nvalid, S * sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
 }
