@@ -957,3 +957,18 @@ def test_batched_sort_equals_per_slab_oracle(ctx, dt):
     for s in range(S):
         one = ctx.sort_profile(q[s], dA=dA[0], mask=mask[0], targets=tbl)
         assert np.array_equal(r2['Q'][s], one['Q'], equal_nan=True) and int(r2['nvalid'][s]) == one['nvalid']
+
+
+def test_readme_example_runs(ctx):
+    """the python block of README.md, verbatim"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = re.search(r"```python\n(.*?)```", open(os.path.join(root, 'README.md')).read(), re.S).group(1)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        ns = {}
+        exec(code, ns)
+    finally:
+        os.chdir(cwd)
+    assert ns['lwa'].shape == (256, 512) and ns['Qx'].shape == (256,) and len(ns['bc']) == 3
