@@ -1,0 +1,79 @@
+/* Plain-C client of the C ABI (include/xcontour_hip.h): what a cgo / JNI / C++ host would do.
+ * Built with gcc only (no HIP headers): tests/test_gpu_parity.py::test_c_client compiles it against
+ * xcontour_amd/libxcontour_hip.so and runs it on the GPU box.
+ * min/max -> levels/edges -> weighted histogram + CDF of a small field, checked against loops written here. */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/xcontour_hip.h"
+
+#define NY 97
+#define NX 203
+#define NLEV 33
+
+static int fail(const char* what, xc_ctx* ctx) { fprintf(stderr, "FAIL %s: %s\n", what, xc_last_error(ctx)); return 1; }
+
+int main(void)
+{
+    xc_ctx* ctx = NULL;
+    if (xc_create(0, &ctx) != XC_OK) return fail("xc_create", NULL);
+    static float q[2][NY][NX];
+    static double dA[NY][NX];
+    uint64_t s = 88172645463325252ull;
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < NY; ++j)
+            for (int i = 0; i < NX; ++i) {
+                s ^= s << 13; s ^= s >> 7; s ^= s << 17;                 /* xorshift64 */
+                q[k][j][i] = (float)((double)(s >> 11) / 9007199254740992.0 + 0.01 * j + k);
+                dA[j][i] = 1.0 + 0.5 * cos(0.03 * j);
+            }
+    q[0][3][4] = NAN;
+
+    double mm[2][2];
+    if (xc_minmax(ctx, q, XC_F32, 2, (int64_t)NY * NX, &mm[0][0]) != XC_OK) return fail("xc_minmax", ctx);
+    for (int k = 0; k < 2; ++k) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int j = 0; j < NY; ++j) for (int i = 0; i < NX; ++i) { const float v = q[k][j][i]; if (v == v) { if (v < lo) lo = v; if (v > hi) hi = v; } }
+        if (mm[k][0] != (double)lo || mm[k][1] != (double)hi) { fprintf(stderr, "FAIL minmax slab %d\n", k); return 1; }
+    }
+
+    double ctr[2][NLEV], edges[2][NLEV + 1];
+    int32_t status[2];
+    if (xc_levels(ctx, &mm[0][0], XC_F32, 2, NLEV, 1, XC_F32, XC_EDGE_NUMPY, &ctr[0][0], &edges[0][0], status) != XC_OK)
+        return fail("xc_levels", ctx);
+    if (status[0] || status[1] || ctr[0][0] != mm[0][0]) { fprintf(stderr, "FAIL levels\n"); return 1; }
+
+    static double cdf[2][1][NLEV];
+    static uint64_t counts[2][NLEV];
+    struct xc_hist_desc d;
+    memset(&d, 0, sizeof d);
+    d.q = q; d.q_dtype = XC_F32; d.nslab = 2; d.ny = NY; d.nx = NX;
+    d.edges = &edges[0][0]; d.nedge = NLEV + 1; d.edges_per_slab = 1; d.last_closed = 1;
+    d.dA = &dA[0][0]; d.dA_rank = XC_DA_PLANE; d.lt = 1;
+    d.cdf = &cdf[0][0][0]; d.counts = &counts[0][0];
+    if (xc_hist(ctx, &d) != XC_OK) return fail("xc_hist", ctx);
+    for (int k = 0; k < 2; ++k) {
+        uint64_t ref_c[NLEV]; double ref_w[NLEV];
+        memset(ref_c, 0, sizeof ref_c); memset(ref_w, 0, sizeof ref_w);
+        for (int j = 0; j < NY; ++j) for (int i = 0; i < NX; ++i) {
+            const double v = (double)q[k][j][i];
+            if (!(v == v) || v < edges[k][0] || v > edges[k][NLEV]) continue;
+            int b = NLEV - 1;                                              /* last bin closed on the right */
+            for (int e = 1; e <= NLEV; ++e) if (v < edges[k][e]) { b = e - 1; break; }
+            ref_c[b]++; ref_w[b] += dA[j][i];
+        }
+        double run = 0.0;
+        for (int b = 0; b < NLEV; ++b) {
+            run += ref_w[b];
+            if (counts[k][b] != ref_c[b]) { fprintf(stderr, "FAIL counts slab %d bin %d: %llu vs %llu\n", k, b, (unsigned long long)counts[k][b], (unsigned long long)ref_c[b]); return 1; }
+            if (fabs(cdf[k][0][b] - run) > 1e-11 * (fabs(run) + 1.0)) { fprintf(stderr, "FAIL cdf slab %d bin %d\n", k, b); return 1; }
+        }
+    }
+    /* error path: non-ascending edges must be refused with a message, not crash */
+    edges[0][5] = edges[0][4];
+    if (xc_hist(ctx, &d) == XC_OK) { fprintf(stderr, "FAIL: bad edges accepted\n"); return 1; }
+    printf("capi_smoke ok (%s): %s\n", xc_version(), xc_last_error(ctx));
+    return xc_destroy(ctx) == XC_OK ? 0 : 1;
+}

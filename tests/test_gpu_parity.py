@@ -972,3 +972,44 @@ def test_readme_example_runs(ctx):
     finally:
         os.chdir(cwd)
     assert ns['lwa'].shape == (256, 512) and ns['Qx'].shape == (256,) and len(ns['bc']) == 3
+
+
+def test_c_client(ctx, tmp_path):
+    """tests/capi_smoke.c: a plain C program (gcc, no HIP headers) drives the C ABI the way a cgo / JNI host would"""
+    import subprocess
+    from xcontour_amd import _native as nat
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'capi_smoke')
+    libdir = os.path.dirname(nat.LIB_PATH)
+    subprocess.run(['gcc', '-O1', '-std=c11', '-o', exe, os.path.join(root, 'tests', 'capi_smoke.c'),
+                    '-L' + libdir, '-lxcontour_hip', '-Wl,-rpath,' + libdir, '-lm'], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and 'capi_smoke ok' in r.stdout, r.stdout + r.stderr
+
+
+def test_two_contexts_from_two_threads(ctx):
+    """one context per thread, driven concurrently (ctypes releases the GIL): same results as one after the other"""
+    import threading
+    from xcontour_amd import _native as nat
+    rng = np.random.default_rng(9)
+    q = rng.standard_normal((4, 200, 300))
+    ed = np.linspace(-4, 4, 42)
+    dA = rng.random((200, 300)) + 0.5
+    ref = ctx.hist(q, ed, dA=dA, want=('counts', 'cdf'))
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            c = nat.Context(0)
+            for _ in range(5):
+                out[i] = c.hist(q, ed, dA=dA, want=('counts', 'cdf'))
+                c.minmax(q)
+            c.close()
+        except Exception as e:            # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for o in out:
+        assert np.array_equal(o['counts'], ref['counts']) and rel(o['cdf'], ref['cdf']) < 1e-13
