@@ -573,7 +573,9 @@ int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& 
     }
     HistArgs b = a;
     static const int xcd_env = [] { const char* e = getenv("XC_HIST_XCDMAP"); return e ? atoi(e) : 1; }();
-    b.bps = g.bps; b.nslab_grid = (int)nslab; b.xcd_map = xcd_env;
+    // the XCD-aware order needs whole groups of 8 row groups, otherwise it would leave XCDs idle (bps = 1 with many
+    // small slabs would put every block on XCD 0): plain slab-fastest order then
+    b.bps = g.bps; b.nslab_grid = (int)nslab; b.xcd_map = (xcd_env && g.bps % 8 == 0) ? 1 : 0;
     const int64_t nblk = b.xcd_map ? (int64_t)8 * ((g.bps + 7) / 8) * nslab : (int64_t)g.bps * nslab;
     if (nblk > 0x7fffffff) return fail(ctx, XC_EBADARG, "xc_hist: grid too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(g.threads), g.lds, ctx->stream, b);
