@@ -105,7 +105,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=32, help='slabs per step per GPU')
+    ap.add_argument('--batch', type=int, default=64, help='slabs per step per GPU')
     ap.add_argument('--group', type=int, default=0, help='slabs per launch set (0: whole batch)')
     ap.add_argument('--variant', type=int, default=0, help='0 PV-like, 1 noise, 2 sin(lat)')
     ap.add_argument('--chain', dest='chain', action='store_true', default=True,
@@ -249,10 +249,12 @@ def main():
             ach = alg / (ms.mean() * 1e-3) / 1e9
             traffic = None
             tf = os.path.join(ROOT, 'profiles', 'hist_traffic.json')
-            if os.path.exists(tf) and B == 32 and not a.row_dA:    # PMC passes were taken at the default batch
+            if os.path.exists(tf) and not a.row_dA and a.variant == 0:
                 try:
                     tj = json.load(open(tf))
-                    traffic = (tj.get('chain', {}) if chain else tj).get('hbm_bytes_per_launch')
+                    tj = tj.get('chain', {}) if chain else tj
+                    if tj.get('slabs_per_launch') == B:                # PMC passes were taken at the default batch
+                        traffic = tj.get('hbm_bytes_per_launch')
                 except Exception:
                     traffic = None
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
