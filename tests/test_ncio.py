@@ -83,7 +83,7 @@ def test_classic_netcdf3(tmp_path, version):
         f.createDimension('time', None); f.createDimension('lat', 9); f.createDimension('lon', 12)
         v = f.createVariable('lat', 'f4', ('lat',)); v[:] = lat; v.units = 'degrees_north'
         v = f.createVariable('lon', 'f8', ('lon',)); v[:] = lon
-        v = f.createVariable('time', 'f8', ('time',)); v[:] = np.arange(4.0)
+        v = f.createVariable('time', 'f8', ('time',)); v[:] = np.arange(4.0); v.units = 'hours since 1985-08-01 06:00:00'
         v = f.createVariable('pv', 'f4', ('time', 'lat', 'lon')); v[:] = pv; v.missing_value = np.float32(-999.0)
         v = f.createVariable('ps', 'i2', ('time', 'lat')); v[:] = ps; v.scale_factor = np.float32(0.5)
         v = f.createVariable('mask', 'i4', ('lat', 'lon')); v[:] = mask
@@ -93,7 +93,11 @@ def test_classic_netcdf3(tmp_path, version):
     assert np.array_equal(ds.ps.values, ps.astype(np.float32) * np.float32(0.5)) and ds.ps.dtype == np.float32
     assert np.array_equal(ds.mask.values, mask) and ds.mask.dims == ('lat', 'lon')
     assert np.array_equal(ds.pv.coords['lat'], lat) and ds.lat.attrs['units'] == 'degrees_north'
-    assert np.array_equal(ds.time.values, np.arange(4.0))
+    t0 = np.datetime64('1985-08-01T06:00:00', 'ns')
+    assert ds.time.dtype == np.dtype('datetime64[ns]') and np.array_equal(ds.time.values, t0 + np.arange(4) * np.timedelta64(3600, 's'))
+    assert np.array_equal(ds.pv.coords['time'], ds.time.values)
+    raw = ncio.open_dataset(path, decode_times=False)
+    assert np.array_equal(raw.time.values, np.arange(4.0))
 
 
 def test_not_a_netcdf_file(tmp_path):

@@ -18,7 +18,8 @@ nothing but numpy + zlib and returns the labelled `Dataset` the façade consumes
 
 CF decoding follows xarray's default (`mask_and_scale=True`): `_FillValue` / `missing_value` -> NaN,
 `scale_factor` / `add_offset` applied; packed integers of <= 2 bytes without an offset decode to
-float32, everything else to float64 (xarray.coding.variables._choose_float_dtype).
+float32, everything else to float64 (xarray.coding.variables._choose_float_dtype); `decode_times=True`
+turns '<unit> since <date>' variables of the standard calendars into datetime64[ns].
 
 Host-side I/O only: nothing here touches the GPU, and nothing on the GPU path depends on it.
 """
@@ -38,7 +39,7 @@ class NetCDFError(Exception):
     pass
 
 
-def open_dataset(path, mask_and_scale=True):
+def open_dataset(path, mask_and_scale=True, decode_times=True):
     """Read every root-group variable of a NetCDF-3 / NetCDF-4 file -> `Dataset` of `DataArray`s
     (dims, 1-D coordinate values, `attrs`); `ds.attrs` holds the global attributes."""
     with open(path, 'rb') as f:
@@ -54,7 +55,13 @@ def open_dataset(path, mask_and_scale=True):
             continue
         if mask_and_scale:
             values = _cf_decode(values, attrs)
-        c = {d: _cf_decode(coords[d], raw[d][2]) if mask_and_scale else coords[d] for d in dims if d in coords}
+        if decode_times:
+            values = _cf_time(values, attrs)
+        c = {}
+        for d in dims:
+            if d in coords:
+                cv = _cf_decode(coords[d], raw[d][2]) if mask_and_scale else coords[d]
+                c[d] = _cf_time(cv, raw[d][2]) if decode_times else cv
         da = DataArray(values, dims, c, name)
         da.attrs = {k: v for k, v in attrs.items() if k not in _INTERNAL_ATTRS}
         ds[name] = da
@@ -92,6 +99,35 @@ def _cf_decode(values, attrs):
         out *= out.dtype.type(_scalar(scale))
     if offset is not None:
         out += out.dtype.type(_scalar(offset))
+    return out
+
+
+_TIME_UNITS = {'days': 86400 * 10 ** 9, 'day': 86400 * 10 ** 9, 'hours': 3600 * 10 ** 9, 'hour': 3600 * 10 ** 9,
+               'minutes': 60 * 10 ** 9, 'minute': 60 * 10 ** 9, 'seconds': 10 ** 9, 'second': 10 ** 9,
+               'milliseconds': 10 ** 6, 'microseconds': 10 ** 3}
+
+
+def _cf_time(values, attrs):
+    """xarray's default decode_times for the standard calendars: '<unit> since <date>' -> datetime64[ns]."""
+    units = attrs.get('units')
+    if not isinstance(units, str) or ' since ' not in units or values.dtype.kind not in 'iuf':
+        return values
+    if str(attrs.get('calendar', 'standard')).lower() not in ('standard', 'gregorian', 'proleptic_gregorian'):
+        return values
+    unit, ref = units.split(' since ', 1)
+    step = _TIME_UNITS.get(unit.strip().lower())
+    if step is None:
+        return values
+    try:
+        ref = ref.strip().replace(' UTC', '').replace('Z', '')
+        parts = ref.split()
+        t0 = np.datetime64(parts[0] + ('T' + parts[1] if len(parts) > 1 else ''), 'ns')
+    except Exception:
+        return values
+    v = np.asarray(values, dtype=np.float64)
+    out = np.full(v.shape, np.datetime64('NaT', 'ns'))
+    ok = np.isfinite(v)
+    out[ok] = t0 + np.round(v[ok] * step).astype('int64').astype('timedelta64[ns]')
     return out
 
 
