@@ -269,6 +269,24 @@ def main():
         # rounded last level (the reference's own behaviour)
         if not (NY * NX - out['counts'].sum(axis=1).astype(np.int64) <= 1).all():
             raise RuntimeError('bench self-check failed: counts %r status %r' % (out['counts'].sum(axis=1), out['status']))
+        if world == 1 and chain and group == B:
+            # transparency: the same work in the plain order (stand-alone K1 launch, then K3), a short extra run
+            # AFTER the timed region (identical per-step outputs; tests/test_gpu_parity.py::test_chained_minmax_is_bit_identical)
+            chain = False
+            K2 = max(5, min(20, K))
+            plan.out_ptr = wres.data_ptr()
+            for k in range(-3, 0):
+                step(k, 0)
+            ctx.sync()
+            t2 = time.perf_counter()
+            for k in range(K2):
+                step(k, 0)
+            ctx.sync()
+            el2 = time.perf_counter() - t2
+            chain = True
+            plan.out_ptr = res.data_ptr()
+            line['unchained'] = {'value': work_step * K2 / el2, 'ms_per_step': el2 / K2 * 1e3, 'steps': K2,
+                                 'note': 'stand-alone min/max launch before every histogram launch (--no-chain), same slabs'}
         if world == 1 and not a.no_cpu:
             cores = os.cpu_count() or 1
             n = a.cpu_slabs or max(8, min(32, 2 * min(cores, 32)))
