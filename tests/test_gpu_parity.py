@@ -1013,3 +1013,18 @@ def test_two_contexts_from_two_threads(ctx):
     assert not errs, errs
     for o in out:
         assert np.array_equal(o['counts'], ref['counts']) and rel(o['cdf'], ref['cdf']) < 1e-13
+
+
+def test_errors_are_reported_not_fatal(ctx):
+    """out-of-memory and bad arguments come back as XContourHipError with a message; the context stays usable"""
+    from xcontour_amd._native import XContourHipError
+    with pytest.raises(XContourHipError) as e:
+        ctx.alloc(1 << 46)                                   # 64 TiB
+    assert str(e.value)
+    q = np.zeros((1, 8, 8))
+    with pytest.raises(XContourHipError):
+        ctx.hist(q, np.array([0.0, 1.0]), dA=np.ones((8, 9)))            # dA shape mismatch
+    with pytest.raises(XContourHipError):
+        ctx.crossing(q, np.array([0.0]), np.ones((8, 8)), pad_mode='mirror')
+    out = ctx.hist(q, np.array([-1.0, 1.0]), dA=np.ones((8, 8)), want=('counts',))   # still alive
+    assert int(out['counts'][0, 0]) == 64
