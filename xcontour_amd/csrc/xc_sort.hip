@@ -13,8 +13,8 @@
 // one block owns one tile of 4096 consecutive elements (4 waves x 1024); stable ranks come from wave
 // ballots (8 ballots give the peer mask of a lane's digit) + per-wave digit counters in LDS; the tile is
 // reordered by digit in LDS before it is stored; the (digit-major) tile histogram is scanned by two
-// small kernels.  float32 tracers skip the three passes whose digits are all zero.  Bandwidth-bound:
-// per pass 8 B/elem (histogram) + 32 B/elem (scatter read + write).
+// small kernels.  The key type is a template parameter: float32 tracers sort 32-bit keys in 4 passes
+// (4 B/elem histogram + 24 B/elem scatter), float64 tracers 64-bit keys in 8 passes (8 + 32 B/elem).
 #include "xc_internal.h"
 
 namespace xc {
@@ -23,25 +23,45 @@ namespace {
 constexpr int TILE_ROUNDS = 16;
 constexpr int TILE = 64 * TILE_ROUNDS;      // elements per wave
 constexpr int BTILE = 4 * TILE;             // elements per block tile
-constexpr unsigned long long KEY_INVALID = ~0ull;
+typedef unsigned long long u64;
+typedef unsigned int u32;
+template <typename K> struct KeyTraits;
+template <> struct KeyTraits<u64> {
+    static constexpr int passes = 8;
+    __device__ static __forceinline__ u64 invalid() { return ~0ull; }
+    __device__ static __forceinline__ u64 encode(double v)
+    {
+        // order-preserving map of IEEE doubles to unsigned integers; -0.0 is folded onto +0.0 so that
+        // equal values keep their original order exactly like numpy's stable sort
+        const u64 u = (u64)__double_as_longlong(v == 0.0 ? 0.0 : v);
+        return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    }
+    __device__ static __forceinline__ double decode(u64 k)
+    {
+        const u64 u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        return __longlong_as_double((long long)u);
+    }
+};
+template <> struct KeyTraits<u32> {            // float32 tracers: the key of the float IS the order of its double
+    static constexpr int passes = 4;
+    __device__ static __forceinline__ u32 invalid() { return ~0u; }
+    __device__ static __forceinline__ u32 encode(double v)
+    {
+        const float f = (float)v;              // exact: v came from a float (possibly negated)
+        const u32 u = (u32)__float_as_int(f == 0.0f ? 0.0f : f);
+        return (u >> 31) ? ~u : (u | 0x80000000u);
+    }
+    __device__ static __forceinline__ double decode(u32 k)
+    {
+        const u32 u = (k >> 31) ? (k & 0x7fffffffu) : ~k;
+        return (double)__int_as_float((int)u);
+    }
+};
 
-__device__ __forceinline__ unsigned long long f64_to_key(double v)
-{
-    // order-preserving map of IEEE doubles to unsigned integers; -0.0 is folded onto +0.0 so that
-    // equal values keep their original order exactly like numpy's stable sort
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v == 0.0 ? 0.0 : v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double key_to_f64(unsigned long long k)
-{
-    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)u);
-}
-
-template <typename TQ, typename TM>
+template <typename TQ, typename TM, typename K>
 __global__ __launch_bounds__(256)
 void k_sort_keys(const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA, int dA_rank,
-                 int64_t nx, int64_t n, int negate, unsigned long long* __restrict__ keys, double* __restrict__ vals,
+                 int64_t nx, int64_t n, int negate, K* __restrict__ keys, double* __restrict__ vals,
                  int64_t mask_stride, int64_t dA_stride)
 {
     const size_t so = (size_t)blockIdx.y * n;
@@ -53,19 +73,20 @@ void k_sort_keys(const TQ* __restrict__ q, const TM* __restrict__ mask, const do
         const double v = negate ? -(double)q[i] : (double)q[i];
         const bool ok = (v == v) && (!mask || mask[i] == (TM)1);
         const double w = (dA_rank == XC_DA_ROW) ? dA[i / nx] : (dA_rank == XC_DA_PLANE ? dA[i] : 1.0);
-        keys[i] = ok ? f64_to_key(v) : KEY_INVALID;        // invalid cells sort to the end
+        keys[i] = ok ? KeyTraits<K>::encode(v) : KeyTraits<K>::invalid();   // invalid cells sort to the end
         vals[i] = ok ? w : 0.0;
     }
 }
 
 // number of valid cells = position of the first KEY_INVALID in the sorted keys (one thread:
 // a per-wave atomic counter in k_sort_keys serialised 100k atomics on one address = 1.1 ms)
-__global__ void k_count_valid(const unsigned long long* __restrict__ keys, int64_t n, unsigned* __restrict__ nvalid)
+template <typename K>
+__global__ void k_count_valid(const K* __restrict__ keys, int64_t n, unsigned* __restrict__ nvalid)
 {
     if (threadIdx.x != 0) return;
     keys += (size_t)blockIdx.x * n; nvalid += blockIdx.x;
     int64_t lo = 0, hi = n;                        // first index with keys[idx] == KEY_INVALID
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < KEY_INVALID) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < KeyTraits<K>::invalid()) lo = mid + 1; else hi = mid; }
     *nvalid = (unsigned)lo;
 }
 
@@ -85,35 +106,43 @@ __device__ __forceinline__ unsigned long long digit_peers(unsigned d, unsigned l
 // Counting needs no ranks: one returnless ds_add_u32 per key on per-wave counters (the ballot ranking
 // of the scatter costs ~60 VALU instructions per 64 keys and made this kernel ALU-bound); a round
 // whose 64 digits are all equal -- sorted or constant data -- is added once by one lane.
+template <typename K>
 __global__ __launch_bounds__(256)
-void k_radix_hist(const unsigned long long* __restrict__ keys, int64_t n, int shift, int ntiles,
-                  unsigned* __restrict__ hist)
+void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, unsigned* __restrict__ hist)
 {
     __shared__ unsigned s_cnt[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = blockIdx.x;
     keys += (size_t)blockIdx.y * n; hist += (size_t)blockIdx.y * 256 * ntiles;
     for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = 0;
-    // counting does not care about the order inside the tile: 16-byte loads, two keys per lane
+    // counting does not care about the order inside the tile: 16-byte loads, KPL keys per lane and load
+    constexpr int KPL = 16 / (int)sizeof(K);
+    struct alignas(16) Pack { K k[KPL]; };
     const int64_t base = t * BTILE + (int64_t)wave * TILE;
-    unsigned long long kreg[TILE_ROUNDS];                  // all loads of the wave's part in flight at once
+    K kreg[TILE_ROUNDS];                                   // all loads of the wave's part in flight at once
     const bool full = base + TILE <= n;
     if (full) {
-        const ulonglong2* k2 = (const ulonglong2*)(keys + base);      // workspace is 256-byte aligned, base a multiple of 1024
+        const Pack* kp = (const Pack*)(keys + base);       // workspace is 256-byte aligned, base a multiple of 1024
 #pragma unroll
-        for (int r = 0; r < TILE_ROUNDS / 2; ++r) { const ulonglong2 u = k2[r * 64 + lane]; kreg[2 * r] = u.x; kreg[2 * r + 1] = u.y; }
+        for (int r = 0; r < TILE_ROUNDS / KPL; ++r) {
+            const Pack u = kp[r * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) kreg[KPL * r + c] = u.k[c];
+        }
     } else {
 #pragma unroll
-        for (int r = 0; r < TILE_ROUNDS / 2; ++r) {
-            const int64_t i = base + (r * 64 + lane) * 2;
-            kreg[2 * r] = i < n ? keys[i] : 0ull; kreg[2 * r + 1] = i + 1 < n ? keys[i + 1] : 0ull;
-        }
+        for (int r = 0; r < TILE_ROUNDS / KPL; ++r)
+#pragma unroll
+            for (int c = 0; c < KPL; ++c) {
+                const int64_t i = base + (int64_t)(r * 64 + lane) * KPL + c;
+                kreg[KPL * r + c] = i < n ? keys[i] : (K)0;
+            }
     }
 #pragma unroll
     for (int r = 0; r < TILE_ROUNDS; ++r) {
-        const int64_t i = base + ((r >> 1) * 64 + lane) * 2 + (r & 1);
+        const int64_t i = base + (int64_t)((r / KPL) * 64 + lane) * KPL + (r % KPL);
         const bool valid = full || i < n;
-        const unsigned d = (unsigned)((kreg[r] >> shift) & 255ull);
+        const unsigned d = (unsigned)((kreg[r] >> shift) & (K)255);
         const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
         if (full && __ballot(d != d0) == 0ull) { if (lane == 0) atomicAdd(&s_cnt[wave][d0], 64u); }
         else if (valid) atomicAdd(&s_cnt[wave][d], 1u);
@@ -155,13 +184,14 @@ void k_radix_scan_rows(unsigned* __restrict__ hist, int ntiles, unsigned* __rest
 // (stable: wave-major, then round, then lane = element order), then written out position by position:
 // consecutive LDS positions with the same digit go to consecutive global addresses, so the stores
 // of a wave cover runs of ~BTILE/256 elements instead of 64 unrelated 8-byte targets.
+template <typename K>
 __global__ __launch_bounds__(256)
-void k_radix_scatter(const unsigned long long* __restrict__ kin, const double* __restrict__ vin,
-                     unsigned long long* __restrict__ kout, double* __restrict__ vout, int64_t n, int shift,
+void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
+                     K* __restrict__ kout, double* __restrict__ vout, int64_t n, int shift,
                      int ntiles, const unsigned* __restrict__ hist, const unsigned* __restrict__ totals)
 {
     extern __shared__ unsigned long long s_dyn[];
-    unsigned long long* s_k = s_dyn;                           // [BTILE] staging: keys first, then the payload
+    K* s_k = (K*)s_dyn;                                        // [BTILE] staging: keys first, then the payload
     double* s_v = (double*)s_dyn;
     unsigned* s_cnt = (unsigned*)(s_dyn + BTILE);              // [4][256] per-wave digit counts -> start offsets
     unsigned* s_gbase = s_cnt + 4 * 256;                       // [256] global position minus tile-local position
@@ -173,13 +203,13 @@ void k_radix_scatter(const unsigned long long* __restrict__ kin, const double* _
     for (int d = lane; d < 256; d += 64) s_cnt[wave * 256 + d] = 0;
     const int64_t tbase = t * BTILE;
     const int64_t base = tbase + (int64_t)wave * TILE;
-    unsigned long long kreg[TILE_ROUNDS];                      // the whole part's loads in flight at once
+    K kreg[TILE_ROUNDS];                                       // the whole part's loads in flight at once
     double vreg[TILE_ROUNDS];
     unsigned short lrank[TILE_ROUNDS];
 #pragma unroll
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
-        kreg[r] = i < n ? kin[i] : 0ull;
+        kreg[r] = i < n ? kin[i] : (K)0;
         vreg[r] = i < n ? vin[i] : 0.0;
     }
     // rank of every element among the wave's elements with the same digit
@@ -187,7 +217,7 @@ void k_radix_scatter(const unsigned long long* __restrict__ kin, const double* _
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
         const bool valid = i < n;
-        const unsigned d = valid ? (unsigned)((kreg[r] >> shift) & 255ull) : 0u;
+        const unsigned d = valid ? (unsigned)((kreg[r] >> shift) & (K)255) : 0u;
         const unsigned long long peers = digit_peers(d, __ballot(valid));
         const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
         unsigned pos = 0;
@@ -216,7 +246,7 @@ void k_radix_scatter(const unsigned long long* __restrict__ kin, const double* _
 #pragma unroll
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
-        const unsigned d = (unsigned)((kreg[r] >> shift) & 255ull);
+        const unsigned d = (unsigned)((kreg[r] >> shift) & (K)255);
         lrank[r] = (unsigned short)(s_cnt[wave * 256 + d] + lrank[r]);      // tile-local position
         if (i < n) s_k[lrank[r]] = kreg[r];
     }
@@ -228,8 +258,8 @@ void k_radix_scatter(const unsigned long long* __restrict__ kin, const double* _
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int p = r * 256 + tid;
         if (p < cnt) {
-            const unsigned long long key = s_k[p];
-            gpos[r] = s_gbase[(unsigned)((key >> shift) & 255ull)] + (unsigned)p;
+            const K key = s_k[p];
+            gpos[r] = s_gbase[(unsigned)((key >> shift) & (K)255)] + (unsigned)p;
             kout[gpos[r]] = key;
         }
     }
@@ -328,17 +358,19 @@ void k_scan_bsums(double* __restrict__ bsum, int nb)        // exclusive scan in
     }
 }
 
+template <typename K>
 __global__ __launch_bounds__(256)
-void k_unkey(const unsigned long long* __restrict__ keys, int64_t n, double* __restrict__ out)
+void k_unkey(const K* __restrict__ keys, int64_t n, double* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     keys += (size_t)blockIdx.y * n; out += (size_t)blockIdx.y * n;
-    if (i < n) out[i] = key_to_f64(keys[i]);
+    if (i < n) out[i] = KeyTraits<K>::decode(keys[i]);
 }
 
 // Q_exact(A_j) = q_sorted[min(searchsorted(acum[:nvalid], A_j, 'right'), nvalid-1)]
+template <typename K>
 __global__ __launch_bounds__(256)
-void k_profile(const unsigned long long* __restrict__ keys, const double* __restrict__ acum,
+void k_profile(const K* __restrict__ keys, const double* __restrict__ acum,
                const unsigned* __restrict__ nvalid, const double* __restrict__ targets, int J,
                double* __restrict__ Q, int64_t ncell)
 {
@@ -351,12 +383,13 @@ void k_profile(const unsigned long long* __restrict__ keys, const double* __rest
     int64_t lo = 0, hi = n;                        // first index with acum[idx] > a
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (acum[mid] <= a) lo = mid + 1; else hi = mid; }
     if (lo > n - 1) lo = n - 1;
-    Q[j] = key_to_f64(keys[lo]);
+    Q[j] = KeyTraits<K>::decode(keys[lo]);
 }
 
 // BPE-like integral: sum_i q_i * z*(A_i - dA_i/2) * dA_i with z* = np.interp(A, tbl, coord)
+template <typename K>
 __global__ __launch_bounds__(256)
-void k_bpe(const unsigned long long* __restrict__ keys, const double* __restrict__ vals,
+void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
            const double* __restrict__ acum, const unsigned* __restrict__ nvalid,
            const double* __restrict__ tbl, const double* __restrict__ coord, int ntbl, double* __restrict__ part,
            int64_t ncell)
@@ -378,7 +411,7 @@ void k_bpe(const unsigned long long* __restrict__ keys, const double* __restrict
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a >= X(mid)) lo = mid; else hi = mid; }
             z = F(lo) + (F(lo + 1) - F(lo)) * (a - X(lo)) / (X(lo + 1) - X(lo));
         }
-        sum += key_to_f64(keys[i]) * z * vals[i];
+        sum += KeyTraits<K>::decode(keys[i]) * z * vals[i];
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     __shared__ double s[4];
@@ -405,23 +438,21 @@ size_t sort_workspace_bytes(int64_t n, int64_t nslab)
     return 4 * al(S * n * 8) + al(S * 256 * ntiles * 4) + al(S * 256 * 4) + al(S * 4) + al(S * nb * 8) + al(S * BPE_BLOCKS * 8);
 }
 
-int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
-                        const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
-                        const double* targets, int J, const double* tbl, const double* coord, int ntbl,
-                        void* workspace, double* out_Q, double* out_qsorted, double* out_acum,
-                        unsigned* out_nvalid, double* out_bpe)
+template <typename TQ, typename K>
+static int sort_profile_typed(xc_ctx* ctx, const TQ* q, const void* mask, int mask_dtype, int mask_per_slab,
+                              const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
+                              const double* targets, int J, const double* tbl, const double* coord, int ntbl,
+                              void* workspace, double* out_Q, double* out_qsorted, double* out_acum,
+                              unsigned* out_nvalid, double* out_bpe)
 {
     const int64_t n = ny * nx;
-    if (!q || !workspace || n < 1 || n > 0x7fffffff || nslab < 1 || nslab > 65535) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad arguments");
-    if (dA_rank < XC_DA_NONE || dA_rank > XC_DA_SLAB) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad dA_rank");
-    if (dA_rank != XC_DA_NONE && !dA) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA is NULL");
     const int64_t ntiles = (n + BTILE - 1) / BTILE;
     const int nb = (int)((n + 2047) / 2048);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t S = (size_t)nslab;
     char* w = (char*)workspace;
-    unsigned long long* kA = (unsigned long long*)w; w += al(S * n * 8);
-    unsigned long long* kB = (unsigned long long*)w; w += al(S * n * 8);
+    K* kA = (K*)w; w += al(S * n * 8);                      // (sized for 64-bit keys either way)
+    K* kB = (K*)w; w += al(S * n * 8);
     double* vA = (double*)w; w += al(S * n * 8);
     double* vB = (double*)w; w += al(S * n * 8);
     unsigned* hist = (unsigned*)w; w += al(S * 256 * ntiles * 4);
@@ -435,32 +466,30 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
     // a per-slab dA plane is the PLANE case with a slab stride
     const int krank = dA_rank == XC_DA_SLAB ? XC_DA_PLANE : dA_rank;
     const int64_t dstride = dA_rank == XC_DA_SLAB ? n : 0, mstride = (mask && mask_per_slab) ? n : 0;
-#define XC_KEYS(TQ, TM) hipLaunchKernelGGL((k_sort_keys<TQ, TM>), dim3(gb, ns), dim3(256), 0, ctx->stream, (const TQ*)q, \
-        (const TM*)mask, dA, krank, nx, n, negate, kA, vA, mstride, dstride)
-    const bool m32 = mask && mask_dtype == XC_F32;
-    if (q_dtype == XC_F64) { if (m32) XC_KEYS(double, float); else XC_KEYS(double, double); }
-    else if (q_dtype == XC_F32) { if (m32) XC_KEYS(float, float); else XC_KEYS(float, double); }
-    else return fail(ctx, XC_EBADARG, "xc_sort_profile: q_dtype must be XC_F32 or XC_F64");
-#undef XC_KEYS
+    if (mask && mask_dtype == XC_F32)
+        hipLaunchKernelGGL((k_sort_keys<TQ, float, K>), dim3(gb, ns), dim3(256), 0, ctx->stream, q, (const float*)mask, dA, krank,
+                           nx, n, negate, kA, vA, mstride, dstride);
+    else
+        hipLaunchKernelGGL((k_sort_keys<TQ, double, K>), dim3(gb, ns), dim3(256), 0, ctx->stream, q, (const double*)mask, dA, krank,
+                           nx, n, negate, kA, vA, mstride, dstride);
     XC_HIP(ctx, hipGetLastError());
     const unsigned gt = (unsigned)ntiles;
     const size_t sc_lds = (size_t)BTILE * 8 + (4 * 256 + 256 + 8) * sizeof(unsigned);
-    XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds));
-    unsigned long long *kin = kA, *kout = kB;
+    XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_scatter<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds));
+    K *kin = kA, *kout = kB;
     double *vin = vA, *vout = vB;
-    // a float32 tracer widened to float64 has 29 zero mantissa bits: the digits of passes 0-2 are all zero
-    for (int pass = (q_dtype == XC_F32 ? 3 : 0); pass < 8; ++pass) {
+    for (int pass = 0; pass < KeyTraits<K>::passes; ++pass) {
         const int shift = pass * 8;
-        hipLaunchKernelGGL(k_radix_hist, dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist);
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist);
         hipLaunchKernelGGL(k_radix_scan_rows, dim3(256, ns), dim3(1024), 0, ctx->stream, hist, (int)ntiles, totals);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
                            (int)ntiles, hist, totals);
         XC_HIP(ctx, hipGetLastError());
-        unsigned long long* tk = kin; kin = kout; kout = tk;
+        K* tk = kin; kin = kout; kout = tk;
         double* tv = vin; vin = vout; vout = tv;
     }
-    // sorted data are in kin / vin (kA / vA after 8 passes, kB / vB after 5)
-    hipLaunchKernelGGL(k_count_valid, dim3(ns), dim3(64), 0, ctx->stream, kin, n, nvalid);
+    // an even number of passes: the sorted data are back in kA / vA (= kin / vin)
+    hipLaunchKernelGGL(k_count_valid<K>, dim3(ns), dim3(64), 0, ctx->stream, kin, n, nvalid);
     double* acum = vout;                                   // reuse the idle payload buffer
     hipLaunchKernelGGL(k_scan_local<false>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(ns), dim3(1024), 0, ctx->stream, bsum, nb);
@@ -468,18 +497,37 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
     XC_HIP(ctx, hipGetLastError());
     if (out_Q && J > 0) {
         if (!targets) return fail(ctx, XC_EBADARG, "xc_sort_profile: targets is NULL");
-        hipLaunchKernelGGL(k_profile, dim3((J + 255) / 256, ns), dim3(256), 0, ctx->stream, kin, acum, nvalid, targets, J, out_Q, n);
+        hipLaunchKernelGGL(k_profile<K>, dim3((J + 255) / 256, ns), dim3(256), 0, ctx->stream, kin, acum, nvalid, targets, J, out_Q, n);
     }
     if (out_bpe) {
         if (!tbl || !coord || ntbl < 2) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
-        hipLaunchKernelGGL(k_bpe, dim3(BPE_BLOCKS, ns), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts, n);
+        hipLaunchKernelGGL(k_bpe<K>, dim3(BPE_BLOCKS, ns), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts, n);
         hipLaunchKernelGGL(k_sum_parts, dim3(ns), dim3(64), 0, ctx->stream, parts, BPE_BLOCKS, out_bpe);
     }
-    if (out_qsorted) hipLaunchKernelGGL(k_unkey, dim3(gb, ns), dim3(256), 0, ctx->stream, kin, n, out_qsorted);
+    if (out_qsorted) hipLaunchKernelGGL(k_unkey<K>, dim3(gb, ns), dim3(256), 0, ctx->stream, kin, n, out_qsorted);
     if (out_acum) XC_HIP(ctx, hipMemcpyAsync(out_acum, acum, S * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (out_nvalid) XC_HIP(ctx, hipMemcpyAsync(out_nvalid, nvalid, S * sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
+}
+
+int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
+                        const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
+                        const double* targets, int J, const double* tbl, const double* coord, int ntbl,
+                        void* workspace, double* out_Q, double* out_qsorted, double* out_acum,
+                        unsigned* out_nvalid, double* out_bpe)
+{
+    const int64_t n = ny * nx;
+    if (!q || !workspace || n < 1 || n > 0x7fffffff || nslab < 1 || nslab > 65535) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad arguments");
+    if (dA_rank < XC_DA_NONE || dA_rank > XC_DA_SLAB) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad dA_rank");
+    if (dA_rank != XC_DA_NONE && !dA) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA is NULL");
+    if (q_dtype == XC_F64)
+        return sort_profile_typed<double, u64>(ctx, (const double*)q, mask, mask_dtype, mask_per_slab, dA, dA_rank, nslab, ny, nx, negate,
+                                               targets, J, tbl, coord, ntbl, workspace, out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
+    if (q_dtype == XC_F32)      // the order of floats is the order of their 32-bit keys: 4 passes of 4-byte keys
+        return sort_profile_typed<float, u32>(ctx, (const float*)q, mask, mask_dtype, mask_per_slab, dA, dA_rank, nslab, ny, nx, negate,
+                                              targets, J, tbl, coord, ntbl, workspace, out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
+    return fail(ctx, XC_EBADARG, "xc_sort_profile: q_dtype must be XC_F32 or XC_F64");
 }
 
 }  // namespace xc
