@@ -727,7 +727,8 @@ def test_misaligned_device_pointers_fall_back(ctx):
 
 # ---------------------------------------------------------------- K9 box-counting contour crossing
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
-@pytest.mark.parametrize('stride,mode', [(1, 'edge'), (2, 'wrap'), (3, 'constant'), (2, 'reflect'), (5, 'symmetric')])
+@pytest.mark.parametrize('stride,mode', [(1, 'edge'), (2, 'wrap'), (3, 'constant'), (2, 'reflect'), (5, 'symmetric'),
+                                         (7, 'wrap'), (13, 'edge'), (31, 'constant'), (63, 'reflect'), (64, 'edge')])
 def test_crossing_random_vs_oracle(ctx, dt, stride, mode):
     """xc_crossing against the oracle: box counts exact, lengths to summation order; NaN cells,
     NaN / negative areas, per-slab contours, padding modes, Jn < In and Jn > In shapes."""

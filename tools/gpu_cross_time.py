@@ -30,7 +30,8 @@ ctr, _, _ = ctx.levels(mm, np.float64, N, True, np.float64)
 ctr_b = ctx.to_device(ctr)
 out_l, out_c = ctx.alloc(S * N * 8), ctx.alloc(S * N * 8)
 e0, e1 = ctx.event(), ctx.event()
-for stride, pad in ((1, 1), (2, 2), (4, 4)):
+STRIDES = [int(t) for t in os.environ.get('XC_STRIDES', '1,2,4').split(',')]
+for stride, pad in [(t, t) for t in STRIDES]:
     for full, want_cnt in ((0, 1), (1, 1), (1, 0)):
         def run():
             ctx._check(ctx.lib.xc_crossing_dev(ctx.handle, q.ptr, nat.XC_F64, S, NY, NX, pad, nat.XC_PAD_WRAP, ctr_b.ptr, N, 1,

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(CROSS_TPB)
 void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                 const double* __restrict__ contours, int N, int contours_per_slab,
                 const TA* __restrict__ area, int area_per_slab,
-                int s_rt, int64_t nbj, int64_t nbi, int64_t ntj, int64_t nti, int bps, int ncopy, int np,
+                int s_rt, int64_t nbj, int64_t nbi, int64_t ntj, int64_t nti, int bps, int ncopy, int np, int rbox,
                 double* __restrict__ part_len, unsigned* __restrict__ part_cnt)
 {
     extern __shared__ double sm[];
@@ -154,6 +154,53 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
 
     for (int64_t tile = blockIdx.x; tile < ntj * nti; tile += bps) {
         const int64_t tj = tile / nti, ti = tile - tj * nti;
+        if constexpr (S == -1) {
+            // strides 2..63: lanes run along the FINE columns (coalesced, every cell loaded once per tile apart from
+            // the span overlap); a lane first folds the s+1 corner rows of a box row vertically, then a sliding-window
+            // min / max over s+1 neighbouring lanes (log2 shuffle steps) gives the box extrema at the lanes l % s == 0.
+            // A wave spans nbw = 63 / s boxes (their last corner column is lane nbw*s <= 63).
+            const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int nbw = 63 / s;
+            const int64_t i0 = (ti * 4 + wave) * nbw;                  // first box of this wave's span
+            if (i0 >= nbi) continue;                                   // wave-uniform; no block barrier in the loop
+            const int64_t j0 = tj * rbox, j1 = (j0 + rbox < nbj) ? j0 + rbox : nbj;
+            int64_t c = i0 * s + lane;                                 // padded fine column of this lane
+            if (c > nbi * s) c = nbi * s;                              // (lanes beyond the last corner column feed no valid box)
+            bool pn = false;
+            if (c >= nx) { c = pad_source(c, nx, pad_mode); pn = c < 0; if (pn) c = 0; }
+            const int bl = lane / s;
+            const int64_t i = i0 + bl;
+            const bool box = (lane - bl * s == 0) && bl < nbw && i < nbi;
+            int64_t ac = i < nbi ? i : nbi - 1;
+            bool nanfill = false;
+            if (ac >= nx) { ac = pad_source(ac, nx, pad_mode); nanfill = ac < 0; if (nanfill) ac = 0; }
+            const int w = s + 1;
+            double cmn, cmx;
+            { const double x = pn ? qnan : (double)qs[(size_t)(j0 * s) * nx + c]; cmn = fmin(inf, x); cmx = fmax(-inf, x); }
+            for (int64_t j = j0; j < j1; ++j) {
+                double vmn = cmn, vmx = cmx;
+                for (int r0 = 1; r0 <= s; r0 += 8) {                   // up to 8 fine rows of loads in flight
+                    TQ v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = (r0 + k <= s) ? r0 + k : s;
+                        v[k] = qs[(size_t)(j * s + r) * nx + c];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (r0 + k > s) break;                         // wave-uniform
+                        const double x = pn ? qnan : (double)v[k];
+                        vmn = fmin(vmn, x); vmx = fmax(vmx, x);
+                        if (r0 + k == s) { cmn = fmin(inf, x); cmx = fmax(-inf, x); }     // shared with the next box row
+                    }
+                }
+                int P = 1;                                             // sliding window of w lanes: doubling, then one overlap step
+                for (; 2 * P <= w; P *= 2) { vmn = fmin(vmn, __shfl_down(vmn, P)); vmx = fmax(vmx, __shfl_down(vmx, P)); }
+                if (w != P) { vmn = fmin(vmn, __shfl_down(vmn, w - P)); vmx = fmax(vmx, __shfl_down(vmx, w - P)); }
+                if (box) box_done<TA, CNT>(s_cx, N, vmn, vmx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, g, my_len, my_cnt);
+            }
+            continue;
+        }
         if constexpr (S == 1) {
             // stride 1: a wave covers 63 boxes with 64 corner columns -- every lane loads ONE value per row and gets
             // its right neighbour from the next lane (DPP), lane 63 only supplies the last corner column
@@ -212,7 +259,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                 mn = fmin(mn, cmn); mx = fmax(mx, cmx);
                 box_done<TA, CNT>(s_cx, N, mn, mx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, g, my_len, my_cnt);
             }
-        } else {
+        } else if constexpr (S > 0) {
             constexpr int B = S == 1 ? 8 : S == 2 ? 4 : S == 3 ? 2 : 1;     // boxes per load batch
             int64_t src[S + 1]; bool pnan[S + 1];      // source columns of the S+1 corner columns (X padding resolved once)
 #pragma unroll
@@ -309,8 +356,15 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
     }
     // the last corner row / column every box touches must exist in the padded slab
     if (nbj * stride > ny - 1 || nbi * stride > nx + pad_x - 1) return fail(ctx, XC_EBADARG, "xc_crossing: boxes leave the padded slab");
+    // stride 1: DPP path; 2..5: one box per thread (loads of several boxes batched for 2 and 4); 6..63: lanes along
+    // the fine columns (measured on cfg2 slabs: 25-35 us flat, where one box per thread needs 36 / 118 / 538 us at
+    // strides 8 / 16 / 32 but only 16 / 18 / 14 us at 2 / 3 / 4); larger: one box per thread again
+    const bool cols = stride >= 6 && stride <= 63;
+    const int nbw = cols ? 63 / stride : 0;
+    const int rbox = cols ? (64 / stride > 1 ? 64 / stride : 1) : CROSS_RB;
     const int64_t tw = stride == 1 ? CROSS_W1 : CROSS_TPB;
-    const int64_t ntj = (nbj + CROSS_RB - 1) / CROSS_RB, nti = (nbi + tw - 1) / tw;
+    const int64_t ntj = (nbj + rbox - 1) / rbox;
+    const int64_t nti = cols ? ((nbi + nbw - 1) / nbw + 3) / 4 : (nbi + tw - 1) / tw;
     int64_t bps = 2048 / nslab; if (bps < 8) bps = 8; if (bps > ntj * nti) bps = ntj * nti;
     const size_t pl = (size_t)nslab * bps * N * 8, pc = (size_t)nslab * bps * N * 4;
     {
@@ -324,9 +378,10 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
         if (lds > 64 * 1024) XC_HIP(ctx, hipFuncSetAttribute((const void*)k_crossing<TQ_, TA_, C_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_crossing<TQ_, TA_, C_, S_>), grid, dim3(CROSS_TPB), lds, ctx->stream, (const TQ_*)q, ny, nx, pad_mode, contours, N, \
                            contours_per_slab, (const TA_*)area, area_per_slab, stride, nbj, nbi, ntj, nti, (int)bps, \
-                           ncopy, np, part_len, part_cnt); } while (0)
-#define XC_CROSS3(TQ_, TA_, C_) do { switch (stride) { case 1: XC_CROSS4(TQ_, TA_, C_, 1); break; case 2: XC_CROSS4(TQ_, TA_, C_, 2); break; \
-        case 4: XC_CROSS4(TQ_, TA_, C_, 4); break; default: XC_CROSS4(TQ_, TA_, C_, 0); } } while (0)
+                           ncopy, np, rbox, part_len, part_cnt); } while (0)
+#define XC_CROSS3(TQ_, TA_, C_) do { if (stride == 1) XC_CROSS4(TQ_, TA_, C_, 1); else if (stride == 2) XC_CROSS4(TQ_, TA_, C_, 2); \
+        else if (stride == 4) XC_CROSS4(TQ_, TA_, C_, 4); else if (cols) XC_CROSS4(TQ_, TA_, C_, -1); \
+        else XC_CROSS4(TQ_, TA_, C_, 0); } while (0)
 #define XC_CROSS2(TQ_, TA_) do { if (out_cnt) XC_CROSS3(TQ_, TA_, true); else XC_CROSS3(TQ_, TA_, false); } while (0)
     if (q_dtype == XC_F64) { if (area_dtype == XC_F64) XC_CROSS2(double, double); else XC_CROSS2(double, float); }
     else { if (area_dtype == XC_F64) XC_CROSS2(float, double); else XC_CROSS2(float, float); }
