@@ -432,6 +432,30 @@ class Context(object):
         if pad_mode not in PAD_MODES:
             raise XContourHipError(XC_EBADARG, 'pad mode must be one of %s' % sorted(PAD_MODES))
         N = contours.shape[-1]
+        if np.ndim(stride) > 0:
+            # several strides on the same padded slab: one upload, one device call per stride
+            # (`stride` may be a list; returns lists of results in the same order)
+            for t in stride:
+                if int(t) < 1:
+                    raise XContourHipError(XC_EBADARG, 'stride must be >= 1')
+            # the host entry point validates the contours; the device one trusts its caller
+            c2 = contours.reshape(-1, N)
+            if np.isnan(c2).any() or (np.diff(c2, axis=1) < 0).any():
+                raise XContourHipError(XC_EEDGES, 'xc_crossing: contours must be ascending without NaN')
+            bufs = [self.to_device(q), self.to_device(contours), self.to_device(area),
+                    self.alloc(nslab * N * 8), self.alloc(nslab * N * 8)]
+            try:
+                out = []
+                for t in stride:
+                    self._check(self.lib.xc_crossing_dev(self.handle, bufs[0].ptr, dtype_code(q.dtype), nslab, ny, nx, int(pad_x),
+                                                         PAD_MODES[pad_mode], bufs[1].ptr, N, 1 if per_slab else 0,
+                                                         bufs[2].ptr, dtype_code(area.dtype), 1 if area.ndim == 3 else 0,
+                                                         int(t), 1 if full_width else 0, bufs[3].ptr, bufs[4].ptr))
+                    out.append((bufs[3].download((nslab, N), np.float64), bufs[4].download((nslab, N), np.uint64)))
+            finally:
+                for b in bufs:
+                    b.free()
+            return out
         lens = np.empty((nslab, N), dtype=np.float64)
         cnts = np.empty((nslab, N), dtype=np.uint64)
         self._check(self.lib.xc_crossing(self.handle, _ptr(q), dtype_code(q.dtype), nslab, ny, nx, int(pad_x),

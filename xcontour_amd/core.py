@@ -546,9 +546,9 @@ class Contour2D(object):
         if ccoord is None:
             ccoord = np.arange(b.shape[1]).astype(self.dtype)
         re = []
-        for strd in strides:
-            lens, _ = self.ctx.crossing(q, bs, area, stride=strd, pad_x=maxStride if has_x else 0,
-                                        pad_mode=mode, full_width=full_width)
+        results = self.ctx.crossing(q, bs, area, stride=strides, pad_x=maxStride if has_x else 0,
+                                    pad_mode=mode, full_width=full_width)      # one upload for all strides
+        for lens, _ in results:
             out = np.empty_like(lens)
             np.put_along_axis(out, order, lens, axis=1)
             re.append(self._wrap_contour(out.astype(self.dtype), lead, lshape, coords, None, self.tracer, ccoord))
