@@ -47,7 +47,10 @@ int ensure_arena(xc_ctx* ctx, size_t bytes);
 int ensure_ones(xc_ctx* ctx, size_t n);
 
 // ---------------------------------------------------------------- launch geometry
-constexpr int kMinmaxBlocks = 1024;   // partial min/max pairs per slab
+constexpr int kMinmaxBlocks = 1024;   // partial min/max pairs per slab (upper bound, see minmax_blocks)
+// blocks per slab of the K1 pass: at least ~8192 cells per block, so that a stack of many small slabs is not
+// shredded into half a million 16-cell blocks (512 slabs of 90x180: 70 -> ~2 ps per cell)
+inline int minmax_blocks(int64_t ncell) { const int64_t p = (ncell + 8191) / 8192; return (int)(p < 1 ? 1 : (p > kMinmaxBlocks ? kMinmaxBlocks : p)); }
 constexpr int kHistThreads  = 1024;   // 16 waves: one block per CU (LDS-bound)
 constexpr int kMaxCopies    = 16;     // lane-privatised LDS histogram copies
 constexpr size_t kLdsBudget = 150 * 1024;
@@ -118,7 +121,7 @@ struct FinalArgs {
 
 // ---------------------------------------------------------------- launchers (defined in the .hip files)
 int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part);
-int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, double* out);
+int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, int P, double* out);
 int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
                   int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status);
 int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int nbin, int nch,

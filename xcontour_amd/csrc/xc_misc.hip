@@ -401,7 +401,7 @@ int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab
 {
     if (!q || !part || nslab < 1 || ncell < 1) return fail(ctx, XC_EBADARG, "xc_minmax: bad arguments");
     if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_minmax: at most 65535 slabs per launch");
-    dim3 grid(kMinmaxBlocks, (unsigned)nslab);
+    dim3 grid((unsigned)minmax_blocks(ncell), (unsigned)nslab);      // partials: [nslab][minmax_blocks(ncell)][2]
     if (q_dtype == XC_F64)
         hipLaunchKernelGGL(k_minmax_partial<double>, grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part);
     else if (q_dtype == XC_F32)
@@ -411,9 +411,9 @@ int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab
     return XC_OK;
 }
 
-int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, double* out)
+int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, int P, double* out)
 {
-    hipLaunchKernelGGL(k_minmax_final, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, part, kMinmaxBlocks, out);
+    hipLaunchKernelGGL(k_minmax_final, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, part, P, out);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
 }
