@@ -52,13 +52,15 @@ void k_lwa_prep(const T* __restrict__ q, const double* __restrict__ Q, const dou
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double* ri = rowinfo + ((size_t)slab * (ny + LWA_RB) + y) * 2;
     if (y >= ny) {                                        // padding rows are never inside a band
-        if (threadIdx.x == 0) { ri[0] = coord[ny - 1]; ri[1] = __longlong_as_double(0x7ff8000000000000LL); }
+        if (threadIdx.x == 0 && blockIdx.z == 0) { ri[0] = coord[ny - 1]; ri[1] = __longlong_as_double(0x7ff8000000000000LL); }
         return;
     }
-    if (threadIdx.x == 0) { ri[0] = coord[y]; ri[1] = Q[(size_t)slab * ny + y]; }
+    if (threadIdx.x == 0 && blockIdx.z == 0) { ri[0] = coord[y]; ri[1] = Q[(size_t)slab * ny + y]; }
     const T* row = q + ((size_t)slab * ny + y) * nx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t st = wave; st < nstrip; st += 4) {
+    // blockIdx.z: chunk of 64 strips (a very wide, short plane would otherwise walk all its strips in one block)
+    const int64_t st1 = ((int64_t)blockIdx.z + 1) * 64 < nstrip ? ((int64_t)blockIdx.z + 1) * 64 : nstrip;
+    for (int64_t st = (int64_t)blockIdx.z * 64 + wave; st < st1; st += 4) {
         const int64_t x = st * 64 + lane;
         double mn = inf, mx = -inf;
         if (x < nx) {
@@ -72,7 +74,7 @@ void k_lwa_prep(const T* __restrict__ q, const double* __restrict__ Q, const dou
             sm[0] = mn; sm[1] = mx;
         }
     }
-    if (slab == 0 && dA_rank == XC_DA_ROW && threadIdx.x == 0) wei[y] = __ddiv_rn(dA[y], dA_max);
+    if (slab == 0 && dA_rank == XC_DA_ROW && threadIdx.x == 0 && blockIdx.z == 0) wei[y] = __ddiv_rn(dA[y], dA_max);
 }
 
 // V2: cal_local_wave_activity2 (core.py:802-905): qe = q[row j] - Q[all rows], opposite sign convention.
@@ -216,7 +218,8 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     double* wei = (double*)ctx->scratch;
     double* rowinfo = wei + nw;
     double* stripmm = rowinfo + (size_t)nslab * (ny + LWA_RB) * 2;
-    const dim3 gp((unsigned)(ny + LWA_RB), (unsigned)nslab);
+    if ((nstrip + 63) / 64 > 65535) return fail(ctx, XC_EBADARG, "xc_lwa: nx too large");
+    const dim3 gp((unsigned)(ny + LWA_RB), (unsigned)nslab, (unsigned)((nstrip + 63) / 64));
     if (q_dtype == XC_F64)
         hipLaunchKernelGGL(k_lwa_prep<double>, gp, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, nstrip, wei, rowinfo, stripmm);
     else if (q_dtype == XC_F32)
