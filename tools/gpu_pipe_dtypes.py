@@ -1,0 +1,25 @@
+import sys, numpy as np, time
+sys.path.insert(0,'/root/repo')
+from xcontour_amd import _native as nat
+from xcontour_amd.pipeline import KeffPlan
+from xcontour_amd.utils import cell_area, table_from_rowsums
+ctx = nat.Context(0)
+NY, NX, N, B = 1801, 3600, 201, 32
+lat = np.linspace(-90, 90, NY); lon = np.arange(NX) * 0.1
+dA = cell_area(lat, lon)
+tbl = table_from_rowsums(ctx.rowsum(None, dA, NY, NX), True)
+e0, e1 = ctx.event(), ctx.event()
+for dt, cdt in ((np.float64, np.float64), (np.float32, np.float32), (np.float32, np.float64)):
+    plan = KeffPlan(ctx, 2 * B, NY, NX, N, dt, cdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=True, lt=True, out_slabs=B)
+    plan.synth(lat, lon, 1, 0)
+    for chain in (False, True):
+        def step(k):
+            s0 = (k % 2) * B; nxt = ((k + 1) % 2) * B
+            plan.run_range(0, s0, B, nxt if chain else None, out_s0=0)
+        for k in range(4): step(k)
+        ctx.sync(); ctx.record(e0)
+        for k in range(20): step(k)
+        ctx.record(e1)
+        ms = ctx.elapsed_ms(e0, e1) / 20
+        print(np.dtype(dt).name, 'ctr', np.dtype(cdt).name, 'chain' if chain else 'plain', '%.1f us/slab' % (ms / B * 1e3), flush=True)
+    plan.free()
