@@ -1029,3 +1029,24 @@ def test_errors_are_reported_not_fatal(ctx):
         ctx.crossing(q, np.array([0.0]), np.ones((8, 8)), pad_mode='mirror')
     out = ctx.hist(q, np.array([-1.0, 1.0]), dA=np.ones((8, 8)), want=('counts',))   # still alive
     assert int(out['counts'][0, 0]) == 64
+
+
+def test_keff_thousands_of_contours(ctx, baro):
+    """N = 2000 / 4500: the epilogue's work arrays no longer fit the LDS and move to global memory
+    (the histogram pass itself takes up to ~5000 levels with two weight channels)"""
+    q, lat, lon = baro
+    dA = O.cell_area(lat, lon)
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import table_from_rowsums
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, 256, 512), True)
+    for N in (2000, 4500):
+        plan = KeffPlan(ctx, 1, 256, 512, N, np.float32, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                        increase=True, lt=True)
+        plan.set_q(q[None])
+        plan.run()
+        r = plan.fetch()
+        plan.free()
+        o = O.keff_pipeline(q, dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float64)
+        assert np.array_equal(r['ctr'][0], o['ctr'])
+        assert rel(r['area'][0], o['area']) < 1e-12 and rel(r['intgrdS'][0], o['intgrdS']) < 1e-11
+        assert rel(r['latEq'][0], o['latEq']) < 1e-9

@@ -42,6 +42,7 @@ static int grow(xc_ctx* ctx, void** p, size_t* have, size_t need)
 
 int ensure_scratch(xc_ctx* ctx, size_t bytes) { return grow(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes); }
 int ensure_arena(xc_ctx* ctx, size_t bytes)   { return grow(ctx, &ctx->arena, &ctx->arena_bytes, bytes); }
+int ensure_big(xc_ctx* ctx, size_t bytes)     { return grow(ctx, &ctx->big, &ctx->big_bytes, bytes); }
 
 int ensure_ones(xc_ctx* ctx, size_t n)
 {
@@ -133,6 +134,7 @@ int xc_destroy(xc_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->big) (void)hipFree(ctx->big);
     if (ctx->ones) (void)hipFree(ctx->ones);
     for (int i = 0; i < 2; ++i) if (ctx->mmnext[i]) (void)hipFree(ctx->mmnext[i]);
     if (ctx->ev_hist0) (void)hipEventDestroy(ctx->ev_hist0);

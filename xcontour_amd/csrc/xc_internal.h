@@ -18,6 +18,7 @@ struct xc_ctx {
     void*  scratch = nullptr;   size_t scratch_bytes = 0;   // kernel workspaces (partials, minmax, edges)
     void*  arena = nullptr;     size_t arena_bytes = 0;     // staging for the host-pointer entry points
     double* ones = nullptr;     size_t ones_n = 0;          // per-row weight 1.0 (dA_rank == XC_DA_NONE)
+    void*  big = nullptr;       size_t big_bytes = 0;       // k_finalize work arrays when they do not fit the LDS (many contours)
     // timing of the dominant kernel
     int timing = 0;
     hipEvent_t ev_hist0 = nullptr, ev_hist1 = nullptr;
@@ -45,6 +46,7 @@ int hipfail(xc_ctx* ctx, hipError_t e, const char* what);
 int ensure_scratch(xc_ctx* ctx, size_t bytes);
 int ensure_arena(xc_ctx* ctx, size_t bytes);
 int ensure_ones(xc_ctx* ctx, size_t n);
+int ensure_big(xc_ctx* ctx, size_t bytes);
 
 // ---------------------------------------------------------------- launch geometry
 constexpr int kMinmaxBlocks = 1024;   // partial min/max pairs per slab (upper bound, see minmax_blocks)
@@ -114,6 +116,7 @@ struct FinalArgs {
     int             ctr_f32;
     const double*   ctr;      // [nslab][nbin] level order
     const double*   tbl;      const double* tbl_coord;   int ntbl;   int tbl_in_lds;
+    double*         big;      size_t big_stride;         // work arrays in global memory instead of LDS (doubles per slab), or null
     const double*   preY;     int npre;
     double          nkeff_mask, lmin_scale;
     double *o_area, *o_intS, *o_latEq, *o_dqdA, *o_dSdA, *o_Leq2, *o_Lmin, *o_nkeff, *o_interp;

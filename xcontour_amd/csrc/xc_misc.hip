@@ -214,9 +214,11 @@ void k_reduce_partials(const double* __restrict__ part_h, const unsigned* __rest
 __global__ __launch_bounds__(1024)
 void k_finalize(const FinalArgs a)
 {
-    extern __shared__ __align__(16) double sm[];
+    extern __shared__ __align__(16) double sm_lds[];
     const int slab = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int N = a.nbin, NCH = a.nch;
+    // thousands of contours: the work arrays live in global memory (same code; __syncthreads orders them)
+    double* sm = a.big ? a.big + (size_t)slab * a.big_stride : sm_lds;
     double* s_pdf = sm;                   // [NCH][N]
     double* s_cdf = sm + (size_t)NCH * N; // [NCH][N] in LEVEL order (after optional reversal)
     double* s_x   = s_cdf + (size_t)NCH * N;   // 7*N scratch for the epilogue
@@ -434,7 +436,14 @@ int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
 {
     FinalArgs a = a_in;
     size_t lds = ((size_t)2 * a.nch * a.nbin + (a.keff ? 7 * (size_t)a.nbin : 0)) * sizeof(double);
-    if (lds > kLdsBudget) return fail(ctx, XC_EBADARG, "xc finalize: too many bins x channels");
+    a.big = nullptr; a.big_stride = 0;
+    if (lds > kLdsBudget) {               // work arrays in global memory instead
+        a.big_stride = lds / sizeof(double);
+        const int rc = ensure_big(ctx, (size_t)nslab * lds);
+        if (rc != XC_OK) return rc;
+        a.big = (double*)ctx->big;
+        lds = 0;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         XC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_finalize),
@@ -442,7 +451,7 @@ int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
         attr_set = true;
     }
     a.tbl_in_lds = 0;
-    if (a.keff && lds + (size_t)2 * a.ntbl * sizeof(double) <= 64 * 1024) {
+    if (!a.big && a.keff && lds + (size_t)2 * a.ntbl * sizeof(double) <= 64 * 1024) {
         a.tbl_in_lds = 1;
         lds += (size_t)2 * a.ntbl * sizeof(double);
     }
