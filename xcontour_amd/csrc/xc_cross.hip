@@ -308,20 +308,29 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
     }
 }
 
+// one block per (contour, slab): thread t adds the partials of blocks t, t+256, ... (fixed order), then a fixed
+// tree over the 256 threads -- a single slab has up to 2048 block partials, far too many for one thread
+// (201 threads walking 2048 dependent loads each took 250 us)
 __global__ __launch_bounds__(256)
 void k_crossing_reduce(const double* __restrict__ part_len, const unsigned* __restrict__ part_cnt, int bps, int N,
                        double* __restrict__ out_len, unsigned long long* __restrict__ out_cnt)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= N) return;
+    const int k = blockIdx.x, tid = threadIdx.x;
     const size_t slab = blockIdx.y;
     double len = 0.0; unsigned long long cnt = 0;
-    for (int b = 0; b < bps; ++b) {
+    for (int b = tid; b < bps; b += 256) {
         len += part_len[(slab * bps + b) * N + k];
         if (out_cnt) cnt += part_cnt[(slab * bps + b) * N + k];
     }
-    if (out_len) out_len[slab * N + k] = len;
-    if (out_cnt) out_cnt[slab * N + k] = cnt;
+    for (int o = 32; o > 0; o >>= 1) { len += __shfl_xor(len, o); cnt += __shfl_xor(cnt, o); }
+    __shared__ double s_l[4];
+    __shared__ unsigned long long s_c[4];
+    if ((tid & 63) == 0) { s_l[tid >> 6] = len; s_c[tid >> 6] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        if (out_len) out_len[slab * N + k] = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+        if (out_cnt) out_cnt[slab * N + k] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    }
 }
 
 }  // namespace
@@ -389,7 +398,7 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
 #undef XC_CROSS3
 #undef XC_CROSS4
     XC_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_crossing_reduce, dim3((unsigned)((N + 255) / 256), (unsigned)nslab), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(k_crossing_reduce, dim3((unsigned)N, (unsigned)nslab), dim3(256), 0, ctx->stream,
                        part_len, part_cnt, (int)bps, N, out_len, (unsigned long long*)out_cnt);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
