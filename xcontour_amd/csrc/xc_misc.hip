@@ -336,22 +336,31 @@ void k_rowsum(const TM* __restrict__ mask, const double* __restrict__ dA, int dA
 // =====================================================================================
 // K4  stand-alone |grad q|^2 (oracle grad2_sphere; no reference call site)
 // =====================================================================================
+// a thread walks GRAD_ROWS rows down its column with the south / centre / north values rolling through registers:
+// one new (coalesced) load per cell for the meridional difference, the zonal neighbours are cache hits
+constexpr int GRAD_ROWS = 16;
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_grad2(const T* __restrict__ q, int64_t ny, int64_t nx, const double* __restrict__ rdx,
              const double* __restrict__ rdy, int periodic_x, double* __restrict__ out)
 {
     const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t y = blockIdx.y;
     if (x >= nx) return;
+    const int64_t y0 = (int64_t)blockIdx.y * GRAD_ROWS, y1 = (y0 + GRAD_ROWS < ny) ? y0 + GRAD_ROWS : ny;
     const T* qs = q + (size_t)blockIdx.z * ny * nx;
+    double* os = out + (size_t)blockIdx.z * ny * nx;
     const int64_t xw = (x == 0) ? (periodic_x ? nx - 1 : 0) : x - 1;
     const int64_t xe = (x == nx - 1) ? (periodic_x ? 0 : nx - 1) : x + 1;
-    const int64_t ys = y > 0 ? y - 1 : 0, yn = y < ny - 1 ? y + 1 : ny - 1;
     const double f = (!periodic_x && (x == 0 || x == nx - 1)) ? 2.0 : 1.0;
-    const double gx = __dmul_rn(__dmul_rn(__dsub_rn((double)qs[y * nx + xe], (double)qs[y * nx + xw]), rdx[y]), f);
-    const double gy = __dmul_rn(__dsub_rn((double)qs[yn * nx + x], (double)qs[ys * nx + x]), rdy[y]);
-    out[(size_t)blockIdx.z * ny * nx + y * nx + x] = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
+    double qS = (double)qs[(y0 > 0 ? y0 - 1 : 0) * nx + x], qC = (double)qs[y0 * nx + x];
+#pragma unroll 4
+    for (int64_t y = y0; y < y1; ++y) {
+        const double qN = (double)qs[(y < ny - 1 ? y + 1 : ny - 1) * nx + x];
+        const double gx = __dmul_rn(__dmul_rn(__dsub_rn((double)qs[y * nx + xe], (double)qs[y * nx + xw]), rdx[y]), f);
+        const double gy = __dmul_rn(__dsub_rn(qN, (y > 0) ? qS : qC), rdy[y]);
+        os[y * nx + x] = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
+        qS = qC; qC = qN;
+    }
 }
 
 // =====================================================================================
@@ -486,9 +495,10 @@ int launch_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* d
 int launch_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny, int64_t nx,
                  const double* rdx, const double* rdy, int periodic_x, double* out)
 {
-    if (!q || !rdx || !rdy || !out || nslab < 1 || ny < 1 || nx < 1 || ny > 65535 || nslab > 65535)
+    if (!q || !rdx || !rdy || !out || nslab < 1 || ny < 1 || nx < 1)
         return fail(ctx, XC_EBADARG, "xc_grad2: bad arguments");
-    dim3 grid((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)nslab);
+    if ((ny + GRAD_ROWS - 1) / GRAD_ROWS > 65535 || nslab > 65535) return fail(ctx, XC_EBADARG, "xc_grad2: ny / nslab too large");
+    dim3 grid((unsigned)((nx + 255) / 256), (unsigned)((ny + GRAD_ROWS - 1) / GRAD_ROWS), (unsigned)nslab);
     if (q_dtype == XC_F64)
         hipLaunchKernelGGL(k_grad2<double>, grid, dim3(256), 0, ctx->stream, (const double*)q, ny, nx, rdx, rdy, periodic_x, out);
     else if (q_dtype == XC_F32)
