@@ -11,6 +11,12 @@ from xcontour_amd.pipeline import KeffPlan
 from xcontour_amd.utils import table_from_rowsums
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+checked = {}
+
+
+def tick(name):
+    checked[name] = checked.get(name, 0) + 1
+
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 ctx = nat.Context(0)
 
@@ -54,6 +60,7 @@ def case_hist():
             assert np.array_equal(out['counts'][s].astype(np.int64), c), 'hist counts'
             p, _ = np.histogram(x[~np.isnan(x)], bins=e, weights=w[~np.isnan(x)])
             assert relerr(out['pdf'][s, 0], p) < 1e-11, 'hist pdf'
+            tick('hist')
 
 
 def case_keff():
@@ -77,6 +84,7 @@ def case_keff():
         assert np.array_equal(r['ctr'][s], o['ctr'].astype(np.float64)), 'keff ctr'
         assert relerr(r['area'][s], o['area']) < 1e-11, 'keff area'
         assert relerr(r['intgrdS'][s], o['intgrdS']) < 1e-9, 'keff intgrdS'
+        tick('keff')
 
 
 def case_crossing():
@@ -98,6 +106,7 @@ def case_crossing():
         ol, oc = O.contour_crossing(O.pad_x(q[s], pad, mode), cs, O.pad_x(area, pad, mode), stride, full)
         assert np.array_equal(cnts[s].astype(np.int64), oc), 'crossing counts %r' % ((S, ny, nx, stride, pad, mode, full),)
         assert relerr(lens[s], ol) < 1e-12, 'crossing lengths'
+        tick('crossing')
 
 
 def case_lwa():
@@ -117,6 +126,7 @@ def case_lwa():
             assert relerr(out[s], ref) < 1e-13, 'lwa nx=1'
         else:
             assert np.array_equal(out[s], ref, equal_nan=True), 'lwa %r' % ((S, ny, nx, inc, pc, var),)
+        tick('lwa')
 
 
 def case_sort():
@@ -135,6 +145,7 @@ def case_sort():
         want = np.sort(x) if np.array_equal(got, np.sort(got)) and not np.array_equal(got, -np.sort(-x)[::-1]) else None
         assert np.array_equal(np.sort(got), got), 'sortedness'
         assert np.array_equal(got, np.sort(x)) or np.array_equal(got, np.sort(-x)), 'sort values'
+        tick('sort')
 
 
 cases = [case_hist, case_keff, case_crossing, case_lwa, case_sort]
@@ -147,4 +158,4 @@ while time.time() - t0 < budget:
     except AssertionError as e:
         print('FAIL', c.__name__, e, 'rng state saved'); np.save('/tmp/fuzz_state.npy', np.array([str(state)])); sys.exit(1)
     n[c.__name__] += 1
-print('fuzz ok', n)
+print('fuzz ok: cases', n, 'slab comparisons', checked)
