@@ -152,7 +152,53 @@ def case_sort():
         tick('sort')
 
 
-cases = [case_hist, case_keff, case_crossing, case_lwa, case_sort]
+def case_facade():
+    """the reference's call sequence through Contour2D / Table with random options, masks, NaNs, flipped coordinates"""
+    import xcontour_amd as xa
+    ny, nx = int(rng.integers(6, 60 * SC)), int(rng.integers(6, 150 * SC))
+    dt = rng.choice([np.float32, np.float64]); cdt = rng.choice([np.float32, np.float64])
+    inc, lt, flip = bool(rng.random() < 0.5), bool(rng.random() < 0.5), bool(rng.random() < 0.5)
+    lat = np.linspace(-85, 85, ny); lon = np.arange(nx) * (360.0 / nx)
+    q = field(1, ny, nx, dt)[0]
+    if flip:
+        lat = lat[::-1].copy()
+    dAv = O.cell_area(np.sort(lat), lon)[::-1].copy() if flip else O.cell_area(lat, lon)
+    maskv = np.ones((ny, nx)); maskv[np.isnan(q)] = 0.0
+    if rng.random() < 0.3:
+        maskv[:, : max(1, nx // 7)] = 0.0
+    c = {'lat': lat, 'lon': lon}
+    tr = xa.DataArray(q, ('lat', 'lon'), c, 'pv'); dA = xa.DataArray(dAv, ('lat', 'lon'), c, 'dA')
+    mask = xa.DataArray(maskv, ('lat', 'lon'), c, 'mask')
+    g2v = rng.random((ny, nx)).astype(dt)
+    g2 = xa.DataArray(g2v, ('lat', 'lon'), c, 'grdS')
+    cm = xa.Contour2D(tr, dA, dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'}, increase=inc, lt=lt, dtype=cdt)
+    N = int(rng.integers(3, 70))
+    try:
+        ctr = cm.cal_contours(N)
+        o_ctr = O.cal_contours(q, N, inc, cdt)
+        assert np.array_equal(ctr.values, o_ctr, equal_nan=True), 'facade ctr'
+        area = cm.cal_integral_within_contours_hist(ctr)
+    except Exception as e:
+        if 'non monotonic' in str(e) or 'bins' in str(e):
+            return                                         # a constant / degenerate field: the reference raises too
+        raise
+    o_area = O.cal_integral_within_contours_hist(q, o_ctr, dAv, None, lt)
+    assert relerr(area.values, o_area) < 1e-11, 'facade area'
+    S_ = cm.cal_integral_within_contours_hist(ctr, integrand=g2)
+    assert relerr(S_.values, O.cal_integral_within_contours_hist(q, o_ctr, dAv, g2v, lt)) < 1e-9, 'facade intS'
+    a2 = cm.cal_integral_within_contours(ctr)
+    assert relerr(a2.values, O.cal_integral_within_contours(q, o_ctr, dAv, None, lt)) < 1e-11, 'facade strict'
+    for hist in (True, False):
+        t = (cm.cal_area_eqCoord_table_hist if hist else cm.cal_area_eqCoord_table)(mask)
+        ot, ocs = (O.cal_area_eqCoord_table_hist if hist else O.cal_area_eqCoord_table)(maskv, dAv, lat, inc, lt)
+        assert relerr(t._table.values, ot) < 1e-12, 'facade table'
+        yeq = t.lookup_coordinates(area)
+        oy = O.lookup_coordinates(o_area, ot, ocs if hist else lat)            # a latitude passes through zero: absolute bar
+        assert np.array_equal(np.isnan(yeq.values), np.isnan(oy)) and np.nanmax(np.abs(yeq.values - oy), initial=0.0) < 1e-9 * 90, 'facade lookup'
+    tick('facade')
+
+
+cases = [case_hist, case_keff, case_crossing, case_lwa, case_sort, case_facade]
 t0 = time.time(); n = {c.__name__: 0 for c in cases}
 while time.time() - t0 < budget:
     c = cases[int(rng.integers(len(cases)))]
