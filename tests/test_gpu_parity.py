@@ -1051,3 +1051,15 @@ def test_keff_thousands_of_contours(ctx, baro):
         assert np.array_equal(r['ctr'][0], o['ctr'])
         assert rel(r['area'][0], o['area']) < 1e-12 and rel(r['intgrdS'][0], o['intgrdS']) < 1e-11
         assert rel(r['latEq'][0], o['latEq']) < 1e-9
+
+
+def test_differential_fuzz_short(ctx):
+    """8 s of tools/gpu_fuzz.py (random shapes / dtypes / flags / NaNs; HIP path vs oracle for hist, the fused pipeline,
+    crossing, LWA, sort and the facade call sequence); the long runs are logged in profiles/r01_notes.md"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('gpu_fuzz', os.path.join(root, 'tools', 'gpu_fuzz.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    n, checked = fz.run(8.0, seed=2024)
+    assert sum(n.values()) > 200 and all(v > 0 for v in checked.values()) and len(checked) == 6

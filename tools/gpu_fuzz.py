@@ -10,14 +10,14 @@ from xcontour_amd import _native as nat
 from xcontour_amd.pipeline import KeffPlan
 from xcontour_amd.utils import table_from_rowsums
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+budget = float(sys.argv[1]) if len(sys.argv) > 1 and __name__ == '__main__' else 60.0
 checked = {}
 
 
 def tick(name):
     checked[name] = checked.get(name, 0) + 1
 
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 and __name__ == '__main__' else 12345)
 ctx = nat.Context(0)
 SC = int(os.environ.get('XC_FUZZ_SCALE', '1'))      # multiplies the maximum plane size (tiling edges of the big kernels)
 
@@ -199,13 +199,25 @@ def case_facade():
 
 
 cases = [case_hist, case_keff, case_crossing, case_lwa, case_sort, case_facade]
-t0 = time.time(); n = {c.__name__: 0 for c in cases}
-while time.time() - t0 < budget:
-    c = cases[int(rng.integers(len(cases)))]
-    state = rng.bit_generator.state
-    try:
+
+
+def run(seconds, seed=None):
+    """run random cases for `seconds`; returns (cases per kind, slab comparisons per kind); raises on a mismatch"""
+    global rng
+    if seed is not None:
+        rng = np.random.default_rng(seed)
+    t0 = time.time(); n = {c.__name__: 0 for c in cases}
+    while time.time() - t0 < seconds:
+        c = cases[int(rng.integers(len(cases)))]
         c()
+        n[c.__name__] += 1
+    return n, dict(checked)
+
+
+if __name__ == '__main__':
+    try:
+        n, chk = run(budget)
     except AssertionError as e:
-        print('FAIL', c.__name__, e, 'rng state saved'); np.save('/tmp/fuzz_state.npy', np.array([str(state)])); sys.exit(1)
-    n[c.__name__] += 1
-print('fuzz ok: cases', n, 'slab comparisons', checked)
+        print('FAIL', e)
+        sys.exit(1)
+    print('fuzz ok: cases', n, 'slab comparisons', chk)
