@@ -99,6 +99,21 @@ __device__ __forceinline__ void box_done(const double* __restrict__ cx, int N, d
     double w = __dmul_rn(sqrt_like_numpy<TA>(araw), fs);    // core.py:1560 (product in f64: numba types f32 * int64 as f64)
     if (nanfill) w = __longlong_as_double(0x7ff8000000000000LL);
     const bool add = (w == w);                         // np.nansum skips NaN (negative or NaN area)
+    if (inv_step > 0.0) {
+        // equally spaced levels: the END of the crossed range also follows from arithmetic (number of levels < mx,
+        // verified by one pair read), so the adds below are fire-and-forget -- a scan that reads the next level
+        // before every add serialises on LDS latency when a noisy field crosses several levels per box
+        int khi = (int)fmin(fmax((mx - c_first) * inv_step + 1.0, 0.0), (double)N);
+        const double h_lo = cx[khi], h_hi = cx[khi + 1];
+        if (!((h_lo < mx) & (mx <= h_hi))) khi = count_below(cx, N, mx);
+        for (; k < khi; ++k) {
+#ifndef XC_CROSS_NOATOM
+            if (add) atomicAdd(&my_len[k], w);
+            if (CNT) atomicAdd(&my_cnt[k], 1u);
+#endif
+        }
+        return;
+    }
     do {                                               // the +inf sentinel ends the scan
 #ifndef XC_CROSS_NOATOM
         if (add) atomicAdd(&my_len[k], w);
