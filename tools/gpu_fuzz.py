@@ -193,8 +193,10 @@ def case_facade():
         ot, ocs = (O.cal_area_eqCoord_table_hist if hist else O.cal_area_eqCoord_table)(maskv, dAv, lat, inc, lt)
         assert relerr(t._table.values, ot) < 1e-12, 'facade table'
         yeq = t.lookup_coordinates(area)
-        oy = O.lookup_coordinates(o_area, ot, ocs if hist else lat)            # a latitude passes through zero: absolute bar
-        assert np.array_equal(np.isnan(yeq.values), np.isnan(oy)) and np.nanmax(np.abs(yeq.values - oy), initial=0.0) < 1e-9 * 90, 'facade lookup'
+        # lookup on the SAME inputs: where a fully masked row makes the table flat, the interpolated coordinate jumps
+        # with the last bit of the area (np.interp on duplicate knots), so end-to-end comparison is ill-posed there
+        oy = O.lookup_coordinates(area.values, t._table.values, t._coord)
+        assert np.array_equal(np.isnan(yeq.values), np.isnan(oy)) and np.nanmax(np.abs(yeq.values - oy), initial=0.0) < 1e-12 * 90, 'facade lookup'
     tick('facade')
 
 
