@@ -152,6 +152,16 @@ def main():
 
     sys.path.insert(0, ROOT)
     from xcontour_amd import _native as nat
+    if not os.path.exists(nat.LIB_PATH):
+        # the in-tree library normally travels with the snapshot; if it did not, build it once per node
+        # (local rank 0 compiles, the others wait for the file) -- still no fallback: without it nothing runs
+        if int(os.environ.get('LOCAL_RANK', '0')) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        for _ in range(600):
+            if os.path.exists(nat.LIB_PATH):
+                break
+            time.sleep(0.5)
     from xcontour_amd.pipeline import KeffPlan
     from xcontour_amd.utils import cell_area, table_from_rowsums, grad_metrics
 
