@@ -475,7 +475,7 @@ void k_hist(const HistArgs a)
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) {              // NaN never wins a compare: NaN-skipping
                         const double v = L[i].qn[c];
-                        nmn = (v < nmn) ? v : nmn; nmx = (v > nmx) ? v : nmx;
+                        nmn = fmin(nmn, v); nmx = fmax(nmx, v);                  // fmin / fmax skip NaN
                     }
                 }
                 if (GRAD) {
