@@ -45,9 +45,12 @@ BYTES_PER_CELL = 16              # algorithmic: tracer f64 once + dA f64 once (S
 
 
 # ----------------------------------------------------------------------------- CPU baseline worker
+CHECK_NAMES = ('ctr', 'area', 'intgrdS', 'latEq', 'dqdA', 'dintSdA', 'Leq2', 'Lmin', 'nkeff')
+
+
 def _cpu_keff_worker(args):
     """One slab through the oracle's Keff call sequence (runs in a spawned process)."""
-    path, idx = args
+    path, idx, want = args
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import xcontour_oracle as O
     q = np.load(path, mmap_mode='r')[idx]
@@ -57,45 +60,95 @@ def _cpu_keff_worker(args):
     t = time.perf_counter()
     r = O.keff_pipeline(np.asarray(q), dA, lat, NCONT, lon=lon, increase=True, lt=True, dtype=np.float64)
     dt = time.perf_counter() - t
-    return dt, float(np.nansum(r['nkeff']))
+    if not want:
+        return dt, None
+    return dt, {k: np.asarray(r[k], dtype=np.float64) for k in CHECK_NAMES + ('counts',)}
 
 
-def cpu_baseline(q_host):
-    """Oracle on a bounded sample: single-thread time per slab, then all host cores in parallel."""
+def _mem_available_bytes():
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 16 << 30
+
+
+def _compare_with_oracle(gpu, ref, s):
+    """GPU result vectors of slab `s` against the oracle's (outside every timed region); raises on a mismatch.
+    Bars: counts and levels bit-exact, float64 sums 1e-11, derived quantities 1e-6 (north_star)."""
+    def rel(a, b, floor=1e-300):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        if not np.array_equal(np.isnan(a), np.isnan(b)):
+            return np.inf
+        m = np.isfinite(b)
+        return float(np.max(np.abs(a[m] - b[m]) / np.maximum(np.abs(b[m]), floor))) if m.any() else 0.0
+    bad = []
+    if not np.array_equal(gpu['counts'][s].astype(np.int64), ref['counts'].astype(np.int64)):
+        bad.append('counts')
+    if not np.array_equal(gpu['ctr'][s], ref['ctr']):
+        bad.append('ctr')
+    ok = ref['Lmin'] > 2 * np.pi * 6371200.0 * 1e-6                      # nkeff = Leq2 / Lmin^2 is ill-conditioned AT the pole
+    for k, tol in (('area', 1e-11), ('intgrdS', 1e-11), ('latEq', 1e-6), ('dqdA', 1e-6), ('dintSdA', 1e-6), ('Leq2', 1e-6)):
+        if not rel(gpu[k][s], ref[k]) < tol:
+            bad.append(k)
+    if not rel(gpu['Lmin'][s], ref['Lmin'], 2 * np.pi * 6371200.0 * 1e-6) < 1e-6:
+        bad.append('Lmin')
+    if not rel(gpu['nkeff'][s][ok], ref['nkeff'][ok]) < 1e-6:
+        bad.append('nkeff')
+    if bad:
+        raise RuntimeError('bench parity check against the oracle FAILED for slab %d: %s' % (s, ', '.join(bad)))
+
+
+def cpu_baseline(q_host, gpu_out, ncheck):
+    """Oracle on a bounded sample: single-thread time per slab, then every logical core of the host in parallel
+    (bounded by memory: ~1.2 GB of numpy temporaries per worker).  The first `ncheck` slabs' vectors are compared
+    with the GPU's (`gpu_out`, same slabs) -- the CPU leg is the checker of the timed GPU result, not only a clock."""
     import multiprocessing as mp
     import shutil
     import tempfile
     cores = os.cpu_count() or 1
-    workers = max(1, min(cores, 32, q_host.shape[0]))
+    workers = max(1, min(cores, int(_mem_available_bytes() * 0.5 // (1.2 * (1 << 30)))))
+    nd = q_host.shape[0]
+    n = max(workers, nd)                                             # one slab per worker at least (slabs cycle)
     tmp = tempfile.mkdtemp(prefix='xc_bench_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
     try:
         path = os.path.join(tmp, 'q.npy')
         np.save(path, q_host)
-        t1, _ = _cpu_keff_worker((path, 0))                       # single thread, in-process
+        t1, r0 = _cpu_keff_worker((path, 0, True))                   # single thread, in-process
+        _compare_with_oracle(gpu_out, r0, 0)
         ctx = mp.get_context('spawn')
-        n = q_host.shape[0]
         with ctx.Pool(workers) as pool:
-            pool.map(_cpu_keff_worker, [(path, 0)] * workers)     # warm the workers (imports, page cache)
+            pool.map(_cpu_keff_worker, [(path, 0, False)] * workers)     # warm the workers (imports, page cache)
             t = time.perf_counter()
-            pool.map(_cpu_keff_worker, [(path, i % n) for i in range(n)], chunksize=1)
+            res = pool.map(_cpu_keff_worker, [(path, i % nd, i < ncheck) for i in range(n)], chunksize=1)
             wall = time.perf_counter() - t
+        for i in range(min(ncheck, n)):
+            _compare_with_oracle(gpu_out, res[i][1], i % nd)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     work = NY * NX * NCONT
-    model = 'unknown CPU'
+    model, phys = 'unknown CPU', set()
     try:
+        pid = None
         for line in open('/proc/cpuinfo'):
-            if line.startswith('model name'):
+            if line.startswith('model name') and model == 'unknown CPU':
                 model = line.split(':', 1)[1].strip()
-                break
+            elif line.startswith('physical id'):
+                pid = line.split(':', 1)[1].strip()
+            elif line.startswith('core id'):
+                phys.add((pid, line.split(':', 1)[1].strip()))
     except OSError:
         pass
     return {
         'value': n * work / wall, 'unit': 'cells*contours/s', 'cores': workers, 'kind': 'port',
-        'sample': '%d slabs of %dx%d f64, %d contours, numpy oracle (port of the reference xarray/'
+        'single_thread_value': work / t1, 'parity_checked_slabs': min(ncheck, n),
+        'sample': '%d slabs (%d distinct) of %dx%d f64, %d contours, numpy oracle (port of the reference xarray/'
                   'xhistogram Keff call sequence) in %d processes: %.2f s wall; single thread %.2f s/slab '
-                  '= %.3e cells*contours/s; host: %s, %d logical cores'
-                  % (n, NX, NY, NCONT, workers, wall, t1, work / t1, model, cores),
+                  '= %.3e cells*contours/s; host: %s, %d logical / %d physical cores; %d slabs compared with the GPU vectors '
+                  '(counts + levels bit-exact, sums 1e-11, derived 1e-6)'
+                  % (n, nd, NX, NY, NCONT, workers, wall, t1, work / t1, model, cores, len(phys) or cores, min(ncheck, n)),
     }
 
 
@@ -120,6 +173,10 @@ def main():
                     help='let the plan detect that the lat-lon dA plane has constant rows and read it as a '
                          'per-row vector (8 B/cell algorithmic instead of 16); off by default: the headline '
                          'keeps the generic 2-D dA read')
+    ap.add_argument('--slab-dA', action='store_true',
+                    help='per-slab (time-varying) weights: every slab reads ITS OWN 2-D f64 dA plane from HBM (XC_DA_SLAB; '
+                         'the reference allows weights with a time dim, core.py:1271-1274).  This is the configuration in '
+                         'which the 16 B/cell roofline numerator is exactly the unique HBM traffic')
     ap.add_argument('--native-rccl', action='store_true',
                     help="do the one end-of-job gather with the library's own RCCL communicator (xc_comm_*) on its "
                          'own stream instead of torch.distributed (the id travels through the torch store)')
@@ -127,7 +184,7 @@ def main():
                     help="process-group backend; 'nccl' IS RCCL on ROCm (default).  'gloo' stages the one gather "
                          'through the host: only for exercising the multi-rank path on a box with fewer GPUs than ranks')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
-    ap.add_argument('--cpu-slabs', type=int, default=0, help='CPU sample size (0: auto)')
+    ap.add_argument('--cpu-slabs', type=int, default=0, help='distinct slabs in the CPU sample, all parity-checked (0: 8)')
     a = ap.parse_args()
 
     import torch
@@ -163,7 +220,7 @@ def main():
                 break
             time.sleep(0.5)
     from xcontour_amd.pipeline import KeffPlan
-    from xcontour_amd.utils import cell_area, table_from_rowsums, grad_metrics
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
 
     ctx = nat.Context(local)
     B, K, W = a.batch, a.steps, a.warmup
@@ -171,7 +228,7 @@ def main():
     lon = np.arange(NX) * 0.1
     dA = cell_area(lat, lon)
     rows = ctx.rowsum(None, dA, NY, NX)                           # K2: A(Yeq) table, once per mask
-    tbl = table_from_rowsums(rows, True)
+    tbl = table_from_rowsums(rows, True, last_row_included(lat, 'xhistogram'))   # f64 latitudes: the last row stays in
 
     # Two resident batches (A, B) of `B` distinct slabs each; steps alternate between them like a
     # time loop over a long record, so the batch whose min/max rides along in a histogram pass
@@ -183,7 +240,7 @@ def main():
     wres = torch.empty(slot // 8, dtype=torch.float64, device='cuda')        # warm-up slot
     plan = KeffPlan(ctx, NB * B, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl,
                     tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.data_ptr(), detect_row_dA=a.row_dA,
-                    out_slabs=B)
+                    out_slabs=B, replicate_dA=a.slab_dA, right_edge='xhistogram')
     plan.synth(lat, lon, SEED + rank * NB * B, a.variant)         # slab s of rank r: seed + r*2B + s
     group = a.group or B
     chain = bool(a.chain)
@@ -248,36 +305,50 @@ def main():
             'config': {'workload': 'cfg2: synthetic %dx%d float64 PV-like slabs, 2-D f64 dA, %d contours, '
                                    'full Keff (min/max + histogram with in-kernel |grad q|^2 + CDF + epilogue)'
                                    % (NX, NY, NCONT),
-                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant, 'dA': 'per-row vector (detected constant rows)' if a.row_dA else '2-D f64 plane',
+                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant, 'dA': 'per-row vector (detected constant rows)' if a.row_dA else ('2-D f64 plane PER SLAB (time-varying weights)' if a.slab_dA else '2-D f64 plane shared by the slabs'),
                        'minmax': 'folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass',
                        'parallelism': 'independent slabs per GPU, one RCCL all-gather at the end' if world > 1 else 'single GPU',
                        'device': ctx.device_name()},
         }
+        cells = B * NY * NX
+        alg = cells * (8 if a.row_dA else BYTES_PER_CELL)              # tracer once + dA once per slab
+        # bytes that MUST cross HBM once per launch: this batch's tracer + the weights that are not shared
+        # (a dA plane shared by the B slabs of a launch is fetched once; per-slab dA planes B times; a per-row vector ~0)
+        uniq = cells * 8 + (cells * 8 if a.slab_dA else (NY * 8 if a.row_dA else NY * NX * 8))
         if group == B:
             ms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in ev])
-            alg = B * NY * NX * (8 if a.row_dA else BYTES_PER_CELL)
             ach = alg / (ms.mean() * 1e-3) / 1e9
-            traffic = None
+            traffic, tcommit = None, None
             tf = os.path.join(ROOT, 'profiles', 'hist_traffic.json')
             if os.path.exists(tf) and not a.row_dA and a.variant == 0:
                 try:
                     tj = json.load(open(tf))
-                    tj = tj.get('chain', {}) if chain else tj
+                    tj = tj.get(('slab_' if a.slab_dA else '') + ('chain' if chain else 'nochain'), {})
                     if tj.get('slabs_per_launch') == B:                # PMC passes were taken at the default batch
                         traffic = tj.get('hbm_bytes_per_launch')
+                        tcommit = tj.get('commit')
                 except Exception:
                     traffic = None
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                                'kernel': 'k_hist<double,2,0,true,true,%s>' % ('true' if chain else 'false'), 'launch_ms': float(ms.mean()),
+                                'traffic_source': None if traffic is None else
+                                'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_bench_traffic.sh), measured at commit %s; '
+                                'not re-measured in this run' % tcommit,
+                                'kernel': 'k_hist<double,%s,%s>' % ('DA_SLAB' if a.slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'),
+                                                                    'NEXT' if chain else 'plain'),
+                                'launch_ms': float(ms.mean()),
                                 'algorithmic_bytes_per_launch': alg,
-                                'streamed_bytes_per_launch': alg + (B * NY * NX * 8 if chain else 0),
-                                'pipeline_frac': (B * NY * NX * (8 if a.row_dA else BYTES_PER_CELL) * K / el / 1e9) / HBM_PEAK_GBS}
-        # parity spot check of the last step against nothing heavy: invariants only (oracle runs in cpu leg)
+                                'hbm_unique_bytes_per_launch': uniq,
+                                'hbm_unique_frac': uniq / (ms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'streamed_bytes_per_launch': alg + (cells * 8 if chain else 0),
+                                'pipeline_frac': (alg * K / el / 1e9) / HBM_PEAK_GBS,
+                                'pipeline_hbm_unique_frac': (uniq * K / el / 1e9) / HBM_PEAK_GBS,
+                                'note': 'frac = 16 B/cell (SURVEY 8d) / launch time / 8 TB/s; hbm_unique_frac counts only bytes that '
+                                        'must come from HBM (a dA plane shared by the %d slabs of a launch counts once); '
+                                        'with --slab-dA the two coincide' % B}
+        # self-check of the last step: every cell lands in exactly one bin (xhistogram rule: last edge + 1e-8 keeps the max cell)
         out = plan.fetch(slot=K - 1)
-        # every cell lands in exactly one bin, except that the slab's max cell may fall outside the
-        # rounded last level (the reference's own behaviour)
-        if not (NY * NX - out['counts'].sum(axis=1).astype(np.int64) <= 1).all():
+        if not (out['counts'].sum(axis=1).astype(np.int64) == NY * NX).all() or out['status'].any():
             raise RuntimeError('bench self-check failed: counts %r status %r' % (out['counts'].sum(axis=1), out['status']))
         if world == 1 and chain and group == B:
             # transparency: the same work in the plain order (stand-alone K1 launch, then K3), a short extra run
@@ -298,15 +369,13 @@ def main():
             line['unchained'] = {'value': work_step * K2 / el2, 'ms_per_step': el2 / K2 * 1e3, 'steps': K2,
                                  'note': 'stand-alone min/max launch before every histogram launch (--no-chain), same slabs'}
         if world == 1 and not a.no_cpu:
-            cores = os.cpu_count() or 1
-            n = a.cpu_slabs or max(8, min(32, 2 * min(cores, 32)))
-            n = min(n, B) if n <= B else n
-            qh = plan.download_q()[:B]
-            if n > B:
-                qh = np.concatenate([qh] * (-(-n // B)))[:n]
-            else:
-                qh = qh[:n]
-            line['cpu_baseline'] = cpu_baseline(qh)
+            # the oracle on slabs of the LAST timed step's batch; their vectors are compared with that step's GPU result
+            nd = max(1, min(a.cpu_slabs or 8, B))
+            s0 = ((K - 1) % NB) * B
+            esz = NY * NX * 8
+            qh = np.empty((nd, NY, NX), dtype=np.float64)
+            ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, plan._q_ptr + s0 * esz, nd * esz))
+            line['cpu_baseline'] = cpu_baseline(qh, out, nd)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

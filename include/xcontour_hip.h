@@ -270,11 +270,13 @@ typedef struct xc_keff_desc {
     const void*   q_next;       /* optional: the batch the NEXT xc_keff_dev call will process (same dtype and
                                    shape, may equal q).  Its per-slab min/max partials are accumulated inside this
                                    call's histogram pass (+8 B/cell of loads, no extra kernel) and the next call on
-                                   that pointer skips its K1 pass.  The caller promises not to modify that batch in
-                                   between.  NULL: off. */
+                                   that pointer skips its K1 pass -- provided the batch is provably unchanged: the
+                                   cached partials are dropped when xc_memcpy_h2d / xc_memset / xc_synth_dev / xc_free
+                                   touch the batch, and whenever `q_gen` differs from the value given with q_next (a
+                                   caller that writes the batch through its own pointer bumps q_gen).  NULL: off. */
     int32_t       dA_pos_finite;/* caller verified that every dA value is finite and >= 0: the kernel then skips the
                                    fillna(0) selects on the dA channel (optional speed-up; 0 is always safe) */
-    int32_t       _pad2;
+    int32_t       q_gen;        /* generation of the tracer buffers (see q_next): any change invalidates chained min/max */
 } xc_keff_desc;
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
 

@@ -21,12 +21,19 @@ The arithmetic of the path lives in un-vendored third-party packages:
     explicit edges, out-of-range and NaN dropped, np.bincount(weights) in
     float64.  Restated here as `weighted_histogram` (digitize + bincount),
     cross-checked against `np.histogram` (numpy IS installed).
-    Last-bin rule: numpy closes the last bin on the right.  xhistogram 0.1.2 -
-    0.3.x (from memory of its core.py `_bincount_2d_vectorized`; source not
-    available offline) instead replaces the last edge by `edge + 1e-8` (in the
-    edge dtype) and keeps the bin half-open.  Both are implemented:
-    `right_edge='numpy'` (default, the SURVEY.md contract) and
-    `right_edge='xhistogram'`.
+    Last-bin rule (the one place where xhistogram differs from np.histogram):
+    xhistogram >= 0.1.2 (`core._bincount_2d_vectorized`: "Add small increment to
+    the last bin edge to make the final bin right-edge inclusive") does
+    `bins = [np.concatenate((b[:-1], b[-1:] + 1e-8)) for b in bins]`, i.e. the
+    bump is evaluated IN THE EDGE DTYPE, then np.digitize with half-open bins and
+    everything outside [first, last) thrown away.  Restated from the published
+    source (not available offline; the reference's own docstrings / demo scripts
+    do not contradict it).  Consequences on the reference's bundled barotropic
+    field: float32 contours of magnitude 1e-4 DO absorb the bump (count 131 072:
+    the max cell is kept), float32 latitudes (89.46) do NOT (the last row drops
+    out of the A(Yeq) table).  `right_edge='xhistogram'` (DEFAULT = what the
+    reference runs) and `right_edge='numpy'` (closed last bin, np.histogram) are
+    both implemented.
   * xarray (README 0.15.1): min/max/where/sum/cumsum/differentiate/fillna/
     apply_ufunc(vectorize=True) -- restated with the numpy calls xarray
     dispatches to (np.nanmin, np.nansum, np.cumsum, np.gradient, np.vectorize).
@@ -127,14 +134,15 @@ def hist_edges(b):
     return edges, bincrease
 
 
-def weighted_histogram(x, edges, weights=None, right_edge='numpy'):
+def weighted_histogram(x, edges, weights=None, right_edge='xhistogram'):
     """N-bin histogram of `x` over ascending `edges` (xhistogram semantics).
 
     bin k = [edges[k], edges[k+1]); NaN and out-of-range values dropped;
     weights summed in float64 by np.bincount (what xhistogram dispatches to).
+    right_edge='xhistogram' : last edge replaced by `edges[-1] + 1e-8` evaluated in
+                              the edge dtype, bin stays half-open (default: the
+                              reference calls xhistogram, core.py:1284, 1307).
     right_edge='numpy'      : last bin closed on the right (np.histogram rule).
-    right_edge='xhistogram' : last edge replaced by `edges[-1] + 1e-8`
-                              evaluated in the edge dtype, bin stays half-open.
     Returns (sums_f64[N], counts_int64[N]).
     """
     x = np.asarray(x).ravel()
@@ -155,7 +163,7 @@ def weighted_histogram(x, edges, weights=None, right_edge='numpy'):
     return sums, counts
 
 
-def histogram_cdf(q, b, weights, lt, right_edge='numpy'):
+def histogram_cdf(q, b, weights, lt, right_edge='xhistogram'):
     """`_histogram(var, bins, dim, weights, lt)` for one slab (core.py:1296-1325).
 
     Result is in ASCENDING-VALUE order (position i <-> i-th smallest level),
@@ -187,7 +195,7 @@ def _weights(dA, integrand, shape):
 
 
 def cal_integral_within_contours_hist(q, ctr, dA, integrand=None, lt=False,
-                                      right_edge='numpy', return_counts=False):
+                                      right_edge='xhistogram', return_counts=False):
     """core.py:412-460 for one slab: out[k] <-> ctr[k] whatever the direction."""
     q = np.asarray(q)
     wei = _weights(dA, integrand, q.shape)
@@ -222,7 +230,7 @@ def cal_integral_within_contours(q, ctr, dA, integrand=None, lt=False):
 # a5  area <-> equivalent-coordinate table                  core.py:73-203
 # ---------------------------------------------------------------------------
 def cal_area_eqCoord_table_hist(mask, dA, coord, increase=True, lt=False,
-                                right_edge='numpy'):
+                                right_edge='xhistogram'):
     """core.py:150-203.  Returns (tbl, coord_ascending)."""
     mask = np.asarray(mask)
     coord = np.asarray(coord)
@@ -333,6 +341,31 @@ def interp_to_coords(predef, eqCoords, var):
     eqCoords = np.asarray(eqCoords)
     inc = bool(eqCoords[0] < eqCoords[-1])
     return interp1d(np.asarray(predef), eqCoords, np.asarray(var), inc)
+
+
+# ---------------------------------------------------------------------------
+# f3  contours at prescribed equivalent coordinates         core.py:269-360
+# ---------------------------------------------------------------------------
+def cal_contours_at(q, predef, tbl, tbl_coord, dA, increase=True, lt=False,
+                    dtype=np.float32, hist=True, right_edge='xhistogram'):
+    """One slab.  `cal_contours_at_hist` (core.py:316-360, hist=True) and its
+    conditional-integration twin `cal_contours_at` (core.py:269-313, hist=False):
+    N = predef.size equally spaced levels (302/349), their enclosed areas
+    (303/350), equivalent coordinates from the A(Yeq) table (304/351), then q(Y)
+    by np.interp of the levels from those coordinates onto `predef` (306/352;
+    direction from dimEq[0] < dimEq[-1], core.py:1080-1088).  np.vectorize'd
+    np.interp returns float64 whatever `dtype` is.  Returns (qIntp, ctr)."""
+    predef = np.asarray(predef)
+    if len(predef.shape) != 1:
+        raise Exception('predef should be a 1D array')            # core.py:294, 341
+    N = predef.size
+    ctr = cal_contours(q, N, increase, dtype)
+    if hist:
+        area = cal_integral_within_contours_hist(q, ctr, dA, None, lt, right_edge)
+    else:
+        area = cal_integral_within_contours(q, ctr, dA, None, lt)
+    dimEq = lookup_coordinates(area, tbl, tbl_coord)
+    return interp_to_coords(predef, dimEq, ctr), ctr
 
 
 # ---------------------------------------------------------------------------
@@ -532,6 +565,21 @@ def sorted_profile(q, dA, tbl_targets, mask=None):
     return xs[idx], xs, acum
 
 
+def sorted_profile_brackets(acum, targets, rtol=1e-11):
+    """Tie rule of `Q_exact` (part of its DEFINITION): the cumulative areas of a parallel scan differ
+    from np.cumsum's by summation order (<= 1e-12 relative), and table values coincide with Acum values in exact
+    arithmetic wherever the sorted order follows the rows.  A target within `rtol * Acum[-1]` of an Acum value may
+    therefore resolve to either neighbouring cell.  Returns (lo, hi): every sorted index in [lo[j], hi[j]] is a
+    valid answer for target j; lo == hi except at such ties."""
+    acum = np.asarray(acum, dtype=np.float64)
+    t = np.asarray(targets, dtype=np.float64)
+    tol = rtol * acum[-1]
+    n = len(acum)
+    lo = np.minimum(np.searchsorted(acum, t - tol, side='right'), n - 1)
+    hi = np.minimum(np.searchsorted(acum, t + tol, side='right'), n - 1)
+    return lo, hi
+
+
 def bpe_integral(q, dA, tbl, coord, mask=None):
     """Background-potential-energy-like integral of the exactly sorted state (a9,
     build-defined): sum_i q_i * z*(A_i - dA_i/2) * dA_i over the sorted cells, with
@@ -652,7 +700,7 @@ def cal_contour_crossing(tracer, ctr, dA, stride=1, mode='edge', has_x=True, dty
 # The reference's Keff call sequence (tests/test_Keff_atmos.py:75-92)
 # ---------------------------------------------------------------------------
 def keff_pipeline(q, dA, lat, N, grdS=None, lon=None, mask=None, increase=True,
-                  lt=True, dtype=np.float32, preLats=None, right_edge='numpy',
+                  lt=True, dtype=np.float32, preLats=None, right_edge='xhistogram',
                   nkeff_mask=1e5):
     """One slab, hist API, steps 1-10 of SURVEY 3.1.  Returns a dict of
     ndarrays on the contour dim (+ '<name>_eq' on preLats if given)."""

@@ -5,7 +5,9 @@
 
 Inputs : tests/golden/baro_{q,lat,lon}.npy   (extract_barotropic.py)
 Outputs: tests/golden/baro_keff_N{121,201}.npz  Keff call sequence, increase, lt,
-                                                 float32 contours, preLats = lat
+                                                 float32 contours, preLats = lat, last-bin rule
+                                                 'xhistogram' (the default); ..._numpy.npz: rule 'numpy'
+         tests/golden/baro_contours_at.npz       cal_contours_at(_hist) (core.py:269-360)
          tests/golden/baro_lwa_N121.npz          sorted state Q(lat) + LWA (legacy dy metric and
                                                  snapshot dA metric), masks at rows 37/125/170/213
 The oracle is pinned against SURVEY.md 8(c)'s known answers in tests/test_oracle_golden.py.
@@ -24,9 +26,13 @@ lat = np.load(os.path.join(HERE, 'baro_lat.npy'))
 lon = np.load(os.path.join(HERE, 'baro_lon.npy'))
 dA = O.cell_area(lat, lon)
 
-for N in (121, 201):
-    r = O.keff_pipeline(q, dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float32, preLats=lat)
-    np.savez_compressed(os.path.join(HERE, 'baro_keff_N%d.npz' % N), **r)
+# both last-bin rules: 'xhistogram' (default = what the reference runs; file names without suffix) and
+# 'numpy' (closed last bin; the rule SURVEY.md 8(c)'s known answers were derived with)
+for rule, sfx in (('xhistogram', ''), ('numpy', '_numpy')):
+    for N in (121, 201):
+        r = O.keff_pipeline(q, dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float32, preLats=lat,
+                            right_edge=rule)
+        np.savez_compressed(os.path.join(HERE, 'baro_keff_N%d%s.npz' % (N, sfx)), **r)
 
 r = O.keff_pipeline(q, dA, lat, 121, lon=lon, increase=True, lt=True, dtype=np.float32, preLats=lat)
 Q = r['ctr_eq']
@@ -39,4 +45,16 @@ lwa_lo = O.cal_local_wave_activity(q, Q, lat, dA, True, 'lower', metric=dy)
 np.savez_compressed(os.path.join(HERE, 'baro_lwa_N121.npz'), Q=Q, dy=dy, lwa_dy=lwa_dy, lwa_dA=lwa_dA,
                     lwa_upper=lwa_up, lwa_lower=lwa_lo, mask_idx=np.array(idx),
                     masks=np.stack(masks).astype(np.int8))
+
+# f3: contours at prescribed equivalent latitudes (core.py:269-360), both twins x both rules x (increase, lt)
+pre = np.linspace(-85, 85, 69).astype(np.float32)
+at = {'predef': pre}
+for rule in ('xhistogram', 'numpy'):
+    for inc in (True, False):
+        for lt in (True, False):
+            tbl, cs = O.cal_area_eqCoord_table_hist(np.ones_like(q), dA, lat, inc, lt, rule)
+            for hist in (True, False):
+                qi, _ = O.cal_contours_at(q, pre, tbl, cs, dA, inc, lt, np.float32, hist, rule)
+                at['%s_inc%d_lt%d_%s' % (rule, inc, lt, 'hist' if hist else 'cond')] = qi
+np.savez_compressed(os.path.join(HERE, 'baro_contours_at.npz'), **at)
 print('wrote golden npz files')

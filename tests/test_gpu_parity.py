@@ -192,8 +192,10 @@ def _baro_da(xa, baro, flip=False):
 @pytest.mark.parametrize('increase', [True, False])
 @pytest.mark.parametrize('lt', [True, False])
 @pytest.mark.parametrize('flip', [False, True])
-def test_keff_call_sequence_8_cases(ctx, baro, increase, lt, flip):
-    """tests/test_hist.py computeKeff_hist / computeKeff for all (increase, lt) x coordinate direction"""
+@pytest.mark.parametrize('rule', ['xhistogram', 'numpy'])
+def test_keff_call_sequence_8_cases(ctx, baro, increase, lt, flip, rule):
+    """tests/test_hist.py computeKeff_hist / computeKeff for all (increase, lt) x coordinate direction, under both
+    last-bin rules (the fixture's latitudes are float32: under 'xhistogram' the last row leaves the table)"""
     import xcontour_amd as xa
     tr, dA, q, lat, lon = _baro_da(xa, baro, flip)
     N = 251
@@ -201,7 +203,7 @@ def test_keff_call_sequence_8_cases(ctx, baro, increase, lt, flip):
     grdS = xa.DataArray(g2, tr.dims, tr.coords, 'grdS')
     mask = xa.DataArray(np.ones_like(q), tr.dims, tr.coords, 'mask')
     cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'},
-                      increase=increase, lt=lt)
+                      increase=increase, lt=lt, right_edge=rule)
     table = cm.cal_area_eqCoord_table_hist(mask)
     ctr = cm.cal_contours(N)
     area = cm.cal_integral_within_contours_hist(ctr).rename('intArea')
@@ -213,10 +215,10 @@ def test_keff_call_sequence_8_cases(ctx, baro, increase, lt, flip):
     Leq2 = cm.cal_sqared_equivalent_length(dgrdSdA, dqdA)
     nkeff = cm.cal_normalized_Keff(Leq2, Lmin, mask=2e7)
     # oracle, same sequence
-    o_tbl, o_cs = O.cal_area_eqCoord_table_hist(np.ones_like(q), dA.values, lat, increase, lt)
+    o_tbl, o_cs = O.cal_area_eqCoord_table_hist(np.ones_like(q), dA.values, lat, increase, lt, rule)
     o_ctr = O.cal_contours(q, N, increase, np.float32)
-    o_area = O.cal_integral_within_contours_hist(q, o_ctr, dA.values, None, lt)
-    o_S = O.cal_integral_within_contours_hist(q, o_ctr, dA.values, g2, lt)
+    o_area = O.cal_integral_within_contours_hist(q, o_ctr, dA.values, None, lt, rule)
+    o_S = O.cal_integral_within_contours_hist(q, o_ctr, dA.values, g2, lt, rule)
     o_Yeq = O.lookup_coordinates(o_area, o_tbl, o_cs)
     o_Lmin = O.latitude_lengths_at(o_Yeq)
     o_dS = O.cal_gradient_wrt_area(o_S, o_area)
@@ -247,16 +249,24 @@ def test_keff_call_sequence_8_cases(ctx, baro, increase, lt, flip):
     assert ds['nkeff'].dims == ('new',)
 
 
-def test_golden_keff_fixtures(ctx, baro):
-    """the committed golden vectors (tests/golden/make_golden.py) through the fused pipeline"""
+@pytest.mark.parametrize('rule,sfx', [('xhistogram', ''), ('numpy', '_numpy')])
+def test_golden_keff_fixtures(ctx, baro, rule, sfx):
+    """the committed golden vectors (tests/golden/make_golden.py) through the fused pipeline, both last-bin rules.
+    The reference's bundled field has float32 latitudes and float32 contours of magnitude 1e-4: under 'xhistogram'
+    (the default) the max cell IS counted (131 072) and the last row leaves the table (end = 0.99994 x total)."""
     import xcontour_amd as xa
     tr, dA, q, lat, lon = _baro_da(xa, baro)
+    assert lat.dtype == np.float32
     mask = xa.DataArray(np.ones_like(q), tr.dims, tr.coords, 'mask')
+    kw = {} if rule == 'xhistogram' else {'right_edge': rule}           # 'xhistogram' must be the default
     cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'},
-                      increase=True, lt=True)
+                      increase=True, lt=True, **kw)
     table = cm.cal_area_eqCoord_table_hist(mask)
+    tot = dA.values.sum()
+    end = table._table.values[-1] / tot
+    assert abs(end - (0.99994 if rule == 'xhistogram' else 1.0)) < (1e-5 if rule == 'xhistogram' else 1e-14)
     for N in (121, 201):
-        g = np.load(os.path.join(GOLD, 'baro_keff_N%d.npz' % N))
+        g = np.load(os.path.join(GOLD, 'baro_keff_N%d%s.npz' % (N, sfx)))
         assert rel(table._table.values, g['tbl']) < 1e-13
         ds = cm.keff(N, table, preY=lat, lat=lat, lon=lon)
         assert np.array_equal(ds['ctr'].values, g['ctr'].astype(np.float64))
@@ -267,19 +277,48 @@ def test_golden_keff_fixtures(ctx, baro):
         assert rel(ds['Lmin'].values, g['Lmin'], LMIN_FLOOR) < RTOL
         for k in ('ctr', 'area', 'latEq', 'nkeff', 'Leq2'):
             assert rel(ds[k + '_eq'].values, g[k + '_eq']) < RTOL, k
+        # the façade's separate calls (reference call sequence) land on the same golden numbers
+        ctr = cm.cal_contours(N)
+        area = cm.cal_integral_within_contours_hist(ctr)
+        assert rel(area.values, g['area']) < TIGHT
+        assert rel(table.lookup_coordinates(area).values, g['latEq']) < 1e-9
+    # the headline differences between the rules, N = 201 above, N = 121 here
+    g = np.load(os.path.join(GOLD, 'baro_keff_N121%s.npz' % sfx))
+    ds = cm.keff(121, table, lat=lat, lon=lon)
+    e, _ = O.hist_edges(g['ctr'])
+    cnt = cm.ctx.hist(q[None], _rule_edges(e, rule), dA=dA.values, last_closed=(rule == 'numpy'), want=('counts',))['counts'][0]
+    assert int(cnt.sum()) == (131072 if rule == 'xhistogram' else 131071) and np.array_equal(cnt.astype(np.int64), g['counts'])
+    assert abs(ds['latEq'].values[-1] - (89.4631 if rule == 'xhistogram' else 89.4399)) < 1e-4
+    assert abs(ds['nkeff'].values[-1] - (104.963 if rule == 'xhistogram' else 95.8586)) < 1e-2
 
 
-@pytest.mark.parametrize('increase,lt,cd,re_', [(True, True, np.float64, 'numpy'), (False, True, np.float32, 'numpy'),
-                                                (True, False, np.float32, 'xhistogram'), (False, False, np.float64, 'numpy')])
-def test_fused_pipeline_batch_vs_oracle(ctx, increase, lt, cd, re_):
-    """xc_keff_dev on a batch of synthetic slabs with per-slab levels, counts bit-exact"""
+def _rule_edges(e, rule):
+    """explicit f64 edges for ctx.hist from level-dtype edges: xhistogram bumps the last one in the edge dtype"""
+    e = np.asarray(e)
+    if rule == 'xhistogram':
+        e = np.concatenate((e[:-1], e[-1:] + 1e-8))
+    return e.astype(np.float64)
+
+
+@pytest.mark.parametrize('increase,lt,cd,re_,latdt', [
+    (True, True, np.float64, 'numpy', np.float64), (False, True, np.float32, 'numpy', np.float32),
+    (True, False, np.float32, 'xhistogram', np.float64), (False, False, np.float64, 'numpy', np.float64),
+    (True, True, np.float64, 'xhistogram', np.float32), (False, False, np.float32, 'xhistogram', np.float32),
+    (False, True, np.float64, 'xhistogram', np.float32), (True, False, np.float64, 'xhistogram', np.float32)])
+def test_fused_pipeline_batch_vs_oracle(ctx, increase, lt, cd, re_, latdt):
+    """xc_keff_dev on a batch of synthetic slabs with per-slab levels, counts bit-exact; the A(Yeq) table comes from
+    the product's own path (K2 row sums + the last-row rule) and float32 latitudes drop its last row under 'xhistogram'"""
     from xcontour_amd.pipeline import KeffPlan
-    from xcontour_amd.utils import cell_area, table_from_rowsums
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
     ny, nx, N, S = 181, 360, 101, 5
-    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 1.0
+    lat = np.linspace(-90, 90, ny).astype(latdt); lon = np.arange(nx) * 1.0
     dA = cell_area(lat, lon)
     ylt = lt if increase else (not lt)
-    tbl = table_from_rowsums(dA.sum(1), ylt)
+    keep = last_row_included(lat, re_)
+    assert keep == (not (re_ == 'xhistogram' and latdt == np.float32))
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, ny, nx), ylt, keep)
+    o_tbl, _ = O.cal_area_eqCoord_table_hist(np.ones((ny, nx)), dA, lat, increase, lt, re_)
+    assert rel(tbl, o_tbl) < 1e-13
     plan = KeffPlan(ctx, S, ny, nx, N, np.float64, cd, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
                     preY=lat, increase=increase, lt=lt, right_edge=re_)
     plan.synth(lat, lon, 77, 0)
@@ -370,33 +409,45 @@ def test_lwa_directions_and_nans(ctx, increase, flip):
 
 # ---------------------------------------------------------------- full-size properties (BASELINE cfg2)
 def test_cfg2_full_size_properties(ctx):
-    """3600x1801 f64, 201 contours: size-independent invariants + a CPU cross-check of the counts"""
-    from xcontour_amd.pipeline import KeffPlan
-    from xcontour_amd.utils import cell_area, table_from_rowsums
+    """BASELINE cfg2 at full size (3600x1801 f64, 2-D f64 dA, 201 contours): ALL result vectors of the fused pipeline
+    against the oracle's Keff call sequence on the same slabs (0.4 s of numpy per slab), counts bit-exact, plus the
+    size-independent invariants"""
+    from xcontour_amd.pipeline import KeffPlan, OUT_NAMES
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
     ny, nx, N = 1801, 3600, 201
     lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 0.1
     dA = cell_area(lat, lon)
     rows = ctx.rowsum(None, dA, ny, nx)
     assert abs(rows.sum() / (4 * np.pi * O.Rearth ** 2) - 1) < 1e-12       # sphere area
-    tbl = table_from_rowsums(rows, True)
-    assert tbl[0] == 0 and abs(tbl[-1] / rows.sum() - 1) < 1e-13           # end point = total area (core.py:133-140)
+    tbl = table_from_rowsums(rows, True, last_row_included(lat))
+    assert tbl[0] == 0 and abs(tbl[-1] / rows.sum() - 1) < 1e-13           # f64 latitudes: end point = total area
+    preY = np.linspace(-90, 90, 181)
     plan = KeffPlan(ctx, 2, ny, nx, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
-                    increase=True, lt=True)
+                    increase=True, lt=True, preY=preY)
     plan.synth(lat, lon, 20241008, 0)
     plan.run()
     out = plan.fetch()
     q = plan.download_q()
     for s in range(2):
-        assert ny * nx - int(out['counts'][s].sum()) in (0, 1)              # every cell in one bin (max cell may miss the rounded last level, SURVEY F9)
+        assert int(out['counts'][s].sum()) == ny * nx                       # xhistogram rule: every cell in one bin
         assert out['area'][s, 0] == 0 and (np.diff(out['area'][s]) >= 0).all()
-        assert abs(out['area'][s, -1] / rows.sum() - 1) < 1e-6              # cdf[-1] == total in-range weight
-        assert (np.diff(out['intgrdS'][s]) >= 0).all()
-        assert (np.diff(out['latEq'][s]) >= 0).all()
-        ctr = O.cal_contours(q[s], N, True, np.float64)
-        assert np.array_equal(out['ctr'][s], ctr)
-        e, _ = O.hist_edges(ctr)
-        h, _ = np.histogram(q[s].ravel(), bins=e)
-        assert np.array_equal(out['counts'][s].astype(np.int64), h)         # bit-exact counts at full size
+        assert abs(out['area'][s, -1] / rows.sum() - 1) < 1e-12             # cdf[-1] == total weight
+        assert (np.diff(out['intgrdS'][s]) >= 0).all() and (np.diff(out['latEq'][s]) >= 0).all()
+        r = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float64, preLats=preY)
+        assert rel(tbl, r['tbl']) < 1e-13
+        assert np.array_equal(out['counts'][s].astype(np.int64), r['counts'])   # bit-exact counts at full size
+        assert np.array_equal(out['ctr'][s], r['ctr'])                           # bit-exact levels
+        assert rel(out['area'][s], r['area']) < TIGHT and rel(out['intgrdS'][s], r['intgrdS']) < TIGHT
+        for k in ('latEq', 'dqdA', 'dintSdA', 'Leq2'):
+            assert rel(out[k][s], r[k]) < RTOL, k
+        assert rel(out['Lmin'][s], r['Lmin'], LMIN_FLOOR) < RTOL
+        ok = r['Lmin'] > LMIN_FLOOR                                            # nkeff = Leq2 / Lmin^2 away from the pole
+        assert rel(out['nkeff'][s][ok], r['nkeff'][ok]) < RTOL
+        assert np.array_equal(np.isnan(out['nkeff'][s]), np.isnan(r['nkeff']))
+        for k in OUT_NAMES:
+            if k in ('Lmin', 'nkeff'):
+                continue
+            assert rel(out[k + '_eq'][s], r[k + '_eq']) < RTOL, k + '_eq'
     # idempotence: a second run of the same plan gives bit-identical counts and 1e-13-close sums
     plan.run()
     out2 = plan.fetch()
@@ -448,12 +499,14 @@ def test_radix_sort_profile_vs_oracle(ctx, baro, dt):
     assert n == q.size
     assert np.array_equal(out['q_sorted'][:n], xs.astype(np.float64))          # the sort itself: exact
     assert rel(out['acum'][:n], acum) < 1e-12                                  # parallel scan vs np.cumsum
-    # Q_exact: identical except where a target sits within rounding of an Acum value
-    same = out['Q'] == Qo
-    assert same.mean() > 0.9          # ties between table values and Acum at row boundaries are rounding-sensitive
-    io = np.minimum(np.searchsorted(acum, tbl, side='right'), n - 1)[~same]     # oracle's sorted index
-    lo, hi = xs[np.maximum(io - 2, 0)], xs[np.minimum(io + 2, n - 1)]
-    assert ((out['Q'][~same] >= lo) & (out['Q'][~same] <= hi)).all()                # at most 2 sorted cells away
+    # Q_exact, strictly: q_sorted[searchsorted(Acum, target, 'right')]; where a target ties with an Acum value to
+    # within 1e-11 of the total (the table IS a cumulative sum of the same areas) either neighbour is valid
+    # (oracle.sorted_profile_brackets) -- no other deviation is tolerated
+    lo, hi = O.sorted_profile_brackets(acum, tbl)
+    assert (out['Q'] >= xs[lo]).all() and (out['Q'] <= xs[hi]).all()
+    assert np.isin(out['Q'], xs).all()
+    untied = lo == hi
+    assert untied.sum() >= 5 and np.array_equal(out['Q'][untied], Qo[untied])      # away from ties: identical to the oracle
     assert abs(out['bpe'] / O.bpe_integral(q, dA, tbl, cs) - 1) < 1e-10
     # relation to the reference's histogram profile: within one contour spacing
     g = np.load(os.path.join(GOLD, 'baro_keff_N121.npz'))
@@ -475,8 +528,9 @@ def test_radix_sort_nan_mask_negatives_and_ties(ctx):
     assert np.array_equal(out['q_sorted'][:n], xs)
     # stability: equal keys keep their original order, so the payload sequence matches numpy's stable sort
     assert rel(out['acum'][:n], acum) < 1e-12
-    io = np.minimum(np.searchsorted(acum, np.linspace(0, w.sum() * nx, 50), side='right'), n - 1)
-    assert ((out['Q'] >= xs[np.maximum(io - 2, 0)]) & (out['Q'] <= xs[np.minimum(io + 2, n - 1)])).all()
+    lo, hi = O.sorted_profile_brackets(acum, np.linspace(0, w.sum() * nx, 50))
+    assert (out['Q'] >= xs[lo]).all() and (out['Q'] <= xs[hi]).all()
+    assert np.array_equal(out['Q'][lo == hi], Qo[lo == hi]) and (lo == hi).sum() >= 40
     # no weights, no mask
     out2 = ctx.sort_profile(q, want_sorted=True)
     ok = ~np.isnan(q)
@@ -529,12 +583,12 @@ def test_cfg5_xz_plane_lape_and_bpe(ctx):
     """tests/test_LAPE.py call sequence on a synthetic X-Z section (internalwave.nc is missing):
     non-periodic X, decreasing Z coordinate, topography mask, increase=False, lt=False."""
     import xcontour_amd as xa
-    nz, nxx = 100, 448
+    nz, nxx = 100, 4480                                                # SURVEY 8(d) cfg5: nz = 100 x nx = 4480
     Z = -(np.arange(nz) + 0.5) * 2.0                                   # 0 ... -200 m, decreasing
     X = (np.arange(nxx) + 0.5) * 20.0
     xx, zz = np.meshgrid(X, Z)
-    T = 20 + 5 * np.tanh((zz + 60 + 15 * np.sin(2 * np.pi * xx / 3000.0)) / 20.0)
-    depth = 200 - 80 * np.exp(-((X - 6000) / 1500.0) ** 2)              # a ridge
+    T = 20 + 5 * np.tanh((zz + 60 + 15 * np.sin(2 * np.pi * xx / 30000.0)) / 20.0)
+    depth = 200 - 80 * np.exp(-((X - 60000) / 15000.0) ** 2)            # a ridge
     maskC = (zz > -depth[None, :]).astype(np.float64)
     b = 2e-4 * (np.where(maskC == 1, T, np.nan) - 20) * 9.81            # buoyancy, NaN in topography
     c = {'Z': Z, 'XC': X}
@@ -951,8 +1005,9 @@ def test_batched_sort_equals_per_slab_oracle(ctx, dt):
         n = len(xs)
         assert np.array_equal(r['q_sorted'][s][:n], xs.astype(np.float64))
         assert rel(r['acum'][s][:n], ac) < 1e-12
-        idx = np.minimum(np.searchsorted(r['acum'][s][:n], tbl, side='right'), n - 1)     # ties in Acum: +-1 cell
-        assert np.all(np.abs(np.searchsorted(xs, r['Q'][s]) - np.searchsorted(xs, xs[idx])) <= 2)
+        lo, hi = O.sorted_profile_brackets(ac, tbl)                                       # the documented tie rule
+        assert (r['Q'][s] >= xs[lo]).all() and (r['Q'][s] <= xs[hi]).all()
+        assert np.array_equal(r['Q'][s][lo == hi], Qo[lo == hi].astype(np.float64))
         assert abs(r['bpe'][s] - O.bpe_integral(q[s], dA[s], tbl, coord, mask[s])) <= 1e-11 * abs(dA[s].sum())
     # shared mask / shared dA variants agree with the per-slab call
     r2 = ctx.sort_profile(q, dA=dA[0], mask=mask[0], targets=tbl)
@@ -1038,8 +1093,8 @@ def test_keff_thousands_of_contours(ctx, baro):
     q, lat, lon = baro
     dA = O.cell_area(lat, lon)
     from xcontour_amd.pipeline import KeffPlan
-    from xcontour_amd.utils import table_from_rowsums
-    tbl = table_from_rowsums(ctx.rowsum(None, dA, 256, 512), True)
+    from xcontour_amd.utils import table_from_rowsums, last_row_included
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, 256, 512), True, last_row_included(lat))
     for N in (2000, 4500):
         plan = KeffPlan(ctx, 1, 256, 512, N, np.float32, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
                         increase=True, lt=True)

@@ -55,14 +55,30 @@ def test_edges_from_levels_match_oracle(dt):
 
 
 def test_table_from_rowsums_matches_histogram_semantics():
+    """table_from_rowsums + last_row_included == the oracle's degenerate histogram (core.py:150-203 -> 1296-1325) for
+    both last-bin rules, float32 / float64 / small-magnitude float32 coordinates, both coordinate directions"""
+    from xcontour_amd.utils import last_row_included
     rng = np.random.default_rng(2)
     J, nx = 9, 4
     dA = rng.random((J, nx)) + 0.1
-    coord = np.linspace(-80, 80, J)
-    for ylt in (True, False):
-        # oracle with increase=True on an increasing coordinate: ylt == lt
-        tbl, _ = O.cal_area_eqCoord_table_hist(np.ones((J, nx)), dA, coord, True, ylt)
-        assert np.allclose(table_from_rowsums(dA.sum(1), ylt), tbl, rtol=1e-14, atol=0)
+    mask = np.ones((J, nx)); mask[3, 1] = 0
+    rows = np.where(mask == 1, dA, 0).sum(1)
+    for coord in (np.linspace(-80, 80, J), np.linspace(-80, 80, J).astype(np.float32), np.linspace(80, -80, J).astype(np.float32),
+                  np.linspace(-0.2, 0.0, J).astype(np.float32), np.linspace(-1e9, 1e9, J), np.arange(J)):
+        asc = rows if coord[-1] > coord[0] else rows[::-1]
+        for rule in ('xhistogram', 'numpy'):
+            keep = last_row_included(coord, rule)
+            if rule == 'numpy':
+                assert keep
+            else:      # f32 of magnitude >= 0.25 and f64 beyond ~1e8 cannot represent the +1e-8 bump
+                assert keep == (not ((coord.dtype == np.float32 and abs(coord).max() > 0.25) or abs(coord).max() > 1e8))
+            for inc in (True, False):
+                for lt in (True, False):
+                    tbl, cs = O.cal_area_eqCoord_table_hist(mask, dA, coord, inc, lt, rule)
+                    ylt = lt if (inc == bool(coord[-1] > coord[0])) else (not lt)
+                    assert np.allclose(table_from_rowsums(asc, ylt, keep), tbl, rtol=1e-14, atol=1e-14), (coord.dtype, rule, inc, lt)
+    with pytest.raises(Exception, match='right_edge'):
+        last_row_included(np.arange(3.), 'closed')
 
 
 def test_contour_space_algebra_matches_oracle(baro):

@@ -29,24 +29,24 @@ def test_survey_known_counts(baro, N, first5, last5, sha):
     ctr = O.cal_contours(q, N, True, np.float32)
     assert ctr.dtype == np.float32 and ctr[0] == q.min()
     assert ctr[-1] == np.float32(0.0001790785) and ctr[-1] != q.max()
-    _, cnt = O.cal_integral_within_contours_hist(q, ctr, dA, None, True, return_counts=True)
-    assert cnt.sum() == 131071                                               # max cell excluded
+    _, cnt = O.cal_integral_within_contours_hist(q, ctr, dA, None, True, 'numpy', return_counts=True)
+    assert cnt.sum() == 131071                                               # numpy rule: max cell excluded
     assert list(cnt[:5]) == first5 and list(cnt[-5:]) == last5
     assert hashlib.sha256(cnt.astype(np.int64).tobytes()).hexdigest().startswith(sha)
     # numpy's own histogram has the same semantics
     e, _ = O.hist_edges(ctr)
     h, _ = np.histogram(q.ravel(), bins=e)
     assert np.array_equal(h, cnt)
-    # the xhistogram (+1e-8) rule keeps the max cell
-    _, c2 = O.cal_integral_within_contours_hist(q, ctr, dA, None, True, 'xhistogram', True)
-    assert c2.sum() == 131072
+    # the xhistogram (+1e-8 in the f32 edge dtype: 1.79e-4 absorbs it) rule keeps the max cell -- the DEFAULT
+    _, c2 = O.cal_integral_within_contours_hist(q, ctr, dA, None, True, return_counts=True)
+    assert c2.sum() == 131072 and np.array_equal(c2[:-1], cnt[:-1]) and c2[-1] == cnt[-1] + 1
 
 
 def test_survey_known_keff_and_lwa(baro):
     q, lat, lon = baro
     dA = O.cell_area(lat, lon)
     assert abs(dA.sum() / (4 * np.pi * O.Rearth ** 2) - 1) < 1e-14
-    r = O.keff_pipeline(q, dA, lat, 121, lon=lon, preLats=lat)
+    r = O.keff_pipeline(q, dA, lat, 121, lon=lon, preLats=lat, right_edge='numpy')     # SURVEY's numbers: numpy rule
     assert abs(r['area'][-1] / 5.1009325369688875e14 - 1) < 1e-12
     assert abs(r['area'][-1] / dA.sum() - 0.9999936) < 1e-7
     nk = r['nkeff']
@@ -62,7 +62,7 @@ def test_survey_known_keff_and_lwa(baro):
     assert abs(lat[np.argmax(lwa.mean(1))] - 29.82) < 0.01
     for j, v in zip((37, 125, 170, 213), (0.285, 3.224, 9.943, 7.817)):
         assert abs(lwa[j].mean() - v) < 1e-3
-    r2 = O.keff_pipeline(q, dA, lat, 201, lon=lon)
+    r2 = O.keff_pipeline(q, dA, lat, 201, lon=lon, right_edge='numpy')
     nk = r2['nkeff']
     assert abs(np.nanmin(nk) - 0.902) < 1e-3 and abs(np.nanmedian(nk) - 2.35) < 1e-2 and abs(np.nanmax(nk) - 98.1) < 0.1
 
@@ -75,15 +75,18 @@ def test_hist_vs_strict_twin(baro):
     for N in (121, 201):
         ctr = O.cal_contours(q, N, True, np.float32)
         for integ in (None, g2):
-            a = O.cal_integral_within_contours_hist(q, ctr, dA, integ, True)
+            a = O.cal_integral_within_contours_hist(q, ctr, dA, integ, True, 'numpy')
             b = O.cal_integral_within_contours(q, ctr, dA, integ, True)
             assert np.max(np.abs(a[1:] - b[1:]) / b[1:]) < 1e-12
+            # default (xhistogram) rule: the last level additionally holds the cells in [ctr[-1], ctr[-1] + 1e-8)
+            ax = O.cal_integral_within_contours_hist(q, ctr, dA, integ, True)
+            assert np.array_equal(ax[:-1], a[:-1]) and ax[-1] > a[-1]
 
 
 def test_histogram_semantics_small():
     """SURVEY A3."""
     x = np.array([np.nan, -1, 0, .5, 1, 2.999, 3, 3 + 5e-9, 3.0001])
-    s, c = O.weighted_histogram(x, np.array([0., 1, 2, 3]))
+    s, c = O.weighted_histogram(x, np.array([0., 1, 2, 3]), right_edge='numpy')
     assert list(c) == [2, 1, 2]          # last bin closed: 2.999, 3
     s, c = O.weighted_histogram(x, np.array([0., 1, 2, 3]), right_edge='xhistogram')
     assert list(c) == [2, 1, 3]          # [2, 3+1e-8): 2.999, 3, 3+5e-9
@@ -91,6 +94,45 @@ def test_histogram_semantics_small():
     e32 = np.array([0., 1, 2, 3], dtype=np.float32)
     s, c = O.weighted_histogram(x.astype(np.float32), e32, right_edge='xhistogram')
     assert list(c) == [2, 1, 1]
+
+
+def test_table_last_row_rule_f32_vs_f64_coordinates(baro):
+    """under the xhistogram rule the last row of the A(Yeq) table drops out iff
+    `coord[-1] + 1e-8 == coord[-1]` in the coordinate dtype -- true for the float32 latitudes of the
+    reference's own barotropic_vorticity.nc, false for float64 ones."""
+    q, lat, lon = baro
+    assert lat.dtype == np.float32 and (lat[-1:] + 1e-8)[0] == lat[-1]
+    dA = O.cell_area(lat, lon)
+    tot = dA.sum()
+    t_x, _ = O.cal_area_eqCoord_table_hist(np.ones_like(q), dA, lat, True, True)              # default rule
+    t_n, _ = O.cal_area_eqCoord_table_hist(np.ones_like(q), dA, lat, True, True, 'numpy')
+    t_64, _ = O.cal_area_eqCoord_table_hist(np.ones_like(q), dA, lat.astype(np.float64), True, True)
+    assert abs(t_n[-1] / tot - 1) < 1e-14 and abs(t_64[-1] / tot - 1) < 1e-14
+    assert abs(t_x[-1] / tot - 0.99994) < 1e-5 and np.array_equal(t_x[:-1], t_n[:-1])
+    assert abs(t_x[-1] - (tot - dA[-1].sum())) < 1e-3 * dA[-1].sum()
+    r = O.keff_pipeline(q, dA, lat, 121, lon=lon)                                              # default rule
+    assert r['counts'].sum() == 131072 and abs(r['latEq'][-1] - 89.4631) < 1e-4 and abs(r['nkeff'][-1] - 104.963) < 1e-2
+    r = O.keff_pipeline(q, dA, lat, 121, lon=lon, right_edge='numpy')
+    assert r['counts'].sum() == 131071 and abs(r['latEq'][-1] - 89.4399) < 1e-4 and abs(r['nkeff'][-1] - 95.8586) < 1e-2
+
+
+def test_contours_at_oracle_golden(baro):
+    """f3 (core.py:269-360): committed vectors == oracle; q(Y) is monotone and brackets the tracer range"""
+    q, lat, lon = baro
+    dA = O.cell_area(lat, lon)
+    g = np.load(os.path.join(GOLD, 'baro_contours_at.npz'))
+    pre = g['predef']
+    for rule in ('xhistogram', 'numpy'):
+        for inc in (True, False):
+            for lt in (True, False):
+                tbl, cs = O.cal_area_eqCoord_table_hist(np.ones_like(q), dA, lat, inc, lt, rule)
+                for hist in (True, False):
+                    qi, ctr = O.cal_contours_at(q, pre, tbl, cs, dA, inc, lt, np.float32, hist, rule)
+                    assert qi.dtype == np.float64 and qi.shape == pre.shape
+                    assert np.array_equal(qi, g['%s_inc%d_lt%d_%s' % (rule, inc, lt, 'hist' if hist else 'cond')])
+                    assert qi.min() >= q.min() and qi.max() <= q.max()
+    with pytest.raises(Exception, match='predef should be a 1D array'):
+        O.cal_contours_at(q, np.zeros((2, 2)), tbl, cs, dA)
 
 
 def test_table_rules():
@@ -117,11 +159,13 @@ def test_table_rules():
 def test_golden_files_match_oracle(baro):
     q, lat, lon = baro
     dA = O.cell_area(lat, lon)
-    for N in (121, 201):
-        g = np.load(os.path.join(GOLD, 'baro_keff_N%d.npz' % N))
-        r = O.keff_pipeline(q, dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float32, preLats=lat)
-        for k in g.files:
-            assert np.array_equal(g[k], r[k], equal_nan=True), k
+    for rule, sfx in (('xhistogram', ''), ('numpy', '_numpy')):
+        for N in (121, 201):
+            g = np.load(os.path.join(GOLD, 'baro_keff_N%d%s.npz' % (N, sfx)))
+            r = O.keff_pipeline(q, dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float32, preLats=lat,
+                                right_edge=rule)
+            for k in g.files:
+                assert np.array_equal(g[k], r[k], equal_nan=True), k
 
 
 def test_crossing_oracle_vectorised_equals_literal_loops():

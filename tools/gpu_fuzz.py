@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import xcontour_oracle as O
 from xcontour_amd import _native as nat
 from xcontour_amd.pipeline import KeffPlan
-from xcontour_amd.utils import table_from_rowsums
+from xcontour_amd.utils import table_from_rowsums, last_row_included
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 and __name__ == '__main__' else 60.0
 checked = {}
@@ -72,11 +72,19 @@ def case_keff():
     dt = rng.choice([np.float32, np.float64]); cdt = rng.choice([np.float32, np.float64])
     q = field(S, ny, nx, dt)
     q[~np.isfinite(q)] = 0.0
-    lat = np.linspace(-80, 80, ny); lon = np.arange(nx) * (360.0 / nx)
+    # float32 coordinates half the time: under the xhistogram rule `lat[-1] + 1e-8 == lat[-1]` then, and the last
+    # row drops out of the A(Yeq) table (the reference's own barotropic_vorticity.nc has float32 latitudes)
+    lat = np.linspace(-80, 80, ny).astype(rng.choice([np.float32, np.float64])); lon = np.arange(nx) * (360.0 / nx)
     dA = O.cell_area(lat, lon)
     N = int(rng.integers(3, 60)); inc = bool(rng.random() < 0.5); lt = bool(rng.random() < 0.5)
-    tbl, cs = O.cal_area_eqCoord_table_hist(np.ones((ny, nx)), dA, lat, inc, lt)
-    plan = KeffPlan(ctx, S, ny, nx, N, dt, cdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=cs, increase=inc, lt=lt)
+    re_ = str(rng.choice(['numpy', 'xhistogram']))
+    ylt = lt if inc else (not lt)
+    rows = ctx.rowsum(None, dA, ny, nx)
+    tbl = table_from_rowsums(rows, ylt, last_row_included(lat, re_))          # the product's own table path (K2 + host rule)
+    otbl, cs = O.cal_area_eqCoord_table_hist(np.ones((ny, nx)), dA, lat, inc, lt, re_)
+    assert relerr(tbl, otbl) < 1e-12, 'keff table'
+    plan = KeffPlan(ctx, S, ny, nx, N, dt, cdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=cs, increase=inc, lt=lt,
+                    right_edge=re_)
     plan.set_q(q); plan.run()
     try:
         r = plan.fetch()
@@ -84,8 +92,10 @@ def case_keff():
         plan.free(); return
     plan.free()
     for s in range(S):
-        o = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=inc, lt=lt, dtype=cdt)
+        o = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=inc, lt=lt, dtype=cdt, right_edge=re_)
         assert np.array_equal(r['ctr'][s], o['ctr'].astype(np.float64)), 'keff ctr'
+        assert np.array_equal(r['counts'][s].astype(np.int64), o['counts']), 'keff counts'
+        assert relerr(r['latEq'][s], o['latEq']) < 1e-9, 'keff latEq'
         assert relerr(r['area'][s], o['area']) < 1e-11, 'keff area'
         assert relerr(r['intgrdS'][s], o['intgrdS']) < 1e-9, 'keff intgrdS'
         tick('keff')
@@ -158,7 +168,7 @@ def case_facade():
     ny, nx = int(rng.integers(6, 60 * SC)), int(rng.integers(6, 150 * SC))
     dt = rng.choice([np.float32, np.float64]); cdt = rng.choice([np.float32, np.float64])
     inc, lt, flip = bool(rng.random() < 0.5), bool(rng.random() < 0.5), bool(rng.random() < 0.5)
-    lat = np.linspace(-85, 85, ny); lon = np.arange(nx) * (360.0 / nx)
+    lat = np.linspace(-85, 85, ny).astype(rng.choice([np.float32, np.float64])); lon = np.arange(nx) * (360.0 / nx)
     q = field(1, ny, nx, dt)[0]
     if flip:
         lat = lat[::-1].copy()

@@ -59,7 +59,7 @@ class KeffDesc(C.Structure):
         ('ctr', _vp), ('area', _vp), ('intgrdS', _vp), ('latEq', _vp),
         ('dqdA', _vp), ('dintSdA', _vp), ('Leq2', _vp), ('Lmin', _vp), ('nkeff', _vp),
         ('counts', _vp), ('interp', _vp), ('status', _vp), ('q_next', _vp),
-        ('dA_pos_finite', _i32), ('_pad2', _i32),
+        ('dA_pos_finite', _i32), ('q_gen', _i32),
     ]
 
 
@@ -302,7 +302,7 @@ class Context(object):
                                        int(q.size // nslab), _ptr(out)))
         return out
 
-    def levels(self, minmax, q_dtype, N, increase, ctr_dtype, right_edge=XC_EDGE_NUMPY):
+    def levels(self, minmax, q_dtype, N, increase, ctr_dtype, right_edge=XC_EDGE_XHISTOGRAM):
         minmax = np.ascontiguousarray(minmax, dtype=np.float64)
         nslab = minmax.shape[0]
         ctr = np.empty((nslab, N), dtype=np.float64)

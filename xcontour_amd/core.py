@@ -20,14 +20,15 @@ Division of labour
 Extensions over the reference (all optional, defaults follow the snapshot):
   * contour sets may differ per leading (time, level, ...) index in the *_hist methods
     (the reference only supports a `time` loop, core.py:1259-1294);
-  * `right_edge='numpy'|'xhistogram'` selects the last-bin rule (see oracle header);
+  * `right_edge='xhistogram'|'numpy'` selects the last-bin rule: the default is what the reference
+    runs (xhistogram: last edge + 1e-8 in the edge dtype, half-open), 'numpy' closes the last bin;
   * `cal_squared_gradient`, `keff` (fused pipeline), `metric=` in cal_local_wave_activity.
 """
 import numpy as np
 
 from . import _native as nat
 from . import labeled as lb
-from .utils import Rearth, grad_metrics, table_from_rowsums
+from .utils import Rearth, grad_metrics, table_from_rowsums, last_row_included
 
 
 def _as_labeled_1d(arr, dim):
@@ -43,7 +44,7 @@ class Contour2D(object):
 
     def __init__(self, trcr, dA, dims, dimEq, arakawa='A',
                  increase=True, lt=False, check_mono=False, dtype=np.float32,
-                 device=0, right_edge='numpy'):
+                 device=0, right_edge='xhistogram'):
         if len(dimEq) != 1:
             raise Exception('dimEq should be one dimension e.g., {"Y","lat"}')
 
@@ -196,7 +197,9 @@ class Contour2D(object):
         yIncre = not (coord[-1] < coord[0])                               # core.py:180-182
         ylt = self.lt if (self.increase == yIncre) else (not self.lt)     # core.py:184-188
         rows_asc = rows if yIncre else rows[::-1]
-        tbl = table_from_rowsums(rows_asc, ylt)
+        # the last row sits ON the last bin edge: kept by numpy's closed last bin, kept by xhistogram only
+        # if `edge + 1e-8` is representable in the coordinate dtype (core.py:1307 -> xhistogram)
+        tbl = table_from_rowsums(rows_asc, ylt, last_row_included(coord, self.right_edge))
         cs = coord if yIncre else coord[::-1]                             # core.py:195-198
         tbl = lb.wrap(tbl, (self.dimEqV,), {self.dimEqV: cs.copy()}, 'AeqCTbl', mask)
         if self.check_mono:
@@ -586,10 +589,15 @@ class Contour2D(object):
         Qv, Qdims, _, _ = lb.unwrap(Q)
         if self.dimEqV not in Qdims:
             raise Exception('Q should be defined on %s' % self.dimEqV)
+        # Q's leading dims in the TRACER's leading-dim order (missing ones broadcast), so that slab s of q meets row s of Q
         Ql = [d for d in Qdims if d != self.dimEqV]
-        Qv = np.transpose(Qv, [Qdims.index(d) for d in Ql] + [Qdims.index(self.dimEqV)])
-        Qv = np.ascontiguousarray(np.broadcast_to(Qv.reshape((-1, ny)) if Ql else Qv[None, :], (nslab, ny)),
-                                  dtype=np.float64)
+        extra = [d for d in Ql if d not in lead]
+        if extra:
+            raise Exception('Q has dims %r that q does not have' % extra)
+        order = [d for d in lead if d in Ql]
+        Qv = np.transpose(Qv, [Qdims.index(d) for d in order] + [Qdims.index(self.dimEqV)])
+        shp = [lshape[lead.index(d)] if d in Ql else 1 for d in lead] + [ny]
+        Qv = np.ascontiguousarray(np.broadcast_to(Qv.reshape(shp), tuple(lshape) + (ny,)), dtype=np.float64).reshape(nslab, ny)
         dA, _ = self._dA_array(ny, nx, 1)
         if dA.ndim == 3:
             dA = dA[0]
@@ -702,9 +710,12 @@ class Contour2D(object):
         q = self._float(q)
         nslab, ny, nx = q.shape
         dA, dA_f32 = self._dA_array(ny, nx, nslab)
-        if dA.ndim == 3:
-            raise Exception('keff(): time-varying dA is not supported by the fused pipeline')
+        slab_dA = dA.ndim == 3                              # weights with a leading (time, ...) dim, core.py:1271-1274
         tv, tdims, tcoords, _ = lb.unwrap(table._table)
+        if tv.ndim != 1:
+            raise Exception('keff() needs a time-invariant A(Yeq) table')
+        if len(tv) != ny:
+            raise Exception('the A(Yeq) table has %d entries but the tracer has %d rows along %s' % (len(tv), ny, self.dimEqV))
         g = None
         if grdS is not None:
             g = self._float(self._plane(grdS)[0])
@@ -717,27 +728,34 @@ class Contour2D(object):
         # dA is the grid metric, not something callers edit in place between calls).
         def small(a):
             return None if a is None else np.ascontiguousarray(a, dtype=np.float64).tobytes()
-        per_slab = ny * nx * (q.dtype.itemsize + (0 if g is None else g.dtype.itemsize))
+        per_slab = ny * nx * (q.dtype.itemsize + (0 if g is None else g.dtype.itemsize) + (8 if slab_dA else 0))
         batch = int(min(nslab, max(1, int(max_batch_bytes) // per_slab), 65535))
         flat = dA.reshape(-1)
+        # a per-slab dA travels with every batch (like the tracer): only its shape enters the key
+        dkey = ('slab',) if slab_dA else (flat[::max(1, flat.size // 4096)].tobytes(), float(flat[0]), float(flat[-1]))
         key = (batch, ny, nx, int(N), q.dtype.str, np.dtype(self.dtype).str, None if g is None else g.dtype.str,
                bool(periodic_x), float(nkeff_mask), bool(self.increase), bool(self.lt), self.right_edge, self.device,
-               dA.shape, flat[::max(1, flat.size // 4096)].tobytes(), float(flat[0]), float(flat[-1]),
+               dA.shape[-2:] if slab_dA else dA.shape, dkey,
                small(tv), small(tcoords[table._dimEq]), small(preY), small(rdx), small(rdy))
         plans = self.__dict__.setdefault('_keff_plans', {})
         plan = plans.pop(key, None)
         if plan is None:
-            plan = KeffPlan(self.ctx, batch, ny, nx, N, q.dtype, self.dtype, dA=dA, rdx=rdx, rdy=rdy,
+            plan = KeffPlan(self.ctx, batch, ny, nx, N, q.dtype, self.dtype, dA=dA[:batch] if slab_dA else dA, rdx=rdx, rdy=rdy,
                             periodic_x=periodic_x, tbl=tv, tbl_coord=tcoords[table._dimEq], preY=preY,
                             increase=self.increase, lt=self.lt, right_edge=self.right_edge,
                             nkeff_mask=nkeff_mask, grdS_dtype=None if g is None else g.dtype,
                             prod_f32=bool(g is not None and g.dtype == np.float32 and dA_f32),
-                            detect_row_dA=True)
+                            detect_row_dA=not slab_dA)
+        if slab_dA:
+            plan.desc.dA_pos_finite = int(bool(np.isfinite(dA).all() and (dA >= 0).all()))
         try:
             parts = []
             for s0 in range(0, nslab, batch):
                 m = min(batch, nslab - s0)
                 plan.q_buf.upload(q[s0:s0 + m])
+                plan.touch()
+                if slab_dA:
+                    plan.dA_buf.upload(dA[s0:s0 + m])
                 if g is not None:
                     plan.grdS_buf.upload(g[s0:s0 + m])
                 plan.run_range(0, 0, m)

@@ -5,6 +5,9 @@
 #include <string.h>
 #include <stdio.h>
 #include <new>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace xc {
 
@@ -54,6 +57,29 @@ int ensure_ones(xc_ctx* ctx, size_t n)
     XC_HIP(ctx, hipMemcpy(ctx->ones, h.data(), want * sizeof(double), hipMemcpyHostToDevice));
     ctx->ones_n = want;
     return XC_OK;
+}
+
+int ensure_big_lds(xc_ctx* ctx, const void* kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_pair(kernel, ctx->device);
+    if (done.count(key)) return XC_OK;
+    XC_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert(key);
+    return XC_OK;
+}
+
+// chained min/max partials (xc_keff_desc.q_next) describe the bytes [mm_q, mm_q + nslab*ny*nx*esize): any write into
+// that range through the library, or freeing it, drops them
+static void mm_touch(xc_ctx* ctx, const void* p, size_t bytes)
+{
+    if (!ctx->mm_valid || !p) return;
+    const char* a0 = (const char*)ctx->mm_q;
+    const char* a1 = a0 + (size_t)ctx->mm_nslab * ctx->mm_ny * ctx->mm_nx * (ctx->mm_dtype == XC_F32 ? 4 : 8);
+    const char* b0 = (const char*)p;
+    if (b0 < a1 && b0 + (bytes ? bytes : 1) > a0) ctx->mm_valid = 0;
 }
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -175,6 +201,7 @@ int xc_free(xc_ctx* ctx, void* dptr)
 {
     XC_CTX(ctx);
     if (!dptr) return XC_OK;
+    mm_touch(ctx, dptr, (size_t)1 << 62);         // an allocation that starts at or below the cached batch may contain it
     XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     XC_HIP(ctx, hipFree(dptr));
     return XC_OK;
@@ -184,6 +211,7 @@ int xc_memcpy_h2d(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes
 {
     XC_CTX(ctx);
     if (bytes && (!dst_dev || !src_host)) return fail(ctx, XC_EBADARG, "xc_memcpy_h2d: NULL pointer");
+    mm_touch(ctx, dst_dev, bytes);
     XC_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return XC_OK;
@@ -202,6 +230,7 @@ int xc_memset(xc_ctx* ctx, void* dptr, int value, size_t bytes)
 {
     XC_CTX(ctx);
     if (bytes && !dptr) return fail(ctx, XC_EBADARG, "xc_memset: NULL pointer");
+    mm_touch(ctx, dptr, bytes);
     XC_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
     return XC_OK;
 }
@@ -698,7 +727,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
 
     // min/max partials: either produced by the previous call's histogram pass (q_next) or by K1 now
     if (ctx->mm_valid && ctx->mm_q == d->q && ctx->mm_nslab == d->nslab && ctx->mm_ny == d->ny &&
-        ctx->mm_nx == d->nx && ctx->mm_dtype == d->q_dtype) {
+        ctx->mm_nx == d->nx && ctx->mm_dtype == d->q_dtype && ctx->mm_gen == d->q_gen) {
         mmpart = ctx->mmnext[ctx->mm_cur]; mmP = ctx->mm_P;
     } else {
         XC_TRY(launch_minmax_partial(ctx, d->q, d->q_dtype, d->nslab, d->ny * d->nx, mmpart));
@@ -731,6 +760,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     if (d->q_next) {
         ctx->mm_cur = 1 - ctx->mm_cur; ctx->mm_valid = 1; ctx->mm_P = g.bps; ctx->mm_q = d->q_next;
         ctx->mm_nslab = d->nslab; ctx->mm_ny = d->ny; ctx->mm_nx = d->nx; ctx->mm_dtype = d->q_dtype;
+        ctx->mm_gen = d->q_gen;
     }
 
     FinalArgs f; memset(&f, 0, sizeof(f));
@@ -752,6 +782,7 @@ int xc_synth_dev(xc_ctx* ctx, void* out, int q_dtype, int64_t nslab, int64_t ny,
                  const double* lat_deg, const double* lon_deg, uint64_t seed, int variant)
 {
     XC_CTX(ctx);
+    if (out && nslab > 0 && ny > 0 && nx > 0) mm_touch(ctx, out, (size_t)nslab * ny * nx * esize(q_dtype));
     return launch_synth(ctx, out, q_dtype, nslab, ny, nx, lat_deg, lon_deg, seed, variant);
 }
 

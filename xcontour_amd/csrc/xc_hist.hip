@@ -565,12 +565,7 @@ template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT>
 int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
 {
     auto kern = k_hist<TQ, VEC, NINT, GRAD, DA2D, NEXT>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-        XC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget + 4096));
-        attr_set = true;
-    }
+    { const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(kern), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; }
     HistArgs b = a;
     static const int xcd_env = [] { const char* e = getenv("XC_HIST_XCDMAP"); return e ? atoi(e) : 1; }();
     // the XCD-aware order needs whole groups of 8 row groups, otherwise it would leave XCDs idle (bps = 1 with many

@@ -28,12 +28,14 @@ struct xc_ctx {
     // min/max partials of the NEXT batch, produced inside the K3 pass (xc_keff_desc.q_next)
     double* mmnext[2] = {nullptr, nullptr};  size_t mmnext_bytes[2] = {0, 0};
     int mm_cur = 0, mm_valid = 0, mm_P = 0, mm_dtype = 0;
-    const void* mm_q = nullptr;  int64_t mm_nslab = 0, mm_ny = 0, mm_nx = 0;
+    const void* mm_q = nullptr;  int64_t mm_nslab = 0, mm_ny = 0, mm_nx = 0;  int mm_gen = 0;
 };
 
 namespace xc {
 
 int fail(xc_ctx* ctx, int code, const std::string& msg);
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device)
+int ensure_big_lds(xc_ctx* ctx, const void* kernel, int bytes);
 int hipfail(xc_ctx* ctx, hipError_t e, const char* what);
 
 #define XC_HIP(ctx, call)                                                     \

@@ -453,12 +453,7 @@ int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
         a.big = (double*)ctx->big;
         lds = 0;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        XC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_finalize),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget + 4096));
-        attr_set = true;
-    }
+    { const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(k_finalize), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; }
     a.tbl_in_lds = 0;
     if (!a.big && a.keff && lds + (size_t)2 * a.ntbl * sizeof(double) <= 64 * 1024) {
         a.tbl_in_lds = 1;

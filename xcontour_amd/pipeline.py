@@ -36,10 +36,11 @@ class KeffPlan(object):
     def __init__(self, ctx, nslab, ny, nx, N, q_dtype=np.float64, ctr_dtype=np.float64,
                  dA=None, lat=None, lon=None, rdx=None, rdy=None, periodic_x=True,
                  tbl=None, tbl_coord=None, preY=None, increase=True, lt=True,
-                 right_edge='numpy', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
+                 right_edge='xhistogram', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
                  prod_f32=False, alloc_q=True, nslots=1, out_ptr=None, detect_row_dA=False,
-                 out_slabs=None):
-        """dA: None | (ny,) | (ny,nx) f64.  Gradient metrics either `rdx, rdy`
+                 out_slabs=None, replicate_dA=False):
+        """dA: None | (ny,) | (ny,nx) | (nslab,ny,nx) f64 (the last: weights that change with the leading
+        (time, level) index, which the reference allows -- core.py:1271-1274).  Gradient metrics either `rdx, rdy`
         (per-row reciprocals) or derived from `lat, lon` (sphere).  If
         `grdS_dtype` is given the squared gradient is an INPUT (set with
         `set_grdS`) instead of being computed in-kernel.
@@ -47,7 +48,9 @@ class KeffPlan(object):
         every step's vectors on the device until one gather at the end); `out_ptr`: use a
         caller-owned device allocation of `out_bytes(…) * nslots` bytes for them.
         `detect_row_dA`: a 2-D dA whose rows are constant (every regular lat-lon `rA`) is passed
-        to the kernels as its first column (identical results, 8 B/cell less traffic)."""
+        to the kernels as its first column (identical results, 8 B/cell less traffic).
+        `replicate_dA`: store a (ny,nx) dA once PER SLAB on the device and run the per-slab-weights path
+        (XC_DA_SLAB) on it -- what a time-varying metric costs, without a (nslab,ny,nx) host array."""
         self.ctx = ctx
         self.nslab, self.ny, self.nx, self.N = int(nslab), int(ny), int(nx), int(N)
         self.q_dtype, self.ctr_dtype = np.dtype(q_dtype), np.dtype(ctr_dtype)
@@ -71,12 +74,22 @@ class KeffPlan(object):
                 dA = np.ascontiguousarray(dA[:, 0])
             if dA.shape == (self.ny,):
                 d.dA_rank = nat.XC_DA_ROW
+            elif dA.shape == (self.ny, self.nx) and replicate_dA:
+                d.dA_rank = nat.XC_DA_SLAB
             elif dA.shape == (self.ny, self.nx):
                 d.dA_rank = nat.XC_DA_PLANE
+            elif dA.shape == (self.nslab, self.ny, self.nx):
+                d.dA_rank = nat.XC_DA_SLAB
             else:
-                raise Exception('dA must be (ny,) or (ny,nx)')
-            self.dA_buf = ctx.to_device(dA)
-            d.dA = self.dA_buf.ptr
+                raise Exception('dA must be (ny,), (ny,nx) or (nslab,ny,nx)')
+            if d.dA_rank == nat.XC_DA_SLAB and dA.ndim == 2:
+                self.dA_buf = ctx.alloc(self.nslab * dA.nbytes)
+                for s_ in range(self.nslab):
+                    ctx._check(ctx.lib.xc_memcpy_h2d(ctx.handle, self.dA_buf.ptr + s_ * dA.nbytes, dA.ctypes.data, dA.nbytes))
+            else:
+                self.dA_buf = ctx.to_device(dA)
+            self._dA_ptr = self.dA_buf.ptr
+            d.dA = self._dA_ptr
             d.dA_pos_finite = int(bool(np.isfinite(dA).all() and (dA >= 0).all()))   # static metric: checked once
         if grdS_dtype is None:
             if rdx is None:
@@ -91,8 +104,19 @@ class KeffPlan(object):
             d.grad, d.grdS, d.grdS_dtype = 0, self.grdS_buf.ptr, nat.dtype_code(self.grdS_dtype)
         d.prod_f32 = int(bool(prod_f32))
         d.periodic_x = int(bool(periodic_x))
-        self.tbl_buf = ctx.to_device(np.asarray(tbl, dtype=np.float64))
-        self.coord_buf = ctx.to_device(np.asarray(tbl_coord, dtype=np.float64))
+        # xc_keff_dev reads exactly ny table entries in ascending-coordinate order (include/xcontour_hip.h)
+        tbl = np.asarray(tbl, dtype=np.float64)
+        tbl_coord = np.asarray(tbl_coord, dtype=np.float64)
+        if tbl.shape != (self.ny,) or tbl_coord.shape != (self.ny,):
+            raise Exception('the A(Yeq) table and its coordinate must have length ny = %d (got %r, %r)'
+                            % (self.ny, tbl.shape, tbl_coord.shape))
+        if not (np.diff(tbl_coord) > 0).all():
+            if (np.diff(tbl_coord) < 0).all():
+                tbl, tbl_coord = tbl[::-1], tbl_coord[::-1]          # e.g. a table from cal_area_eqCoord_table on a descending coordinate
+            else:
+                raise Exception('the table coordinate must be strictly monotonic')
+        self.tbl_buf = ctx.to_device(tbl)
+        self.coord_buf = ctx.to_device(tbl_coord)
         d.tbl, d.tbl_coord = self.tbl_buf.ptr, self.coord_buf.ptr
         d.npre = self.npre
         if self.npre:
@@ -144,18 +168,32 @@ class KeffPlan(object):
         d.status = base + self._off['status'] + o0 * 4
         d.nslab = n
         d.q = self._q_ptr + s0 * self.ny * self.nx * self.q_dtype.itemsize
+        if d.dA_rank == nat.XC_DA_SLAB:
+            d.dA = self._dA_ptr + s0 * self.ny * self.nx * 8
         if self.grdS_buf is not None:
             d.grdS = self.grdS_buf.ptr + s0 * self.ny * self.nx * self.grdS_dtype.itemsize
 
     # -- inputs
+    def touch(self):
+        """Tell the library that the tracer bytes changed behind its back (a caller writing through its own device
+        pointer): bumps `xc_keff_desc.q_gen`, which invalidates min/max partials chained from an earlier call."""
+        self.desc.q_gen = (self.desc.q_gen + 1) & 0x7fffffff
+
     def set_q(self, q):
         q = np.ascontiguousarray(q, dtype=self.q_dtype).reshape(self.nslab, self.ny, self.nx)
         self.q_buf.upload(q)
+        self.touch()
 
     def set_q_device(self, ptr):
         """Use an existing device pointer ([nslab][ny][nx], q_dtype) as the tracer."""
         self._q_ptr = int(ptr)
         self.desc.q = self._q_ptr
+        self.touch()
+
+    def set_dA_device(self, ptr):
+        """Use an existing device pointer as dA (same rank and shape as the dA given to the constructor)."""
+        self._dA_ptr = int(ptr)
+        self.desc.dA = self._dA_ptr
 
     def set_grdS(self, g):
         g = np.ascontiguousarray(g, dtype=self.grdS_dtype).reshape(self.nslab, self.ny, self.nx)
@@ -171,6 +209,7 @@ class KeffPlan(object):
         self.ctx.sync()
         lat_b.free()
         lon_b.free()
+        self.touch()
 
     # -- compute
     def run(self, slot=0, group=None, chain=False):

@@ -79,20 +79,41 @@ def cartesian_metrics(y, dx):
     return np.full(ny, 1.0 / (2.0 * dx)), 1.0 / (y[jn] - y[js])
 
 
-def table_from_rowsums(rows_asc, ylt):
+def last_row_included(coord, right_edge='xhistogram'):
+    """Does the row on the LAST (largest) coordinate value enter the A(Yeq) table?
+
+    The reference histograms the coordinate field against its own values (core.py:176-193), so
+    the cells of the last row sit exactly on the last bin edge.  np.histogram closes that edge
+    (`right_edge='numpy'`: always included).  xhistogram instead replaces the last edge by
+    `edge + 1e-8` evaluated in the edge dtype and keeps the bin half-open (`_histogram`,
+    core.py:1307, calls xhistogram): the row is kept only if the bump is representable, i.e.
+    dropped for every float32 coordinate of magnitude >= 0.25 (float32 latitudes!), kept for
+    float64 coordinates up to ~1e8."""
+    if right_edge == 'numpy':
+        return True
+    if right_edge != 'xhistogram':
+        raise Exception('right_edge should be "numpy" or "xhistogram"')
+    c = np.asarray(coord)
+    hi = c.max()
+    return bool((np.array([hi]) + 1e-8)[0] > hi)
+
+
+def table_from_rowsums(rows_asc, ylt, include_last=True):
     """A(Yeq) table from per-row sums taken in ASCENDING-coordinate order.
 
     The reference histograms the coordinate field against its own values
     (core.py:176-193); every cell sits on an edge, so the histogram is
-    pdf = [0, r_0, ..., r_{J-3}, r_{J-2} + r_{J-1}] (dummy bin first, last bin closed),
-    then `cumsum` and, if not `ylt`, `cdf[-1] - cdf` (core.py:1320-1323)."""
+    pdf = [0, r_0, ..., r_{J-3}, r_{J-2} (+ r_{J-1} if `include_last`)] (dummy bin first; the last
+    row sits on the last edge: see `last_row_included`), then `cumsum` and, if not `ylt`,
+    `cdf[-1] - cdf` (core.py:1320-1323)."""
     r = np.asarray(rows_asc, dtype=np.float64)
     J = len(r)
     pdf = np.zeros(J, dtype=np.float64)
     if J >= 2:
-        pdf[1:J - 1] = r[0:J - 2]
-        pdf[J - 1] = r[J - 2] + r[J - 1]
-    else:
+        pdf[1:J] = r[0:J - 1]
+        if include_last:
+            pdf[J - 1] = r[J - 2] + r[J - 1]
+    elif include_last:
         pdf[0] = r[0]
     cdf = np.cumsum(pdf)
     if not ylt:
