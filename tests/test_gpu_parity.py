@@ -91,7 +91,7 @@ def test_hist_random_shapes(ctx, nx, dt):
         out = ctx.hist(x, ed, dA=dA)
         for s in range(S):
             w = np.ones((ny, nx)) if dA is None else (dA[:, None] if dA.ndim == 1 else (dA if dA.ndim == 2 else dA[s]))
-            p, c = O.weighted_histogram(x[s], ed[s], np.broadcast_to(w, (ny, nx)))
+            p, c = O.weighted_histogram(x[s], ed[s], np.broadcast_to(w, (ny, nx)), 'numpy')   # ctx.hist: explicit edges, closed last bin
             assert np.array_equal(out['counts'][s].astype(np.int64), c)
             assert np.allclose(out['pdf'][s, 0], p, rtol=1e-12, atol=1e-13)
             assert np.allclose(out['cdf'][s, 0], np.cumsum(p), rtol=1e-12, atol=1e-13)
@@ -122,7 +122,7 @@ def test_hist_nonuniform_levels_binary_search(ctx):
     ed = np.concatenate(([-4.0], -3 + np.cumsum(np.abs(rng.standard_normal(300)) ** 3 * 0.02)))
     out = ctx.hist(x, ed, dA=None)
     for s in range(2):
-        _, c = O.weighted_histogram(x[s], ed)
+        _, c = O.weighted_histogram(x[s], ed, None, 'numpy')
         assert np.array_equal(out['counts'][s].astype(np.int64), c)
 
 
@@ -134,8 +134,8 @@ def test_hist_many_bins_reduced_copies(ctx):
     for nb in (401, 1001, 3000):
         ed = np.linspace(-3, 3, nb + 1)
         out = ctx.hist(x, ed, dA=w, integrands=[x], want=('pdf', 'counts'))
-        p, c = O.weighted_histogram(x[0], ed, w)
-        p1, _ = O.weighted_histogram(x[0], ed, w * x[0])
+        p, c = O.weighted_histogram(x[0], ed, w, 'numpy')
+        p1, _ = O.weighted_histogram(x[0], ed, w * x[0], 'numpy')
         assert np.array_equal(out['counts'][0].astype(np.int64), c)
         assert np.allclose(out['pdf'][0, 0], p, rtol=1e-12, atol=1e-14)
         assert np.allclose(out['pdf'][0, 1], p1, rtol=1e-11, atol=1e-13)
@@ -164,7 +164,7 @@ def test_grad_in_kernel_matches_standalone_and_oracle(ctx, baro, dt):
     edges, _ = O.hist_edges(ctr)
     out = ctx.hist(q[None], edges.astype(np.float64), dA=dA, grad=(rdx, rdy, True))
     w = np.where(np.isnan(g2 * dA), 0, g2 * dA)
-    p1, c = O.weighted_histogram(q, edges, w)
+    p1, c = O.weighted_histogram(q, edges, w, 'numpy')
     assert np.array_equal(out['counts'][0].astype(np.int64), c)
     assert rel(out['pdf'][0, 1], p1) < TIGHT
     # non-periodic walls (X-Z planes): one-sided differences
@@ -175,7 +175,7 @@ def test_grad_in_kernel_matches_standalone_and_oracle(ctx, baro, dt):
     gg2 = ctx.grad2(q2[None], rdx2, rdy2, False)
     assert rel(gg2[0], gx * gx + gy * gy) < 1e-12
     out2 = ctx.hist(q2[None], edges.astype(np.float64), dA=None, grad=(rdx2, rdy2, False))
-    p2, _ = O.weighted_histogram(q2, edges, gg2[0])
+    p2, _ = O.weighted_histogram(q2, edges, gg2[0], 'numpy')
     assert rel(out2['pdf'][0, 1], p2) < TIGHT
 
 
@@ -775,7 +775,7 @@ def test_misaligned_device_pointers_fall_back(ctx):
     d.counts = dc.ptr
     ctx._check(ctx.lib.xc_hist_dev(ctx.handle, C.byref(d)))
     cnt = dc.download((41,), np.uint64)
-    _, c = O.weighted_histogram(x[0], ed)
+    _, c = O.weighted_histogram(x[0], ed, None, 'numpy')
     assert np.array_equal(cnt.astype(np.int64), c)
 
 

@@ -56,7 +56,7 @@ def test_contours_at_both_twins(ctx, baro, rule, increase, lt):
         assert rel(got.values, want) < 1e-9
         # labelled predef (the reference accepts a DataArray with its own dim name, core.py:297-299)
         got2 = fn(xa.DataArray(pre, ('latitude',), {'latitude': pre}), table)
-        assert np.array_equal(got2.values, got.values) and got2.dims == ('contour',)
+        assert rel(got2.values, got.values) < 1e-12 and got2.dims == ('contour',)      # LDS atomics: sums vary in the last bits run to run
     with pytest.raises(Exception, match='predef should be a 1D array'):
         cm.cal_contours_at_hist(np.zeros((3, 3)), table)
 
