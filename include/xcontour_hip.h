@@ -266,7 +266,7 @@ typedef struct xc_keff_desc {
     double*       dqdA;         double* dintSdA; double* Leq2;   double* Lmin;  double* nkeff;
     uint64_t*     counts;       /* uint64[nslab][N] */
     double*       interp;       /* double[nslab][9][npre]: ctr, area, intgrdS, latEq, dintSdA, dqdA, Leq2, Lmin, nkeff on preY */
-    int32_t*      status;       /* int32[nslab] 0 ok, 1 degenerate levels */
+    int32_t*      status;       /* int32[nslab] 0 ok, 1 degenerate levels, 2 / 3 not computed (see xc_set_keff_mode) */
     const void*   q_next;       /* optional: the batch the NEXT xc_keff_dev call will process (same dtype and
                                    shape, may equal q).  Its per-slab min/max partials are accumulated inside this
                                    call's histogram pass (+8 B/cell of loads, no extra kernel) and the next call on
@@ -279,6 +279,31 @@ typedef struct xc_keff_desc {
     int32_t       q_gen;        /* generation of the tracer buffers (see q_next): any change invalidates chained min/max */
 } xc_keff_desc;
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
+
+/* Schedules of xc_keff_dev.
+ * XC_KEFF_TWO_PASS: the streaming path -- min/max pass (K1, or partials chained from the previous call, q_next), then
+ *   the histogram pass (K3).  The tracer crosses the fabric twice; no synchronisation between workgroups.
+ * XC_KEFF_PERSISTENT: ONE persistent launch that reads the tracer ONCE (xc_keffp.hip): a slab is spread over the
+ *   register files of a group of CUs, stays there between the min/max and the binning, and is refilled row by row
+ *   with the group's next slab.  Needs >= 65 536 cells per slab, even nx, 16-byte aligned pointers, the in-kernel
+ *   gradient and a slab that fits the chip (cfg2's 3600 x 1801 f64 just does); other shapes fall back to two-pass.
+ *   Levels and counts are bit-identical to the two-pass path, sums agree to summation order.  A launch that cannot
+ *   co-schedule its workgroups (another process holding CUs) gives up after 0.3 s with status[slab] == 2 for the slabs
+ *   it did not finish; a slab whose levels are not equally spaced to a quarter of a bin (float32 contours of a tiny
+ *   range, infinite extrema) is left out with status[slab] == 3.  Re-run such slabs with XC_KEFF_TWO_PASS
+ *   (xcontour_amd.pipeline.KeffPlan.fetch does).
+ * XC_KEFF_AUTO (default): two-pass.  Measured on MI355X the persistent kernel moves about half the bytes but loses
+ *   ~13 us per cfg2 slab to grid-wide synchronisation and arrival skew (one slab in flight; a second does not fit on
+ *   chip), so it is 10-15 % slower than the chained streaming schedule; XC_KEFF_PERSIST=1 in the environment makes
+ *   AUTO pick it.  xc_last_keff_path: 1 persistent, 0 two-pass. */
+#define XC_KEFF_AUTO     0
+#define XC_KEFF_TWO_PASS 1
+#define XC_KEFF_PERSISTENT 2
+int xc_set_keff_mode(xc_ctx* ctx, int mode);
+int xc_last_keff_path(xc_ctx* ctx, int* out_path);
+/* Diagnostics: with a non-NULL device buffer of nslab * CUs * 8 uint64, the persistent kernel's thread 0 of every
+ * workgroup stores the 100 MHz wall clock at the phase boundaries of every slab (tools/gpu_persist_check.py --stamps). */
+int xc_dbg_set_stamps(xc_ctx* ctx, void* dev_ptr);
 
 /* time of the dominant kernel (the histogram pass) of the last xc_keff_dev / xc_hist_dev
  * call, from HIP events recorded on the context's stream around that launch only.

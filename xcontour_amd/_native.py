@@ -20,6 +20,7 @@ XC_F32, XC_F64 = 0, 1
 XC_DA_NONE, XC_DA_ROW, XC_DA_PLANE, XC_DA_SLAB = 0, 1, 2, 3
 XC_EDGE_NUMPY, XC_EDGE_XHISTOGRAM = 0, 1
 XC_MAX_INTEGRANDS = 2
+XC_KEFF_AUTO, XC_KEFF_TWO_PASS, XC_KEFF_PERSISTENT = 0, 1, 2
 MAX_SLABS_PER_LAUNCH = 65535
 XC_PAD_EDGE, XC_PAD_WRAP, XC_PAD_NAN, XC_PAD_REFLECT, XC_PAD_SYMMETRIC = 0, 1, 2, 3, 4
 PAD_MODES = {'edge': XC_PAD_EDGE, 'wrap': XC_PAD_WRAP, 'constant': XC_PAD_NAN, 'reflect': XC_PAD_REFLECT,
@@ -109,6 +110,9 @@ PROTOTYPES = {
     'xc_sort_profile_batch': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i64, _i64, _i64, C.c_int,
                                         _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'xc_keff_dev': (C.c_int, [_vp, C.POINTER(KeffDesc)]),
+    'xc_set_keff_mode': (C.c_int, [_vp, C.c_int]),
+    'xc_last_keff_path': (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    'xc_dbg_set_stamps': (C.c_int, [_vp, _vp]),
     'xc_set_kernel_timing': (C.c_int, [_vp, C.c_int]),
     'xc_last_hist_ms': (C.c_int, [_vp, C.POINTER(C.c_float)]),
     'xc_set_hist_events': (C.c_int, [_vp, _vp, _vp]),
@@ -261,6 +265,17 @@ class Context(object):
         ms = C.c_float()
         self._check(self.lib.xc_event_elapsed_ms(self.handle, e0, e1, C.byref(ms)))
         return ms.value
+
+    def set_keff_mode(self, mode):
+        """XC_KEFF_AUTO (= two-pass unless XC_KEFF_PERSIST=1), XC_KEFF_TWO_PASS or XC_KEFF_PERSISTENT (single-read kernel
+        where the shape suits it; see include/xcontour_hip.h)"""
+        self._check(self.lib.xc_set_keff_mode(self.handle, int(mode)))
+        self._keff_mode = int(mode)
+
+    def last_keff_path(self):
+        p = C.c_int()
+        self._check(self.lib.xc_last_keff_path(self.handle, C.byref(p)))
+        return p.value
 
     def set_kernel_timing(self, on):
         self._check(self.lib.xc_set_kernel_timing(self.handle, 1 if on else 0))

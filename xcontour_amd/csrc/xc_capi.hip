@@ -708,6 +708,51 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     if (d->grad ? (!d->rdx || !d->rdy) : !d->grdS) return fail(ctx, XC_EBADARG, "xc_keff: need rdx/rdy (grad=1) or grdS (grad=0)");
     if (d->npre < 0 || (d->npre > 0 && d->interp && !d->preY)) return fail(ctx, XC_EBADARG, "xc_keff: preY is NULL");
     const int N = d->N, nch = 2;
+    // ---- the persistent single-read kernel (xc_keffp.hip) when the shape suits it: in-kernel gradient, one tracer pass
+    PersistGeom pg;
+    const double* dA_eff = d->dA; int dA_rank_eff = d->dA_rank;
+    if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); dA_eff = ctx->ones; dA_rank_eff = XC_DA_ROW; }
+    if (d->grad && d->nslab <= 0x7fffffff &&
+        persist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, d->q, dA_eff, dA_rank_eff, &pg)) {
+        const size_t S = (size_t)d->nslab;
+        const size_t sync_b = al(S * 8 * sizeof(SyncShard) + 64);
+        const size_t ph = al(S * pg.G * nch * N * sizeof(double));
+        const size_t pc = al(S * pg.G * N * sizeof(unsigned));
+        const size_t rh = al(S * nch * N * sizeof(double));
+        const size_t rc = al(S * N * sizeof(unsigned long long));
+        XC_TRY(ensure_scratch(ctx, sync_b + ph + pc + rh + rc));
+        char* base = (char*)ctx->scratch;
+        XC_HIP(ctx, hipMemsetAsync(base, 0, sync_b, ctx->stream));
+        PersistArgs a; memset(&a, 0, sizeof(a));
+        a.q = d->q; a.dA = dA_eff; a.dA_rank = dA_rank_eff; a.rdx = d->rdx; a.rdy = d->rdy;
+        a.periodic_x = d->periodic_x; a.dA_pos_finite = (d->dA_rank == XC_DA_NONE) ? 1 : d->dA_pos_finite;
+        a.last_closed = d->right_edge == XC_EDGE_NUMPY;
+        a.ny = d->ny; a.nx = d->nx; a.nslab = (int)d->nslab; a.nbin = N; a.ncopy = pg.ncopy;
+        a.increase = d->increase; a.q_f32 = d->q_dtype == XC_F32; a.ctr_f32 = d->ctr_dtype == XC_F32;
+        a.right_edge = d->right_edge; a.inv_nm1 = 1.0 / (double)(N - 1); a.inv_n = 1.0 / (double)N;
+        a.G = pg.G; a.ngroups = pg.ngroups; a.nstrip = pg.nstrip; a.cps = pg.cps; a.rpc = pg.rpc;
+        a.sync = (SyncShard*)base; a.abort = (unsigned*)(base + S * 8 * sizeof(SyncShard));
+        a.part_h = (double*)(base + sync_b); a.part_c = (unsigned*)(base + sync_b + ph);
+        a.ctr_out = d->ctr; a.status = d->status; a.stamps = ctx->dbg_stamps;
+        ctx->mm_valid = 0;
+        XC_TRY(hist_ev_begin(ctx));
+        XC_TRY(launch_keff_persist(ctx, d->q_dtype, a, pg));
+        XC_TRY(hist_ev_end(ctx));
+        ctx->last_keff_path = 1;
+        FinalArgs f; memset(&f, 0, sizeof(f));
+        f.part_h = a.part_h; f.part_c = a.part_c; f.bps = pg.G; f.nch = nch; f.nbin = N;
+        f.red_h = (double*)(base + sync_b + ph + pc); f.red_c = (unsigned long long*)(base + sync_b + ph + pc + rh);
+        f.lt = d->lt; f.reverse = !d->increase;
+        f.counts = d->counts;
+        f.keff = 1; f.ctr_f32 = a.ctr_f32; f.ctr = d->ctr;
+        f.tbl = d->tbl; f.tbl_coord = d->tbl_coord; f.ntbl = (int)d->ny;
+        f.preY = d->preY; f.npre = d->interp ? d->npre : 0;
+        f.nkeff_mask = d->nkeff_mask; f.lmin_scale = d->lmin_scale;
+        f.o_area = d->area; f.o_intS = d->intgrdS; f.o_latEq = d->latEq; f.o_dqdA = d->dqdA; f.o_dSdA = d->dintSdA;
+        f.o_Leq2 = d->Leq2; f.o_Lmin = d->Lmin; f.o_nkeff = d->nkeff; f.o_interp = d->interp;
+        return launch_finalize(ctx, d->nslab, f);
+    }
+    ctx->last_keff_path = 0;
     HistGeom g;
     {
         const void* gi[1] = {d->grdS}; const int32_t gt[1] = {d->grdS_dtype};
@@ -775,6 +820,29 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     f.o_area = d->area; f.o_intS = d->intgrdS; f.o_latEq = d->latEq; f.o_dqdA = d->dqdA; f.o_dSdA = d->dintSdA;
     f.o_Leq2 = d->Leq2; f.o_Lmin = d->Lmin; f.o_nkeff = d->nkeff; f.o_interp = d->interp;
     return launch_finalize(ctx, d->nslab, f);
+}
+
+int xc_set_keff_mode(xc_ctx* ctx, int mode)
+{
+    if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
+    if (mode != XC_KEFF_AUTO && mode != XC_KEFF_TWO_PASS && mode != XC_KEFF_PERSISTENT)
+        return fail(ctx, XC_EBADARG, "xc_set_keff_mode: mode must be XC_KEFF_AUTO, XC_KEFF_TWO_PASS or XC_KEFF_PERSISTENT");
+    ctx->keff_mode = mode;
+    return XC_OK;
+}
+
+int xc_dbg_set_stamps(xc_ctx* ctx, void* dev_ptr)
+{
+    if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
+    ctx->dbg_stamps = (unsigned long long*)dev_ptr;
+    return XC_OK;
+}
+
+int xc_last_keff_path(xc_ctx* ctx, int* out_path)
+{
+    if (!ctx || !out_path) return fail(ctx, XC_EBADARG, "xc_last_keff_path: bad arguments");
+    *out_path = ctx->last_keff_path;
+    return XC_OK;
 }
 
 // ------------------------------------------------------------------------------------ synthetic slabs

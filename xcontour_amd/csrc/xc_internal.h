@@ -29,6 +29,9 @@ struct xc_ctx {
     double* mmnext[2] = {nullptr, nullptr};  size_t mmnext_bytes[2] = {0, 0};
     int mm_cur = 0, mm_valid = 0, mm_P = 0, mm_dtype = 0;
     const void* mm_q = nullptr;  int64_t mm_nslab = 0, mm_ny = 0, mm_nx = 0;  int mm_gen = 0;
+    int keff_mode = 0;          // xc_set_keff_mode: XC_KEFF_AUTO / XC_KEFF_TWO_PASS / XC_KEFF_PERSISTENT
+    unsigned long long* dbg_stamps = nullptr;   // xc_dbg_set_stamps
+    int last_keff_path = 0;     // 1 = the last xc_keff_dev call ran the persistent kernel, 0 = two-pass
 };
 
 namespace xc {
@@ -123,6 +126,48 @@ struct FinalArgs {
     double          nkeff_mask, lmin_scale;
     double *o_area, *o_intS, *o_latEq, *o_dqdA, *o_dSdA, *o_Leq2, *o_Lmin, *o_nkeff, *o_interp;
 };
+
+// ---------------------------------------------------------------- persistent single-read Keff kernel (xc_keffp.hip)
+constexpr int kPersistThreads = 768;  // 12 waves per workgroup, 3 per SIMD: 168 VGPRs each
+constexpr int kPersistRows = 18;      // rows of the slab a wave holds in registers (+ 2 halo rows)
+constexpr int kPersistLdsRows = 8;    // rows of the NEXT slab's tile that wait in LDS instead of being refilled late (float64 tracers)
+constexpr int kPersistCols = 124;     // computed columns of a wave's strip (62 lanes x 2 cells; lanes 0 / 63 are halos)
+
+struct PersistGeom {
+    int G, ngroups;          // workgroups per group, groups (G * ngroups = CUs)
+    int nstrip, cps, rpc;    // strips of kPersistCols columns, chunks per strip, rows per chunk (<= kPersistRows)
+    int ncopy;               // LDS histogram copies
+    size_t lds;
+};
+
+struct SyncShard {            // one eighth of a slab's sync record, on its own 64 bytes
+    unsigned long long kmn, kmx;   // ~key(min), key(max) under atomic max
+    unsigned cnt;                  // arrivals in this shard
+    unsigned pad[11];
+};
+
+struct PersistArgs {
+    const void*   q;
+    const double* dA;  int dA_rank;
+    const double* rdx; const double* rdy;
+    int           periodic_x, dA_pos_finite, last_closed;
+    int64_t       ny, nx;
+    int           nslab, nbin, ncopy;
+    int           increase, q_f32, ctr_f32, right_edge;
+    double        inv_nm1, inv_n;
+    int           G, ngroups, nstrip, cps, rpc;
+    SyncShard*    sync;        // [nslab][8]  zeroed before the launch
+    unsigned*     abort;       // [1]         zeroed before the launch
+    double*       part_h;      // [nslab][G][2][nbin]
+    unsigned*     part_c;      // [nslab][G][nbin]
+    double*       ctr_out;     // [nslab][nbin]
+    int32_t*      status;      // [nslab]
+    unsigned long long* stamps;   // diagnostics: [nslab][blocks][8] wall-clock stamps, or null
+};
+
+bool persist_geometry(const xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int N,
+                      const void* q, const double* dA, int dA_rank, PersistGeom* g);
+int launch_keff_persist(xc_ctx* ctx, int q_dtype, const PersistArgs& a, const PersistGeom& g);
 
 // ---------------------------------------------------------------- launchers (defined in the .hip files)
 int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part);

@@ -148,6 +148,7 @@ class KeffPlan(object):
             self.out_buf = None
             self.out_ptr = int(out_ptr)
         self._point(0, 0, self.nslab)
+        self._log = []          # launch sets enqueued since the last fetch (replayed if the persistent kernel gave up)
 
     @staticmethod
     def out_bytes(nslab, N, npre=0):
@@ -229,6 +230,7 @@ class KeffPlan(object):
             ok = chain and min(g, self.nslab - nxt) == n          # same shape only
             self.desc.q_next = (self._q_ptr + nxt * esz) if ok else None
             self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
+            self._note(slot, s0, n, None)
 
     def run_range(self, slot, s0, n, next_s0=None, out_s0=None):
         """One launch set over slabs [s0, s0+n) into result slot `slot`; `next_s0`: first slab of
@@ -238,6 +240,12 @@ class KeffPlan(object):
         esz = self.ny * self.nx * self.q_dtype.itemsize
         self.desc.q_next = (self._q_ptr + next_s0 * esz) if next_s0 is not None else None
         self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
+        self._note(slot, s0, n, out_s0)
+
+    def _note(self, slot, s0, n, out_s0):
+        self._log.append((slot, s0, n, out_s0, self._q_ptr, self.out_ptr))
+        if len(self._log) > 4096:
+            del self._log[:2048]
 
     def unpack(self, raw):
         """one result slot (bytes as a uint8 ndarray) -> dict of arrays"""
@@ -259,6 +267,29 @@ class KeffPlan(object):
         self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, raw.ctypes.data,
                                                    self.out_ptr + slot * self.slot_bytes, self.slot_bytes))
         out = self.unpack(raw)
+        if (out['status'] >= 2).any():
+            # the persistent kernel left slabs to the two-pass path: status 2 = it could not co-schedule its workgroups
+            # (another process on the GPU) and gave up -- the context then stays in two-pass mode; status 3 = that slab's
+            # levels are not equally spaced to a quarter of a bin (float32 contours of a tiny range, infinite extrema).
+            # Replay everything enqueued since the last fetch through the two-pass path, once.
+            log, self._log = self._log, []
+            stay = bool((out['status'] == 2).any())
+            mode_before = getattr(self.ctx, '_keff_mode', nat.XC_KEFF_AUTO)
+            self.ctx.set_keff_mode(nat.XC_KEFF_TWO_PASS)
+            keep = (self._q_ptr, self.out_ptr)
+            for (sl, s0, n, o0, qp, op) in log:
+                self._q_ptr, self.out_ptr = qp, op
+                self._point(sl, s0, n, o0)
+                self.desc.q_next = None
+                self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
+            self._q_ptr, self.out_ptr = keep
+            if not stay:
+                self.ctx.set_keff_mode(mode_before)
+            self.ctx.sync()
+            self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, raw.ctypes.data,
+                                                       self.out_ptr + slot * self.slot_bytes, self.slot_bytes))
+            out = self.unpack(raw)
+        self._log = []
         if check and out['status'].any():
             raise Exception('non monotonic bins')          # reference core.py:1233-1251
         return out
