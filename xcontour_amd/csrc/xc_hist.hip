@@ -63,7 +63,9 @@ struct RowBuf {
 
 // DA2D: dA is a [ny][nx] plane (vector loads); otherwise one value per row (scalar).
 // NEXT: also stream the same cells of a.q_next and emit its per-block min/max partials.
-template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT>
+// FAST (Keff layout only): periodic X and dA verified finite and >= 0 are COMPILE-time facts -- the wall selects and
+// the fillna selects vanish from the row body.
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT, bool FAST = false>
 __global__ __launch_bounds__(kHistThreads)
 void k_hist(const HistArgs a)
 {
@@ -109,7 +111,7 @@ void k_hist(const HistArgs a)
     const double* __restrict__ rdyp = a.rdy;
     const int copy = lane & (ncopy - 1);
     const int cshift = __builtin_ctz((unsigned)ncopy);            // ncopy is a power of two
-    const int periodic_x = a.periodic_x;
+    const int periodic_x = FAST ? 1 : a.periodic_x;
 
     // segment state (wave-uniform scalars + per-lane 32-bit byte offsets inside a row)
     int y0 = 0, y1 = 0;
@@ -256,8 +258,18 @@ void k_hist(const HistArgs a)
     const double e0 = s_edges[0], eN = s_edges[N];
     const double inv = (double)N / (eN - e0);
     const int last_closed = a.last_closed;
+    // Are the edges equally spaced to a quarter of a bin?  Then the NEAREST edge j = floor((v - e0) / h + 1/2) brackets v
+    // between e[j-1] and e[j+1], and ONE exact comparison against e[j] gives np.digitize's answer (one 8-byte LDS read
+    // and one compare per cell instead of two reads, two compares and a call on a miss).  Checked per slab, wave-uniform.
+    bool uni;
+    {
+        const double hstep = (eN - e0) / (double)N;
+        int bad = 0;
+        for (int k = tid; k <= N; k += blockDim.x) bad |= !(fabs(s_edges[k] - (e0 + (double)k * hstep)) <= 0.25 * hstep);
+        uni = !__syncthreads_or(bad);
+    }
     const int negate = a.negate;
-    const bool wpos = a.dA_pos_finite != 0;
+    const bool wpos = FAST ? true : (a.dA_pos_finite != 0);
     XC_STAMP(2);
 
     double   acc[NCH];
@@ -285,7 +297,17 @@ void k_hist(const HistArgs a)
         double w[NCH][VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-            const int kb = find_bin((!GRAD && negate) ? -qc[c] : qc[c], s_edges, N, e0, eN, inv, last_closed);
+            const double vb = (!GRAD && negate) ? -qc[c] : qc[c];
+            int kb;
+            if (uni) {
+                int j = (int)__builtin_fma(vb - e0, inv, 0.5);                      // NaN -> 0
+                asm("v_med3_i32 %0, %1, 0, %2" : "=v"(j) : "v"(j), "s"(N));         // clamp to [0, N]
+                kb = (vb >= s_edges[j]) ? j : j - 1;                                // NaN -> -1
+                if (last_closed && vb == eN) kb = N - 1;
+                kb = ((unsigned)kb < (unsigned)N) ? kb : -1;                        // out of range on either side: dropped
+            } else {
+                kb = find_bin(vb, s_edges, N, e0, eN, inv, last_closed);
+            }
             k[c] = full_strip ? kb : (active ? kb : -1);                      // wave-uniform: selects only in a ragged strip
             const double dv = dAv[c];
             w[0][c] = wpos ? dv : ((dv != dv) ? 0.0 : dv);                    // fillna(0), core.py:449 (wpos: host checked dA finite)
@@ -441,10 +463,10 @@ extern "C" int xc_dbg_set_stamps(unsigned long long* p)
 namespace {
 #endif
 
-template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT>
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT, bool FAST = false>
 int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
 {
-    auto kern = k_hist<TQ, VEC, NINT, GRAD, DA2D, NEXT>;
+    auto kern = k_hist<TQ, VEC, NINT, GRAD, DA2D, NEXT, FAST>;
     { const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(kern), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; }
     HistArgs b = a;
     static const int xcd_env = [] { const char* e = getenv("XC_HIST_XCDMAP"); return e ? atoi(e) : 1; }();
@@ -463,6 +485,12 @@ int launch_two(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
 {
     // the NEXT variant exists for the two channel layouts of the Keff pipeline only
     constexpr bool kHasNext = (NINT == 0 && GRAD) || (NINT == 1 && !GRAD);
+    if constexpr (NINT == 0 && GRAD && VEC == 2) {                  // the Keff layout: compile-time periodic / fillna-free variant
+        if (a.periodic_x && a.dA_pos_finite && !a.negate) {
+            if (a.q_next) return launch_three<TQ, VEC, NINT, GRAD, DA2D, true, true>(ctx, g, nslab, a);
+            return launch_three<TQ, VEC, NINT, GRAD, DA2D, false, true>(ctx, g, nslab, a);
+        }
+    }
     if (a.q_next) {
         if constexpr (kHasNext) return launch_three<TQ, VEC, NINT, GRAD, DA2D, true>(ctx, g, nslab, a);
         else return fail(ctx, XC_EBADARG, "xc_hist: q_next is only supported by the Keff pipeline layouts");
