@@ -62,6 +62,68 @@ def test_sharded_gather_equals_single_rank(world, nslab):
         assert np.array_equal(got[r], ref)          # every rank holds all slabs, in slab order
 
 
+def _chunk_worker(rank, world, port, nslab, chunk, q):
+    """the cfg4 driver's data flow on CPU: every rank sweeps its block in launch sets of `chunk` slabs that write result
+    slots laid out [9][chunk][N] (+ tail fields), unpacks them with chunks_to_slabs and joins the one gather"""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from xcontour_amd.distributed import all_gather_slabs, chunks_to_slabs
+    from xcontour_amd.pipeline import shard_slabs, KeffPlan
+    N = 11
+    lo, hi = shard_slabs(nslab, rank, world)
+    n = hi - lo
+    slot = KeffPlan.out_bytes(chunk, N) // 8
+    nchunk = -(-n // chunk) if n else 0
+    res = torch.full((max(nchunk, 1) * slot,), float('nan'), dtype=torch.float64)
+    for c in range(nchunk):
+        m = min(chunk, n - c * chunk)
+        head = res[c * slot:c * slot + 9 * chunk * N].view(9, chunk, N)
+        for i in range(m):
+            head[:, i, :] = torch.from_numpy(_slab_result(lo + c * chunk + i))
+    mine = chunks_to_slabs(res, slot, chunk, n, N)
+    out = all_gather_slabs(mine, nslab, rank, world)
+    dist.barrier()
+    q.put((rank, out.numpy().copy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,nslab,chunk', [(2, 9, 2), (2, 7, 4), (3, 10, 3), (2, 1, 4)])
+def test_chunked_result_slots_to_gather(world, nslab, chunk):
+    """ragged blocks AND ragged last launch sets: the gathered (S, 9, N) equals the 1-rank result bit for bit"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, nslab, chunk, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _process(0, nslab)
+    for r in range(world):
+        assert got[r].shape == ref.shape and np.array_equal(got[r], ref)
+
+
+def test_chunks_to_slabs_numpy():
+    sys.path.insert(0, ROOT)
+    from xcontour_amd.distributed import chunks_to_slabs
+    from xcontour_amd.pipeline import KeffPlan
+    N, chunk, n = 5, 3, 7
+    slot = KeffPlan.out_bytes(chunk, N) // 8
+    res = np.full(3 * slot, np.nan)
+    for c in range(3):
+        head = res[c * slot:c * slot + 9 * chunk * N].reshape(9, chunk, N)
+        for i in range(min(chunk, n - c * chunk)):
+            head[:, i, :] = 100 * (c * chunk + i) + np.arange(9)[:, None] * 10 + np.arange(N)[None, :]
+    out = chunks_to_slabs(res, slot, chunk, n, N)
+    assert out.shape == (7, 9, 5) and not np.isnan(out).any()
+    assert all(out[s, v, k] == 100 * s + 10 * v + k for s in range(7) for v in (0, 8) for k in (0, 4))
+    assert chunks_to_slabs(res, slot, chunk, 0, N).shape == (0, 9, N)
+
+
 def test_single_rank_passthrough():
     sys.path.insert(0, ROOT)
     from xcontour_amd.distributed import all_gather_slabs

@@ -28,7 +28,7 @@ NY, NX, NCONT, SEED = 721, 1440, 201, 20241008
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--slabs', type=int, default=512 * 37)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--chunk', type=int, default=256, help='slabs per launch set')
     a = ap.parse_args()
@@ -44,14 +44,14 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     from xcontour_amd import _native as nat
     from xcontour_amd.pipeline import KeffPlan, shard_slabs, OUT_NAMES
-    from xcontour_amd.distributed import all_gather_slabs
-    from xcontour_amd.utils import cell_area, table_from_rowsums
+    from xcontour_amd.distributed import all_gather_slabs, chunks_to_slabs
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
 
     ctx = nat.Context(local)
     lat = np.linspace(-90, 90, NY)
     lon = np.arange(NX) * 0.25
     dA = cell_area(lat, lon)
-    tbl = table_from_rowsums(ctx.rowsum(None, dA, NY, NX), True)
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, NY, NX), True, last_row_included(lat, 'xhistogram'))
     S = a.slabs
     lo, hi = shard_slabs(S, rank, world)
     n = hi - lo
@@ -92,12 +92,7 @@ def main():
         sweep()
     ctx.sync()
     # per-slab vectors of this rank's block -> (n, 9, N), then the one collective
-    parts = []
-    for ci in range(nchunk):
-        m = min(C, n - ci * C)
-        raw = res[ci * slot // 8:ci * slot // 8 + 9 * C * NCONT].view(9, C, NCONT)
-        parts.append(raw[:, :m, :].permute(1, 0, 2))
-    mine = torch.cat(parts, dim=0).contiguous() if parts else torch.zeros((0, 9, NCONT), dtype=torch.float64, device='cuda')
+    mine = chunks_to_slabs(res, slot // 8, C, n, NCONT)
     full = all_gather_slabs(mine, S, rank, world)
     torch.cuda.synchronize()
     if world > 1:

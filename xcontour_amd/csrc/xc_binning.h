@@ -24,6 +24,26 @@ template <> struct RowLoad<float, 1> {
     static __device__ __forceinline__ void ld(const float* p, double (&v)[1]) { v[0] = (double)*p; }
 };
 
+// The same loads with the non-temporal (streaming) hint: the tracer is read once per pass and should not push the
+// weights -- shared by every slab of a launch -- out of the XCD's L2.
+typedef double xc_d2v __attribute__((ext_vector_type(2)));
+typedef float  xc_f2v __attribute__((ext_vector_type(2)));
+template <typename T, int VEC> struct RowLoadNT;
+template <> struct RowLoadNT<double, 2> {
+    static __device__ __forceinline__ void ld(const double* p, double (&v)[2]) {
+        const xc_d2v t = __builtin_nontemporal_load(reinterpret_cast<const xc_d2v*>(p)); v[0] = t.x; v[1] = t.y; }
+};
+template <> struct RowLoadNT<double, 1> {
+    static __device__ __forceinline__ void ld(const double* p, double (&v)[1]) { v[0] = __builtin_nontemporal_load(p); }
+};
+template <> struct RowLoadNT<float, 2> {
+    static __device__ __forceinline__ void ld(const float* p, double (&v)[2]) {
+        const xc_f2v t = __builtin_nontemporal_load(reinterpret_cast<const xc_f2v*>(p)); v[0] = (double)t.x; v[1] = (double)t.y; }
+};
+template <> struct RowLoadNT<float, 1> {
+    static __device__ __forceinline__ void ld(const float* p, double (&v)[1]) { v[0] = (double)__builtin_nontemporal_load(p); }
+};
+
 // ---- contour levels, bit-for-bit the arithmetic of cal_contours (core.py:228-246)
 // under np.vectorize: (stop-start) in the tracer dtype, everything else in f64,
 // cast to the contour dtype at the end.  __d*_rn / __f*_rn forbid FMA contraction.

@@ -166,9 +166,17 @@ void k_hist(const HistArgs a)
         yq = yq < ny - 1 ? yq : ny - 1;
         yw = yw < ny - 1 ? yw : ny - 1;
         const char* qrow = qbase + (size_t)yq * rowq;                          // wave-uniform
+#ifdef XC_HIST_QNT
+        RowLoadNT<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
+#else
         RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
+#endif
         if (GRAD) r.h = (double)*reinterpret_cast<const TQ*>(qrow + xo_h);
+#ifdef XC_HIST_QNT
+        if (NEXT) RowLoadNT<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
+#else
         if (NEXT) RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
+#endif
         if (DA2D) {
             RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(dbase + (size_t)yw * rowd + xo_d), r.dA);
         } else {

@@ -41,6 +41,29 @@ def all_gather_slabs(local, nslab, rank, world):
     return torch.cat(parts, dim=0)
 
 
+def chunks_to_slabs(res, slot_elems, chunk, nlocal, N, nvec=9):
+    """Result slots of a chunked KeffPlan sweep -> this rank's (nlocal, nvec, N) block.
+
+    A rank works through its `nlocal` slabs in launch sets of `chunk` slabs; launch set c writes result slot c of a flat
+    float64 buffer `res` (torch tensor or ndarray; `slot_elems` = KeffPlan.out_bytes(chunk, N) // 8 elements per slot)
+    whose head is laid out [nvec][chunk][N] (pipeline.OUT_NAMES order).  The last set may be short (ragged): only its
+    first nlocal - c * chunk slabs are real.  Returns the slab-major block in slab order."""
+    nchunk = -(-int(nlocal) // int(chunk)) if nlocal else 0
+    parts = []
+    for c in range(nchunk):
+        m = min(chunk, nlocal - c * chunk)
+        head = res[c * slot_elems:c * slot_elems + nvec * chunk * N].reshape(nvec, chunk, N)
+        head = head[:, :m, :]
+        parts.append(head.permute(1, 0, 2) if hasattr(head, 'permute') else head.transpose(1, 0, 2))
+    if not parts:
+        return res[:0].reshape(0, nvec, N)
+    if hasattr(parts[0], 'permute'):
+        import torch
+        return torch.cat(parts, dim=0).contiguous()
+    import numpy as np
+    return np.ascontiguousarray(np.concatenate(parts, axis=0))
+
+
 def run_sharded(process, nslab, rank, world, device=None):
     """Process slabs [lo, hi) on this rank with `process(lo, hi) -> ndarray (hi-lo, ...)`
     (e.g. a KeffPlan over the rank's block) and gather every rank's result."""

@@ -186,10 +186,11 @@ class KeffPlan(object):
         self.touch()
 
     def set_q_device(self, ptr):
-        """Use an existing device pointer ([nslab][ny][nx], q_dtype) as the tracer."""
+        """Use an existing device pointer ([nslab][ny][nx], q_dtype) as the tracer.  (Chained min/max partials are
+        keyed on the pointer: pointing at OTHER resident data needs no `touch()`; new contents behind the SAME
+        pointer, written by someone else than this library, do.)"""
         self._q_ptr = int(ptr)
         self.desc.q = self._q_ptr
-        self.touch()
 
     def set_dA_device(self, ptr):
         """Use an existing device pointer as dA (same rank and shape as the dA given to the constructor)."""
