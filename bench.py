@@ -193,6 +193,12 @@ def main():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="process-group backend; 'nccl' IS RCCL on ROCm (default).  'gloo' stages the one gather "
                          'through the host: only for exercising the multi-rank path on a box with fewer GPUs than ranks')
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
+                    help="BASELINE.json configuration: cfg2 (default, the headline metric's), or one of the secondary ones as "
+                         'a bench line of the same contract (tools/bench_configs.py; single GPU; --steps / --warmup apply)')
+    ap.add_argument('--persistent', action='store_true',
+                    help='run the Keff pipeline through the persistent single-read kernel (xc_keffp.hip, XC_KEFF_PERSISTENT): '
+                         'the tracer crosses the fabric once; slower than the chained streaming schedule on MI355X (DESIGN.md)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-slabs', type=int, default=0, help='distinct slabs in the CPU sample, all parity-checked (0: 8)')
     a = ap.parse_args()
@@ -233,6 +239,16 @@ def main():
     from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
 
     ctx = nat.Context(local)
+    if a.config != 'cfg2':
+        if world > 1:
+            raise SystemExit('--config %s is a single-GPU line (the multi-GPU cfg4 driver is tools/bench_cfg4.py)' % a.config)
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import bench_configs
+        print(json.dumps(bench_configs.run(a.config, ctx, a.steps, a.warmup)), flush=True)
+        ctx.close()
+        return
+    if a.persistent:
+        ctx.set_keff_mode(nat.XC_KEFF_PERSISTENT)
     B, K, W = a.batch, a.steps, a.warmup
     lat = np.linspace(-90, 90, NY)
     lon = np.arange(NX) * 0.1
@@ -253,7 +269,7 @@ def main():
                     out_slabs=B, replicate_dA=a.slab_dA, right_edge='xhistogram')
     plan.synth(lat, lon, SEED + rank * NB * B, a.variant)         # slab s of rank r: seed + r*2B + s
     group = a.group or B
-    chain = bool(a.chain)
+    chain = bool(a.chain) and not a.persistent          # the persistent kernel finds its min/max itself
 
     def step(k, slot_idx):
         s0 = (k % NB) * B                                         # this step's batch
@@ -316,7 +332,8 @@ def main():
                                    'full Keff (min/max + histogram with in-kernel |grad q|^2 + CDF + epilogue)'
                                    % (NX, NY, NCONT),
                        'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant, 'dA': 'per-row vector (detected constant rows)' if a.row_dA else ('2-D f64 plane PER SLAB (time-varying weights)' if a.slab_dA else '2-D f64 plane shared by the slabs'),
-                       'minmax': 'folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass',
+                       'minmax': ('inside the persistent single-read kernel' if a.persistent else
+                                  ('folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass')),
                        'parallelism': 'independent slabs per GPU, one RCCL all-gather at the end' if world > 1 else 'single GPU',
                        'device': ctx.device_name()},
         }
@@ -333,7 +350,7 @@ def main():
             if os.path.exists(tf) and not a.row_dA and a.variant == 0:
                 try:
                     tj = json.load(open(tf))
-                    tj = tj.get(('slab_' if a.slab_dA else '') + ('chain' if chain else 'nochain'), {})
+                    tj = tj.get(('slab_' if a.slab_dA else '') + ('persistent' if a.persistent else ('chain' if chain else 'nochain')), {})
                     if tj.get('slabs_per_launch') == B:                # PMC passes were taken at the default batch
                         traffic = tj.get('hbm_bytes_per_launch')
                         tcommit = tj.get('commit')
@@ -344,8 +361,9 @@ def main():
                                 'traffic_source': None if traffic is None else
                                 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_bench_traffic.sh), measured at commit %s; '
                                 'not re-measured in this run' % tcommit,
-                                'kernel': 'k_hist<double,%s,%s>' % ('DA_SLAB' if a.slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'),
-                                                                    'NEXT' if chain else 'plain'),
+                                'kernel': ('k_keff_persist<double,%s>' if a.persistent else 'k_hist<double,%s,%s>')
+                                          % (('DA_SLAB' if a.slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'),) if a.persistent else
+                                             ('DA_SLAB' if a.slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'), 'NEXT' if chain else 'plain')),
                                 'launch_ms': float(ms.mean()),
                                 'algorithmic_bytes_per_launch': alg,
                                 'hbm_unique_bytes_per_launch': uniq,
@@ -360,7 +378,7 @@ def main():
         out = plan.fetch(slot=K - 1)
         if not (out['counts'].sum(axis=1).astype(np.int64) == NY * NX).all() or out['status'].any():
             raise RuntimeError('bench self-check failed: counts %r status %r' % (out['counts'].sum(axis=1), out['status']))
-        if world == 1 and chain and group == B:
+        if world == 1 and chain and group == B and not a.persistent:
             # transparency: the same work in the plain order (stand-alone K1 launch, then K3), a short extra run
             # AFTER the timed region (identical per-step outputs; tests/test_gpu_parity.py::test_chained_minmax_is_bit_identical)
             chain = False

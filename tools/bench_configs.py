@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""The secondary BASELINE.json configurations as bench lines (`python bench.py --config cfg3|cfg4|cfg5`), each with the
+`roofline` and `cpu_baseline` objects of the bench contract.  cfg2 (the headline) lives in bench.py itself.
+
+  cfg3  barotropic_vorticity local wave activity (256x512 f32, Q from 121 contours, J = 256 target latitudes), K7
+  cfg4  stack of 1440x721 f64 slabs, Keff per slab with per-slab levels, chained launch sets of 256, K1+K3+K5/K6
+  cfg5  X-Z stand-in for the missing internalwave.nc (100 x 4480 f64, topography): exact adiabatic sort + Q(z*) + BPE, K8
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK_GBS = 8000.0
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import xcontour_oracle as O
+    return O
+
+
+def _timed_events(ctx, fn, reps, warm=3):
+    e0, e1 = ctx.event(), ctx.event()
+    for _ in range(warm):
+        fn()
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.record(e0)
+    for _ in range(reps):
+        fn()
+    ctx.record(e1)
+    ms = ctx.elapsed_ms(e0, e1)
+    return ms / reps, time.perf_counter() - t0
+
+
+def _host():
+    model = 'unknown CPU'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return '%s, %d logical cores' % (model, os.cpu_count() or 1)
+
+
+def run_cfg3(ctx, steps, warmup):
+    from xcontour_amd import _native as nat
+    O = _oracle()
+    g = os.path.join(ROOT, 'tests', 'golden')
+    q = np.load(g + '/baro_q.npy'); lat = np.load(g + '/baro_lat.npy'); lon = np.load(g + '/baro_lon.npy')
+    L = np.load(g + '/baro_lwa_N121.npz')
+    dA = O.cell_area(lat, lon)
+    dq, dQ, dc = ctx.to_device(q), ctx.to_device(L['Q']), ctx.to_device(lat.astype(np.float64))
+    dd, dM = ctx.to_device(dA), ctx.to_device(L['dy'])
+    out = ctx.alloc(q.size * 8)
+    fn = lambda: ctx._check(ctx.lib.xc_lwa_dev(ctx.handle, dq.ptr, nat.XC_F32, dQ.ptr, dc.ptr, dd.ptr, nat.XC_DA_PLANE,
+                                              float(dA.max()), dM.ptr, nat.XC_DA_ROW, 1, 256, 512, 1, 0, 0, None, 0, out.ptr, None))
+    ms, wall = _timed_events(ctx, fn, steps, warmup)
+    got = out.download((256, 512), np.float64)
+    t = time.perf_counter()
+    ref = O.cal_local_wave_activity(q, L['Q'], lat, dA, True, 'all', metric=L['dy'])
+    tc = time.perf_counter() - t
+    if not np.array_equal(got, ref):
+        raise RuntimeError('cfg3 parity check against the oracle FAILED')
+    work = 256 * 256 * 512
+    alg = q.nbytes + 256 * 8 + 256 * 8 + dA.nbytes + got.nbytes          # q, Q, coord, dA, LWA out: each once
+    return {
+        'metric': 'local wave activity: target-row x cell pairs / s (cfg3)', 'value': work / (ms * 1e-3), 'unit': 'cell-rows/s',
+        'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f64 (f32 tracer)', 'data': 'tests/golden barotropic_vorticity (the reference\'s bundled field)',
+        'config': {'workload': 'cfg3: barotropic_vorticity 256x512 f32, sorted state from 121 contours, J = 256 target latitudes, '
+                               'cal_local_wave_activity part=all, legacy dy metric', 'device': ctx.device_name()},
+        'roofline': {'bound': 'hbm', 'achieved': alg / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_lwa (+ k_lwa_prep)', 'launch_ms': ms,
+                     'algorithmic_bytes_per_launch': alg,
+                     'note': 'compulsory bytes are 2.6 MB for 33.5 M (target row, cell) pairs: the kernel is bound by the latency of its '
+                             'widest contributing band and by f64 VALU, not by HBM; the fraction is reported as the contract asks'},
+        'cpu_baseline': {'value': work / tc, 'unit': 'cell-rows/s', 'cores': 1, 'kind': 'port',
+                         'sample': 'the whole cfg3 workload once through the numpy oracle (the reference\'s 256-iteration python loop, '
+                                   'core.py:752-791): %.3f s; bit-identical to the GPU result; host: %s' % (tc, _host())},
+    }
+
+
+def run_cfg5(ctx, steps, warmup):
+    from xcontour_amd import _native as nat
+    O = _oracle()
+    nz, nxx = 100, 4480
+    Z = -(np.arange(nz) + 0.5) * 2.0
+    X = (np.arange(nxx) + 0.5) * 20.0
+    xx, zz = np.meshgrid(X, Z)
+    T = 20 + 5 * np.tanh((zz + 60 + 15 * np.sin(2 * np.pi * xx / 30000.0)) / 20.0)
+    depth = 200 - 80 * np.exp(-((X - 60000) / 15000.0) ** 2)
+    maskC = (zz > -depth[None, :]).astype(np.float64)
+    b = 2e-4 * (np.where(maskC == 1, T, np.nan) - 20) * 9.81
+    yA = np.full((nz, nxx), 40.0)
+    tbl, cs = O.cal_area_eqCoord_table_hist(maskC, yA, Z, False, False)
+    S = 3                                                      # three time steps in one batched (segmented) sort
+    b3 = np.stack([b, b * 1.01, b[:, ::-1]])
+    db3, dmk, dya = ctx.to_device(b3), ctx.to_device(maskC), ctx.to_device(yA)
+    dt_, dcs = ctx.to_device(tbl), ctx.to_device(cs)
+    dQ3 = ctx.alloc(S * nz * 8); nv3 = ctx.alloc(64); dbpe3 = ctx.alloc(S * 8)
+    fn = lambda: ctx._check(ctx.lib.xc_sort_profile_batch_dev(ctx.handle, db3.ptr, nat.XC_F64, dmk.ptr, nat.XC_F64, 0, dya.ptr,
+                                                             nat.XC_DA_PLANE, S, nz, nxx, 0, dt_.ptr, nz, dt_.ptr, dcs.ptr, nz,
+                                                             dQ3.ptr, None, None, nv3.ptr, dbpe3.ptr))
+    ms, wall = _timed_events(ctx, fn, steps, warmup)
+    bpe = dbpe3.download((S,), np.float64)
+    t = time.perf_counter()
+    ref = [O.bpe_integral(b3[s], yA, tbl, cs, maskC) for s in range(S)]
+    tc = time.perf_counter() - t
+    err = max(abs(bpe[s] / ref[s] - 1) for s in range(S))
+    if not err < 1e-10:
+        raise RuntimeError('cfg5 parity check against the oracle FAILED (BPE rel err %g)' % err)
+    nvalid = int(maskC.sum())
+    cells = S * nz * nxx
+    passes = 8                                                 # 64-bit keys, 8-bit digits
+    alg = S * nvalid * (passes * (8 + 2 * 16) + 8 + 8)         # per pass: key read for the histogram + (key, payload) read and written
+    return {
+        'metric': 'exact adiabatic sort + Q(z*) + BPE: cells / s (cfg5 stand-in)', 'value': cells / (ms * 1e-3), 'unit': 'cells/s',
+        'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f64 (64-bit keys)', 'data': 'synthetic (internalwave.nc is not in the reference snapshot)',
+        'config': {'workload': 'cfg5 stand-in: %d time steps of a %dx%d f64 X-Z buoyancy section with topography, one batched radix '
+                               'sort of (buoyancy, area) pairs + cumulative area + Q at %d levels + BPE integral' % (S, nz, nxx, nz),
+                   'device': ctx.device_name()},
+        'roofline': {'bound': 'hbm', 'achieved': alg / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_radix_hist + k_radix_scan_rows + k_radix_scatter x 8 passes',
+                     'launch_ms': ms, 'algorithmic_bytes_per_launch': alg,
+                     'note': 'pass traffic of an 8-pass LSD radix sort (40 B per valid pair and pass); at 0.4 M pairs per section the '
+                             '~25 dependent launches are latency-bound, the 6.48 M-pair sort of a cfg2 slab reaches ~3.5 TB/s (profiles/)'},
+        'cpu_baseline': {'value': cells / tc, 'unit': 'cells/s', 'cores': 1, 'kind': 'port',
+                         'sample': 'the %d sections once through the numpy oracle (stable argsort + cumsum + interp + sum): %.3f s; '
+                                   'BPE relative difference %.1e; host: %s' % (S, tc, err, _host())},
+    }
+
+
+def run_cfg4(ctx, steps, warmup, slabs=2048, chunk=256):
+    """one GPU: `slabs` of the 18 944 slabs of cfg4 (the multi-GPU driver is tools/bench_cfg4.py: static slab partition +
+    one RCCL gather; here the single-GPU rate with the histogram pass timed launch by launch)"""
+    import ctypes as C
+    from xcontour_amd import _native as nat
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
+    O = _oracle()
+    NY, NX, NCONT, SEED = 721, 1440, 201, 20241008
+    lat = np.linspace(-90, 90, NY); lon = np.arange(NX) * 0.25
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, NY, NX), True, last_row_included(lat, 'xhistogram'))
+    n, Cn = slabs, min(chunk, slabs)
+    nchunk = -(-n // Cn)
+    slab_bytes = NY * NX * 8
+    qbuf = ctx.alloc(n * slab_bytes)
+    lat_b, lon_b = ctx.to_device(lat), ctx.to_device(lon)
+    for c0 in range(0, n, Cn):
+        m = min(Cn, n - c0)
+        ctx._check(ctx.lib.xc_synth_dev(ctx.handle, qbuf.ptr + c0 * slab_bytes, nat.XC_F64, m, NY, NX, lat_b.ptr, lon_b.ptr, SEED + c0, 0))
+    ctx.sync()
+    plan = KeffPlan(ctx, Cn, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                    increase=True, lt=True, nslots=nchunk, alloc_q=False)
+    evs = []
+
+    def sweep(record):
+        for ci in range(nchunk):
+            c0 = ci * Cn
+            m = min(Cn, n - c0)
+            plan.set_q_device(qbuf.ptr + c0 * slab_bytes)
+            nxt = ((ci + 1) % nchunk) * Cn
+            chain = min(Cn, n - nxt) == m
+            plan._point(ci, 0, m)
+            plan.desc.q_next = (qbuf.ptr + nxt * slab_bytes) if chain else None
+            if record and m == Cn:
+                e = (ctx.event(), ctx.event()); evs.append(e)
+                ctx.set_hist_events(e[0], e[1])
+            ctx._check(ctx.lib.xc_keff_dev(ctx.handle, C.byref(plan.desc)))
+
+    for _ in range(warmup):
+        sweep(False)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sweep(True)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    out = plan.fetch(slot=0)
+    if not (out['counts'].sum(axis=1).astype(np.int64) == NY * NX).all():
+        raise RuntimeError('cfg4 self-check failed')
+    # CPU leg: the oracle on 4 slabs of the first launch set, compared with the GPU vectors
+    nd = 4
+    qh = np.empty((nd, NY, NX))
+    ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, qbuf.ptr, nd * slab_bytes))
+    t = time.perf_counter()
+    for s in range(nd):
+        r = O.keff_pipeline(qh[s], dA, lat, NCONT, lon=lon, increase=True, lt=True, dtype=np.float64)
+        if not (np.array_equal(out['counts'][s].astype(np.int64), r['counts']) and np.array_equal(out['ctr'][s], r['ctr'])
+                and np.allclose(out['area'][s], r['area'], rtol=1e-11, atol=0) and np.allclose(out['intgrdS'][s], r['intgrdS'], rtol=1e-10, atol=0)):
+            raise RuntimeError('cfg4 parity check against the oracle FAILED for slab %d' % s)
+    tc = (time.perf_counter() - t) / nd
+    ms = float(np.mean([ctx.elapsed_ms(a, b) for a, b in evs])) if evs else None
+    work = NY * NX * NCONT
+    alg_launch = Cn * NY * NX * 16
+    line = {
+        'metric': 'lat-lon cells*contours/s, full Keff pipeline (cfg4 stack, one GPU)', 'value': n * work * steps / el,
+        'unit': 'cells*contours/s', 'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': el / steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'cfg4: %d of the 18 944 slabs of 1440x721 float64 resident in HBM, 201 contours, per-slab levels, '
+                               'chained launch sets of %d slabs' % (n, Cn), 'us_per_slab': el / steps / n * 1e6, 'device': ctx.device_name()},
+        'roofline': {'bound': 'hbm', 'achieved': None if ms is None else alg_launch / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': None if ms is None else alg_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                     'kernel': 'k_hist<double,2,0,true,true,NEXT,FAST>', 'launch_ms': ms, 'algorithmic_bytes_per_launch': alg_launch,
+                     'pipeline_frac': (n * NY * NX * 16 * steps / el / 1e9) / HBM_PEAK_GBS},
+        'cpu_baseline': {'value': work / tc, 'unit': 'cells*contours/s', 'cores': 1, 'kind': 'port',
+                         'sample': '%d slabs of 1440x721 f64 through the numpy oracle, single thread: %.3f s per slab; counts + levels '
+                                   'bit-exact and sums 1e-11 against the GPU vectors; host: %s' % (nd, tc, _host())},
+    }
+    plan.free(); qbuf.free()
+    return line
+
+
+def run(config, ctx, steps, warmup):
+    if config == 'cfg3':
+        return run_cfg3(ctx, steps, warmup)
+    if config == 'cfg4':
+        return run_cfg4(ctx, steps, warmup)
+    if config == 'cfg5':
+        return run_cfg5(ctx, steps, warmup)
+    raise SystemExit('unknown --config %r' % config)
