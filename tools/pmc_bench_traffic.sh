@@ -1,25 +1,56 @@
 #!/bin/bash
-# tools/pmc_bench_traffic.sh (run on the GPU box via gpurun): HBM traffic of the bench's kernels, FETCH_SIZE and
-# WRITE_SIZE in separate --pmc passes, for the default (chained) schedule and for --no-chain; plus the
-# kernel-trace statistics of the default command.  Summaries go to gpurun_out/.
+# tools/pmc_bench_traffic.sh (run on the GPU box via gpurun): fabric traffic of the bench's dominant kernel, FETCH_SIZE and
+# WRITE_SIZE in SEPARATE --pmc passes (the guide's rule), for every schedule bench.py can run:
+#   chain (default) | nochain | persistent, each with the shared dA plane and with per-slab dA (--slab-dA);
+# plus rocprofv3 --kernel-trace --stats summaries of the default command and of --no-chain / --persistent.
+# Writes gpurun_out/hist_traffic.json (copy to profiles/) and gpurun_out/kt_<mode>/.
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && cd $R
-for mode in chain nochain; do
-  arg=""; [ $mode = nochain ] && arg="--no-chain"
+COMMIT=${1:-unknown}
+for mode in chain nochain persistent slab_chain slab_nochain slab_persistent; do
+  arg=""
+  case $mode in *nochain) arg="--no-chain";; *persistent) arg="--persistent";; esac
+  case $mode in slab_*) arg="$arg --slab-dA";; esac
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb_${mode}_$c -- python3 bench.py --steps 20 --warmup 5 --no-cpu $arg > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb_${mode}_$c -- python3 bench.py --steps 12 --warmup 3 --no-cpu $arg > /dev/null 2>&1
   done
+done
+for mode in chain nochain persistent; do
+  arg=""; [ $mode = nochain ] && arg="--no-chain"; [ $mode = persistent ] && arg="--persistent"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_$mode -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu $arg > $R/gpurun_out/kt_$mode.log 2>&1
 done
 python3 - <<PY
 import csv,glob,collections,json
-out={}
+B, NY, NX = 64, 1801, 3600
+out = {'commit': '$COMMIT', 'slabs_per_launch': B,
+       'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over python3 bench.py --steps 12 --warmup 3 --no-cpu '
+                 '[--no-chain|--persistent] [--slab-dA]; median over the dispatches of the dominant kernel; FETCH_SIZE x 2 '
+                 '(gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md; calibrated on k_minmax_partial: '
+                 'known bytes / reported KB) + WRITE_SIZE x 1; KB = 1024 B'}
+raw = collections.defaultdict(dict)
 for f in sorted(glob.glob("$R/gpurun_out/pmcb_*/*/*counter_collection.csv")):
-    mode=f.split('/')[-3].replace('pmcb_','')
-    agg=collections.defaultdict(list)
+    mode = f.split('/')[-3].replace('pmcb_', '').rsplit('_', 2)[0]
+    agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'k_hist' in r['Kernel_Name'] or 'k_minmax_partial' in r['Kernel_Name']:
-            agg[(r['Kernel_Name'].split('(')[0].replace('void xc::(anonymous namespace)::',''), r['Counter_Name'])].append(float(r['Counter_Value']))
-    for k,v in sorted(agg.items()):
-        v=sorted(v); out['%s | %s | %s' % (mode, k[0], k[1])] = v[len(v)//2]
-print(json.dumps(out, indent=1))
+        k = r['Kernel_Name']
+        name = 'k_keff_persist' if 'k_keff_persist' in k else ('k_hist' if 'k_hist<' in k else ('k_minmax_partial' if 'k_minmax_partial' in k else None))
+        if name:
+            agg[(name, r['Counter_Name'])].append(float(r['Counter_Value']))
+    for (name, ctr), v in agg.items():
+        v = sorted(v); raw[mode][name + ':' + ctr] = v[len(v) // 2]
+cal = None
+if 'k_minmax_partial:FETCH_SIZE' in raw.get('nochain', {}):
+    known = B * NY * NX * 8 / 1024.0
+    cal = known / raw['nochain']['k_minmax_partial:FETCH_SIZE']
+    out['fetch_calibration'] = {'kernel': 'k_minmax_partial<double>', 'known_KB': known, 'FETCH_SIZE_KB_raw': raw['nochain']['k_minmax_partial:FETCH_SIZE'], 'factor': cal}
+for mode, d in raw.items():
+    dom = 'k_keff_persist' if 'persistent' in mode else 'k_hist'
+    if dom + ':FETCH_SIZE' not in d: continue
+    slab = mode.startswith('slab_')
+    cells = B * NY * NX
+    out[mode] = {'kernel': dom, 'slabs_per_launch': B, 'commit': '$COMMIT', 'FETCH_SIZE_KB_raw': d[dom + ':FETCH_SIZE'], 'WRITE_SIZE_KB': d.get(dom + ':WRITE_SIZE'),
+                 'hbm_bytes_per_launch': (d[dom + ':FETCH_SIZE'] * 2 + d.get(dom + ':WRITE_SIZE', 0.0)) * 1024,
+                 'algorithmic_bytes_per_launch': cells * 16,
+                 'hbm_unique_bytes_per_launch': cells * 8 + (cells * 8 if slab else NY * NX * 8)}
+json.dump(out, open("$R/gpurun_out/hist_traffic.json", 'w'), indent=1)
+print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if kk in ('hbm_bytes_per_launch', 'FETCH_SIZE_KB_raw', 'factor')}) for k, v in out.items() if k != 'method'}, indent=1))
 PY

@@ -31,6 +31,13 @@ namespace {
 #ifndef XC_U
 #define XC_U 2
 #endif
+// Cache policy of the two tracer streams (bit 0: the binned batch, bit 1: the NEXT batch whose min / max rides along).
+// Measured on MI355X (bench.py, 64 slabs per launch): the non-temporal hint on the NEXT stream -- read once, used for
+// two compares, never needed again by this launch -- keeps the shared dA plane in the XCD L2s: 1.367 -> 1.285 ms per
+// launch; the same hint on the binned stream costs 9 % (its halo / neighbour re-reads want the line), on both 7 %.
+#ifndef XC_HIST_QNT
+#define XC_HIST_QNT 2
+#endif
 constexpr int U = XC_U;   // rows per prefetch batch (double-buffered)
 
 // Grid mapping (1-D grid).  Workgroups go round-robin to the 8 XCDs (workgroup id % 8), each XCD has its own
@@ -166,13 +173,13 @@ void k_hist(const HistArgs a)
         yq = yq < ny - 1 ? yq : ny - 1;
         yw = yw < ny - 1 ? yw : ny - 1;
         const char* qrow = qbase + (size_t)yq * rowq;                          // wave-uniform
-#ifdef XC_HIST_QNT
+#if (XC_HIST_QNT & 1)
         RowLoadNT<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
 #else
         RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
 #endif
         if (GRAD) r.h = (double)*reinterpret_cast<const TQ*>(qrow + xo_h);
-#ifdef XC_HIST_QNT
+#if (XC_HIST_QNT & 2)
         if (NEXT) RowLoadNT<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
 #else
         if (NEXT) RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
