@@ -1117,4 +1117,4 @@ def test_differential_fuzz_short(ctx):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     n, checked = fz.run(8.0, seed=2024)
-    assert sum(n.values()) > 200 and all(v > 0 for v in checked.values()) and len(checked) == 6
+    assert sum(n.values()) > 200 and all(v > 0 for v in checked.values()) and len(checked) >= 6
