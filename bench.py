@@ -111,9 +111,9 @@ def cpu_baseline(q_host, gpu_out, ncheck):
     cores = os.cpu_count() or 1
     workers = max(1, min(cores, int(_mem_available_bytes() * 0.5 // (1.2 * (1 << 30)))))
     nd = q_host.shape[0]
-    # the host's real best: all logical cores, and (this path is memory-bound numpy) half and a quarter of them; the
-    # best rate is reported as `value`, every tried worker count goes into `sample`
-    tries = sorted({max(1, workers // 4), max(1, workers // 2), workers})
+    # the host's real best: all logical cores, and (this path is memory-bound numpy: more processes than memory channels
+    # slow it down) 1/2, 1/4, 1/8, 1/16 of them; the best rate is `value`, every tried count goes into `by_workers`
+    tries = sorted({max(1, workers // 16), max(1, workers // 8), max(1, workers // 4), max(1, workers // 2), workers})
     os.environ.setdefault('OMP_NUM_THREADS', '1')
     os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')
     tmp = tempfile.mkdtemp(prefix='xc_bench_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
