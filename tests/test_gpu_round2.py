@@ -79,6 +79,39 @@ def test_contours_at_leading_dims(ctx, baro):
         assert rel(got.values[k], want) < 1e-9
 
 
+def test_levels_against_the_reference_notebook_printout(ctx):
+    """a2 against a REFERENCE-HELD known answer: the contours the reference itself printed in
+    notebooks/1.Keff_atmos.ipynb cell 3 (PV.nc, 15 x 241 x 480 float32, N = 121; tests/golden/nb1_ctr_printout.json).
+    PV.nc is not bundled: a stand-in stack with exactly the printed minima and the (few-ulp) maxima that the printout
+    admits goes through K1 + the level kernel on the device -- all 36 printed values must come back bit for bit."""
+    import xcontour_amd as xa
+    from test_oracle_golden import nb1_rows, nb1_max_candidates
+    N, rows = nb1_rows()
+    lvl = lambda mn, mx: O.cal_contours(np.array([[mn, mx]], np.float32), N, True, np.float32)
+    rng = np.random.default_rng(11)
+    lat = np.linspace(-90, 90, 241).astype(np.float32); lon = (np.arange(480) * 0.75).astype(np.float32)
+    keys = sorted(rows)
+    st = np.empty((len(keys), 241, 480), np.float32)
+    for i, k in enumerate(keys):
+        first, last = rows[k]
+        mx = nb1_max_candidates(first, last, N, lvl)[0]
+        pl = rng.uniform(first[0], mx, (241, 480)).astype(np.float32)
+        pl = np.clip(pl, first[0], mx)
+        pl[rng.integers(241), rng.integers(480)] = first[0]
+        pl[5, 7] = mx
+        pl[100, 3] = np.nan                                    # xarray's min / max skip NaN (core.py:224-225)
+        st[i] = pl
+    c = {'level': np.arange(len(keys)), 'latitude': lat, 'longitude': lon}
+    tr = xa.DataArray(st, ('level', 'latitude', 'longitude'), c, 'pv')
+    dA = xa.DataArray(O.cell_area(lat, lon), ('latitude', 'longitude'), {'latitude': lat, 'longitude': lon}, 'rA')
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True)
+    ctr = cm.cal_contours(N)
+    assert ctr.dims == ('level', 'contour') and ctr.values.dtype == np.float32
+    for i, k in enumerate(keys):
+        first, last = rows[k]
+        assert np.array_equal(ctr.values[i, :3], first) and np.array_equal(ctr.values[i, -3:], last), k
+
+
 # ---------------------------------------------------------------- BASELINE configs[3]: 1440x721 f64 slabs, per-slab levels, chained
 def test_cfg4_shape_chained_launch_sets(ctx):
     """74 slabs of 721x1440 f64 generated on device (seed + slab id), N = 201, processed in two chained launch sets of

@@ -212,3 +212,42 @@ def test_fractal_golden_fixture():
     assert np.array_equal(ctr, G['ctr'])
     for s, r in zip(G['strides'], O.cal_contour_crossing(q, ctr, dA, [int(t) for t in G['strides']], 'edge')):
         assert np.array_equal(r, G['bclens%d' % s])
+
+
+def nb1_rows():
+    """the 36 contour values the reference itself printed in notebooks/1.Keff_atmos.ipynb (cell 3)"""
+    import json
+    d = json.load(open(os.path.join(GOLD, 'nb1_ctr_printout.json')))
+    return d['N'], {int(k): (np.array(v[0], np.float32), np.array(v[1], np.float32)) for k, v in d['rows'].items()}
+
+
+def nb1_max_candidates(first, last, N, levels_fn, span=40):
+    """PV.nc is not bundled, so a slab's max is unknown -- but ctr[0] IS its min (core.py:229-239) and the max lies within
+    a few ulp of the printed ctr[-1]: return every float32 max for which `levels_fn(min, max)` reproduces all six
+    printed values of the row bit for bit (float32)."""
+    mn, c = first[0], last[2]
+    for _ in range(span):
+        c = np.nextafter(c, np.float32(-1))
+    found = []
+    for _ in range(2 * span + 1):
+        ctr = levels_fn(mn, c)
+        if np.array_equal(ctr[:3], first) and np.array_equal(ctr[-3:], last):
+            found.append(c)
+        c = np.nextafter(c, np.float32(1))
+    return found
+
+
+def test_levels_against_the_reference_notebook_printout():
+    """A REFERENCE-HELD known answer for a2 (core.py:205-266): the level arithmetic of the oracle (the tracer-dtype
+    difference, the float64 product / sum, the float32 cast) reproduces the reference's own printed contours.  The
+    second and third value from each end are fully determined by (min, max); a wrong dtype rule (e.g. all-float32 or
+    np.linspace) fails this test for at least one row -- checked below."""
+    N, rows = nb1_rows()
+    for k, (first, last) in rows.items():
+        found = nb1_max_candidates(first, last, N, lambda mn, mx: O.cal_contours(np.array([[mn, mx]], np.float32), N, True, np.float32))
+        assert 1 <= len(found) <= 3, (k, found)
+
+    def all_f32(mn, mx):                      # the tempting wrong rule: everything in the tracer dtype
+        st = np.float32(1.0 / (N - 1)) * (mx - mn)
+        return (st * np.arange(N, dtype=np.float32) + mn).astype(np.float32)
+    assert any(len(nb1_max_candidates(f, l, N, all_f32)) == 0 for f, l in rows.values())
