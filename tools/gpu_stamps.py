@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pkg = types.ModuleType('xcontour_amd'); pkg.__path__ = [os.path.join(ROOT, 'xcontour_amd')]; sys.modules['xcontour_amd'] = pkg
 import xcontour_amd._native as nat
-nat.LIB_PATH = os.path.join(ROOT, 'xcontour_amd', 'libxcontour_hip_stamps.so')
+nat.LIB_PATH = os.path.join(ROOT, 'xcontour_amd', 'libxc_stamps.so')
 import xcontour_amd.pipeline as pl
 import xcontour_amd.utils as U
 ctx = nat.Context(0)
@@ -17,15 +17,15 @@ for ny in [int(a) for a in sys.argv[1:]] or [33, 1801]:
     plan.synth(lat, lon, 1, 0)
     nb = 256
     st = ctx.alloc(nb * 8 * 8)
-    ctx.lib.xc_dbg_set_stamps.argtypes = [C.c_void_p]
+    ctx.lib.xc_dbg_set_hist_stamps.argtypes = [C.c_void_p]
     for _ in range(3): plan.run()
     ctx.sync()
-    assert ctx.lib.xc_dbg_set_stamps(st.ptr) == 0
+    assert ctx.lib.xc_dbg_set_hist_stamps(st.ptr) == 0
     plan.run(); ctx.sync()
     s = st.download((nb, 8), np.uint64).astype(np.int64)
     t0 = s[:, 0].min()
     rel = (s[:, :6] - t0) * 10  # ns
     print('ny', ny, 'phase end times (ns, median over blocks):', np.median(rel, axis=0), 'max', rel.max(axis=0))
     print('   start spread', rel[:, 0].max(), ' durations median', np.median(np.diff(rel, axis=1), axis=0))
-    ctx.lib.xc_dbg_set_stamps(None)
+    ctx.lib.xc_dbg_set_hist_stamps(None)
     plan.free()

@@ -99,6 +99,7 @@ struct HistArgs {
     int64_t       ny, nx;
     int           nstrip, ncopy;
     int           bps, nslab_grid, xcd_map;   // launch geometry (set by launch_hist): blocks per slab, slabs, XCD-aware block order
+    int           nchunk;       // > 0: wave -> (row chunk, strip) with the strip fastest (see k_hist); 0: even split of the strip-major pairs
     double*       part_h;       // [nslab][bps][nch][nbin]
     unsigned*     part_c;       // [nslab][bps][nbin]
     double*       ctr_out;      // [nslab][nbin]   (levels mode, may be null)
