@@ -792,7 +792,7 @@ def test_crossing_random_vs_oracle(ctx, dt, stride, mode):
         q[rng.random(q.shape) < 0.05] = np.nan
         q[1, :4, :] = np.nan                                          # boxes with no valid corner
         area = (rng.random((ny, nx)) * 9 + 1).astype(dt)
-        area[2, 3] = np.nan; area[5, 1] = -1.0
+        area[2, 3] = np.nan; area[5, 1] = -1.0; area[7, 2] = np.inf      # skipped / skipped / an infinite length at the crossed levels
         cs = np.sort(rng.standard_normal((3, 17)), axis=1)
         cs[0, 3] = cs[0, 4]                                           # duplicated level
         pad = stride + 2                                              # max(stride list) > stride
@@ -810,6 +810,28 @@ def test_crossing_random_vs_oracle(ctx, dt, stride, mode):
     for s in range(2):
         ol, oc = O.contour_crossing(q[s], c1, a3[s], stride)
         assert np.array_equal(cnts[s].astype(np.int64), oc) and rel(lens[s], ol) < 1e-13
+
+
+@pytest.mark.parametrize('adt', [np.float32, np.float64])
+def test_crossing_stack_sharing_one_area_plane(ctx, adt):
+    """>= 8 slabs with a shared area plane take the square roots once (k_cross_weights); equally spaced levels go through the
+    difference-array accumulation, other levels through the scan: counts exact, lengths to summation order, per level"""
+    rng = np.random.default_rng(77)
+    ny, nx, S = 61, 200, 9
+    lat = np.linspace(-1, 1, ny)
+    q = lat[None, :, None] + 0.15 * rng.standard_normal((S, ny, nx))
+    q[rng.random(q.shape) < 0.02] = np.nan
+    area = (rng.random((ny, nx)) * 9 + 1).astype(adt)
+    area[2, 3] = np.nan; area[5, 1] = -1.0; area[7, 2] = np.inf; area[9, 9] = 0.0
+    for levels in (np.linspace(-1.2, 1.2, 33), np.sort(rng.uniform(-1.2, 1.2, 33))):
+        for stride, mode in ((1, 'wrap'), (1, 'constant'), (2, 'edge'), (7, 'constant')):
+            lens, cnts = ctx.crossing(q, levels, area, stride=stride, pad_x=stride + 1, pad_mode=mode, full_width=True)
+            for s in range(S):
+                ol, oc = O.contour_crossing(O.pad_x(q[s], stride + 1, mode), levels, O.pad_x(area, stride + 1, mode), stride, True)
+                assert np.array_equal(cnts[s].astype(np.int64), oc)
+                fin = np.isfinite(ol)
+                assert np.array_equal(np.isinf(lens[s]), np.isinf(ol))
+                assert np.all(np.abs(lens[s][fin] - ol[fin]) <= 1e-12 * np.maximum(ol[fin], 1e-300) + 0.0)       # per level, and 0 stays exactly 0
 
 
 def test_crossing_literal_loops_small(ctx):

@@ -15,6 +15,8 @@ from xcontour_amd import _native as nat      # noqa: E402
 from xcontour_amd.utils import cell_area     # noqa: E402
 import xcontour_oracle as O                  # noqa: E402
 
+if os.environ.get('XC_LIB'):
+    nat.LIB_PATH = os.path.join(ROOT, 'xcontour_amd', os.environ['XC_LIB'])      # a diagnostic build (tools/build_variant.sh)
 S, NY, NX, N = int(os.environ.get('XC_SLABS', '16')), 1801, 3600, 201
 ctx = nat.Context(0)
 lat = np.linspace(-90, 90, NY); lon = np.arange(NX) * 0.1

@@ -26,6 +26,9 @@ namespace {
 
 constexpr int CROSS_RB = 32;     // box rows per tile
 constexpr int CROSS_TPB = 256;   // threads = box columns per tile
+#ifndef XC_CROSS_GROUP
+#define XC_CROSS_GROUP 2
+#endif
 constexpr int CROSS_W1 = 252;    // box columns per tile at stride 1 (4 waves x 63 boxes, see k_crossing)
 
 // source column of padded column c >= nx (np.pad semantics on the last axis); -1 = NaN fill
@@ -85,35 +88,46 @@ template <> __device__ __forceinline__ double sqrt_like_numpy<double>(double a) 
 template <typename TA, bool CNT>
 __device__ __forceinline__ void box_done(const double* __restrict__ cx, int N, double mn, double mx, TA araw, bool nanfill,
                                          double fs, double c_first, double inv_step, int& g,
-                                         double* __restrict__ my_len, unsigned* __restrict__ my_cnt)
+                                         double* __restrict__ my_len, unsigned* __restrict__ my_cnt, double* __restrict__ s_dir)
 {
     if (!(mn < mx)) return;                            // one value, or no valid corner at all
-    // equally spaced levels (what cal_contours produces, inv_step > 0): the position follows from arithmetic;
-    // otherwise start from the previous box's answer.  One adjacent-pair LDS read verifies, bisection is the fallback.
-    if (inv_step > 0.0) g = (int)fmin(fmax((mn - c_first) * inv_step + 1.0, 0.0), (double)N);
+    if (inv_step > 0.0) {
+        // Equally spaced levels (what cal_contours produces): BOTH ends of the crossed range follow from arithmetic -- klo = number
+        // of levels < mn, khi = number of levels < mx -- each verified by one adjacent-pair LDS read, bisection as the fallback.
+        // The box then adds +w at klo and -w at khi: a DIFFERENCE array, two adds whatever the number of crossed levels (the
+        // per-lane level loop of a noisy field -- 3.6 levels per box on the PV-like slabs, up to ~10 in a wave, 39 on white
+        // noise -- was half of the kernel's instructions); the block turns the differences into sums with one pass over the
+        // levels before it writes its partials (k_crossing epilogue).  Counts are exact (integer differences modulo 2^32);
+        // lengths agree with the oracle to summation order, level by level.
+        int klo = (int)fmin(fmax((mn - c_first) * inv_step + 1.0, 0.0), (double)N);
+        const double c_lo = cx[klo];
+        double c_hi = cx[klo + 1];
+        if (!((c_lo < mn) & (mn <= c_hi))) { klo = count_below(cx, N, mn); c_hi = cx[klo + 1]; }
+        if (!(c_hi < mx)) return;                          // no level in [mn, mx): the common case on a smooth field ends here
+        int khi = (int)fmin(fmax((mx - c_first) * inv_step + 1.0, 0.0), (double)N);
+        const double h_lo = cx[khi], h_hi = cx[khi + 1];
+        if (!((h_lo < mx) & (mx <= h_hi))) khi = count_below(cx, N, mx);
+        double w = __dmul_rn(sqrt_like_numpy<TA>(araw), fs);    // core.py:1560 (product in f64: numba types f32 * int64 as f64)
+        if (nanfill) w = __longlong_as_double(0x7ff8000000000000LL);
+#ifndef XC_CROSS_NOATOM
+        if (w == w) {                                      // np.nansum skips NaN (negative or NaN area)
+            if (w < __longlong_as_double(0x7ff0000000000000LL)) { atomicAdd(&my_len[klo], w); atomicAdd(&my_len[khi], -w); }
+            else for (int t = klo; t < khi; ++t) atomicAdd(&s_dir[t], w);        // an infinite area: +inf / -inf differences would turn into NaN
+        }
+        if (CNT) { atomicAdd(&my_cnt[klo], 1u); atomicAdd(&my_cnt[khi], 0xffffffffu); }
+#endif
+        return;
+    }
+    // any ascending levels: start from the previous box's answer (walking down a column the tracer changes slowly), one
+    // adjacent-pair LDS read verifies, bisection is the fallback; then scan the crossed levels
     const double c_lo = cx[g], c_hi = cx[g + 1];
     if (!((c_lo < mn) & (mn <= c_hi))) g = count_below(cx, N, mn);
     int k = g;
     double ck = cx[k + 1];
     if (!(ck < mx)) return;
-    double w = __dmul_rn(sqrt_like_numpy<TA>(araw), fs);    // core.py:1560 (product in f64: numba types f32 * int64 as f64)
+    double w = __dmul_rn(sqrt_like_numpy<TA>(araw), fs);
     if (nanfill) w = __longlong_as_double(0x7ff8000000000000LL);
-    const bool add = (w == w);                         // np.nansum skips NaN (negative or NaN area)
-    if (inv_step > 0.0) {
-        // equally spaced levels: the END of the crossed range also follows from arithmetic (number of levels < mx,
-        // verified by one pair read), so the adds below are fire-and-forget -- a scan that reads the next level
-        // before every add serialises on LDS latency when a noisy field crosses several levels per box
-        int khi = (int)fmin(fmax((mx - c_first) * inv_step + 1.0, 0.0), (double)N);
-        const double h_lo = cx[khi], h_hi = cx[khi + 1];
-        if (!((h_lo < mx) & (mx <= h_hi))) khi = count_below(cx, N, mx);
-        for (; k < khi; ++k) {
-#ifndef XC_CROSS_NOATOM
-            if (add) atomicAdd(&my_len[k], w);
-            if (CNT) atomicAdd(&my_cnt[k], 1u);
-#endif
-        }
-        return;
-    }
+    const bool add = (w == w);
     do {                                               // the +inf sentinel ends the scan
 #ifndef XC_CROSS_NOATOM
         if (add) atomicAdd(&my_len[k], w);
@@ -123,6 +137,61 @@ __device__ __forceinline__ void box_done(const double* __restrict__ cx, int N, d
 #endif
         ++k; ck = cx[k + 1];
     } while (ck < mx);
+}
+
+// G finished boxes of a lane at once, equally spaced levels only (inv_step > 0): the same decisions as box_done, arranged in
+// phases -- the LDS reads of a phase are in flight together, the G square roots are independent chains (measured on noisy
+// cfg2 slabs: G = 2 is 1-2 us per slab faster than one box at a time, 4 the same, 8 slower: registers).
+template <typename TA, bool CNT, int G>
+__device__ __forceinline__ void boxes_group(const double* __restrict__ cx, int N, const double (&mn)[G], const double (&mx)[G],
+                                            const TA (&araw)[G], const bool (&valid)[G], bool nanfill, double fs, double c_first,
+                                            double inv_step, double* __restrict__ my_len, unsigned* __restrict__ my_cnt,
+                                            double* __restrict__ s_dir)
+{
+    const double dN = (double)N;
+    int klo[G], khi[G];
+    double c_lo[G], c_hi[G];
+    bool cross[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        klo[i] = (int)fmin(fmax((mn[i] - c_first) * inv_step + 1.0, 0.0), dN);          // NaN / -inf -> 0, +inf -> N: always a valid index
+        c_lo[i] = cx[klo[i]]; c_hi[i] = cx[klo[i] + 1];
+    }
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const bool ok = valid[i] && (mn[i] < mx[i]);                                    // one value, or no valid corner at all: nothing
+        if (ok && !((c_lo[i] < mn[i]) & (mn[i] <= c_hi[i]))) { klo[i] = count_below(cx, N, mn[i]); c_hi[i] = cx[klo[i] + 1]; }
+        cross[i] = ok && (c_hi[i] < mx[i]);
+        any = any || cross[i];
+    }
+    if (!any) return;                                                                   // the common case on a smooth field
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        khi[i] = (int)fmin(fmax((mx[i] - c_first) * inv_step + 1.0, 0.0), dN);
+        c_lo[i] = cx[khi[i]]; c_hi[i] = cx[khi[i] + 1];
+    }
+    double w[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        w[i] = __dmul_rn(sqrt_like_numpy<TA>(araw[i]), fs);                             // core.py:1560
+        if (nanfill) w[i] = __longlong_as_double(0x7ff8000000000000LL);
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+        if (cross[i] && !((c_lo[i] < mx[i]) & (mx[i] <= c_hi[i]))) khi[i] = count_below(cx, N, mx[i]);
+#ifndef XC_CROSS_NOATOM
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        if (cross[i]) {
+            if (w[i] == w[i]) {                            // np.nansum skips NaN (negative or NaN area)
+                if (w[i] < __longlong_as_double(0x7ff0000000000000LL)) { atomicAdd(&my_len[klo[i]], w[i]); atomicAdd(&my_len[khi[i]], -w[i]); }
+                else for (int t = klo[i]; t < khi[i]; ++t) atomicAdd(&s_dir[t], w[i]);
+            }
+            if (CNT) { atomicAdd(&my_cnt[klo[i]], 1u); atomicAdd(&my_cnt[khi[i]], 0xffffffffu); }
+        }
+    }
+#endif
 }
 
 // CNT: also count the crossed boxes (exact integer output).  S: compile-time stride (loads of a batch
@@ -141,6 +210,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
     double* s_cx = sm;                                   // [N + 2]  -inf, ascending contours of this slab, +inf
     double* s_len = sm + (N + 2);                        // [ncopy][np]
     unsigned* s_cnt = (unsigned*)(s_len + (size_t)ncopy * np);   // [ncopy][np]
+    double* s_dir = (double*)(s_cnt + (size_t)ncopy * np + (((size_t)ncopy * np) & 1));   // [N] direct sums of boxes with an infinite weight
     const int tid = threadIdx.x;
     const int64_t slab = blockIdx.y;
     const double* cs = contours + (contours_per_slab ? (size_t)slab * N : 0);
@@ -148,6 +218,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
     for (int k = tid; k < N; k += CROSS_TPB) s_cx[k + 1] = cs[k];
     if (tid == 0) { s_cx[0] = -inf; s_cx[N + 1] = inf; }
     for (int k = tid; k < ncopy * np; k += CROSS_TPB) { s_len[k] = 0.0; if (CNT) s_cnt[k] = 0u; }
+    for (int k = tid; k < N; k += CROSS_TPB) s_dir[k] = 0.0;
     __syncthreads();
     double* my_len = s_len + (size_t)(tid & (ncopy - 1)) * np;
     unsigned* my_cnt = s_cnt + (size_t)(tid & (ncopy - 1)) * np;
@@ -212,7 +283,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                 int P = 1;                                             // sliding window of w lanes: doubling, then one overlap step
                 for (; 2 * P <= w; P *= 2) { vmn = fmin(vmn, __shfl_down(vmn, P)); vmx = fmax(vmx, __shfl_down(vmx, P)); }
                 if (w != P) { vmn = fmin(vmn, __shfl_down(vmn, w - P)); vmx = fmax(vmx, __shfl_down(vmx, w - P)); }
-                if (box) box_done<TA, CNT>(s_cx, N, vmn, vmx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, g, my_len, my_cnt);
+                if (box) box_done<TA, CNT>(s_cx, N, vmn, vmx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, g, my_len, my_cnt, s_dir);
             }
             continue;
         }
@@ -243,6 +314,24 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                     av[b] = as[(size_t)jj * nx + ac];
                     v[b] = qs[(size_t)(jj + 1) * nx + c];
                 }
+                if (inv_step > 0.0) {                                  // block-uniform: equally spaced levels, boxes in groups
+                    constexpr int G = XC_CROSS_GROUP;
+#pragma unroll
+                    for (int b0 = 0; b0 < B; b0 += G) {
+                        double mnb[G], mxb[G]; TA ab[G]; bool vb[G];
+#pragma unroll
+                        for (int i = 0; i < G; ++i) {
+                            const int b = b0 + i;
+                            const double x = pn ? qnan : (double)v[b], xr = from_right_lane(x);
+                            const double rmn = fmin(fmin(inf, x), xr), rmx = fmax(fmax(-inf, x), xr);
+                            mnb[i] = fmin(cmn, rmn); mxb[i] = fmax(cmx, rmx);
+                            cmn = rmn; cmx = rmx;
+                            ab[i] = av[b]; vb[i] = box && (jb + b < j1);
+                        }
+                        boxes_group<TA, CNT, G>(s_cx, N, mnb, mxb, ab, vb, nanfill, fs, c_first, inv_step, my_len, my_cnt, s_dir);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
                     if (jb + b >= j1) break;                          // wave-uniform
@@ -250,7 +339,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                     const double rmn = fmin(fmin(inf, x), xr), rmx = fmax(fmax(-inf, x), xr);
                     const double mn = fmin(cmn, rmn), mx = fmax(cmx, rmx);
                     cmn = rmn; cmx = rmx;
-                    if (box) box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, g, my_len, my_cnt);
+                    if (box) box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, g, my_len, my_cnt, s_dir);
                 }
             }
             continue;
@@ -272,7 +361,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                 cmn = inf; cmx = -inf;
                 row_segment(qs + (size_t)(j * s + s) * nx, c0, s, nx, pad_mode, cmn, cmx);
                 mn = fmin(mn, cmn); mx = fmax(mx, cmx);
-                box_done<TA, CNT>(s_cx, N, mn, mx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, g, my_len, my_cnt);
+                box_done<TA, CNT>(s_cx, N, mn, mx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, g, my_len, my_cnt, s_dir);
             }
         } else if constexpr (S > 0) {
             constexpr int B = S == 1 ? 8 : S == 2 ? 4 : S == 3 ? 2 : 1;     // boxes per load batch
@@ -308,7 +397,73 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
 #pragma unroll
                     for (int d = 0; d <= S; ++d) { const double x = pnan[d] ? qnan : (double)v[b][S - 1][d]; cmn = fmin(cmn, x); cmx = fmax(cmx, x); }
                     mn = fmin(mn, cmn); mx = fmax(mx, cmx);
-                    box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, g, my_len, my_cnt);
+                    box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, g, my_len, my_cnt, s_dir);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // copies -> copy 0 (thread k touches index k of every copy only)
+    for (int k = tid; k <= N; k += CROSS_TPB) {
+        double l = 0.0; unsigned n = 0;
+        for (int c = 0; c < ncopy; ++c) { l += s_len[(size_t)c * np + k]; if (CNT) n += s_cnt[(size_t)c * np + k]; }
+        s_len[k] = l;
+        if (CNT) s_cnt[k] = n;
+    }
+    __syncthreads();
+    if (inv_step > 0.0 && tid < 64) {
+        // equally spaced levels: the cells hold DIFFERENCES D[0..N] (box_done) whose total is zero, so the sum at level k is
+        // both the prefix D[0] + .. + D[k] and minus the suffix D[k+1] + .. + D[N].  The lower half of the levels takes the
+        // prefix, the upper half the suffix: a level's rounding error then scales with the mass on ITS side of the range --
+        // small where the sums themselves are small, and a level no box crosses at either end comes out as exactly 0.
+        // One wave, fixed order: lane l owns a run of levels, the lane totals are scanned with shuffles.  (More than ~1000
+        // contours: the runs no longer fit the registers, prefix for all levels.)
+        const int H0 = (N + 1) / 2;
+        const bool two = (N - H0 + 63) / 64 <= 8;
+        const int H = two ? H0 : N;                             // levels [0, H): prefix; [H, N): suffix over the cells k+1 .. N
+        {
+            const int per = (H + 63) / 64;
+            const int k0 = tid * per, k1 = (k0 + per < H) ? k0 + per : H;
+            double run = 0.0; unsigned crun = 0u;
+            for (int k = k0; k < k1; ++k) { run += s_len[k]; if (CNT) crun += s_cnt[k]; }
+            for (int o = 1; o < 64; o <<= 1) {
+                const double t = __shfl_up(run, o); const unsigned ct = __shfl_up(crun, o);
+                if (tid >= o) { run += t; crun += ct; }
+            }
+            double base = __shfl_up(run, 1); unsigned cbase = __shfl_up(crun, 1);
+            if (tid == 0) { base = 0.0; cbase = 0u; }
+            for (int k = k0; k < k1; ++k) {                     // a lane reads and writes its own run only
+                base += s_len[k]; s_len[k] = base;
+                if (CNT) { cbase += s_cnt[k]; s_cnt[k] = cbase; }
+            }
+        }
+        if (two) {
+            // cells N, N-1, .. H+1 from the top; level k = cell - 1 receives -(D[cell] + .. + D[N]).  Lane l owns the cells
+            // (c1, c0]; every lane first takes its run into registers (the result of a lane's last cell lands on the next
+            // lane's first cell), then the results are written -- one wave, so the two phases are ordered.
+            const int per = (N - H + 63) / 64;                  // <= 8
+            const int c0 = N - tid * per;
+            int c1 = c0 - per; if (c1 < H) c1 = H;
+            double v[8]; unsigned cv[8];
+            double run = 0.0; unsigned crun = 0u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c0 - i; const bool in = i < per && c > c1;
+                v[i] = in ? s_len[c] : 0.0; cv[i] = (CNT && in) ? s_cnt[c] : 0u;
+                run += v[i]; crun += cv[i];
+            }
+            for (int o = 1; o < 64; o <<= 1) {
+                const double t = __shfl_up(run, o); const unsigned ct = __shfl_up(crun, o);
+                if (tid >= o) { run += t; crun += ct; }
+            }
+            double base = __shfl_up(run, 1); unsigned cbase = __shfl_up(crun, 1);
+            if (tid == 0) { base = 0.0; cbase = 0u; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c0 - i;
+                if (i < per && c > c1) {
+                    base += v[i]; s_len[c - 1] = -base;
+                    if (CNT) { cbase += cv[i]; s_cnt[c - 1] = 0u - cbase; }
                 }
             }
         }
@@ -316,10 +471,8 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
     __syncthreads();
     const size_t pb = ((size_t)slab * bps + blockIdx.x) * N;
     for (int k = tid; k < N; k += CROSS_TPB) {
-        double l = 0.0; unsigned n = 0;
-        for (int c = 0; c < ncopy; ++c) { l += s_len[(size_t)c * np + k]; if (CNT) n += s_cnt[(size_t)c * np + k]; }
-        part_len[pb + k] = l;
-        if (CNT) part_cnt[pb + k] = n;
+        part_len[pb + k] = s_len[k] + s_dir[k];
+        if (CNT) part_cnt[pb + k] = s_cnt[k];
     }
 }
 
@@ -365,11 +518,11 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
     if (stride < 1 || pad_x < 0) return fail(ctx, XC_EBADARG, "xc_crossing: stride must be >= 1 and pad_x >= 0");
     if (pad_mode < XC_PAD_EDGE || pad_mode > XC_PAD_SYMMETRIC) return fail(ctx, XC_EBADARG, "xc_crossing: unknown pad_mode");
     if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_crossing: nslab too large");
-    const int np = N | 1;                                 // odd row pitch: the copies of one contour fall in different banks
+    const int np = (N + 1) | 1;                           // N + 1 cells (the difference form writes at index N), odd row pitch: the copies of one contour fall in different banks
     int ncopy = 8;
     if (const char* e = getenv("XC_CROSS_NCOPY")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ncopy = v; }
-    while (ncopy > 1 && (size_t)(N + 2) * 8 + (size_t)ncopy * np * 12 > 48 * 1024) ncopy >>= 1;   // several blocks per CU
-    const size_t lds = (size_t)(N + 2) * 8 + (size_t)ncopy * np * 12;
+    while (ncopy > 1 && (size_t)(2 * N + 3) * 8 + (size_t)ncopy * np * 12 > 48 * 1024) ncopy >>= 1;   // several blocks per CU
+    const size_t lds = (size_t)(2 * N + 3) * 8 + (size_t)ncopy * np * 12;
     if (lds > kLdsBudget) return fail(ctx, XC_EBADARG, "xc_crossing: too many contours for one pass");
     const int64_t Jn = coarse(ny, stride), In = coarse(nx + pad_x, stride);
     const int64_t nbj = Jn - 1, nbi = full_width ? In - 1 : (Jn < In ? Jn : In) - 1;
