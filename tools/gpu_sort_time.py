@@ -1,6 +1,9 @@
 import sys, numpy as np
 sys.path.insert(0, ".")
 from xcontour_amd import _native as nat
+import os
+if os.environ.get("XC_LIB"):
+    nat.LIB_PATH = os.path.join("xcontour_amd", os.environ["XC_LIB"])      # a diagnostic build (tools/build_variant.sh)
 ctx = nat.Context(0)
 n = 1801*3600
 q = np.random.default_rng(0).standard_normal((1801, 3600))

@@ -16,7 +16,6 @@
 // small kernels.  The key type is a template parameter: float32 tracers sort 32-bit keys in 4 passes
 // (4 B/elem histogram + 24 B/elem scatter), float64 tracers 64-bit keys in 8 passes (8 + 32 B/elem).
 #include "xc_internal.h"
-#include <stdlib.h>
 
 namespace xc {
 namespace {
@@ -59,28 +58,25 @@ template <> struct KeyTraits<u32> {            // float32 tracers: the key of th
     }
 };
 
+// the (key, payload) pair of cell i, straight from the tracer / mask / dA: pass 0 of the sort builds its pairs
+// with this, so the unsorted pairs are never written and read back (24-32 B per cell; 0.60 -> 0.57 ms for 6.48 M pairs)
 template <typename TQ, typename TM, typename K>
-__global__ __launch_bounds__(256)
-void k_sort_keys(const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA, int dA_rank,
-                 int64_t nx, int64_t n, int negate, K* __restrict__ keys, double* __restrict__ vals,
-                 int64_t mask_stride, int64_t dA_stride)
+__device__ __forceinline__ void make_pair(const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA,
+                                          int dA_rank, int64_t nx, int negate, int64_t i, K& key, double& val)
 {
-    const size_t so = (size_t)blockIdx.y * n;
-    q += so; keys += so; vals += so;
-    if (mask) mask += (size_t)blockIdx.y * mask_stride;
-    if (dA) dA += (size_t)blockIdx.y * dA_stride;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        const double v = negate ? -(double)q[i] : (double)q[i];
-        const bool ok = (v == v) && (!mask || mask[i] == (TM)1);
-        const double w = (dA_rank == XC_DA_ROW) ? dA[i / nx] : (dA_rank == XC_DA_PLANE ? dA[i] : 1.0);
-        keys[i] = ok ? KeyTraits<K>::encode(v) : KeyTraits<K>::invalid();   // invalid cells sort to the end
-        vals[i] = ok ? w : 0.0;
-    }
+    const double v = negate ? -(double)q[i] : (double)q[i];
+    const bool ok = (v == v) && (!mask || mask[i] == (TM)1);
+    const double w = (dA_rank == XC_DA_ROW) ? dA[i / nx] : (dA_rank == XC_DA_PLANE ? dA[i] : 1.0);
+    key = ok ? KeyTraits<K>::encode(v) : KeyTraits<K>::invalid();       // invalid cells sort to the end
+    val = ok ? w : 0.0;
 }
+struct PairSrc {                 // where pass 0 finds its input (per-slab strides applied by the kernels)
+    const void* q; const void* mask; const double* dA;
+    int dA_rank, negate; int64_t nx, mask_stride, dA_stride;
+};
 
 // number of valid cells = position of the first KEY_INVALID in the sorted keys (one thread:
-// a per-wave atomic counter in k_sort_keys serialised 100k atomics on one address = 1.1 ms)
+// a per-wave atomic counter while building the keys serialised 100k atomics on one address = 1.1 ms)
 template <typename K>
 __global__ void k_count_valid(const K* __restrict__ keys, int64_t n, unsigned* __restrict__ nvalid)
 {
@@ -107,15 +103,41 @@ __device__ __forceinline__ unsigned long long digit_peers(unsigned d, unsigned l
 // Counting needs no ranks: one returnless ds_add_u32 per key on per-wave counters (the ballot ranking
 // of the scatter costs ~60 VALU instructions per 64 keys and made this kernel ALU-bound); a round
 // whose 64 digits are all equal -- sorted or constant data -- is added once by one lane.
-template <typename K>
+template <typename K, bool FIRST = false, typename TQ = double, typename TM = double>
 __global__ __launch_bounds__(256)
-void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, unsigned* __restrict__ hist)
+void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, unsigned* __restrict__ hist, const PairSrc src)
 {
     __shared__ unsigned s_cnt[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = blockIdx.x;
     keys += (size_t)blockIdx.y * n; hist += (size_t)blockIdx.y * 256 * ntiles;
     for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = 0;
+    if constexpr (FIRST) {
+        // pass 0: the keys do not exist yet -- encode them from the tracer (the order inside the tile is irrelevant here)
+        const TQ* q = (const TQ*)src.q + (size_t)blockIdx.y * n;
+        const TM* mask = src.mask ? (const TM*)src.mask + (size_t)blockIdx.y * src.mask_stride : nullptr;
+        const int64_t base = t * BTILE + (int64_t)wave * TILE;
+        K kreg[TILE_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < TILE_ROUNDS; ++r) {
+            const int64_t i = base + r * 64 + lane;
+            double dummy;
+            if (i < n) make_pair<TQ, TM, K>(q, mask, nullptr, XC_DA_NONE, src.nx, src.negate, i, kreg[r], dummy);
+            else kreg[r] = (K)0;
+        }
+#pragma unroll
+        for (int r = 0; r < TILE_ROUNDS; ++r) {
+            const int64_t i = base + r * 64 + lane;
+            const bool valid = i < n;
+            const unsigned d = (unsigned)((kreg[r] >> shift) & (K)255);
+            const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+            if (base + TILE <= n && __ballot(d != d0) == 0ull) { if (lane == 0) atomicAdd(&s_cnt[wave][d0], 64u); }
+            else if (valid) atomicAdd(&s_cnt[wave][d], 1u);
+        }
+        __syncthreads();
+        hist[(size_t)threadIdx.x * ntiles + t] = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        return;
+    }
     // counting does not care about the order inside the tile: 16-byte loads, KPL keys per lane and load
     constexpr int KPL = 16 / (int)sizeof(K);
     struct alignas(16) Pack { K k[KPL]; };
@@ -185,11 +207,12 @@ void k_radix_scan_rows(unsigned* __restrict__ hist, int ntiles, unsigned* __rest
 // (stable: wave-major, then round, then lane = element order), then written out position by position:
 // consecutive LDS positions with the same digit go to consecutive global addresses, so the stores
 // of a wave cover runs of ~BTILE/256 elements instead of 64 unrelated 8-byte targets.
-template <typename K>
+template <typename K, bool FIRST = false, typename TQ = double, typename TM = double>
 __global__ __launch_bounds__(256)
 void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
                      K* __restrict__ kout, double* __restrict__ vout, int64_t n, int shift,
-                     int ntiles, const unsigned* __restrict__ hist, const unsigned* __restrict__ totals, int inline_scan)
+                     int ntiles, const unsigned* __restrict__ hist, const unsigned* __restrict__ totals, int inline_scan,
+                     const PairSrc src)
 {
     extern __shared__ unsigned long long s_dyn[];
     K* s_k = (K*)s_dyn;                                        // [BTILE] staging: keys first, then the payload
@@ -207,11 +230,24 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
     K kreg[TILE_ROUNDS];                                       // the whole part's loads in flight at once
     double vreg[TILE_ROUNDS];
     unsigned short lrank[TILE_ROUNDS];
+    if constexpr (FIRST) {
+        // pass 0 builds its pairs from the tracer / mask / dA (kin / vin do not exist yet; their slab offset above is harmless)
+        const TQ* q = (const TQ*)src.q + (size_t)blockIdx.y * n;
+        const TM* mask = src.mask ? (const TM*)src.mask + (size_t)blockIdx.y * src.mask_stride : nullptr;
+        const double* dA = src.dA ? src.dA + (size_t)blockIdx.y * src.dA_stride : nullptr;
 #pragma unroll
-    for (int r = 0; r < TILE_ROUNDS; ++r) {
-        const int64_t i = base + r * 64 + lane;
-        kreg[r] = i < n ? kin[i] : (K)0;
-        vreg[r] = i < n ? vin[i] : 0.0;
+        for (int r = 0; r < TILE_ROUNDS; ++r) {
+            const int64_t i = base + r * 64 + lane;
+            if (i < n) make_pair<TQ, TM, K>(q, mask, dA, src.dA_rank, src.nx, src.negate, i, kreg[r], vreg[r]);
+            else { kreg[r] = (K)0; vreg[r] = 0.0; }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < TILE_ROUNDS; ++r) {
+            const int64_t i = base + r * 64 + lane;
+            kreg[r] = i < n ? kin[i] : (K)0;
+            vreg[r] = i < n ? vin[i] : 0.0;
+        }
     }
     // rank of every element among the wave's elements with the same digit
 #pragma unroll
@@ -283,212 +319,6 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
         const int p = r * 256 + tid;
         if (p < cnt) vout[gpos[r]] = s_v[p];
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// One-kernel-per-pass variant ("onesweep" order of work): the tile histograms of ALL passes are taken in ONE read of the
-// tracer before the first pass (k_radix_hist_all: digit totals do not depend on the order of the elements), and a
-// scatter block learns how many elements with its digit precede its tile from the blocks before it (decoupled
-// look-back over per-(tile, digit) status words) instead of from a per-pass tile-histogram kernel + row scan.  Pass 0
-// builds the (key, payload) pairs from the tracer / mask / dA itself, so the pairs are never written unsorted.
-// Per pass: 16 B read + 16 B written per pair (64-bit keys), nothing else; before: 8 + 32 B and three launches.
-//
-// Status word of (tile, digit): tag in the top 5 bits, count in the low 27 (n < 2^27 per plane, else the three-kernel
-// path).  Tags carry the pass number -- AGG = 2 pass + 1 (the tile's own count), PFX = 2 pass + 2 (count of this and all
-// earlier tiles) -- so one zero-initialised array serves every pass without resets.  Tiles are numbered by a ticket taken
-// at block start, hence a block only ever waits for blocks that are already running.  Every wait is bounded by the wall
-// clock; on a timeout the abort flag goes up, everybody stops waiting, and nvalid reports 0xffffffff.
-constexpr unsigned LB_SHIFT = 27, LB_MASK = (1u << LB_SHIFT) - 1u;
-constexpr unsigned long long kSortTimeoutTicks = 50000000ull;       // 0.5 s of the 100 MHz wall clock
-
-struct SweepCtl {               // per call, zeroed by one memset
-    unsigned abort;
-    unsigned pad[63];
-};
-
-template <typename TQ, typename TM, typename K>
-__device__ __forceinline__ void make_pair(const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA,
-                                          int dA_rank, int64_t nx, int negate, int64_t i, K& key, double& val)
-{
-    const double v = negate ? -(double)q[i] : (double)q[i];
-    const bool ok = (v == v) && (!mask || mask[i] == (TM)1);
-    const double w = (dA_rank == XC_DA_ROW) ? dA[i / nx] : (dA_rank == XC_DA_PLANE ? dA[i] : 1.0);
-    key = ok ? KeyTraits<K>::encode(v) : KeyTraits<K>::invalid();       // invalid cells sort to the end
-    val = ok ? w : 0.0;
-}
-
-// digit totals of every pass in one read of the tracer: ghist[slab][pass][256]
-template <typename TQ, typename TM, typename K>
-__global__ __launch_bounds__(256)
-void k_radix_hist_all(const TQ* __restrict__ q, const TM* __restrict__ mask, int64_t n, int negate, int64_t mask_stride,
-                      unsigned* __restrict__ ghist)
-{
-    constexpr int P = KeyTraits<K>::passes;
-    __shared__ unsigned s_cnt[P * 256];
-    const int tid = threadIdx.x, lane = tid & 63;
-    q += (size_t)blockIdx.y * n;
-    if (mask) mask += (size_t)blockIdx.y * mask_stride;
-    ghist += (size_t)blockIdx.y * P * 256;
-    for (int i = tid; i < P * 256; i += 256) s_cnt[i] = 0u;
-    __syncthreads();
-    for (int64_t b = (int64_t)blockIdx.x * 1024; b < n; b += (int64_t)gridDim.x * 1024) {
-        K key[4]; bool in[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                                        // 4 coalesced loads in flight
-            const int64_t i = b + r * 256 + tid;
-            in[r] = i < n;
-            const int64_t ii = in[r] ? i : n - 1;
-            const double v = negate ? -(double)q[ii] : (double)q[ii];
-            const bool ok = (v == v) && (!mask || mask[ii] == (TM)1);
-            key[r] = ok ? KeyTraits<K>::encode(v) : KeyTraits<K>::invalid();
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned long long act = __ballot(in[r]);
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const unsigned d = (unsigned)((key[r] >> (8 * p)) & (K)255);
-                // a wave whose 64 digits coincide (the high bytes of most fields) adds once: 64 adds on one address serialise
-                const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
-                if (act == ~0ull && __ballot(d != d0) == 0ull) { if (lane == 0) atomicAdd(&s_cnt[p * 256 + d0], 64u); }
-                else if (in[r]) atomicAdd(&s_cnt[p * 256 + d], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < P * 256; i += 256) { const unsigned c = s_cnt[i]; if (c) atomicAdd(&ghist[i], c); }
-}
-
-// One pass: scatter of one block tile with its offsets found by look-back.  FIRST: the pairs come from the tracer.
-template <typename K, bool FIRST, typename TQ, typename TM>
-__global__ __launch_bounds__(256)
-void k_radix_sweep(const K* __restrict__ kin, const double* __restrict__ vin, K* __restrict__ kout, double* __restrict__ vout,
-                   int64_t n, int pass, int ntiles, const unsigned* __restrict__ ghist, unsigned* __restrict__ status,
-                   unsigned* __restrict__ tickets, SweepCtl* __restrict__ ctl,
-                   const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA, int dA_rank, int64_t nx,
-                   int negate, int64_t mask_stride, int64_t dA_stride)
-{
-    constexpr int P = KeyTraits<K>::passes;
-    extern __shared__ unsigned long long s_dyn[];
-    K* s_k = (K*)s_dyn;                                        // [BTILE] staging: keys first, then the payload
-    double* s_v = (double*)s_dyn;
-    unsigned* s_cnt = (unsigned*)(s_dyn + BTILE);              // [4][256] per-wave digit counts -> start offsets
-    unsigned* s_gbase = s_cnt + 4 * 256;                       // [256] global position minus tile-local position
-    unsigned* s_wsum = s_gbase + 256;                          // [8]
-    unsigned* s_tile = s_wsum + 8;                             // [1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int shift = pass * 8;
-    { const size_t so = (size_t)blockIdx.y * n; kout += so; vout += so; if (!FIRST) { kin += so; vin += so; } else { q += so; } }
-    if (FIRST) { if (mask) mask += (size_t)blockIdx.y * mask_stride; if (dA) dA += (size_t)blockIdx.y * dA_stride; }
-    ghist += ((size_t)blockIdx.y * P + pass) * 256;
-    status += (size_t)blockIdx.y * ntiles * 256;
-    if (tid == 0) *s_tile = atomicAdd(&tickets[(size_t)blockIdx.y * P + pass], 1u);
-    for (int d = lane; d < 256; d += 64) s_cnt[wave * 256 + d] = 0;
-    __syncthreads();
-    const int64_t t = (int64_t)*s_tile;                        // tiles in ticket order: every earlier tile is already running
-    const int64_t tbase = t * BTILE;
-    const int64_t base = tbase + (int64_t)wave * TILE;
-    K kreg[TILE_ROUNDS];
-    double vreg[TILE_ROUNDS];
-    unsigned short lrank[TILE_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < TILE_ROUNDS; ++r) {
-        const int64_t i = base + r * 64 + lane;
-        if (FIRST) {
-            if (i < n) make_pair<TQ, TM, K>(q, mask, dA, dA_rank, nx, negate, i, kreg[r], vreg[r]);
-            else { kreg[r] = (K)0; vreg[r] = 0.0; }
-        } else {
-            kreg[r] = i < n ? kin[i] : (K)0;
-            vreg[r] = i < n ? vin[i] : 0.0;
-        }
-    }
-    // rank of every element among the wave's elements with the same digit
-#pragma unroll
-    for (int r = 0; r < TILE_ROUNDS; ++r) {
-        const int64_t i = base + r * 64 + lane;
-        const bool valid = i < n;
-        const unsigned d = valid ? (unsigned)((kreg[r] >> shift) & (K)255) : 0u;
-        const unsigned long long peers = digit_peers(d, __ballot(valid));
-        const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
-        unsigned pos = 0;
-        if (valid) pos = s_cnt[wave * 256 + d] + rank;          // all peers read the same counter first ...
-        if (valid && rank == 0) s_cnt[wave * 256 + d] += (unsigned)__popcll(peers);   // ... then the leader advances it
-        lrank[r] = (unsigned short)pos;
-    }
-    __syncthreads();
-    {   // thread d: publish the tile's count of digit d, look back for the count in earlier tiles, digit bases
-        const int d = tid;
-        const unsigned c0 = s_cnt[d], c1 = s_cnt[256 + d], c2 = s_cnt[512 + d], c3 = s_cnt[768 + d];
-        const unsigned tot = c0 + c1 + c2 + c3;
-        const unsigned AGG = (unsigned)(2 * pass + 1), PFX = (unsigned)(2 * pass + 2);
-        unsigned* mine = status + (size_t)t * 256 + d;
-        __hip_atomic_store(mine, ((t == 0 ? PFX : AGG) << LB_SHIFT) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned gtot = ghist[d];
-        unsigned before = 0;
-        if (t > 0) {
-            int64_t tt = t - 1;
-            const unsigned long long t0 = wall_clock64();
-            for (;;) {
-                const unsigned v = __hip_atomic_load(status + (size_t)tt * 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned tag = v >> LB_SHIFT;
-                if (tag == PFX) { before += v & LB_MASK; break; }
-                if (tag == AGG) { before += v & LB_MASK; --tt; continue; }        // tile 0 always answers with PFX
-                __builtin_amdgcn_s_sleep(1);
-                if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                if (wall_clock64() - t0 > kSortTimeoutTicks) { __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-            __hip_atomic_store(mine, (PFX << LB_SHIFT) | ((before + tot) & LB_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned x = tot, gx = gtot;                       // two exclusive scans over the digits: tile-local and global
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned y = __shfl_up(x, o), gy = __shfl_up(gx, o);
-            if (lane >= o) { x += y; gx += gy; }
-        }
-        if (lane == 63) { s_wsum[wave] = x; s_wsum[4 + wave] = gx; }
-        __syncthreads();
-        unsigned start = x - tot, gbase = gx - gtot;
-        for (int w = 0; w < wave; ++w) { start += s_wsum[w]; gbase += s_wsum[4 + w]; }
-        s_cnt[d] = start; s_cnt[256 + d] = start + c0; s_cnt[512 + d] = start + c0 + c1; s_cnt[768 + d] = start + c0 + c1 + c2;
-        s_gbase[d] = gbase + before - start;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < TILE_ROUNDS; ++r) {
-        const int64_t i = base + r * 64 + lane;
-        const unsigned d = (unsigned)((kreg[r] >> shift) & (K)255);
-        lrank[r] = (unsigned short)(s_cnt[wave * 256 + d] + lrank[r]);      // tile-local position
-        if (i < n) s_k[lrank[r]] = kreg[r];
-    }
-    __syncthreads();
-    const int64_t left = n - tbase;
-    const int cnt = left < BTILE ? (int)left : BTILE;
-    unsigned gpos[TILE_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < TILE_ROUNDS; ++r) {
-        const int p = r * 256 + tid;
-        if (p < cnt) {
-            const K key = s_k[p];
-            gpos[r] = s_gbase[(unsigned)((key >> shift) & (K)255)] + (unsigned)p;
-            if (gpos[r] < (unsigned)n) kout[gpos[r]] = key;      // (the bound only matters after an abort: offsets are garbage then)
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < TILE_ROUNDS; ++r) {
-        const int64_t i = base + r * 64 + lane;
-        if (i < n) s_v[lrank[r]] = vreg[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < TILE_ROUNDS; ++r) {
-        const int p = r * 256 + tid;
-        if (p < cnt && gpos[r] < (unsigned)n) vout[gpos[r]] = s_v[p];
-    }
-}
-
-__global__ void k_sweep_check(const SweepCtl* __restrict__ ctl, unsigned* __restrict__ nvalid, int nslab)
-{
-    if (ctl->abort) for (int s = threadIdx.x; s < nslab; s += blockDim.x) nvalid[s] = 0xffffffffu;
 }
 
 // ---- inclusive f64 scan (cumulative area of the sorted state): block sums, their exclusive scan, then
@@ -649,8 +479,7 @@ size_t sort_workspace_bytes(int64_t n, int64_t nslab)
     const int64_t nb = (n + 2047) / 2048;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t S = (size_t)nslab;
-    return 4 * al(S * n * 8) + al(S * 256 * ntiles * 4) + al(S * 256 * 4) + al(S * 4) + al(S * nb * 8) + al(S * BPE_BLOCKS * 8)
-           + al(S * 8 * 256 * 4) + al(S * 8 * 4) + al(sizeof(SweepCtl));       // look-back path: digit totals, tickets, control
+    return 4 * al(S * n * 8) + al(S * 256 * ntiles * 4) + al(S * 256 * 4) + al(S * 4) + al(S * nb * 8) + al(S * BPE_BLOCKS * 8);
 }
 
 template <typename TQ, typename K>
@@ -674,66 +503,44 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, const void* mask, int ma
     unsigned* totals = (unsigned*)w; w += al(S * 256 * 4);
     unsigned* nvalid = (unsigned*)w; w += al(S * 4);
     double* bsum = (double*)w; w += al(S * nb * 8);
-    double* parts = (double*)w; w += al(S * BPE_BLOCKS * 8);
-    unsigned* ghist = (unsigned*)w; w += al(S * 8 * 256 * 4);
-    unsigned* tickets = (unsigned*)w; w += al(S * 8 * 4);
-    SweepCtl* ctl = (SweepCtl*)w;
+    double* parts = (double*)w;
     const unsigned ns = (unsigned)nslab;
 
     const unsigned gb = (unsigned)((n + 255) / 256);
     // a per-slab dA plane is the PLANE case with a slab stride
     const int krank = dA_rank == XC_DA_SLAB ? XC_DA_PLANE : dA_rank;
     const int64_t dstride = dA_rank == XC_DA_SLAB ? n : 0, mstride = (mask && mask_per_slab) ? n : 0;
+    const PairSrc src = {q, mask, dA, krank, negate, nx, mstride, dstride};
     const unsigned gt = (unsigned)ntiles;
-    const size_t sc_lds = (size_t)BTILE * 8 + (4 * 256 + 256 + 8 + 2) * sizeof(unsigned);
-    static const int sweep_env = [] { const char* e = getenv("XC_SORT_LOOKBACK"); return e ? atoi(e) : 1; }();
+    const size_t sc_lds = (size_t)BTILE * 8 + (4 * 256 + 256 + 8) * sizeof(unsigned);
+    const int inline_scan = ntiles <= 32 ? 1 : 0;       // measured: the O(ntiles) walk per block costs ~0.14 us per tile, the scan launch ~5 us
     K *kin = kA, *kout = kB;
     double *vin = vA, *vout = vB;
-    const bool sweep = sweep_env && n < (int64_t)LB_MASK && ntiles >= 2;
-    if (sweep) {
-        // digit totals, tickets and the control word sit behind each other; the status words reuse the tile-histogram array
-        XC_HIP(ctx, hipMemsetAsync(ghist, 0, (size_t)((char*)ctl - (char*)ghist) + sizeof(SweepCtl), ctx->stream));
-        XC_HIP(ctx, hipMemsetAsync(hist, 0, S * 256 * ntiles * 4, ctx->stream));
-        const unsigned hb = (unsigned)((n + 1023) / 1024 < 512 ? (n + 1023) / 1024 : 512);
-#define XC_SWEEP(TM_) do { \
-        hipLaunchKernelGGL((k_radix_hist_all<TQ, TM_, K>), dim3(hb, ns), dim3(256), 0, ctx->stream, q, (const TM_*)mask, n, negate, mstride, ghist); \
-        XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_sweep<K, true, TQ, TM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds)); \
-        XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_sweep<K, false, TQ, TM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds)); \
-        for (int pass = 0; pass < KeyTraits<K>::passes; ++pass) { \
-            if (pass == 0) hipLaunchKernelGGL((k_radix_sweep<K, true, TQ, TM_>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, pass, \
-                                              (int)ntiles, ghist, hist, tickets, ctl, q, (const TM_*)mask, dA, krank, nx, negate, mstride, dstride); \
-            else hipLaunchKernelGGL((k_radix_sweep<K, false, TQ, TM_>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, pass, \
-                                    (int)ntiles, ghist, hist, tickets, ctl, q, (const TM_*)mask, dA, krank, nx, negate, mstride, dstride); \
-            XC_HIP(ctx, hipGetLastError()); \
-            K* tk = kin; kin = kout; kout = tk; \
-            double* tv = vin; vin = vout; vout = tv; \
-        } } while (0)
-        if (mask && mask_dtype == XC_F32) XC_SWEEP(float); else XC_SWEEP(double);
-#undef XC_SWEEP
-    } else {
-    if (mask && mask_dtype == XC_F32)
-        hipLaunchKernelGGL((k_sort_keys<TQ, float, K>), dim3(gb, ns), dim3(256), 0, ctx->stream, q, (const float*)mask, dA, krank,
-                           nx, n, negate, kA, vA, mstride, dstride);
-    else
-        hipLaunchKernelGGL((k_sort_keys<TQ, double, K>), dim3(gb, ns), dim3(256), 0, ctx->stream, q, (const double*)mask, dA, krank,
-                           nx, n, negate, kA, vA, mstride, dstride);
-    XC_HIP(ctx, hipGetLastError());
+    const bool mf32 = mask && mask_dtype == XC_F32;
     XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_scatter<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds));
-    const int inline_scan = ntiles <= 32 ? 1 : 0;       // measured: the O(ntiles) walk per block costs ~0.14 us per tile, the scan launch ~5 us
+    if (mf32) XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_scatter<K, true, TQ, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds));
+    else XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_scatter<K, true, TQ, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds));
     for (int pass = 0; pass < KeyTraits<K>::passes; ++pass) {
         const int shift = pass * 8;
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist);
+        // pass 0 reads the tracer itself (no k_sort_keys launch, the unsorted pairs never touch memory)
+        if (pass == 0) {
+            if (mf32) hipLaunchKernelGGL((k_radix_hist<K, true, TQ, float>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
+            else hipLaunchKernelGGL((k_radix_hist<K, true, TQ, double>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
+        } else hipLaunchKernelGGL(k_radix_hist<K>, dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
         if (!inline_scan) hipLaunchKernelGGL(k_radix_scan_rows, dim3(256, ns), dim3(1024), 0, ctx->stream, hist, (int)ntiles, totals);
-        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
-                           (int)ntiles, hist, totals, inline_scan);
+        if (pass == 0) {
+            if (mf32) hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, float>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+                                         (int)ntiles, hist, totals, inline_scan, src);
+            else hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, double>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+                                    (int)ntiles, hist, totals, inline_scan, src);
+        } else hipLaunchKernelGGL(k_radix_scatter<K>, dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+                                  (int)ntiles, hist, totals, inline_scan, src);
         XC_HIP(ctx, hipGetLastError());
         K* tk = kin; kin = kout; kout = tk;
         double* tv = vin; vin = vout; vout = tv;
     }
-    }
     // an even number of passes: the sorted data are back in kA / vA (= kin / vin)
     hipLaunchKernelGGL(k_count_valid<K>, dim3(ns), dim3(64), 0, ctx->stream, kin, n, nvalid);
-    if (sweep) hipLaunchKernelGGL(k_sweep_check, dim3(1), dim3(64), 0, ctx->stream, ctl, nvalid, (int)nslab);
     double* acum = vout;                                   // reuse the idle payload buffer
     hipLaunchKernelGGL(k_scan_local<false>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(ns), dim3(1024), 0, ctx->stream, bsum, nb);
