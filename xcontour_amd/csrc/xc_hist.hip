@@ -96,9 +96,12 @@ void k_hist(const HistArgs a)
     const int epad = (N + 2) & ~1;
     double*   s_red   = smem;                                   // 64 doubles
     double*   s_edges = smem + 64;                              // N+1
-    double*   s_h     = s_edges + epad;                         // [NCH][N*ncopy]
-    unsigned* s_c     = reinterpret_cast<unsigned*>(s_h + (size_t)NCH * N * ncopy);   // [N*ncopy]
-    const int hsz = N * ncopy;
+    // one CELL per (bin, copy): the NCH sums and the count side by side (count = low word of the last slot), so a cell's
+    // three adds share ONE address computation; bin N is a trash bin -- NaN, out-of-range and inactive cells add there
+    // unconditionally instead of branching around the adds (round 2: 86 -> 7x VALU instructions per 128-cell wave-row)
+    constexpr int CW = NCH + 1;
+    double*   s_cell  = s_edges + epad;                         // [(N + 1) * ncopy][CW]
+    const int hsz = (N + 1) * ncopy;
 
     // ------------------------------------------------------------------ this wave's share of (strip,row) pairs
     const int ny = (int)a.ny, nx = (int)a.nx;                    // host guarantees < 2^31
@@ -238,8 +241,7 @@ void k_hist(const HistArgs a)
         load_batch(A, y0);
     }
 
-    for (int i = tid; i < NCH * hsz; i += blockDim.x) s_h[i] = 0.0;
-    for (int i = tid; i < hsz; i += blockDim.x) s_c[i] = 0u;
+    for (int i = tid; i < CW * hsz; i += blockDim.x) s_cell[i] = 0.0;
     XC_STAMP(1);
 
     // ------------------------------------------------------------------ edges -> LDS
@@ -282,7 +284,7 @@ void k_hist(const HistArgs a)
     }
     const double e0 = s_edges[0], eN = s_edges[N];
     const double inv = (double)N / (eN - e0);
-    const int last_closed = a.last_closed;
+    const int last_closed = FAST ? 0 : a.last_closed;           // FAST: the half-open (xhistogram) rule is a compile-time fact
     // Are the edges equally spaced to a quarter of a bin?  Then the NEAREST edge j = floor((v - e0) / h + 1/2) brackets v
     // between e[j-1] and e[j+1], and ONE exact comparison against e[j] gives np.digitize's answer (one 8-byte LDS read
     // and one compare per cell instead of two reads, two compares and a call on a miss).  Checked per slab, wave-uniform.
@@ -300,14 +302,16 @@ void k_hist(const HistArgs a)
     double   acc[NCH];
     unsigned cnt = 0;
     int      cur = -1;                   // wave-uniform: bin of the register accumulators
+    int      fp_skip = 0, fp_miss = 0;   // wave-uniform: rows left without the one-bin test / consecutive rows that failed it
 #pragma unroll
     for (int c = 0; c < NCH; ++c) acc[c] = 0.0;
 
     auto flush = [&]() {
         if (cnt) {
+            double* cp = s_cell + (size_t)(cur * ncopy + copy) * CW;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) lds_add(&s_h[c * hsz + cur * ncopy + copy], acc[c]);
-            lds_add(&s_c[cur * ncopy + copy], cnt);
+            for (int c = 0; c < NCH; ++c) lds_add(cp + c, acc[c]);
+            lds_add(reinterpret_cast<unsigned*>(cp + NCH), cnt);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[c] = 0.0;
@@ -318,7 +322,7 @@ void k_hist(const HistArgs a)
     auto do_row = [&](const double (&qc)[VEC], const double (&qS)[VEC], const double (&qN)[VEC],
                       double hc, const double (&dAv)[VEC], const double (&inv_)[NINT > 0 ? NINT : 1][VEC],
                       double rdx, double rdy) {
-        int k[VEC];
+        unsigned k[VEC];                 // bin, or N (the trash bin) for a dropped cell
         double w[NCH][VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
@@ -327,13 +331,14 @@ void k_hist(const HistArgs a)
             if (uni) {
                 int j = (int)__builtin_fma(vb - e0, inv, 0.5);                      // NaN -> 0
                 asm("v_med3_i32 %0, %1, 0, %2" : "=v"(j) : "v"(j), "s"(N));         // clamp to [0, N]
-                kb = (vb >= s_edges[j]) ? j : j - 1;                                // NaN -> -1
+                kb = (vb >= s_edges[j]) ? j : j - 1;                                // NaN -> -1; at or beyond the last edge -> N
                 if (last_closed && vb == eN) kb = N - 1;
-                kb = ((unsigned)kb < (unsigned)N) ? kb : -1;                        // out of range on either side: dropped
             } else {
-                kb = find_bin(vb, s_edges, N, e0, eN, inv, last_closed);
+                kb = find_bin(vb, s_edges, N, e0, eN, inv, last_closed);            // -1 when dropped
             }
-            k[c] = full_strip ? kb : (active ? kb : -1);                      // wave-uniform: selects only in a ragged strip
+            unsigned ku = (unsigned)kb < (unsigned)N ? (unsigned)kb : (unsigned)N;  // v_min_u32: -1 and N both land in the trash bin
+            if (!full_strip) ku = active ? ku : (unsigned)N;                        // wave-uniform: selects only in a ragged strip
+            k[c] = ku;
             const double dv = dAv[c];
             w[0][c] = wpos ? dv : ((dv != dv) ? 0.0 : dv);                    // fillna(0), core.py:449 (wpos: host checked dA finite)
 #pragma unroll
@@ -365,12 +370,23 @@ void k_hist(const HistArgs a)
                 w[NCH - 1][c] = wpos ? fmax(p, 0.0) : ((p != p) ? 0.0 : p);
             }
         }
-        // wave-uniform fast path: every valid cell of the row in one bin
-        const int rb = __builtin_amdgcn_readfirstlane(k[0]);
-        bool match = true;
+        // wave-uniform fast path: every valid cell of the row in one bin -> per-lane registers, no LDS traffic.  A field with
+        // grid-scale noise never takes it, and the test itself (readfirstlane, compares, ballot) is a tenth of the row: after 8
+        // consecutive failures the wave stops testing for 48 rows, then looks again (smooth fields never stop)
+        bool one_bin = false;
+        int rb = 0;
+        if (fp_skip == 0) {
+            rb = __builtin_amdgcn_readfirstlane((int)k[0]);
+            bool match = true;
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) match = match && (k[c] == rb);
-        if (rb >= 0 && (__ballot(match) | inactive_mask) == ~0ull) {
+            for (int c = 0; c < VEC; ++c) match = match && ((int)k[c] == rb);
+            one_bin = rb < N && (__ballot(match) | inactive_mask) == ~0ull;
+            if (one_bin) fp_miss = 0;
+            else if (++fp_miss >= 8) { fp_skip = 48; fp_miss = 7; }
+        } else {
+            --fp_skip;
+        }
+        if (one_bin) {
             if (rb != cur) { flush(); cur = rb; }
             if (active) {
 #pragma unroll
@@ -383,12 +399,10 @@ void k_hist(const HistArgs a)
         } else {
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
-                if (k[c] >= 0) {
-                    const int o = (k[c] << cshift) + XC_ROT(copy, k[c], ncopy);
+                double* cp = s_cell + (size_t)((k[c] << cshift) + XC_ROT(copy, k[c], ncopy)) * CW;
 #pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch) lds_add(&s_h[ch * hsz + o], w[ch][c]);
-                    lds_add(&s_c[o], 1u);
-                }
+                for (int ch = 0; ch < NCH; ++ch) lds_add(cp + ch, w[ch][c]);
+                lds_add(reinterpret_cast<unsigned*>(cp + NCH), 1u);
             }
         }
     };
@@ -465,15 +479,16 @@ void k_hist(const HistArgs a)
     // 64 lanes of a wave hit distinct LDS banks (a fixed, thread-determined order)
     for (int i = tid; i < NCH * N; i += blockDim.x) {
         const int ch = i / N, b = i - ch * N;
-        const double* src = &s_h[ch * hsz + b * ncopy];
+        const double* src = s_cell + (size_t)b * ncopy * CW + ch;
         double sum = 0.0;
-        for (int c = 0; c < ncopy; ++c) sum += src[(c + tid) & (ncopy - 1)];
+        for (int c = 0; c < ncopy; ++c) sum += src[(size_t)((c + tid) & (ncopy - 1)) * CW];
         ph[i] = sum;
     }
     unsigned* pc = a.part_c + pb * N;
     for (int b = tid; b < N; b += blockDim.x) {
         unsigned sum = 0u;
-        for (int c = 0; c < ncopy; ++c) sum += s_c[b * ncopy + ((c + tid) & (ncopy - 1))];
+        for (int c = 0; c < ncopy; ++c)
+            sum += *reinterpret_cast<const unsigned*>(s_cell + (size_t)(b * ncopy + ((c + tid) & (ncopy - 1))) * CW + NCH);
         pc[b] = sum;
     }
     XC_STAMP(5);
@@ -518,7 +533,7 @@ int launch_two(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
     // the NEXT variant exists for the two channel layouts of the Keff pipeline only
     constexpr bool kHasNext = (NINT == 0 && GRAD) || (NINT == 1 && !GRAD);
     if constexpr (NINT == 0 && GRAD && VEC == 2) {                  // the Keff layout: compile-time periodic / fillna-free variant
-        if (a.periodic_x && a.dA_pos_finite && !a.negate) {
+        if (a.periodic_x && a.dA_pos_finite && !a.negate && !a.last_closed) {
             if (a.q_next) return launch_three<TQ, VEC, NINT, GRAD, DA2D, true, true>(ctx, g, nslab, a);
             return launch_three<TQ, VEC, NINT, GRAD, DA2D, false, true>(ctx, g, nslab, a);
         }
@@ -589,11 +604,12 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     // largest power-of-two copy count that fits the LDS budget
     int ncopy = (env_ncopy >= 1 && env_ncopy <= kMaxCopies && (env_ncopy & (env_ncopy - 1)) == 0) ? env_ncopy : kMaxCopies;
     const size_t fixed = (64 + ((nbin + 2) & ~1)) * sizeof(double);
-    while (ncopy > 1 && fixed + (size_t)nbin * ncopy * (nch * 8 + 4) > kLdsBudget) ncopy >>= 1;
-    if (fixed + (size_t)nbin * ncopy * (nch * 8 + 4) > kLdsBudget)
+    const size_t cell = (size_t)(nch + 1) * 8;             // nch sums + the count, side by side; nbin + 1 bins (the last is the trash bin)
+    while (ncopy > 1 && fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget) ncopy >>= 1;
+    if (fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget)
         return fail(ctx, XC_EBADARG, "xc_hist: too many bins x channels for the LDS histogram");
     g->ncopy = ncopy;
-    g->lds = fixed + (size_t)nbin * ncopy * (nch * 8 + 4);
+    g->lds = fixed + (size_t)(nbin + 1) * ncopy * cell;
     g->lds = (g->lds + 15) & ~(size_t)15;
     // blocks per slab
     const int64_t total = (int64_t)g->nstrip * ny;
