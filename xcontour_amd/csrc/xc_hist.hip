@@ -308,7 +308,7 @@ void k_hist(const HistArgs a)
 
     auto flush = [&]() {
         if (cnt) {
-            double* cp = s_cell + (size_t)(cur * ncopy + copy) * CW;
+            double* cp = s_cell + (unsigned)(cur * ncopy + copy) * (unsigned)CW;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) lds_add(cp + c, acc[c]);
             lds_add(reinterpret_cast<unsigned*>(cp + NCH), cnt);
@@ -399,7 +399,7 @@ void k_hist(const HistArgs a)
         } else {
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
-                double* cp = s_cell + (size_t)((k[c] << cshift) + XC_ROT(copy, k[c], ncopy)) * CW;
+                double* cp = s_cell + ((k[c] << cshift) + (unsigned)XC_ROT(copy, k[c], ncopy)) * (unsigned)CW;      // 32-bit LDS offset
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) lds_add(cp + ch, w[ch][c]);
                 lds_add(reinterpret_cast<unsigned*>(cp + NCH), 1u);
