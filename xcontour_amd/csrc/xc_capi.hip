@@ -731,6 +731,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
         a.increase = d->increase; a.q_f32 = d->q_dtype == XC_F32; a.ctr_f32 = d->ctr_dtype == XC_F32;
         a.right_edge = d->right_edge; a.inv_nm1 = 1.0 / (double)(N - 1); a.inv_n = 1.0 / (double)N;
         a.G = pg.G; a.ngroups = pg.ngroups; a.nstrip = pg.nstrip; a.cps = pg.cps; a.rpc = pg.rpc;
+        a.slots = pg.slots; a.ngps = pg.ngps; a.cus = ctx->cus;
         a.sync = (SyncShard*)base; a.abort = (unsigned*)(base + S * 8 * sizeof(SyncShard));
         a.part_h = (double*)(base + sync_b); a.part_c = (unsigned*)(base + sync_b + ph);
         a.ctr_out = d->ctr; a.status = d->status; a.stamps = ctx->dbg_stamps;

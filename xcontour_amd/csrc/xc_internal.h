@@ -135,7 +135,8 @@ constexpr int kPersistLdsRows = 8;    // rows of the NEXT slab's tile that wait 
 constexpr int kPersistCols = 124;     // computed columns of a wave's strip (62 lanes x 2 cells; lanes 0 / 63 are halos)
 
 struct PersistGeom {
-    int G, ngroups;          // workgroups per group, groups (G * ngroups = CUs)
+    int G, ngroups;          // workgroups per group, groups in all (G * ngroups = CUs * slots)
+    int slots, ngps;         // workgroups per CU (1, 2, 4: 768 / 384 / 192 threads each), groups per slot (ngroups = slots * ngps)
     int nstrip, cps, rpc;    // strips of kPersistCols columns, chunks per strip, rows per chunk (<= kPersistRows)
     int ncopy;               // LDS histogram copies
     size_t lds;
@@ -157,6 +158,7 @@ struct PersistArgs {
     int           increase, q_f32, ctr_f32, right_edge;
     double        inv_nm1, inv_n;
     int           G, ngroups, nstrip, cps, rpc;
+    int           slots, ngps, cus;   // workgroups per CU, groups per slot, CUs (grid = cus * slots)
     SyncShard*    sync;        // [nslab][8]  zeroed before the launch
     unsigned*     abort;       // [1]         zeroed before the launch
     double*       part_h;      // [nslab][G][2][nbin]

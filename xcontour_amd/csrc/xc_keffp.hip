@@ -41,10 +41,10 @@ namespace {
 #endif
 constexpr bool kNT = XC_PERSIST_NT != 0;
 constexpr int PR = kPersistRows;       // rows of a chunk
-constexpr int NT = kPersistThreads;    // threads of a workgroup
-constexpr int NW = NT / 64;            // its waves
 constexpr int PT = PR + 2;             // tile rows (halo row below and above)
-constexpr int KL = kPersistLdsRows;    // tile rows of the NEXT slab that wait in LDS (f64 tracers): the last KL rows of the tile
+// threads of a workgroup: 768 (one workgroup per CU), 384 (two) or 192 (four) -- always 12 waves per CU, 3 per SIMD, 168 VGPRs.
+// tile rows of the NEXT slab that wait in LDS (f64 tracers; the last KL rows of the tile): 8, or 4 when four workgroups share the LDS
+constexpr int persist_lds_rows(int nth) { return nth >= 384 ? kPersistLdsRows : kPersistLdsRows / 2; }
 constexpr int PCOLS = kPersistCols;    // computed columns of a strip (lanes 1..62, two cells each)
 constexpr unsigned long long kTimeoutTicks = 30000000ull;   // 0.3 s of the 100 MHz wall clock
 
@@ -85,10 +85,12 @@ __device__ __forceinline__ double uniform_d(double v)      // a wave-uniform dou
 
 // FAST: periodic X, dA verified finite and >= 0, half-open last bin (the xhistogram rule) -- the selects for walls,
 // fillna and the closed last edge are compiled out.  Otherwise they are runtime (wave-uniform) flags.
-template <typename TQ, bool DA2D, bool FAST>
-__global__ __launch_bounds__(kPersistThreads)
+template <typename TQ, bool DA2D, bool FAST, int NT>
+__global__ __attribute__((amdgpu_flat_work_group_size(NT, NT), amdgpu_waves_per_eu(3, 3)))
 void k_keff_persist(const PersistArgs a)
 {
+    constexpr int NW = NT / 64;                                // waves of a workgroup
+    constexpr int KL = persist_lds_rows(NT);
     extern __shared__ __align__(16) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,7 +108,11 @@ void k_keff_persist(const PersistArgs a)
     constexpr bool LDSR = sizeof(TQ) == 8;                     // LDS-DMA moves 16 bytes per lane: float64 rows only
 
     const int ny = (int)a.ny, nx = (int)a.nx;
-    const int group = (int)blockIdx.x % a.ngroups, rank = (int)blockIdx.x / a.ngroups;
+    // Workgroup b lands on CU b % cus in arrival slot b / cus (tools/probe/wg_placement.hip, measured on MI355X): with `slots`
+    // workgroups per CU the groups of DIFFERENT slots share every CU, so while one group waits for its grid-wide min / max
+    // the waves of the others keep the CU busy.  Inside a slot: ngps groups of G = cus / ngps workgroups, as before.
+    const int slot = (int)blockIdx.x / a.cus, bslot = (int)blockIdx.x - slot * a.cus;
+    const int group = slot * a.ngps + bslot % a.ngps, rank = bslot / a.ngps;
     const int gw = rank * NW + wave;                            // wave index inside the group
     const int strip = gw / a.cps, chunk = gw - strip * a.cps;
     const bool work = strip < a.nstrip;
@@ -405,14 +411,25 @@ void k_keff_persist(const PersistArgs a)
     if (prev >= 0) flush(prev);
 }
 
-template <typename TQ, bool DA2D, bool FAST>
-int launch_p3(xc_ctx* ctx, const PersistArgs& a, size_t lds)
+template <typename TQ, bool DA2D, bool FAST, int NT>
+int launch_p4(xc_ctx* ctx, const PersistArgs& a, size_t lds)
 {
-    auto kern = k_keff_persist<TQ, DA2D, FAST>;
+    auto kern = k_keff_persist<TQ, DA2D, FAST, NT>;
     { const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(kern), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.G * a.ngroups)), dim3(NT), lds, ctx->stream, a);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
+}
+
+template <typename TQ, bool DA2D, bool FAST>
+int launch_p3(xc_ctx* ctx, const PersistArgs& a, size_t lds)
+{
+    switch (a.slots) {
+        case 1: return launch_p4<TQ, DA2D, FAST, kPersistThreads>(ctx, a, lds);
+        case 2: return launch_p4<TQ, DA2D, FAST, kPersistThreads / 2>(ctx, a, lds);
+        case 4: return launch_p4<TQ, DA2D, FAST, kPersistThreads / 4>(ctx, a, lds);
+    }
+    return fail(ctx, XC_EBADARG, "persistent kernel: slots must be 1, 2 or 4");
 }
 
 template <typename TQ>
@@ -442,28 +459,39 @@ bool persist_geometry(const xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny,
     if (reinterpret_cast<uintptr_t>(q) % (2 * esz) != 0) return false;           // two-cell vector loads
     if ((dA_rank == XC_DA_PLANE || dA_rank == XC_DA_SLAB) && reinterpret_cast<uintptr_t>(dA) % 16 != 0) return false;
     if (ny * nx < 65536) return false;                                           // tiny planes: the streaming path
-    // LDS: edges + (2 doubles + 1 count) per bin and copy; the ds offsets stay small with <= 16 copies
-    int ncopy = kMaxCopies;
-    const size_t tile_lds = (q_dtype == XC_F64) ? (size_t)(kPersistThreads / 64) * kPersistLdsRows * 1024 : 0;
-    const size_t fixed = (64 + ((N + 2) & ~1)) * sizeof(double) + 64 + 16 + tile_lds;
-    while (ncopy > 1 && fixed + (size_t)N * ncopy * 20 > kLdsBudget) ncopy >>= 1;
-    if (fixed + (size_t)N * ncopy * 20 > kLdsBudget) return false;
     const int nstrip = (int)((nx + kPersistCols - 1) / kPersistCols);
     const int cps_min = (int)((ny + kPersistRows - 1) / kPersistRows);
-    // as many independent groups as fit (their waits then interleave), each slab spread over G = cus / ngroups CUs
-    int ngroups = 0;
-    for (int ng = 8; ng >= 1; ng >>= 1) {
-        if (ng > nslab) continue;
-        const int64_t waves = (int64_t)(cus / ng) * (kPersistThreads / 64);
-        if ((int64_t)nstrip * cps_min <= waves) { ngroups = ng; break; }
+    // Workgroups per CU (slots): 1, 2 or 4, always 12 waves per CU.  More slots = more groups sharing a CU = the waits of one
+    // group hidden behind the work of the others -- possible when a slab is small enough for a group of cus x 12 / slots waves.
+    // Default: the most slots whose group still holds a slab; XC_PERSIST_SLOTS forces a value (experiments).
+    static const int env_slots = [] { const char* e = getenv("XC_PERSIST_SLOTS"); return e ? atoi(e) : 0; }();
+    int slots = 0, ngps = 0;
+    for (int sl = 4; sl >= 1; sl >>= 1) {
+        if (env_slots > 0 && sl != env_slots) continue;
+        const int nw = kPersistThreads / 64 / sl;
+        for (int ng = 8; ng >= 1; ng >>= 1) {                                    // groups per slot: as many as fit
+            if ((int64_t)ng * sl > nslab && !(ng == 1 && sl == 1)) continue;
+            if ((int64_t)nstrip * cps_min <= (int64_t)(cus / ng) * nw) { slots = sl; ngps = ng; break; }
+        }
+        if (slots) break;
     }
-    if (!ngroups) return false;
-    const int G = cus / ngroups;
-    int cps = (int)(((int64_t)G * (kPersistThreads / 64)) / nstrip);
+    if (!slots) return false;
+    const int nwaves = kPersistThreads / 64 / slots, nthreads = kPersistThreads / slots;
+    // LDS of ONE workgroup: edges + (2 doubles + 1 count) per bin and copy + the waiting tile rows; `slots` workgroups share a CU
+    int ncopy = kMaxCopies;
+    const size_t budget = kLdsBudget / slots;
+    const size_t tile_lds = (q_dtype == XC_F64) ? (size_t)nwaves * persist_lds_rows(nthreads) * 1024 : 0;
+    const size_t fixed = (64 + ((N + 2) & ~1)) * sizeof(double) + 64 + 16 + tile_lds;
+    while (ncopy > 1 && fixed + (size_t)N * ncopy * 20 > budget) ncopy >>= 1;
+    if (fixed + (size_t)N * ncopy * 20 > budget) return false;
+    const int G = cus / ngps;
+    const int ngroups = ngps * slots;
+    int cps = (int)(((int64_t)G * nwaves) / nstrip);
     int rpc = (int)((ny + cps - 1) / cps);
     if (rpc < 4) rpc = 4;                                                        // halo rows cost 2 loads per chunk
     if (rpc > kPersistRows) rpc = kPersistRows;
     cps = (int)((ny + rpc - 1) / rpc);
+    g->slots = slots; g->ngps = ngps;
     g->G = G; g->ngroups = ngroups; g->nstrip = nstrip; g->cps = cps; g->rpc = rpc; g->ncopy = ncopy;
     g->lds = (fixed + (size_t)N * ncopy * 20 + 15) & ~(size_t)15;
     return true;
