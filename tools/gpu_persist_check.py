@@ -138,14 +138,15 @@ def timing(S, ny=1801, nx=3600):
         plan.free()
 
 
-def stamps(S):
-    ny, nx, N = 1801, 3600, 201
+def stamps(S, ny=1801, nx=3600):
+    N = 201
     lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 0.1
     dA = cell_area(lat, lon)
     tbl = table_from_rowsums(ctx.rowsum(None, dA, ny, nx), True)
     plan = KeffPlan(ctx, S, ny, nx, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=True, lt=True)
     plan.synth(lat, lon, 20241008, 0)
-    nb = ctx.device_cus()
+    slots = int(os.environ.get('XC_PERSIST_SLOTS', '1'))
+    nb = ctx.device_cus() * slots                  # workgroups of the launch (the kernel indexes the stamps by blockIdx)
     buf = ctx.alloc(S * nb * 8 * 8)
     ctx.set_keff_mode(nat.XC_KEFF_PERSISTENT)
     for k in range(3):
@@ -154,20 +155,33 @@ def stamps(S):
     plan.run(); ctx.sync()
     ctx._check(ctx.lib.xc_dbg_set_stamps(ctx.handle, None))
     st = buf.download((S, nb, 8), np.uint64).astype(np.int64)
-    t0 = st[0, :, 0].min()
+    live = st[:, :, 0] > 0                        # a workgroup stamps the slabs of its own group only
+    t0 = st[:, :, 0][live].min()
     st = (st - t0) / 100.0                     # us
     names = ['top', 'minmax+barrier', 'publish issued', 'flushed prev', 'sync done', 'edges done', 'B done']
     for s in (0, 1, 2, S // 2, S - 1):
-        print('slab %2d:' % s, '  '.join('%s %.1f/%.1f/%.1f' % (names[k], st[s, :, k].min(), np.median(st[s, :, k]), st[s, :, k].max()) for k in range(7)))
+        m = live[s]
+        print('slab %2d (%d workgroups):' % (s, m.sum()), '  '.join('%s %.1f/%.1f/%.1f' % (names[k], st[s, m, k].min(), np.median(st[s, m, k]), st[s, m, k].max()) for k in range(7)))
     d = np.diff(st, axis=2)
-    print('median phase lengths (us) over slabs 2..: ', '  '.join('%s->%s %.2f' % (names[k], names[k + 1], np.median(d[2:, :, k])) for k in range(6)))
-    print('slab period (us): %.2f' % np.median(np.diff(st[1:, :, 0], axis=0)))
+    sel = live.copy(); sel[:8] = False
+    print('median phase lengths (us) over the later slabs: ', '  '.join('%s->%s %.2f' % (names[k], names[k + 1], np.median(d[:, :, k][sel])) for k in range(6)))
+    per = []
+    for w in range(nb):
+        ss = np.nonzero(live[:, w])[0]
+        if len(ss) > 3:
+            per.append(np.median(np.diff(st[ss[2:], w, 0])))
+    ng = int(np.median([np.median(np.diff(np.nonzero(live[:, w])[0])) for w in range(nb) if live[:, w].sum() > 1]))
+    print('groups %d; period of a group (us): %.2f -> %.2f us per slab;  whole launch %.1f us for %d slabs = %.2f us per slab'
+          % (ng, np.median(per), np.median(per) / ng, st[:, :, 6][live].max(), S, st[:, :, 6][live].max() / S))
     plan.free()
 
 
 if __name__ == '__main__':
     if '--stamps' in sys.argv:
-        stamps(16)
+        if '--cfg4' in sys.argv:
+            stamps(64, 721, 1440)
+        else:
+            stamps(16)
         sys.exit(0)
     S = 16
     if '--slabs' in sys.argv:

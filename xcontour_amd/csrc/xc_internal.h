@@ -136,7 +136,7 @@ constexpr int kPersistCols = 124;     // computed columns of a wave's strip (62 
 
 struct PersistGeom {
     int G, ngroups;          // workgroups per group, groups in all (G * ngroups = CUs * slots)
-    int slots, ngps;         // workgroups per CU (1, 2, 4: 768 / 384 / 192 threads each), groups per slot (ngroups = slots * ngps)
+    int slots, ngps;         // workgroups per CU (1 or 3: 768 / 256 threads each), groups per slot (ngroups = slots * ngps)
     int nstrip, cps, rpc;    // strips of kPersistCols columns, chunks per strip, rows per chunk (<= kPersistRows)
     int ncopy;               // LDS histogram copies
     size_t lds;

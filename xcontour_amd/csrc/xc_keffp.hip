@@ -42,9 +42,12 @@ namespace {
 constexpr bool kNT = XC_PERSIST_NT != 0;
 constexpr int PR = kPersistRows;       // rows of a chunk
 constexpr int PT = PR + 2;             // tile rows (halo row below and above)
-// threads of a workgroup: 768 (one workgroup per CU), 384 (two) or 192 (four) -- always 12 waves per CU, 3 per SIMD, 168 VGPRs.
-// tile rows of the NEXT slab that wait in LDS (f64 tracers; the last KL rows of the tile): 8, or 4 when four workgroups share the LDS
-constexpr int persist_lds_rows(int nth) { return nth >= 384 ? kPersistLdsRows : kPersistLdsRows / 2; }
+// threads of a workgroup: 768 (one workgroup per CU) or 256 (three) -- always 12 waves per CU, 3 per SIMD, 168 VGPRs.  (A
+// workgroup's waves are dealt to the SIMDs from SIMD 0: 6- or 3-wave workgroups pile up on the first SIMDs, a second / fourth
+// one then finds no registers there and waits for the first to END -- measured, tools/gpu_persist_check.py --stamps; whole
+// multiples of 4 waves fill the SIMDs evenly.)
+// tile rows of the NEXT slab that wait in LDS (f64 tracers; the last KL rows of the tile): 8, or 4 when three workgroups share the LDS
+constexpr int persist_lds_rows(int nth) { return nth >= 768 ? kPersistLdsRows : kPersistLdsRows / 2; }
 constexpr int PCOLS = kPersistCols;    // computed columns of a strip (lanes 1..62, two cells each)
 constexpr unsigned long long kTimeoutTicks = 30000000ull;   // 0.3 s of the 100 MHz wall clock
 
@@ -426,10 +429,9 @@ int launch_p3(xc_ctx* ctx, const PersistArgs& a, size_t lds)
 {
     switch (a.slots) {
         case 1: return launch_p4<TQ, DA2D, FAST, kPersistThreads>(ctx, a, lds);
-        case 2: return launch_p4<TQ, DA2D, FAST, kPersistThreads / 2>(ctx, a, lds);
-        case 4: return launch_p4<TQ, DA2D, FAST, kPersistThreads / 4>(ctx, a, lds);
+        case 3: return launch_p4<TQ, DA2D, FAST, kPersistThreads / 3>(ctx, a, lds);
     }
-    return fail(ctx, XC_EBADARG, "persistent kernel: slots must be 1, 2 or 4");
+    return fail(ctx, XC_EBADARG, "persistent kernel: slots must be 1 or 3");
 }
 
 template <typename TQ>
@@ -461,12 +463,12 @@ bool persist_geometry(const xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny,
     if (ny * nx < 65536) return false;                                           // tiny planes: the streaming path
     const int nstrip = (int)((nx + kPersistCols - 1) / kPersistCols);
     const int cps_min = (int)((ny + kPersistRows - 1) / kPersistRows);
-    // Workgroups per CU (slots): 1, 2 or 4, always 12 waves per CU.  More slots = more groups sharing a CU = the waits of one
-    // group hidden behind the work of the others -- possible when a slab is small enough for a group of cus x 12 / slots waves.
-    // Default: the most slots whose group still holds a slab; XC_PERSIST_SLOTS forces a value (experiments).
+    // Workgroups per CU (slots): 1 or 3, always 12 waves per CU.  Three slots = three groups sharing every CU = the waits of one
+    // group hidden behind the work of the others -- possible when a slab is small enough for a group of cus x 4 waves.
+    // Default: three slots when a group of that size holds a slab; XC_PERSIST_SLOTS forces a value (experiments).
     static const int env_slots = [] { const char* e = getenv("XC_PERSIST_SLOTS"); return e ? atoi(e) : 0; }();
     int slots = 0, ngps = 0;
-    for (int sl = 4; sl >= 1; sl >>= 1) {
+    for (int sl = 3; sl >= 1; sl -= 2) {
         if (env_slots > 0 && sl != env_slots) continue;
         const int nw = kPersistThreads / 64 / sl;
         for (int ng = 8; ng >= 1; ng >>= 1) {                                    // groups per slot: as many as fit
@@ -479,7 +481,7 @@ bool persist_geometry(const xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny,
     const int nwaves = kPersistThreads / 64 / slots, nthreads = kPersistThreads / slots;
     // LDS of ONE workgroup: edges + (2 doubles + 1 count) per bin and copy + the waiting tile rows; `slots` workgroups share a CU
     int ncopy = kMaxCopies;
-    const size_t budget = kLdsBudget / slots;
+    const size_t budget = (kLdsBudget / slots) & ~(size_t)15;
     const size_t tile_lds = (q_dtype == XC_F64) ? (size_t)nwaves * persist_lds_rows(nthreads) * 1024 : 0;
     const size_t fixed = (64 + ((N + 2) & ~1)) * sizeof(double) + 64 + 16 + tile_lds;
     while (ncopy > 1 && fixed + (size_t)N * ncopy * 20 > budget) ncopy >>= 1;
