@@ -292,6 +292,16 @@ def main():
         ctx.comm_init(world, rank, uid[0])
     gdev = 'cuda' if a.backend == 'nccl' else 'cpu'
     gathered = torch.empty(res.numel() * world, dtype=torch.float64, device=gdev) if world > 1 else None
+    if world > 1:
+        # warm-up of the collective, like the W warm-up steps of the compute: the first all-gather of a communicator sets up
+        # its channels / proxy connections (tens of ms), which is start-up cost and not part of a steady-state job
+        if a.native_rccl:
+            ctx.comm_allgather(res.data_ptr(), gathered.data_ptr(), res.numel() * 8)
+            ctx.sync()
+        else:
+            dist.all_gather_into_tensor(gathered, res if a.backend == 'nccl' else res.cpu())
+        torch.cuda.synchronize()
+        res.zero_(); gathered.zero_()                               # the timed region fills them again
 
     if world > 1:
         dist.barrier()
