@@ -517,8 +517,9 @@ int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& 
         static const int tile_env = [] { const char* e = getenv("XC_HIST_TILEMAP"); return e ? atoi(e) : 1; }();
         const int64_t nw = (int64_t)g.bps * (g.threads / 64);
         const int64_t nchunk = nw / g.nstrip;
-        // needs at least one chunk and at least 8 rows per chunk (two halo rows are loaded per chunk)
-        b.nchunk = (tile_env && nchunk >= 1 && a.ny / nchunk >= 8) ? (int)nchunk : 0;
+        // needs at least one chunk, at least 8 rows per chunk (two halo rows are loaded per chunk) and no more than a tenth of
+        // the waves left without a chunk (waves beyond nchunk x nstrip idle; the even strip-major split uses them all)
+        b.nchunk = (tile_env && nchunk >= 1 && a.ny / nchunk >= 8 && (nw - nchunk * g.nstrip) * 10 <= nw) ? (int)nchunk : 0;
     }
     const int64_t nblk = b.xcd_map ? (int64_t)8 * ((g.bps + 7) / 8) * nslab : (int64_t)g.bps * nslab;
     if (nblk > 0x7fffffff) return fail(ctx, XC_EBADARG, "xc_hist: grid too large");
