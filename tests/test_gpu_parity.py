@@ -834,6 +834,32 @@ def test_crossing_stack_sharing_one_area_plane(ctx, adt):
                 assert np.all(np.abs(lens[s][fin] - ol[fin]) <= 1e-12 * np.maximum(ol[fin], 1e-300) + 0.0)       # per level, and 0 stays exactly 0
 
 
+def test_crossing_values_on_and_next_to_levels(ctx):
+    """equally spaced levels take the arithmetic route (count_below_uniform): corner values exactly ON a level, one ulp either
+    side, and levels that are only nearly equally spaced (float32 contours of a 300 +- 1 field: ~1e-3 of a spacing off) must give
+    the oracle's counts exactly"""
+    rng = np.random.default_rng(5)
+    ny, nx, N = 90, 130, 41
+    for lev in (np.linspace(-1.0, 1.0, N),                                        # exact in the mean, rounded per level
+                np.linspace(299.0, 301.0, N).astype(np.float32).astype(np.float64),   # float32 contours far from zero
+                np.linspace(-2e-4, 3e-4, N).astype(np.float32).astype(np.float64)):   # the barotropic magnitude
+        span = lev[-1] - lev[0]
+        q = lev[0] + span * (np.linspace(-0.05, 1.05, ny)[:, None] + 0.04 * rng.standard_normal((ny, nx)))
+        k = rng.integers(0, N, size=(ny, nx))
+        on = rng.random((ny, nx))
+        q = np.where(on < 0.15, lev[k], q)                                        # exactly on a level
+        q = np.where((on >= 0.15) & (on < 0.25), np.nextafter(lev[k], np.inf), q)
+        q = np.where((on >= 0.25) & (on < 0.35), np.nextafter(lev[k], -np.inf), q)
+        q[3, 4] = np.inf; q[5, 6] = -np.inf; q[7, 8] = np.nan
+        area = rng.random((ny, nx)) + 0.5
+        for dt in (np.float64, np.float32):
+            qq = q.astype(dt)[None]
+            lens, cnts = ctx.crossing(qq, lev, area, stride=1, pad_x=1, pad_mode='wrap', full_width=True)
+            ol, oc = O.contour_crossing(O.pad_x(qq[0], 1, 'wrap'), lev, O.pad_x(area, 1, 'wrap'), 1, True)
+            assert np.array_equal(cnts[0].astype(np.int64), oc)
+            assert rel(lens[0], ol) < 1e-13
+
+
 def test_crossing_literal_loops_small(ctx):
     """the pure-python loop restatement of core.py:1490-1566, contour by contour"""
     rng = np.random.default_rng(5)

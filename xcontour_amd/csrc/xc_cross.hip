@@ -78,6 +78,23 @@ __device__ __forceinline__ int count_below(const double* __restrict__ cx, int N,
     return lo;
 }
 
+// Equally spaced levels: number of contours < v from arithmetic.  The block measured how far the levels sit from their ideal
+// positions (zlo = twice that, in units of the spacing, plus the rounding of t): when the fractional position of v lies
+// outside that zone of either neighbouring level the arithmetic answer IS the count and no LDS read is needed; otherwise
+// (v within a hair of a level, NaN, infinities) one adjacent-pair read verifies, bisection is the fallback.
+__device__ __forceinline__ int count_below_uniform(const double* __restrict__ cx, int N, double v, double c_first,
+                                                   double inv_step, double zlo)
+{
+    const double t = (v - c_first) * inv_step;
+    int k = (int)fmin(fmax(t + 1.0, 0.0), (double)N);          // floor(t) + 1 clamped to [0, N]; NaN -> 0
+    const double fr = __builtin_amdgcn_fract(t);
+    if (!((fr > zlo) & (fr < 1.0 - zlo))) {
+        const double c_lo = cx[k], c_hi = cx[k + 1];
+        if (!((c_lo < v) & (v <= c_hi))) k = count_below(cx, N, v);
+    }
+    return k;
+}
+
 template <typename TA> __device__ __forceinline__ double sqrt_like_numpy(TA a);
 // f32 area: np.sqrt rounds in f32; an f64 root rounded once more to f32 IS the correctly rounded f32 root (53 >= 2*24+2)
 template <> __device__ __forceinline__ double sqrt_like_numpy<float>(float a) { return (double)(float)__dsqrt_rn((double)a); }
@@ -87,26 +104,22 @@ template <> __device__ __forceinline__ double sqrt_like_numpy<double>(double a) 
 // (walking down a column the tracer changes slowly: one adjacent-pair LDS read confirms the guess).
 template <typename TA, bool CNT>
 __device__ __forceinline__ void box_done(const double* __restrict__ cx, int N, double mn, double mx, TA araw, bool nanfill,
-                                         double fs, double c_first, double inv_step, int& g,
+                                         double fs, double c_first, double inv_step, double zlo, int& g,
                                          double* __restrict__ my_len, unsigned* __restrict__ my_cnt, double* __restrict__ s_dir)
 {
     if (!(mn < mx)) return;                            // one value, or no valid corner at all
     if (inv_step > 0.0) {
         // Equally spaced levels (what cal_contours produces): BOTH ends of the crossed range follow from arithmetic -- klo = number
-        // of levels < mn, khi = number of levels < mx -- each verified by one adjacent-pair LDS read, bisection as the fallback.
+        // of levels < mn, khi = number of levels < mx -- each verified by one adjacent-pair LDS read only when the value
+        // lies within the measured irregularity of the levels (count_below_uniform), bisection as the fallback.
         // The box then adds +w at klo and -w at khi: a DIFFERENCE array, two adds whatever the number of crossed levels (the
         // per-lane level loop of a noisy field -- 3.6 levels per box on the PV-like slabs, up to ~10 in a wave, 39 on white
         // noise -- was half of the kernel's instructions); the block turns the differences into sums with one pass over the
         // levels before it writes its partials (k_crossing epilogue).  Counts are exact (integer differences modulo 2^32);
         // lengths agree with the oracle to summation order, level by level.
-        int klo = (int)fmin(fmax((mn - c_first) * inv_step + 1.0, 0.0), (double)N);
-        const double c_lo = cx[klo];
-        double c_hi = cx[klo + 1];
-        if (!((c_lo < mn) & (mn <= c_hi))) { klo = count_below(cx, N, mn); c_hi = cx[klo + 1]; }
-        if (!(c_hi < mx)) return;                          // no level in [mn, mx): the common case on a smooth field ends here
-        int khi = (int)fmin(fmax((mx - c_first) * inv_step + 1.0, 0.0), (double)N);
-        const double h_lo = cx[khi], h_hi = cx[khi + 1];
-        if (!((h_lo < mx) & (mx <= h_hi))) khi = count_below(cx, N, mx);
+        const int klo = count_below_uniform(cx, N, mn, c_first, inv_step, zlo);
+        const int khi = count_below_uniform(cx, N, mx, c_first, inv_step, zlo);
+        if (khi <= klo) return;                            // no level in [mn, mx): the common case on a smooth field ends here
         double w = __dmul_rn(sqrt_like_numpy<TA>(araw), fs);    // core.py:1560 (product in f64: numba types f32 * int64 as f64)
         if (nanfill) w = __longlong_as_double(0x7ff8000000000000LL);
 #ifndef XC_CROSS_NOATOM
@@ -145,41 +158,26 @@ __device__ __forceinline__ void box_done(const double* __restrict__ cx, int N, d
 template <typename TA, bool CNT, int G>
 __device__ __forceinline__ void boxes_group(const double* __restrict__ cx, int N, const double (&mn)[G], const double (&mx)[G],
                                             const TA (&araw)[G], const bool (&valid)[G], bool nanfill, double fs, double c_first,
-                                            double inv_step, double* __restrict__ my_len, unsigned* __restrict__ my_cnt,
+                                            double inv_step, double zlo, double* __restrict__ my_len, unsigned* __restrict__ my_cnt,
                                             double* __restrict__ s_dir)
 {
-    const double dN = (double)N;
     int klo[G], khi[G];
-    double c_lo[G], c_hi[G];
     bool cross[G];
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-        klo[i] = (int)fmin(fmax((mn[i] - c_first) * inv_step + 1.0, 0.0), dN);          // NaN / -inf -> 0, +inf -> N: always a valid index
-        c_lo[i] = cx[klo[i]]; c_hi[i] = cx[klo[i] + 1];
-    }
     bool any = false;
 #pragma unroll
     for (int i = 0; i < G; ++i) {
-        const bool ok = valid[i] && (mn[i] < mx[i]);                                    // one value, or no valid corner at all: nothing
-        if (ok && !((c_lo[i] < mn[i]) & (mn[i] <= c_hi[i]))) { klo[i] = count_below(cx, N, mn[i]); c_hi[i] = cx[klo[i] + 1]; }
-        cross[i] = ok && (c_hi[i] < mx[i]);
+        klo[i] = count_below_uniform(cx, N, mn[i], c_first, inv_step, zlo);
+        khi[i] = count_below_uniform(cx, N, mx[i], c_first, inv_step, zlo);
+        cross[i] = valid[i] && (mn[i] < mx[i]) && (khi[i] > klo[i]);                    // one value, no valid corner, no level in [mn, mx): nothing
         any = any || cross[i];
     }
     if (!any) return;                                                                   // the common case on a smooth field
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-        khi[i] = (int)fmin(fmax((mx[i] - c_first) * inv_step + 1.0, 0.0), dN);
-        c_lo[i] = cx[khi[i]]; c_hi[i] = cx[khi[i] + 1];
-    }
     double w[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         w[i] = __dmul_rn(sqrt_like_numpy<TA>(araw[i]), fs);                             // core.py:1560
         if (nanfill) w[i] = __longlong_as_double(0x7ff8000000000000LL);
     }
-#pragma unroll
-    for (int i = 0; i < G; ++i)
-        if (cross[i] && !((c_lo[i] < mx[i]) & (mx[i] <= c_hi[i]))) khi[i] = count_below(cx, N, mx[i]);
 #ifndef XC_CROSS_NOATOM
 #pragma unroll
     for (int i = 0; i < G; ++i) {
@@ -231,10 +229,22 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
     const double c_first = s_cx[1];
     double inv_step = (N > 1) ? (double)(N - 1) / (s_cx[N] - c_first) : 0.0;
     if (!(inv_step > 0.0 && inv_step < inf)) inv_step = 0.0;
-    {   // equally spaced?  (block-uniform answer)
+    double zlo = 0.5;
+    {   // equally spaced?  (block-uniform answer) -- and how exactly: the largest distance of a level from its ideal position
         int ok = inv_step > 0.0;
-        for (int k = tid; k < N && ok; k += CROSS_TPB) ok = fabs((s_cx[k + 1] - c_first) * inv_step - (double)k) < 0.01;
+        double dev = 0.0;
+        for (int k = tid; k < N && ok; k += CROSS_TPB) {
+            const double d = fabs((s_cx[k + 1] - c_first) * inv_step - (double)k);
+            ok = d < 0.01; dev = fmax(dev, d);
+        }
         if (!__syncthreads_and(ok)) inv_step = 0.0;
+        for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o));
+        __shared__ double s_dev[CROSS_TPB / 64];
+        if ((tid & 63) == 0) s_dev[tid >> 6] = dev;
+        __syncthreads();
+        dev = s_dev[0];
+        for (int w = 1; w < CROSS_TPB / 64; ++w) dev = fmax(dev, s_dev[w]);
+        zlo = 2.0 * dev + 1e-9;                                  // + the rounding of t itself (|t| <= ~N: 1e-13 at most)
     }
     int g = 0;
 
@@ -283,7 +293,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                 int P = 1;                                             // sliding window of w lanes: doubling, then one overlap step
                 for (; 2 * P <= w; P *= 2) { vmn = fmin(vmn, __shfl_down(vmn, P)); vmx = fmax(vmx, __shfl_down(vmx, P)); }
                 if (w != P) { vmn = fmin(vmn, __shfl_down(vmn, w - P)); vmx = fmax(vmx, __shfl_down(vmx, w - P)); }
-                if (box) box_done<TA, CNT>(s_cx, N, vmn, vmx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, g, my_len, my_cnt, s_dir);
+                if (box) box_done<TA, CNT>(s_cx, N, vmn, vmx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
             }
             continue;
         }
@@ -328,7 +338,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                             cmn = rmn; cmx = rmx;
                             ab[i] = av[b]; vb[i] = box && (jb + b < j1);
                         }
-                        boxes_group<TA, CNT, G>(s_cx, N, mnb, mxb, ab, vb, nanfill, fs, c_first, inv_step, my_len, my_cnt, s_dir);
+                        boxes_group<TA, CNT, G>(s_cx, N, mnb, mxb, ab, vb, nanfill, fs, c_first, inv_step, zlo, my_len, my_cnt, s_dir);
                     }
                     continue;
                 }
@@ -339,7 +349,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                     const double rmn = fmin(fmin(inf, x), xr), rmx = fmax(fmax(-inf, x), xr);
                     const double mn = fmin(cmn, rmn), mx = fmax(cmx, rmx);
                     cmn = rmn; cmx = rmx;
-                    if (box) box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, g, my_len, my_cnt, s_dir);
+                    if (box) box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
                 }
             }
             continue;
@@ -361,7 +371,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                 cmn = inf; cmx = -inf;
                 row_segment(qs + (size_t)(j * s + s) * nx, c0, s, nx, pad_mode, cmn, cmx);
                 mn = fmin(mn, cmn); mx = fmax(mx, cmx);
-                box_done<TA, CNT>(s_cx, N, mn, mx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, g, my_len, my_cnt, s_dir);
+                box_done<TA, CNT>(s_cx, N, mn, mx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
             }
         } else if constexpr (S > 0) {
             constexpr int B = S == 1 ? 8 : S == 2 ? 4 : S == 3 ? 2 : 1;     // boxes per load batch
@@ -397,7 +407,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
 #pragma unroll
                     for (int d = 0; d <= S; ++d) { const double x = pnan[d] ? qnan : (double)v[b][S - 1][d]; cmn = fmin(cmn, x); cmx = fmax(cmx, x); }
                     mn = fmin(mn, cmn); mx = fmax(mx, cmx);
-                    box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, g, my_len, my_cnt, s_dir);
+                    box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
                 }
             }
         }
