@@ -112,6 +112,71 @@ def test_levels_against_the_reference_notebook_printout(ctx):
         assert np.array_equal(ctr.values[i, :3], first) and np.array_equal(ctr.values[i, -3:], last), k
 
 
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_keff_ocean_call_sequence_with_land_mask(ctx, dt):
+    """tests/test_Keff_ocean.py computeKeff: an ocean domain -- tracer NaN over land (`where(tracer != 0)`), `maskC` (0 / 1) for
+    the A(Yeq) table, 401 contours, a user-supplied Lmin (zonal sum of mask * dx interpolated to Yeq), nkeff mask 2e7,
+    interp_to_dataset -- step by step against the oracle, and the fused pipeline on the same input"""
+    import xcontour_amd as xa
+    rng = np.random.default_rng(31)
+    ny, nx, N = 146, 360, 401
+    lat = np.linspace(-70, 75, ny); lon = np.arange(nx) * 1.0
+    land = np.zeros((ny, nx), bool)
+    land[40:90, 60:130] = True; land[95:140, 200:300] = True; land[:6, :] = True      # two continents and a polar cap
+    land |= rng.random((ny, nx)) < 0.01                                               # islands
+    maskC = (~land).astype(np.float64)
+    q = (np.tanh(np.deg2rad(lat) * 2)[:, None] * 10 + 15 + 1.5 * np.sin(np.deg2rad(lon) * 3)[None, :] * np.cos(np.deg2rad(lat))[:, None]
+         + 0.3 * rng.standard_normal((ny, nx))).astype(dt)
+    q[land] = np.nan
+    c = {'latitude': lat, 'longitude': lon}
+    dAv = O.cell_area(lat, lon)
+    g2 = O.grad2_sphere(np.where(land, np.nan, q), lat, lon)                           # NaN next to the coasts, like a masked fd.grad
+    tr = xa.DataArray(q, ('latitude', 'longitude'), c, 'PTRACER04')
+    dA = xa.DataArray(dAv, ('latitude', 'longitude'), c, 'rA')
+    grdS = xa.DataArray(g2, tr.dims, tr.coords, 'grdS')
+    mask = xa.DataArray(maskC, tr.dims, tr.coords, 'mask')
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True, check_mono=False)
+    table = cm.cal_area_eqCoord_table_hist(mask)
+    ctr = cm.cal_contours(N)
+    area = cm.cal_integral_within_contours_hist(ctr).rename('intArea')
+    intgrdS = cm.cal_integral_within_contours_hist(ctr, integrand=grdS).rename('intgrdS')
+    Yeq = table.lookup_coordinates(area).rename('Yeq')
+    dx = O.Rearth * np.cos(np.deg2rad(lat)) * np.deg2rad(1.0)
+    preLmin = (maskC * dx[:, None]).sum(1)                                             # (mask * dxF).sum('longitude')
+    Lmin = xa.DataArray(np.interp(Yeq.values, lat, preLmin), Yeq.dims, Yeq.coords, 'Lmin')   # .interp(latitude=Yeq)
+    dgrdSdA = cm.cal_gradient_wrt_area(intgrdS, area)
+    dqdA = cm.cal_gradient_wrt_area(ctr, area)
+    Leq2 = cm.cal_sqared_equivalent_length(dgrdSdA, dqdA)
+    nkeff = cm.cal_normalized_Keff(Leq2, Lmin, mask=2e7)
+    # the oracle, same sequence
+    o_tbl, o_cs = O.cal_area_eqCoord_table_hist(maskC, dAv, lat, True, True)
+    o_ctr = O.cal_contours(q, N, True, np.float32)
+    o_area, o_cnt = O.cal_integral_within_contours_hist(q, o_ctr, dAv, None, True, return_counts=True)
+    o_S = O.cal_integral_within_contours_hist(q, o_ctr, dAv, g2, True)
+    o_Yeq = O.lookup_coordinates(o_area, o_tbl, o_cs)
+    o_Lmin = np.interp(o_Yeq, lat, preLmin)
+    o_dS = O.cal_gradient_wrt_area(o_S, o_area); o_dq = O.cal_gradient_wrt_area(o_ctr, o_area)
+    o_Leq2 = O.cal_sqared_equivalent_length(o_dS, o_dq)
+    o_nk = O.cal_normalized_Keff(o_Leq2, o_Lmin, 2e7)
+    assert int((~land).sum()) - o_cnt.sum() in (0, 1)        # every ocean cell, no land cell (float32 contours: the max cell may sit above ctr[-1], SURVEY A1)
+    assert abs(o_tbl[-1] / (maskC * dAv).sum() - 1) < 1e-12                            # the table ends at the ocean area
+    assert rel(table._table.values, o_tbl) < 1e-13
+    assert np.array_equal(ctr.values, o_ctr)
+    assert rel(area.values, o_area) < TIGHT and rel(intgrdS.values, o_S) < TIGHT
+    assert rel(Yeq.values, o_Yeq) < 1e-9
+    assert rel(dqdA.values, o_dq) < 1e-8 and rel(dgrdSdA.values, o_dS) < 1e-8
+    assert rel(Leq2.values, o_Leq2) < RTOL and rel(nkeff.values, o_nk) < RTOL
+    preY = np.linspace(-70, 75, N)
+    interp = cm.interp_to_dataset(preY, Yeq, [ctr, area, Yeq, intgrdS, dgrdSdA, dqdA, Leq2, Lmin, nkeff]).rename({'new': 'latitude'})
+    assert rel(interp['nkeff'].values, O.interp_to_coords(preY, o_Yeq, o_nk)) < RTOL
+    assert rel(interp['intArea'].values, O.interp_to_coords(preY, o_Yeq, o_area)) < 1e-9
+    # the fused pipeline on the same field: levels, counts, area, intgrdS (in-kernel gradient == the supplied grdS), Yeq
+    ds = cm.keff(N, table, lat=lat, lon=lon, periodic_x=True)
+    assert np.array_equal(ds['ctr'].values, o_ctr.astype(np.float64))
+    assert rel(ds['area'].values, o_area) < TIGHT and rel(ds['intgrdS'].values, o_S) < TIGHT
+    assert rel(ds['latEq'].values, o_Yeq) < 1e-9
+
+
 # ---------------------------------------------------------------- BASELINE configs[3]: 1440x721 f64 slabs, per-slab levels, chained
 def test_cfg4_shape_chained_launch_sets(ctx):
     """74 slabs of 721x1440 f64 generated on device (seed + slab id), N = 201, processed in two chained launch sets of

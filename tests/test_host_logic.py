@@ -126,6 +126,12 @@ def test_labeled_array_basics():
     a = xa.DataArray(np.arange(24.).reshape(2, 3, 4), ('time', 'lat', 'lon'),
                      {'time': np.arange(2), 'lat': np.arange(3.), 'lon': np.arange(4.)}, 'x')
     assert a.rename('y').name == 'y' and a.rename({'lat': 'Y'}).dims == ('time', 'Y', 'lon')
+    # Dataset.rename, as tests/test_Keff_ocean.py:76 uses it on the merged result
+    from xcontour_amd.labeled import Dataset
+    b = xa.DataArray(np.arange(3.0), ('new',), {'new': np.arange(3.0)}, 'nkeff')
+    r = Dataset([('nkeff', b)]).rename({'new': 'latitude'})
+    assert r['nkeff'].dims == ('latitude',) and list(r['nkeff'].coords) == ['latitude'] and r.nkeff.name == 'nkeff'
+    assert Dataset([('nkeff', b)]).rename({'nkeff': 'K'})['K'].name == 'K'
     assert a.isel({'time': 1}).shape == (3, 4) and a['lat'].values.tolist() == [0., 1., 2.]
     assert a.transpose('lon', 'lat', 'time').shape == (4, 3, 2)
     assert a.isel({'lat': slice(None, None, -1)}).coords['lat'].tolist() == [2., 1., 0.]

@@ -130,6 +130,27 @@ class Dataset(dict):
         except KeyError:
             raise AttributeError(k)
 
+    # the little of xarray.Dataset the reference's scripts use on the merged results
+    # (tests/test_Keff_ocean.py:76: `cm.interp_to_dataset(preY, Yeq, origin).rename({'new': 'latitude'})`)
+    def rename(self, new):
+        """rename dimensions / coordinates (in every member) and variables, like xarray.Dataset.rename"""
+        out = Dataset()
+        for k, v in self.items():
+            a = v.rename(new)
+            nk = new.get(k, k)
+            out[nk] = a.rename(nk) if a.name == k else a
+        return out
+
+    @property
+    def data_vars(self):
+        return dict(self)
+
+    def load(self):
+        return self
+
+    def __repr__(self):
+        return '<xcontour_amd.Dataset %s>' % ', '.join('%s%r' % (k, tuple(v.dims)) for k, v in self.items())
+
 
 # ---------------------------------------------------------------------------
 # unwrap / rewrap helpers used by the facade
