@@ -552,7 +552,10 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
     const int64_t tw = stride == 1 ? CROSS_W1 : CROSS_TPB;
     const int64_t ntj = (nbj + rbox - 1) / rbox;
     const int64_t nti = cols ? ((nbi + nbw - 1) / nbw + 3) / 4 : (nbi + tw - 1) / tw;
-    int64_t bps = 2048 / nslab; if (bps < 8) bps = 8; if (bps > ntj * nti) bps = ntj * nti;
+    static const int env_blocks = [] { const char* e = getenv("XC_CROSS_BLOCKS"); return e ? atoi(e) : 0; }();     // experiment knob
+    // blocks in all: the column-parallel path (strides 6..63) has one memory round trip per box row and tile in flight per wave
+    // and wants more, shorter blocks (cfg2 slabs, stride 8 / 32: 23.2 / 31.3 -> 19.3 / 25.9 us with 8192); stride 1 is best at 2048
+    int64_t bps = (env_blocks > 0 ? env_blocks : (cols ? 8192 : 2048)) / nslab; if (bps < 8) bps = 8; if (bps > ntj * nti) bps = ntj * nti;
     const size_t pl = (size_t)nslab * bps * N * 8, pc = (size_t)nslab * bps * N * 4;
     {
         const int rc = ensure_scratch(ctx, ((pl + 255) & ~(size_t)255) + pc);
