@@ -273,27 +273,42 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
             const int w = s + 1;
             double cmn, cmx;
             { const double x = pn ? qnan : (double)qs[(size_t)(j0 * s) * nx + c]; cmn = fmin(inf, x); cmx = fmax(-inf, x); }
-            for (int64_t j = j0; j < j1; ++j) {
-                double vmn = cmn, vmx = cmx;
-                for (int r0 = 1; r0 <= s; r0 += 8) {                   // up to 8 fine rows of loads in flight
-                    TQ v[8];
+            // the fine rows below the first corner row as one stream of 8-row batches, double-buffered: the loads of the next batch
+            // are in flight while this one is folded (one batch at a time left the wave idle for a memory round trip per box row:
+            // cfg2 slabs at stride 8 / 16 / 32: 23.2 / 27 / 31.3 -> 13.4 / 14.8 / 15.7 us)
+            const int64_t frow0 = j0 * s, nfr = (j1 - j0) * s;
+            const TQ* col = qs + (size_t)frow0 * nx + c;
+            auto load8 = [&](TQ (&v)[8], int64_t r) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int r = (r0 + k <= s) ? r0 + k : s;
-                        v[k] = qs[(size_t)(j * s + r) * nx + c];
-                    }
+                for (int k = 0; k < 8; ++k) { const int64_t rr = (r + k <= nfr) ? r + k : nfr; v[k] = col[(size_t)rr * nx]; }
+            };
+            double vmn = cmn, vmx = cmx;
+            int inbox = 0;
+            int64_t j = j0;
+            auto fold8 = [&](const TQ (&v)[8], int64_t r) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (r0 + k > s) break;                         // wave-uniform
-                        const double x = pn ? qnan : (double)v[k];
-                        vmn = fmin(vmn, x); vmx = fmax(vmx, x);
-                        if (r0 + k == s) { cmn = fmin(inf, x); cmx = fmax(-inf, x); }     // shared with the next box row
+                for (int k = 0; k < 8; ++k) {
+                    if (r + k > nfr) break;                                 // wave-uniform
+                    const double x = pn ? qnan : (double)v[k];
+                    vmn = fmin(vmn, x); vmx = fmax(vmx, x);
+                    if (++inbox == s) {                                     // wave-uniform: the last corner row of this box row
+                        cmn = fmin(inf, x); cmx = fmax(-inf, x);            // ... is the first of the next
+                        int P = 1;                                          // sliding window of w lanes: doubling, then one overlap step
+                        for (; 2 * P <= w; P *= 2) { vmn = fmin(vmn, __shfl_down(vmn, P)); vmx = fmax(vmx, __shfl_down(vmx, P)); }
+                        if (w != P) { vmn = fmin(vmn, __shfl_down(vmn, w - P)); vmx = fmax(vmx, __shfl_down(vmx, w - P)); }
+                        if (box) box_done<TA, CNT>(s_cx, N, vmn, vmx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
+                        ++j; inbox = 0; vmn = cmn; vmx = cmx;
                     }
                 }
-                int P = 1;                                             // sliding window of w lanes: doubling, then one overlap step
-                for (; 2 * P <= w; P *= 2) { vmn = fmin(vmn, __shfl_down(vmn, P)); vmx = fmax(vmx, __shfl_down(vmx, P)); }
-                if (w != P) { vmn = fmin(vmn, __shfl_down(vmn, w - P)); vmx = fmax(vmx, __shfl_down(vmx, w - P)); }
-                if (box) box_done<TA, CNT>(s_cx, N, vmn, vmx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
+            };
+            TQ A[8], B[8];
+            load8(A, 1);
+            for (int64_t r = 1; r <= nfr; r += 16) {
+                if (r + 8 <= nfr) load8(B, r + 8);
+                fold8(A, r);
+                if (r + 8 > nfr) break;
+                if (r + 16 <= nfr) load8(A, r + 16);
+                fold8(B, r + 8);
             }
             continue;
         }
@@ -553,9 +568,7 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
     const int64_t ntj = (nbj + rbox - 1) / rbox;
     const int64_t nti = cols ? ((nbi + nbw - 1) / nbw + 3) / 4 : (nbi + tw - 1) / tw;
     static const int env_blocks = [] { const char* e = getenv("XC_CROSS_BLOCKS"); return e ? atoi(e) : 0; }();     // experiment knob
-    // blocks in all: the column-parallel path (strides 6..63) has one memory round trip per box row and tile in flight per wave
-    // and wants more, shorter blocks (cfg2 slabs, stride 8 / 32: 23.2 / 31.3 -> 19.3 / 25.9 us with 8192); stride 1 is best at 2048
-    int64_t bps = (env_blocks > 0 ? env_blocks : (cols ? 8192 : 2048)) / nslab; if (bps < 8) bps = 8; if (bps > ntj * nti) bps = ntj * nti;
+    int64_t bps = (env_blocks > 0 ? env_blocks : 2048) / nslab; if (bps < 8) bps = 8; if (bps > ntj * nti) bps = ntj * nti;
     const size_t pl = (size_t)nslab * bps * N * 8, pc = (size_t)nslab * bps * N * 4;
     {
         const int rc = ensure_scratch(ctx, ((pl + 255) & ~(size_t)255) + pc);
