@@ -280,6 +280,28 @@ typedef struct xc_keff_desc {
 } xc_keff_desc;
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
 
+/* K5 / K6 alone -- the Keff epilogue without the cell-touching passes (SURVEY 8b `xc_keff_epilogue`): from the per-bin sums of
+ * dA and |grad q|^2 dA (the PDFs xc_hist returns, ascending-VALUE bin order, bin 0 = the dummy bin) to the nine Keff vectors.
+ * Replaces, per slab: cumsum + `cdf[-1] - cdf` when not lt + reversal to level order (core.py:1320-1323, 454-455),
+ * Table.lookup_coordinates (1136-1174), cal_gradient_wrt_area (463-488), cal_sqared_equivalent_length (619-637),
+ * latitude_lengths_at (utils.py:518-534), cal_normalized_Keff (945-966) and, with npre > 0, interp_to_dataset (1050-1100).
+ *   pdf   double[nslab][2][N]   channel 0: sum of dA per bin, channel 1: sum of integrand * dA per bin
+ *   ctr   double[nslab][N]      the contour levels in LEVEL order (ctr_dtype: XC_F32 when they are float32 values: d/dk then
+ *                               runs in float32 like np.gradient on a float32 array)
+ *   tbl / tbl_coord  double[ntbl]  A(Yeq) table, ascending-coordinate order;  preY double[npre] or NULL
+ *   outputs double[nslab][N] each (any may be NULL); interp double[nslab][9][npre] or NULL.
+ * The _dev form takes device pointers and only enqueues; the host form stages through the context's arena. */
+int xc_keff_epilogue_dev(xc_ctx* ctx, const double* pdf, const double* ctr, int ctr_dtype, int64_t nslab, int N,
+                         int increase, int lt, const double* tbl, const double* tbl_coord, int ntbl,
+                         const double* preY, int npre, double nkeff_mask, double lmin_scale,
+                         double* area, double* intgrdS, double* latEq, double* dqdA, double* dintSdA,
+                         double* Leq2, double* Lmin, double* nkeff, double* interp);
+int xc_keff_epilogue(xc_ctx* ctx, const double* pdf, const double* ctr, int ctr_dtype, int64_t nslab, int N,
+                     int increase, int lt, const double* tbl, const double* tbl_coord, int ntbl,
+                     const double* preY, int npre, double nkeff_mask, double lmin_scale,
+                     double* area, double* intgrdS, double* latEq, double* dqdA, double* dintSdA,
+                     double* Leq2, double* Lmin, double* nkeff, double* interp);
+
 /* Schedules of xc_keff_dev.
  * XC_KEFF_TWO_PASS: the streaming path -- min/max pass (K1, or partials chained from the previous call, q_next), then
  *   the histogram pass (K3).  The tracer crosses the fabric twice; no synchronisation between workgroups.

@@ -177,6 +177,36 @@ def test_keff_ocean_call_sequence_with_land_mask(ctx, dt):
     assert rel(ds['latEq'].values, o_Yeq) < 1e-9
 
 
+@pytest.mark.parametrize('increase', [True, False])
+@pytest.mark.parametrize('lt', [True, False])
+@pytest.mark.parametrize('cd', [np.float32, np.float64])
+def test_keff_epilogue_alone(ctx, baro, increase, lt, cd):
+    """xc_keff_epilogue (K5 / K6 without the cell-touching passes): PDFs from numpy's own histogram of the barotropic field go
+    in, the nine Keff vectors and their interpolation to the latitudes come out -- against the oracle's step-by-step sequence"""
+    q, lat, lon = baro
+    dA = O.cell_area(lat, lon)
+    N = 121
+    r = O.keff_pipeline(q, dA, lat, N, lon=lon, increase=increase, lt=lt, dtype=cd, preLats=lat.astype(np.float64))
+    ctr = r['ctr']
+    g2 = O.grad2_sphere(q, lat, lon)
+    e, _ = O.hist_edges(ctr)                                         # ascending-value edges (core.py:1296-1305)
+    w1 = np.where(np.isnan(g2 * dA), 0.0, g2 * dA)
+    pdf = np.stack([O.weighted_histogram(q, e, dA)[0], O.weighted_histogram(q, e, w1)[0]])[None]      # np.digitize + np.bincount
+    out = ctx.keff_epilogue(pdf, ctr[None].astype(np.float64), r['tbl'], r['tbl_coord'], increase=increase, lt=lt,
+                            ctr_dtype=cd, preY=lat.astype(np.float64))
+    assert rel(out['area'][0], r['area']) < TIGHT and rel(out['intgrdS'][0], r['intgrdS']) < TIGHT
+    for k in ('latEq', 'dqdA', 'dintSdA', 'Leq2'):
+        assert rel(out[k][0], r[k]) < RTOL, k
+    assert rel(out['Lmin'][0], r['Lmin'], LMIN_FLOOR) < RTOL
+    okm = r['Lmin'] > LMIN_FLOOR
+    assert rel(out['nkeff'][0][okm], r['nkeff'][okm]) < RTOL
+    names = ('ctr', 'area', 'intgrdS', 'latEq', 'dintSdA', 'dqdA', 'Leq2', 'Lmin', 'nkeff')
+    for v in (0, 1, 3):
+        assert rel(out['interp'][0, v], r[names[v] + '_eq']) < RTOL, names[v]
+    with pytest.raises(Exception):
+        ctx.keff_epilogue(pdf, ctr[None].astype(np.float64), r['tbl'][:1], r['tbl_coord'][:1])      # a table needs >= 2 entries
+
+
 # ---------------------------------------------------------------- BASELINE configs[3]: 1440x721 f64 slabs, per-slab levels, chained
 def test_cfg4_shape_chained_launch_sets(ctx):
     """74 slabs of 721x1440 f64 generated on device (seed + slab id), N = 201, processed in two chained launch sets of

@@ -110,6 +110,10 @@ PROTOTYPES = {
     'xc_sort_profile_batch': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i64, _i64, _i64, C.c_int,
                                         _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'xc_keff_dev': (C.c_int, [_vp, C.POINTER(KeffDesc)]),
+    'xc_keff_epilogue_dev': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int,
+                                       C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'xc_keff_epilogue': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int,
+                                   C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xc_set_keff_mode': (C.c_int, [_vp, C.c_int]),
     'xc_last_keff_path': (C.c_int, [_vp, C.POINTER(C.c_int)]),
     'xc_dbg_set_stamps': (C.c_int, [_vp, _vp]),
@@ -415,6 +419,27 @@ class Context(object):
         out = np.empty(ny, dtype=np.float64)
         self._check(self.lib.xc_rowsum(self.handle, _ptr(mask), dtype_code(mask.dtype) if mask is not None else XC_F64,
                                        _ptr(dA), rank, ny, nx, 1 if multiply else 0, _ptr(out)))
+        return out
+
+    def keff_epilogue(self, pdf, ctr, tbl, tbl_coord, increase=True, lt=True, ctr_dtype=np.float64, preY=None,
+                      nkeff_mask=1e5, lmin_scale=2.0 * np.pi * 6371200.0):
+        """K5 / K6 alone (xc_keff_epilogue): pdf (nslab, 2, N) per-bin sums of dA and integrand * dA in ascending-value bin
+        order, ctr (nslab, N) levels in level order -> dict of the Keff vectors (nslab, N) (+ 'interp' (nslab, 9, npre))."""
+        pdf = np.ascontiguousarray(pdf, dtype=np.float64); ctr = np.ascontiguousarray(ctr, dtype=np.float64)
+        assert pdf.ndim == 3 and pdf.shape[1] == 2 and ctr.shape == (pdf.shape[0], pdf.shape[2])
+        nslab, _, N = pdf.shape
+        tbl = np.ascontiguousarray(tbl, dtype=np.float64); crd = np.ascontiguousarray(tbl_coord, dtype=np.float64)
+        assert tbl.shape == crd.shape and tbl.ndim == 1
+        names = ('area', 'intgrdS', 'latEq', 'dqdA', 'dintSdA', 'Leq2', 'Lmin', 'nkeff')
+        out = {k: np.empty((nslab, N), dtype=np.float64) for k in names}
+        pre = None if preY is None else np.ascontiguousarray(preY, dtype=np.float64)
+        interp = None if pre is None else np.empty((nslab, 9, len(pre)), dtype=np.float64)
+        self._check(self.lib.xc_keff_epilogue(self.handle, _ptr(pdf), _ptr(ctr), dtype_code(np.dtype(ctr_dtype)), nslab, N,
+                                              1 if increase else 0, 1 if lt else 0, _ptr(tbl), _ptr(crd), len(tbl),
+                                              _ptr(pre), 0 if pre is None else len(pre), float(nkeff_mask), float(lmin_scale),
+                                              *[_ptr(out[k]) for k in names], _ptr(interp)))
+        if interp is not None:
+            out['interp'] = interp
         return out
 
     def grad2(self, q, rdx, rdy, periodic_x=True):

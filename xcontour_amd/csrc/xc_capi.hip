@@ -695,6 +695,67 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
                                  out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
 }
 
+// ------------------------------------------------------------------------------------ K5 / K6 alone
+int xc_keff_epilogue_dev(xc_ctx* ctx, const double* pdf, const double* ctr, int ctr_dtype, int64_t nslab, int N,
+                         int increase, int lt, const double* tbl, const double* tbl_coord, int ntbl,
+                         const double* preY, int npre, double nkeff_mask, double lmin_scale,
+                         double* area, double* intgrdS, double* latEq, double* dqdA, double* dintSdA,
+                         double* Leq2, double* Lmin, double* nkeff, double* interp)
+{
+    XC_CTX(ctx);
+    if (!pdf || !ctr || !tbl || !tbl_coord) return fail(ctx, XC_EBADARG, "xc_keff_epilogue: pdf / ctr / tbl / tbl_coord must be given");
+    if (nslab < 1 || N < 2 || ntbl < 2 || npre < 0) return fail(ctx, XC_EBADARG, "xc_keff_epilogue: need nslab >= 1, N >= 2, ntbl >= 2");
+    if (ctr_dtype != XC_F32 && ctr_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_keff_epilogue: bad ctr_dtype");
+    if (npre > 0 && interp && !preY) return fail(ctx, XC_EBADARG, "xc_keff_epilogue: preY is NULL");
+    // the reduce stage sums ONE "partial" per slab (the pdf itself); its count channel reads zeros
+    const int nch = 2;
+    const size_t S = (size_t)nslab;
+    const size_t pc = al(S * N * sizeof(unsigned)), rh = al(S * nch * N * sizeof(double)), rc = al(S * N * sizeof(unsigned long long));
+    XC_TRY(ensure_scratch(ctx, pc + rh + rc));
+    char* base = (char*)ctx->scratch;
+    XC_HIP(ctx, hipMemsetAsync(base, 0, pc, ctx->stream));
+    ctx->mm_valid = 0;                          // the scratch may have moved
+    FinalArgs f; memset(&f, 0, sizeof(f));
+    f.part_h = pdf; f.part_c = (const unsigned*)base; f.bps = 1; f.nch = nch; f.nbin = N;
+    f.red_h = (double*)(base + pc); f.red_c = (unsigned long long*)(base + pc + rh);
+    f.lt = lt; f.reverse = !increase;
+    f.keff = 1; f.ctr_f32 = ctr_dtype == XC_F32; f.ctr = ctr;
+    f.tbl = tbl; f.tbl_coord = tbl_coord; f.ntbl = ntbl;
+    f.preY = preY; f.npre = interp ? npre : 0;
+    f.nkeff_mask = nkeff_mask; f.lmin_scale = lmin_scale;
+    f.o_area = area; f.o_intS = intgrdS; f.o_latEq = latEq; f.o_dqdA = dqdA; f.o_dSdA = dintSdA;
+    f.o_Leq2 = Leq2; f.o_Lmin = Lmin; f.o_nkeff = nkeff; f.o_interp = interp;
+    return launch_finalize(ctx, nslab, f);
+}
+
+int xc_keff_epilogue(xc_ctx* ctx, const double* pdf, const double* ctr, int ctr_dtype, int64_t nslab, int N,
+                     int increase, int lt, const double* tbl, const double* tbl_coord, int ntbl,
+                     const double* preY, int npre, double nkeff_mask, double lmin_scale,
+                     double* area, double* intgrdS, double* latEq, double* dqdA, double* dintSdA,
+                     double* Leq2, double* Lmin, double* nkeff, double* interp)
+{
+    XC_CTX(ctx);
+    if (!pdf || !ctr || !tbl || !tbl_coord || nslab < 1 || N < 2 || ntbl < 2 || npre < 0)
+        return fail(ctx, XC_EBADARG, "xc_keff_epilogue: bad arguments");
+    const size_t S = (size_t)nslab, vb = S * N * 8, pb = 2 * vb, tb = (size_t)ntbl * 8, yb = (size_t)npre * 8, ib = S * 9 * npre * 8;
+    XC_TRY(ensure_arena(ctx, al(pb) + al(vb) + 2 * al(tb) + al(yb) + 8 * al(vb) + al(ib)));
+    Stage st(ctx);
+    double* dp = (double*)st.take(pb); double* dc = (double*)st.take(vb);
+    double* dt = (double*)st.take(tb); double* dy = (double*)st.take(tb);
+    double* dpre = npre > 0 ? (double*)st.take(yb) : nullptr;
+    double* o[8]; for (int i = 0; i < 8; ++i) o[i] = (double*)st.take(vb);
+    double* di = (interp && npre > 0) ? (double*)st.take(ib) : nullptr;
+    XC_TRY(h2d(ctx, dp, pdf, pb)); XC_TRY(h2d(ctx, dc, ctr, vb));
+    XC_TRY(h2d(ctx, dt, tbl, tb)); XC_TRY(h2d(ctx, dy, tbl_coord, tb));
+    if (dpre) { if (!preY) return fail(ctx, XC_EBADARG, "xc_keff_epilogue: preY is NULL"); XC_TRY(h2d(ctx, dpre, preY, yb)); }
+    XC_TRY(xc_keff_epilogue_dev(ctx, dp, dc, ctr_dtype, nslab, N, increase, lt, dt, dy, ntbl, dpre, npre, nkeff_mask, lmin_scale,
+                                o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], di));
+    double* host[8] = {area, intgrdS, latEq, dqdA, dintSdA, Leq2, Lmin, nkeff};
+    for (int i = 0; i < 8; ++i) if (host[i]) XC_TRY(d2h(ctx, host[i], o[i], vb));
+    if (interp && di) XC_TRY(d2h(ctx, interp, di, ib));
+    return xc_sync(ctx);
+}
+
 // ------------------------------------------------------------------------------------ fused Keff pipeline
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
 {
