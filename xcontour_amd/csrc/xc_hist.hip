@@ -9,18 +9,22 @@
 //   * a slab is [ny][nx], X fastest.  It is cut into column strips of W = 64*VEC
 //     cells (VEC cells per lane, one 8/16-byte load per lane per row: fully
 //     coalesced 512 B / 1 KiB per wave-instruction).
-//   * the (strip, row) pairs of a slab are linearised strip-major and divided
-//     EVENLY over all waves of the slab's blocks: every wave sweeps ~the same
-//     number of rows top-to-bottom inside a strip, so y-neighbours live in
-//     registers and x-neighbours come from the adjacent lane (__shfl) plus one
-//     2-lane halo load per row.
-//   * bin search: uniform guess + fix-up against the explicit f64 edges in LDS
-//     (exactly np.digitize semantics, any ascending edges).
+//   * a wave sweeps a chunk of consecutive rows top-to-bottom inside a strip, so
+//     y-neighbours live in registers and x-neighbours come from the adjacent lane
+//     (DPP) plus one halo load per row.  Wave w of a slab takes strip w % nstrip of
+//     row chunk w / nstrip: the waves of a workgroup sweep the same rows of adjacent
+//     strips side by side and a halo line is a line the neighbour wave streams at
+//     the same moment (an L2 hit).  Fallback when a slab has fewer waves than
+//     strips: the (strip, row) pairs linearised strip-major and divided evenly.
+//   * bin search: nearest-edge guess + ONE exact comparison against the f64 edge
+//     in LDS when the edges are equally spaced (checked per slab), else a bracket
+//     test + fix-up (exactly np.digitize semantics, any ascending edges).
 //   * accumulation: rows whose 64*VEC cells all fall in one bin (the common case
 //     on smooth geophysical fields) accumulate in per-lane registers with no
 //     cross-lane traffic; other rows use LDS atomics on `ncopy` lane-privatised
-//     histogram copies.  Per-block partials are written with plain stores and
-//     reduced in fixed order by k_finalize: no global atomics.
+//     copies of one CELL per bin (sums and count side by side; bin N is a trash bin
+//     for dropped cells).  Per-block partials are written with plain stores and
+//     reduced in fixed order by k_reduce_partials: no global atomics.
 #include "xc_internal.h"
 #include <stdlib.h>
 
