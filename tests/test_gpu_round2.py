@@ -242,6 +242,37 @@ def test_cfg4_shape_chained_launch_sets(ctx):
     plan.free()
 
 
+@pytest.mark.parametrize('nx', [1440, 1040])
+def test_float32_tracers_four_cells_per_lane(ctx, nx):
+    """float32 tracers with nx % 4 == 0 and nx >= 1024 take the four-cells-per-lane histogram variant (256-column strips; 1040
+    columns leave a ragged last strip of 16) in the Keff FAST layout: chained and unchained launch sets, NaNs, both contour
+    dtypes -- counts against the oracle on every slab, all nine vectors on three"""
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
+    rng = np.random.default_rng(nx)
+    ny, N, S = 181, 121, 10
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * (360.0 / nx)
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, ny, nx), True, last_row_included(lat))
+    q = (np.sin(np.deg2rad(lat))[None, :, None] * (1 + 0.2 * rng.random((S, 1, 1))) + 0.05 * rng.standard_normal((S, ny, nx))).astype(np.float32)
+    q[2, 40:44, 100:300] = np.nan; q[7, :, 5] = np.nan
+    for cd in (np.float32, np.float64):
+        plan = KeffPlan(ctx, S, ny, nx, N, np.float32, cd, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=True, lt=True, nslots=2)
+        plan.set_q(q)
+        plan.run(0)                                   # unchained
+        plan.run(1, 5, chain=True)                    # two chained launch sets of 5
+        ref, b = plan.fetch(slot=0), plan.fetch(slot=1)
+        assert np.array_equal(b['ctr'], ref['ctr']) and np.array_equal(b['counts'], ref['counts'])
+        assert rel(b['area'], ref['area']) < 1e-13 and rel(b['intgrdS'], ref['intgrdS']) < 1e-13
+        for s in range(S):
+            ctr = O.cal_contours(q[s], N, True, cd)
+            _, cnt = O.cal_integral_within_contours_hist(q[s], ctr, dA, None, True, return_counts=True)
+            assert np.array_equal(b['counts'][s].astype(np.int64), cnt), s
+        for s in (0, 2, 7):
+            check_nine(b, s, O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=True, lt=True, dtype=cd))
+        plan.free()
+
+
 # ---------------------------------------------------------------- ADVICE r1: the chained min/max cache must not go stale
 def test_chain_then_new_batch_is_not_stale(ctx):
     """run(chain=True) leaves min/max partials keyed on the batch pointer; set_q / synth / a raw upload / touch() of a

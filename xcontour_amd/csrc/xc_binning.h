@@ -13,6 +13,15 @@ template <> struct RowLoad<double, 2> {
     static __device__ __forceinline__ void ld(const double* p, double (&v)[2]) {
         const double2 t = *reinterpret_cast<const double2*>(p); v[0] = t.x; v[1] = t.y; }
 };
+template <> struct RowLoad<double, 4> {        // two 16-byte loads per lane: 2 KiB per wave and row
+    static __device__ __forceinline__ void ld(const double* p, double (&v)[4]) {
+        const double2 t = *reinterpret_cast<const double2*>(p), u = *reinterpret_cast<const double2*>(p + 2);
+        v[0] = t.x; v[1] = t.y; v[2] = u.x; v[3] = u.y; }
+};
+template <> struct RowLoad<float, 4> {
+    static __device__ __forceinline__ void ld(const float* p, double (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p); v[0] = (double)t.x; v[1] = (double)t.y; v[2] = (double)t.z; v[3] = (double)t.w; }
+};
 template <> struct RowLoad<double, 1> {
     static __device__ __forceinline__ void ld(const double* p, double (&v)[1]) { v[0] = *p; }
 };
@@ -32,6 +41,18 @@ template <typename T, int VEC> struct RowLoadNT;
 template <> struct RowLoadNT<double, 2> {
     static __device__ __forceinline__ void ld(const double* p, double (&v)[2]) {
         const xc_d2v t = __builtin_nontemporal_load(reinterpret_cast<const xc_d2v*>(p)); v[0] = t.x; v[1] = t.y; }
+};
+typedef float xc_f4v __attribute__((ext_vector_type(4)));
+template <> struct RowLoadNT<double, 4> {
+    static __device__ __forceinline__ void ld(const double* p, double (&v)[4]) {
+        const xc_d2v t = __builtin_nontemporal_load(reinterpret_cast<const xc_d2v*>(p));
+        const xc_d2v u = __builtin_nontemporal_load(reinterpret_cast<const xc_d2v*>(p + 2));
+        v[0] = t.x; v[1] = t.y; v[2] = u.x; v[3] = u.y; }
+};
+template <> struct RowLoadNT<float, 4> {
+    static __device__ __forceinline__ void ld(const float* p, double (&v)[4]) {
+        const xc_f4v t = __builtin_nontemporal_load(reinterpret_cast<const xc_f4v*>(p));
+        v[0] = (double)t.x; v[1] = (double)t.y; v[2] = (double)t.z; v[3] = (double)t.w; }
 };
 template <> struct RowLoadNT<double, 1> {
     static __device__ __forceinline__ void ld(const double* p, double (&v)[1]) { v[0] = __builtin_nontemporal_load(p); }

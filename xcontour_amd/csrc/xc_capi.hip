@@ -818,8 +818,10 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     HistGeom g;
     {
         const void* gi[1] = {d->grdS}; const int32_t gt[1] = {d->grdS_dtype};
+        const bool fast_layout = d->grad && (d->dA_rank == XC_DA_PLANE || d->dA_rank == XC_DA_SLAB) && d->periodic_x &&
+                                 d->dA_pos_finite && d->right_edge != XC_EDGE_NUMPY;
         XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, nch,
-                             vec_align_bits(d->q, d->q_dtype, d->q_next, d->dA, d->dA_rank, gi, gt, d->grad ? 0 : 1), &g));
+                             vec_align_bits(d->q, d->q_dtype, d->q_next, d->dA, d->dA_rank, gi, gt, d->grad ? 0 : 1), &g, fast_layout ? 1 : 0));
     }
     const size_t mb = al((size_t)d->nslab * kMinmaxBlocks * 2 * sizeof(double));
     const size_t ph = al((size_t)d->nslab * g.bps * nch * N * sizeof(double));

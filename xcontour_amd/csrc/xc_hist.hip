@@ -42,7 +42,7 @@ namespace {
 #ifndef XC_HIST_QNT
 #define XC_HIST_QNT 2
 #endif
-constexpr int U = XC_U;   // rows per prefetch batch (double-buffered)
+template <int VEC> struct RowsPerBatch { static constexpr int value = VEC >= 4 ? 1 : XC_U; };   // rows per prefetch batch (double-buffered): the same bytes in flight
 
 // Grid mapping (1-D grid).  Workgroups go round-robin to the 8 XCDs (workgroup id % 8), each XCD has its own
 // L2, and every slab of a launch reads the SAME dA rows in its block `bx`.  XCD-aware order (default): XCD x
@@ -82,6 +82,7 @@ void k_hist(const HistArgs a)
 {
     constexpr int NCH = 1 + NINT + (GRAD ? 1 : 0);
     constexpr int W = 64 * VEC;
+    constexpr int U = RowsPerBatch<VEC>::value;
     extern __shared__ __align__(16) double smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -583,7 +584,7 @@ int launch_nint(xc_ctx* ctx, int nint, int grad, const HistGeom& g, int64_t nsla
 // a kernel is never launched on shapes it does not assume (ny, nx >= 1; nx even for
 // VEC = 2; 16-byte aligned rows for the vector loads).
 int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int nbin, int nch,
-                  const void* q, HistGeom* g)
+                  const void* q, HistGeom* g, int keff_fast_layout)
 {
     if (nslab < 1 || ny < 1 || nx < 1) return fail(ctx, XC_EBADARG, "xc_hist: nslab, ny, nx must be >= 1");
     if (nbin < 1) return fail(ctx, XC_EBADARG, "xc_hist: need at least 2 edges");
@@ -593,6 +594,15 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     // (`q` here is the OR of every streamed pointer's low bits, see vec_align_bits)
     const bool even = (nx % 2) == 0 && (reinterpret_cast<uintptr_t>(q) % (2 * esz)) == 0;
     g->vec = even ? 2 : 1;
+    {
+        // Four cells per lane (256-column strips, one 16-byte load per lane and row for float32): instantiated for the Keff FAST
+        // layout only (xc_keff_dev says when its call qualifies).  Measured on cfg2-sized stacks: float32 tracers 14.7 -> 13.2 us
+        // per slab chained, 16.7 -> 15.5 unchained (half the per-row fixed work and halo loads per cell); float64 tracers LOSE
+        // (chained 1.14 -> 1.44 ms per 64 slabs, cfg4 +17 %), so the default is float32 only.  XC_HIST_VEC4: 0 never, 1 always.
+        static const int env_v4 = [] { const char* e = getenv("XC_HIST_VEC4"); return e ? atoi(e) : -1; }();
+        const bool want = env_v4 < 0 ? (q_dtype == XC_F32) : (env_v4 != 0);
+        if (want && keff_fast_layout && even && nx % 4 == 0 && nx >= 1024 && (reinterpret_cast<uintptr_t>(q) % 16) == 0) g->vec = 4;
+    }
     if (ny > 0x7fffffff || nx > 0x7fffffff || (int64_t)((nx + 127) / 128) * ny > 0x7fffffffLL)
         return fail(ctx, XC_EBADARG, "xc_hist: slab too large (ny, nx and strips*ny must fit 31 bits)");
     const int W = 64 * g->vec;
@@ -647,6 +657,16 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
 
 int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a)
 {
+    if (g.vec == 4) {                                    // chosen by hist_geometry for the Keff FAST layout only
+        const bool da2d = a.dA_rank == XC_DA_PLANE || a.dA_rank == XC_DA_SLAB;
+        if (nint != 0 || !grad || !da2d || !a.periodic_x || !a.dA_pos_finite || a.negate || a.last_closed)
+            return fail(ctx, XC_EBADARG, "xc_hist: the four-cell variant exists for the Keff FAST layout only");
+        if (q_dtype == XC_F64)
+            return a.q_next ? launch_three<double, 4, 0, true, true, true, true>(ctx, g, nslab, a)
+                            : launch_three<double, 4, 0, true, true, false, true>(ctx, g, nslab, a);
+        return a.q_next ? launch_three<float, 4, 0, true, true, true, true>(ctx, g, nslab, a)
+                        : launch_three<float, 4, 0, true, true, false, true>(ctx, g, nslab, a);
+    }
     if (q_dtype == XC_F64) {
         return g.vec == 2 ? launch_nint<double, 2>(ctx, nint, grad, g, nslab, a)
                           : launch_nint<double, 1>(ctx, nint, grad, g, nslab, a);

@@ -64,7 +64,7 @@ constexpr size_t kLdsBudget = 150 * 1024;
 
 struct HistGeom {
     int threads;    // threads per block (multiple of 64, <= kHistThreads)
-    int vec;        // cells per lane per row load (1 or 2)
+    int vec;        // cells per lane per row load (1, 2 or 4)
     int nstrip;     // column strips of 64*vec cells
     int bps;        // blocks per slab
     int ncopy;      // LDS histogram copies (power of two)
@@ -178,7 +178,7 @@ int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, int P, d
 int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
                   int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status);
 int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int nbin, int nch,
-                  const void* q, HistGeom* g);
+                  const void* q, HistGeom* g, int keff_fast_layout = 0);
 int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a);
 int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a);
 int launch_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
