@@ -271,6 +271,19 @@ def test_float32_tracers_four_cells_per_lane(ctx, nx):
         for s in (0, 2, 7):
             check_nine(b, s, O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=True, lt=True, dtype=cd))
         plan.free()
+    # the reference's own workflow: a SUPPLIED float32 squared gradient (its notebooks pass grdSpv) -- same variant, other layout
+    g2 = np.stack([O.grad2_sphere(q[s], lat, lon) for s in range(S)]).astype(np.float32)
+    g2[3, 10, 20:40] = np.nan                                             # fillna(0) on the product, core.py:449
+    plan = KeffPlan(ctx, S, ny, nx, N, np.float32, np.float32, dA=dA, tbl=tbl, tbl_coord=lat, increase=True, lt=True,
+                    grdS_dtype=np.float32, nslots=2)
+    plan.set_q(q); plan.set_grdS(g2)
+    plan.run(0); plan.run(1, 5, chain=True)
+    ref, b = plan.fetch(slot=0), plan.fetch(slot=1)
+    assert np.array_equal(b['counts'], ref['counts']) and rel(b['intgrdS'], ref['intgrdS']) < 1e-13
+    for s in (0, 3, 9):
+        r = O.keff_pipeline(q[s], dA, lat, N, grdS=g2[s], increase=True, lt=True, dtype=np.float32)
+        check_nine(b, s, r)
+    plan.free()
 
 
 # ---------------------------------------------------------------- the chained min/max cache must not go stale

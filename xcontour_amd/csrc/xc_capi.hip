@@ -818,10 +818,14 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     HistGeom g;
     {
         const void* gi[1] = {d->grdS}; const int32_t gt[1] = {d->grdS_dtype};
-        const bool fast_layout = d->grad && (d->dA_rank == XC_DA_PLANE || d->dA_rank == XC_DA_SLAB) && d->periodic_x &&
-                                 d->dA_pos_finite && d->right_edge != XC_EDGE_NUMPY;
+        const bool da2d = d->dA_rank == XC_DA_PLANE || d->dA_rank == XC_DA_SLAB;
+        const bool fast_layout = d->grad && da2d && d->periodic_x && d->dA_pos_finite && d->right_edge != XC_EDGE_NUMPY;
+        // float32 tracer with a supplied float32 squared gradient (the reference's own workflow): four cells per lane too
+        const bool supplied_f32 = !d->grad && da2d && d->q_dtype == XC_F32 && d->grdS_dtype == XC_F32 &&
+                                  reinterpret_cast<uintptr_t>(d->grdS) % 16 == 0;
         XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, nch,
-                             vec_align_bits(d->q, d->q_dtype, d->q_next, d->dA, d->dA_rank, gi, gt, d->grad ? 0 : 1), &g, fast_layout ? 1 : 0));
+                             vec_align_bits(d->q, d->q_dtype, d->q_next, d->dA, d->dA_rank, gi, gt, d->grad ? 0 : 1), &g,
+                             fast_layout ? 1 : (supplied_f32 ? 2 : 0)));
     }
     const size_t mb = al((size_t)d->nslab * kMinmaxBlocks * 2 * sizeof(double));
     const size_t ph = al((size_t)d->nslab * g.bps * nch * N * sizeof(double));

@@ -602,6 +602,7 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
         static const int env_v4 = [] { const char* e = getenv("XC_HIST_VEC4"); return e ? atoi(e) : -1; }();
         const bool want = env_v4 < 0 ? (q_dtype == XC_F32) : (env_v4 != 0);
         if (want && keff_fast_layout && even && nx % 4 == 0 && nx >= 1024 && (reinterpret_cast<uintptr_t>(q) % 16) == 0) g->vec = 4;
+        if (keff_fast_layout == 2 && q_dtype != XC_F32) g->vec = even ? 2 : 1;      // the supplied-grdS variant exists for float32 only
     }
     if (ny > 0x7fffffff || nx > 0x7fffffff || (int64_t)((nx + 127) / 128) * ny > 0x7fffffffLL)
         return fail(ctx, XC_EBADARG, "xc_hist: slab too large (ny, nx and strips*ny must fit 31 bits)");
@@ -657,10 +658,13 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
 
 int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a)
 {
-    if (g.vec == 4) {                                    // chosen by hist_geometry for the Keff FAST layout only
+    if (g.vec == 4) {                                    // chosen by hist_geometry for the two Keff layouts only (xc_keff_dev)
         const bool da2d = a.dA_rank == XC_DA_PLANE || a.dA_rank == XC_DA_SLAB;
+        if (!grad && nint == 1 && da2d && q_dtype == XC_F32 && a.integ_f32[0] && !a.negate)      // float32 tracer + supplied float32 grdS
+            return a.q_next ? launch_three<float, 4, 1, false, true, true, false>(ctx, g, nslab, a)
+                            : launch_three<float, 4, 1, false, true, false, false>(ctx, g, nslab, a);
         if (nint != 0 || !grad || !da2d || !a.periodic_x || !a.dA_pos_finite || a.negate || a.last_closed)
-            return fail(ctx, XC_EBADARG, "xc_hist: the four-cell variant exists for the Keff FAST layout only");
+            return fail(ctx, XC_EBADARG, "xc_hist: the four-cell variant exists for the Keff layouts only");
         if (q_dtype == XC_F64)
             return a.q_next ? launch_three<double, 4, 0, true, true, true, true>(ctx, g, nslab, a)
                             : launch_three<double, 4, 0, true, true, false, true>(ctx, g, nslab, a);
