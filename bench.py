@@ -24,6 +24,14 @@ batch of min/max AND one batch of histogram + epilogue (nothing is skipped or re
 bit-identical to the unchained order, tests/test_gpu_parity.py::test_chained_minmax_is_bit_identical);
 the stand-alone min/max launch merely disappears.  `--no-chain` runs K1 then K3 per step.
 
+After the timed region rank 0's line also carries (all outside the timed region, all parity-checked):
+  * `variants.slab_dA` -- the same chained schedule with per-slab (time-varying) weights: every byte of the 16 B/cell
+    numerator is then unique HBM traffic, so `frac == hbm_unique_frac` is a genuine HBM fraction;
+  * `long_run` -- >= 0.5 s of the same steps with HIP events around every histogram launch (mean / spread);
+  * `cfg4_strong` -- BASELINE.json configs[3]: 18 944 slabs of 1440 x 721 float64 partitioned contiguously over the
+    ranks (strong scaling: total work fixed), Keff per slab, ONE gather of all nine result vectors inside its own
+    timed region (barrier + sync on both sides, max over ranks).
+
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel = the histogram pass, timed
 with HIP events on its own stream around every launch of the timed region) and, at N=1,
 `cpu_baseline` (the numpy oracle = a port of the reference's xarray/xhistogram call
@@ -162,6 +170,179 @@ def cpu_baseline(q_host, gpu_out, ncheck):
     }
 
 
+# ----------------------------------------------------------------------------- helpers
+def hist_source_sha():
+    """sha256 over the sources of the dominant kernel: a stored PMC traffic figure is quoted only while they are unchanged"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('xc_hist.hip', 'xc_hist_kernel.h', 'xc_binning.h'):
+        h.update(open(os.path.join(ROOT, 'xcontour_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()
+
+
+def stored_traffic(key, B):
+    """fabric bytes per launch of the dominant kernel from profiles/hist_traffic.json (rocprofv3 --pmc, separate passes:
+    tools/pmc_bench_traffic.sh) -- or None when the file is missing, was taken at another batch size, or was taken
+    with OTHER kernel sources than the ones in this tree (sha256 of xc_hist.hip + xc_hist_kernel.h + xc_binning.h)."""
+    tf = os.path.join(ROOT, 'profiles', 'hist_traffic.json')
+    try:
+        tj = json.load(open(tf))
+        if tj.get('source_sha256') != hist_source_sha():
+            return None, 'profiles/hist_traffic.json was measured on other kernel sources (sha256 mismatch): not quoted'
+        e = tj.get(key, {})
+        if e.get('slabs_per_launch') != B or e.get('hbm_bytes_per_launch') is None:
+            return None, 'no PMC entry for this schedule / batch size'
+        return e['hbm_bytes_per_launch'], ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_bench_traffic.sh) at commit %s, '
+                                           'same kernel sources as this tree (sha256 %s); not re-measured in this run'
+                                           % (e.get('commit', tj.get('commit')), tj['source_sha256'][:16]))
+    except Exception as ex:            # noqa: BLE001 -- a missing / malformed file only nulls the optional figure
+        return None, 'profiles/hist_traffic.json unreadable: %s' % ex
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if not np.array_equal(np.isnan(a), np.isnan(b)):
+        return np.inf
+    m = np.isfinite(b) & (b != 0)
+    return float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m]))) if m.any() else 0.0
+
+
+# ----------------------------------------------------------------------------- cfg4: strong scaling over the ranks
+def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
+    """BASELINE.json configs[3]: `--cfg4-slabs` (18 944 = 512 x 37) slabs of 1440 x 721 float64, Keff per slab with per-slab
+    levels; the flattened (time, level) index is cut into contiguous blocks of ceil(S/G) slabs (pipeline.shard_slabs), every
+    rank sweeps its block in chained launch sets of `--cfg4-chunk` slabs, and ONE all-gather of the nine per-slab result
+    vectors ends the job.  A job = sweep + gather; `--cfg4-reps` jobs are timed between barriers, max over ranks."""
+    from xcontour_amd.pipeline import KeffPlan, shard_slabs, OUT_NAMES
+    from xcontour_amd.distributed import all_gather_slabs, chunks_to_slabs
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
+    import ctypes as C
+    NY4, NX4 = 721, 1440
+    S, R = int(a.cfg4_slabs), max(1, int(a.cfg4_reps))
+    lat = np.linspace(-90, 90, NY4)
+    lon = np.arange(NX4) * 0.25
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, NY4, NX4), True, last_row_included(lat, 'xhistogram'))
+    lo, hi = shard_slabs(S, rank, world)
+    n = hi - lo
+    Cn = min(int(a.cfg4_chunk), max(n, 1))
+    nchunk = -(-n // Cn) if n else 0
+    slab_bytes = NY4 * NX4 * 8
+    qbuf, err = None, ''
+    try:
+        qbuf = ctx.alloc(max(n, 1) * slab_bytes)                 # this rank's block of the stack, resident in HBM
+    except nat.XContourHipError as e:
+        err = str(e)
+    ok = torch.tensor([0 if qbuf is None else 1], dtype=torch.int32, device=gdev)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                # every rank skips if one could not hold its block
+    if int(ok.item()) == 0:
+        if qbuf is not None:
+            qbuf.free()
+        return {'skipped': 'a rank could not allocate its %d-slab block (%.1f GB): %s' % (n, n * slab_bytes / 1e9, err)}
+    lat_b, lon_b = ctx.to_device(lat), ctx.to_device(lon)
+    for c0 in range(0, n, Cn):                                   # slab s of the stack: seed + s, whatever rank owns it
+        m = min(Cn, n - c0)
+        ctx._check(ctx.lib.xc_synth_dev(ctx.handle, qbuf.ptr + c0 * slab_bytes, nat.XC_F64, m, NY4, NX4,
+                                        lat_b.ptr, lon_b.ptr, SEED + lo + c0, 0))
+    ctx.sync()
+    slot = KeffPlan.out_bytes(Cn, NCONT)
+    res = torch.zeros(max(nchunk, 1) * slot // 8, dtype=torch.float64, device='cuda')
+    plan = KeffPlan(ctx, Cn, NY4, NX4, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                    increase=True, lt=True, nslots=max(nchunk, 1), out_ptr=res.data_ptr(), alloc_q=False, right_edge='xhistogram')
+
+    def sweep():
+        for ci in range(nchunk):
+            c0 = ci * Cn
+            m = min(Cn, n - c0)
+            plan.set_q_device(qbuf.ptr + c0 * slab_bytes)
+            nxt = ((ci + 1) % nchunk) * Cn
+            chain = min(Cn, n - nxt) == m                          # equal-shape launch sets chain their min/max (q_next)
+            plan._point(ci, 0, m)
+            plan.desc.q_next = (qbuf.ptr + nxt * slab_bytes) if chain else None
+            ctx._check(ctx.lib.xc_keff_dev(ctx.handle, C.byref(plan.desc)))
+
+    def job():
+        sweep()
+        ctx.sync()                                               # the library's own stream
+        mine = chunks_to_slabs(res, slot // 8, Cn, n, NCONT)     # this rank's (n, 9, N) block in slab order
+        full = all_gather_slabs(mine if gdev == 'cuda' else mine.cpu(), S, rank, world)   # the ONE collective
+        torch.cuda.synchronize()
+        return mine, full
+
+    job()                                                        # warm-up: kernels, scratch growth, the communicator's channels
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(R):
+        mine, full = job()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=gdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    block = None
+    if rank == 0:
+        assert tuple(full.shape) == (S, 9, NCONT)
+        fb = full.view(torch.int64).cpu().numpy()                 # bit patterns: the vectors hold NaNs
+        assert np.array_equal(fb[lo:hi], mine.view(torch.int64).cpu().numpy()), 'rank 0 block is not where it belongs'
+        # every other rank's block sits at its place with that rank's data: recompute the FIRST slab of each block here
+        checked = []
+        one = KeffPlan(ctx, 1, NY4, NX4, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                       increase=True, lt=True, right_edge='xhistogram')
+        fnp = full.cpu().numpy()
+        for r in range(world):
+            rlo, rhi = shard_slabs(S, r, world)
+            if rhi <= rlo:
+                continue
+            one.synth(lat, lon, SEED + rlo, 0)
+            one.run()
+            o = one.fetch()
+            if not np.array_equal(o['ctr'][0], fnp[rlo, OUT_NAMES.index('ctr')]):
+                raise RuntimeError('cfg4_strong: slab %d (first of rank %d) does not carry that slab\'s levels' % (rlo, r))
+            for k in ('area', 'intgrdS', 'latEq'):
+                e = rel_err(fnp[rlo, OUT_NAMES.index(k)], o[k][0])
+                if not e < 1e-11:
+                    raise RuntimeError('cfg4_strong: slab %d (first of rank %d): %s differs by %g' % (rlo, r, k, e))
+            checked.append(rlo)
+        oracle_checked = 0
+        if not a.no_cpu:
+            sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+            import xcontour_oracle as O
+            qh = np.empty((2, NY4, NX4))
+            ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, qbuf.ptr, min(2, n) * slab_bytes))
+            for s_ in range(min(2, n)):
+                rr = O.keff_pipeline(qh[s_], dA, lat, NCONT, lon=lon, increase=True, lt=True, dtype=np.float64)
+                gpu = {k: fnp[lo:lo + 2, OUT_NAMES.index(k)] for k in OUT_NAMES}
+                gpu['counts'] = np.stack([rr['counts']] * 2)    # the nine gathered vectors carry no counts
+                _compare_with_oracle(gpu, rr, s_)
+                oracle_checked += 1
+        one.free()
+        nk = fnp[:, OUT_NAMES.index('nkeff'), :]
+        work = S * NY4 * NX4 * NCONT
+        block = {
+            'metric': 'lat-lon cells*contours/s, full Keff pipeline, cfg4 stack (sweep + one gather)', 'value': work * R / el,
+            'unit': 'cells*contours/s', 'n_gpus': world, 'scaling': 'strong', 'jobs_timed': R, 'ms_per_job': el / R * 1e3,
+            'slabs': S, 'slab_shape': [NY4, NX4], 'slabs_per_gpu': -(-S // world), 'slabs_per_launch': Cn,
+            'us_per_slab_per_gpu': el / R / max(1, -(-S // world)) * 1e6,
+            'gathered_bytes': int(S * 9 * NCONT * 8), 'gather': ('torch.distributed all_gather_into_tensor, backend %s' % a.backend) if world > 1 else 'single rank (no collective)',
+            'algorithmic_bytes': int(S * NY4 * NX4 * BYTES_PER_CELL), 'pipeline_frac': (S * NY4 * NX4 * BYTES_PER_CELL * R / el / 1e9) / HBM_PEAK_GBS / world,
+            'checks': {'rank0_block_bit_identical': True, 'first_slab_of_each_rank_recomputed': checked,
+                       'oracle_checked_slabs': oracle_checked, 'finite_nkeff_fraction': float(np.isfinite(nk).mean())},
+            'config': 'cfg4: %d slabs of %dx%d float64 (seed + slab id), %d contours, per-slab levels, contiguous blocks of '
+                      'ceil(S/G) slabs per rank, chained launch sets of %d, ONE all-gather of (S, 9, N) f64 inside the timed job'
+                      % (S, NX4, NY4, NCONT, Cn),
+        }
+    plan.free()
+    qbuf.free()
+    del res
+    torch.cuda.empty_cache()
+    return block
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -186,7 +367,11 @@ def main():
     ap.add_argument('--slab-dA', action='store_true',
                     help='per-slab (time-varying) weights: every slab reads ITS OWN 2-D f64 dA plane from HBM (XC_DA_SLAB; '
                          'the reference allows weights with a time dim, core.py:1271-1274).  This is the configuration in '
-                         'which the 16 B/cell roofline numerator is exactly the unique HBM traffic')
+                         'which the 16 B/cell roofline numerator is exactly the unique HBM traffic (the default run reports it '
+                         'as `variants.slab_dA` after the timed region)')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='order-free fixed-point accumulation (xc_keff_desc.deterministic): bit-reproducible sums at about twice the '
+                         'histogram cost')
     ap.add_argument('--native-rccl', action='store_true',
                     help="do the one end-of-job gather with the library's own RCCL communicator (xc_comm_*) on its "
                          'own stream instead of torch.distributed (the id travels through the torch store)')
@@ -196,11 +381,14 @@ def main():
     ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
                     help="BASELINE.json configuration: cfg2 (default, the headline metric's), or one of the secondary ones as "
                          'a bench line of the same contract (tools/bench_configs.py; single GPU; --steps / --warmup apply)')
-    ap.add_argument('--persistent', action='store_true',
-                    help='run the Keff pipeline through the persistent single-read kernel (xc_keffp.hip, XC_KEFF_PERSISTENT): '
-                         'the tracer crosses the fabric once; slower than the chained streaming schedule on MI355X (DESIGN.md)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-slabs', type=int, default=0, help='distinct slabs in the CPU sample, all parity-checked (0: 8)')
+    ap.add_argument('--no-extras', action='store_true', help='skip variants / long_run / unchained after the timed region')
+    ap.add_argument('--long-run-s', type=float, default=0.5, help='seconds of extra steps with per-launch events (long_run)')
+    ap.add_argument('--no-cfg4', action='store_true', help='skip the cfg4 strong-scaling block')
+    ap.add_argument('--cfg4-slabs', type=int, default=512 * 37)
+    ap.add_argument('--cfg4-chunk', type=int, default=256, help='slabs per launch set of the cfg4 sweep')
+    ap.add_argument('--cfg4-reps', type=int, default=2, help='timed cfg4 jobs (sweep + gather)')
     a = ap.parse_args()
 
     import torch
@@ -241,14 +429,12 @@ def main():
     ctx = nat.Context(local)
     if a.config != 'cfg2':
         if world > 1:
-            raise SystemExit('--config %s is a single-GPU line (the multi-GPU cfg4 driver is tools/bench_cfg4.py)' % a.config)
+            raise SystemExit('--config %s is a single-GPU line; the multi-GPU cfg4 job is the `cfg4_strong` block of the default run' % a.config)
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import bench_configs
         print(json.dumps(bench_configs.run(a.config, ctx, a.steps, a.warmup)), flush=True)
         ctx.close()
         return
-    if a.persistent:
-        ctx.set_keff_mode(nat.XC_KEFF_PERSISTENT)
     B, K, W = a.batch, a.steps, a.warmup
     lat = np.linspace(-90, 90, NY)
     lon = np.arange(NX) * 0.1
@@ -266,18 +452,20 @@ def main():
     wres = torch.empty(slot // 8, dtype=torch.float64, device='cuda')        # warm-up slot
     plan = KeffPlan(ctx, NB * B, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl,
                     tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.data_ptr(), detect_row_dA=a.row_dA,
-                    out_slabs=B, replicate_dA=a.slab_dA, right_edge='xhistogram')
+                    out_slabs=B, replicate_dA=a.slab_dA, right_edge='xhistogram', deterministic=a.deterministic)
     plan.synth(lat, lon, SEED + rank * NB * B, a.variant)         # slab s of rank r: seed + r*2B + s
     group = a.group or B
-    chain = bool(a.chain) and not a.persistent          # the persistent kernel finds its min/max itself
+    chain = bool(a.chain)
 
-    def step(k, slot_idx):
+    def step(k, slot_idx, pl=None, ch=None):
+        pl = plan if pl is None else pl
+        ch = chain if ch is None else ch
         s0 = (k % NB) * B                                         # this step's batch
         nxt = ((k + 1) % NB) * B                                  # the batch of the next step
         for g0 in range(s0, s0 + B, group):
             n = min(group, s0 + B - g0)
             g1 = g0 + group if g0 + group < s0 + B else nxt       # what runs after this launch set
-            plan.run_range(slot_idx, g0, n, g1 if (chain and min(group, B) == n) else None, out_s0=g0 - s0)
+            pl.run_range(slot_idx, g0, n, g1 if (ch and min(group, B) == n) else None, out_s0=g0 - s0)
 
     plan.out_ptr = wres.data_ptr()
     for k in range(-W, 0):                                        # ends on batch B; its pass carries batch A's min/max
@@ -331,8 +519,10 @@ def main():
             mine = res.view(torch.int64).cpu()
             assert torch.equal(g[0], mine) and all(not torch.equal(g[r], g[0]) for r in range(1, world))
 
+    line = None
     if rank == 0:
         work_step = world * B * NY * NX * NCONT
+        dA_kind = 'per-row vector (detected constant rows)' if a.row_dA else ('2-D f64 plane PER SLAB (time-varying weights)' if a.slab_dA else '2-D f64 plane shared by the slabs')
         line = {
             'metric': 'lat-lon cells*contours/s, full Keff pipeline', 'value': work_step * K / el,
             'unit': 'cells*contours/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -341,71 +531,134 @@ def main():
             'config': {'workload': 'cfg2: synthetic %dx%d float64 PV-like slabs, 2-D f64 dA, %d contours, '
                                    'full Keff (min/max + histogram with in-kernel |grad q|^2 + CDF + epilogue)'
                                    % (NX, NY, NCONT),
-                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant, 'dA': 'per-row vector (detected constant rows)' if a.row_dA else ('2-D f64 plane PER SLAB (time-varying weights)' if a.slab_dA else '2-D f64 plane shared by the slabs'),
-                       'minmax': ('inside the persistent single-read kernel' if a.persistent else
-                                  ('folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass')),
+                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant, 'dA': dA_kind,
+                       'minmax': 'folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass',
+                       'sums': 'order-free fixed point (deterministic)' if a.deterministic else 'float64 LDS atomics',
                        'parallelism': 'independent slabs per GPU, one RCCL all-gather at the end' if world > 1 else 'single GPU',
                        'device': ctx.device_name()},
         }
         cells = B * NY * NX
         alg = cells * (8 if a.row_dA else BYTES_PER_CELL)              # tracer once + dA once per slab
-        # bytes that MUST cross HBM once per launch: this batch's tracer + the weights that are not shared
-        # (a dA plane shared by the B slabs of a launch is fetched once; per-slab dA planes B times; a per-row vector ~0)
-        uniq = cells * 8 + (cells * 8 if a.slab_dA else (NY * 8 if a.row_dA else NY * NX * 8))
+
+        def uniq_bytes(slab_dA):
+            # bytes that MUST cross HBM once per launch: this batch's tracer + the weights that are not shared
+            # (a dA plane shared by the B slabs of a launch is fetched once; per-slab dA planes B times; a per-row vector ~0)
+            return cells * 8 + (cells * 8 if slab_dA else (NY * 8 if a.row_dA else NY * NX * 8))
+
+        def kernel_name(slab_dA, ch):
+            return 'k_hist<double,%s,%s>' % ('DA_SLAB' if slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'), 'NEXT' if ch else 'plain')
+
         if group == B:
             ms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in ev])
             ach = alg / (ms.mean() * 1e-3) / 1e9
-            traffic, tcommit = None, None
-            tf = os.path.join(ROOT, 'profiles', 'hist_traffic.json')
-            if os.path.exists(tf) and not a.row_dA and a.variant == 0:
-                try:
-                    tj = json.load(open(tf))
-                    tj = tj.get(('slab_' if a.slab_dA else '') + ('persistent' if a.persistent else ('chain' if chain else 'nochain')), {})
-                    if tj.get('slabs_per_launch') == B:                # PMC passes were taken at the default batch
-                        traffic = tj.get('hbm_bytes_per_launch')
-                        tcommit = tj.get('commit')
-                except Exception:
-                    traffic = None
+            uniq = uniq_bytes(a.slab_dA)
+            traffic, tsrc = (None, 'not measured for this variant') if (a.row_dA or a.variant != 0 or a.deterministic) else \
+                stored_traffic(('slab_' if a.slab_dA else '') + ('chain' if chain else 'nochain'), B)
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                                'traffic_source': None if traffic is None else
-                                'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_bench_traffic.sh), measured at commit %s; '
-                                'not re-measured in this run' % tcommit,
-                                'kernel': ('k_keff_persist<double,%s>' if a.persistent else 'k_hist<double,%s,%s>')
-                                          % (('DA_SLAB' if a.slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'),) if a.persistent else
-                                             ('DA_SLAB' if a.slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'), 'NEXT' if chain else 'plain')),
-                                'launch_ms': float(ms.mean()),
+                                'frac': ach / HBM_PEAK_GBS,
+                                'hbm_unique_frac': uniq / (ms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'traffic': traffic, 'traffic_source': tsrc,
+                                'kernel': kernel_name(a.slab_dA, chain),
+                                'launch_ms': float(ms.mean()), 'launch_ms_std': float(ms.std()),
                                 'algorithmic_bytes_per_launch': alg,
                                 'hbm_unique_bytes_per_launch': uniq,
-                                'hbm_unique_frac': uniq / (ms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 'streamed_bytes_per_launch': alg + (cells * 8 if chain else 0),
                                 'pipeline_frac': (alg * K / el / 1e9) / HBM_PEAK_GBS,
                                 'pipeline_hbm_unique_frac': (uniq * K / el / 1e9) / HBM_PEAK_GBS,
-                                'note': 'frac = 16 B/cell (SURVEY 8d) / launch time / 8 TB/s; hbm_unique_frac counts only bytes that '
-                                        'must come from HBM (a dA plane shared by the %d slabs of a launch counts once); '
-                                        'with --slab-dA the two coincide' % B}
+                                'note': 'frac = 16 B/cell (SURVEY 8d) / launch time / 8 TB/s; its numerator counts the dA plane once per '
+                                        'slab although the %d slabs of a launch share it (cache-served after the first fetch) -- '
+                                        'hbm_unique_frac counts only bytes that must come from HBM.  variants.slab_dA is the '
+                                        'configuration where the two coincide' % B}
         # self-check of the last step: every cell lands in exactly one bin (xhistogram rule: last edge + 1e-8 keeps the max cell)
         out = plan.fetch(slot=K - 1)
         if not (out['counts'].sum(axis=1).astype(np.int64) == NY * NX).all() or out['status'].any():
             raise RuntimeError('bench self-check failed: counts %r status %r' % (out['counts'].sum(axis=1), out['status']))
-        if world == 1 and chain and group == B and not a.persistent:
+        extras = world == 1 and group == B and not a.no_extras
+        if extras and chain:
             # transparency: the same work in the plain order (stand-alone K1 launch, then K3), a short extra run
             # AFTER the timed region (identical per-step outputs; tests/test_gpu_parity.py::test_chained_minmax_is_bit_identical)
-            chain = False
             K2 = max(5, min(20, K))
             plan.out_ptr = wres.data_ptr()
             for k in range(-3, 0):
-                step(k, 0)
+                step(k, 0, ch=False)
             ctx.sync()
             t2 = time.perf_counter()
             for k in range(K2):
-                step(k, 0)
+                step(k, 0, ch=False)
             ctx.sync()
             el2 = time.perf_counter() - t2
-            chain = True
             plan.out_ptr = res.data_ptr()
             line['unchained'] = {'value': work_step * K2 / el2, 'ms_per_step': el2 / K2 * 1e3, 'steps': K2,
                                  'note': 'stand-alone min/max launch before every histogram launch (--no-chain), same slabs'}
+        if extras and a.long_run_s > 0:
+            # the timed region above is K steps (tens of ms at the default K); the same steps for >= long_run_s seconds, every
+            # histogram launch between its own pair of HIP events: a steadier twin of the headline (results go to the warm-up slot)
+            nlr = int(min(4000, max(K, np.ceil(a.long_run_s / (el / K)))))
+            lev = [(ctx.event(), ctx.event()) for _ in range(nlr)]
+            plan.out_ptr = wres.data_ptr()
+            for k in range(-2, 0):
+                step(k, 0)
+            ctx.sync()
+            t2 = time.perf_counter()
+            for k in range(nlr):
+                ctx.set_hist_events(lev[k][0], lev[k][1])
+                step(k, 0)
+            ctx.sync()
+            el3 = time.perf_counter() - t2
+            plan.out_ptr = res.data_ptr()
+            lms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in lev])
+            line['long_run'] = {'steps': nlr, 'seconds': el3, 'ms_per_step': el3 / nlr * 1e3, 'value': work_step * nlr / el3,
+                                'launch_ms_mean': float(lms.mean()), 'launch_ms_std': float(lms.std()), 'launch_ms_min': float(lms.min()),
+                                'launch_ms_p05': float(np.percentile(lms, 5)), 'launch_ms_p95': float(np.percentile(lms, 95)),
+                                'launch_ms_max': float(lms.max()), 'frac': alg / (lms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'hbm_unique_frac': uniq_bytes(a.slab_dA) / (lms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                'note': 'same schedule and slabs as the timed region, run after it'}
+            for e0, e1 in lev:
+                ctx.lib.xc_event_destroy(ctx.handle, e0); ctx.lib.xc_event_destroy(ctx.handle, e1)
+        if extras and not a.slab_dA and not a.row_dA:
+            # the configuration whose roofline numerator is 100 % unique HBM bytes: per-slab dA planes (XC_DA_SLAB), same tracer
+            # batches, same chained schedule; its vectors are compared with the main leg's (same dA values -> same answers)
+            p2 = None
+            try:
+                p2 = KeffPlan(ctx, NB * B, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                              increase=True, lt=True, nslots=1, out_slabs=B, replicate_dA=True, right_edge='xhistogram',
+                              alloc_q=False, deterministic=a.deterministic)
+                p2.set_q_device(plan._q_ptr)
+                p2.desc.q_gen = plan.desc.q_gen
+                KV = 10 + ((K - 10) % NB)                        # ends on the batch of the main leg's last step
+                vev = [(ctx.event(), ctx.event()) for _ in range(KV)]
+                for k in range(-3, 0):
+                    step(k, 0, pl=p2)
+                ctx.sync()
+                t2 = time.perf_counter()
+                for k in range(KV):
+                    ctx.set_hist_events(vev[k][0], vev[k][1])
+                    step(k, 0, pl=p2)
+                ctx.sync()
+                el4 = time.perf_counter() - t2
+                vms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in vev])
+                vo = p2.fetch(slot=0)
+                bad = [k for k in ('ctr', 'counts') if not np.array_equal(vo[k], out[k])]
+                bad += [k for k in ('area', 'intgrdS', 'latEq', 'dqdA', 'dintSdA', 'Leq2') if not rel_err(vo[k], out[k]) < 1e-9]
+                if bad or vo['status'].any():
+                    raise RuntimeError('variants.slab_dA: results differ from the main leg: %s' % bad)
+                ub = uniq_bytes(True)
+                vt, vsrc = stored_traffic('slab_chain' if chain else 'slab_nochain', B) if (a.variant == 0 and not a.deterministic) else (None, 'not measured')
+                line['variants'] = {'slab_dA': {
+                    'steps': KV, 'ms_per_step': el4 / KV * 1e3, 'value': work_step * KV / el4, 'kernel': kernel_name(True, chain),
+                    'launch_ms': float(vms.mean()), 'launch_ms_std': float(vms.std()),
+                    'frac': alg / (vms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'hbm_unique_frac': ub / (vms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'pipeline_hbm_unique_frac': (ub * KV / el4 / 1e9) / HBM_PEAK_GBS,
+                    'algorithmic_bytes_per_launch': alg, 'hbm_unique_bytes_per_launch': ub, 'traffic': vt, 'traffic_source': vsrc,
+                    'parity': 'levels + counts bit-identical to the main leg, sums / derived <= 1e-9 (the main leg is oracle-checked below)',
+                    'note': 'every slab reads ITS OWN 2-D f64 dA plane (time-varying weights, core.py:1271-1274): all 16 B/cell of the '
+                            'numerator cross HBM, frac == hbm_unique_frac'}}
+            except nat.XContourHipError as e:
+                line['variants'] = {'slab_dA': {'skipped': str(e)}}
+            finally:
+                if p2 is not None:
+                    p2.free()
         if world == 1 and not a.no_cpu:
             # the oracle on slabs of the LAST timed step's batch; their vectors are compared with that step's GPU result
             nd = max(1, min(a.cpu_slabs or 8, B))
@@ -414,6 +667,15 @@ def main():
             qh = np.empty((nd, NY, NX), dtype=np.float64)
             ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, plan._q_ptr + s0 * esz, nd * esz))
             line['cpu_baseline'] = cpu_baseline(qh, out, nd)
+    # ---- cfg4 strong scaling: every rank takes part (its own timed region, after the cfg2 buffers are gone)
+    plan.free()
+    del res, wres, gathered
+    torch.cuda.empty_cache()
+    if not a.no_cfg4:
+        blk = cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev)
+        if rank == 0:
+            line['cfg4_strong'] = blk
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

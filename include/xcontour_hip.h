@@ -142,9 +142,22 @@ typedef struct xc_hist_desc {
     double*       pdf;
     uint64_t*     counts;
     double*       cdf;
+    int32_t       deterministic;/* != 0: order-free fixed-point sums (see "Deterministic sums" below); 0: float64 LDS atomics */
+    int32_t       reserved0;
 } xc_hist_desc;
 int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d);
 int xc_hist(xc_ctx* ctx, const xc_hist_desc* d);
+
+/* Deterministic sums (`deterministic != 0` in xc_hist_desc / xc_keff_desc).  The reference's per-bin sums come out of
+ * np.bincount inside xhistogram (core.py:1284, 1307): the same input gives the same bits.  The default histogram pass
+ * adds float64 weights with LDS atomics, so the last bits of pdf / cdf (area, intgrdS) depend on the order in which
+ * waves reach the LDS and differ from run to run (~1e-13 relative).  With `deterministic` the pass runs twice:
+ * (1) per (bin, channel) maximum |w| and exact counts; (2) every weight becomes the 64-bit integer rint(w * 2^k), k chosen
+ * per (bin, channel) from (1) so that the bin's sum stays below 2^62 -- a function of the cell alone -- and the integers
+ * are added with ds_add_u64.  Integer addition is associative: results are bit-identical between runs, launch geometries,
+ * slabs per launch and numbers of ranks.  Cost: about twice the histogram pass (measured: DESIGN.md).  Precision: 62 -
+ * ceil(log2 count) bits below the largest weight of the bin (no worse than float64 summation in any order); a
+ * bin that received an infinite weight reports NaN.  Levels, edges and counts are the same bits in both modes. */
 
 /* ------------------------------------------------------------------ K2  row sums for the A(Yeq) table
  * Replaces the degenerate histogram of cal_area_eqCoord_table_hist   core.py:176-193
@@ -201,6 +214,14 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
                     const double* dA, int dA_rank, int64_t ny, int64_t nx, int negate,
                     const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                     double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
+
+/* float64 tracers take a three-pass path: a stable LSD sort on the 24-bit RANGE key floor((q - min) * (2^24 - 1) / (max - min))
+ * (monotone in q), then a stable in-LDS insertion sort of every run of equal range key that is out of order, then a
+ * sortedness check whose flag is read back -- the ONE host round trip these calls (also the _dev ones) make; a stack that
+ * fails it (distinct values packed into less than 2^-24 of the range, more than 128 of them) is sorted again with the
+ * eight key passes.  The result is the same stable sort either way.  xc_last_sort_path: 0 = key passes only (float32
+ * tracers, or XC_SORT_RANGE=0 in the environment at xc_create), 1 = range-key path, 2 = range-key path failed the check. */
+int xc_last_sort_path(xc_ctx* ctx, int* out_path);
 
 /* The same for a stack of nslab planes in ONE set of launches (segmented sort: every plane keeps its own
  * tile histograms, digit bases and cumulative area).  q: [nslab][ny][nx]; mask: [ny][nx] shared or
@@ -266,7 +287,7 @@ typedef struct xc_keff_desc {
     double*       dqdA;         double* dintSdA; double* Leq2;   double* Lmin;  double* nkeff;
     uint64_t*     counts;       /* uint64[nslab][N] */
     double*       interp;       /* double[nslab][9][npre]: ctr, area, intgrdS, latEq, dintSdA, dqdA, Leq2, Lmin, nkeff on preY */
-    int32_t*      status;       /* int32[nslab] 0 ok, 1 degenerate levels, 2 / 3 not computed (see xc_set_keff_mode) */
+    int32_t*      status;       /* int32[nslab] 0 ok, 1 degenerate levels ('non monotonic bins', core.py:1233) */
     const void*   q_next;       /* optional: the batch the NEXT xc_keff_dev call will process (same dtype and
                                    shape, may equal q).  Its per-slab min/max partials are accumulated inside this
                                    call's histogram pass (+8 B/cell of loads, no extra kernel) and the next call on
@@ -277,6 +298,8 @@ typedef struct xc_keff_desc {
     int32_t       dA_pos_finite;/* caller verified that every dA value is finite and >= 0: the kernel then skips the
                                    fillna(0) selects on the dA channel (optional speed-up; 0 is always safe) */
     int32_t       q_gen;        /* generation of the tracer buffers (see q_next): any change invalidates chained min/max */
+    int32_t       deterministic;/* != 0: order-free fixed-point sums (below); q_next is then ignored (stand-alone K1 pass) */
+    int32_t       reserved0;
 } xc_keff_desc;
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
 
@@ -301,31 +324,6 @@ int xc_keff_epilogue(xc_ctx* ctx, const double* pdf, const double* ctr, int ctr_
                      const double* preY, int npre, double nkeff_mask, double lmin_scale,
                      double* area, double* intgrdS, double* latEq, double* dqdA, double* dintSdA,
                      double* Leq2, double* Lmin, double* nkeff, double* interp);
-
-/* Schedules of xc_keff_dev.
- * XC_KEFF_TWO_PASS: the streaming path -- min/max pass (K1, or partials chained from the previous call, q_next), then
- *   the histogram pass (K3).  The tracer crosses the fabric twice; no synchronisation between workgroups.
- * XC_KEFF_PERSISTENT: ONE persistent launch that reads the tracer ONCE (xc_keffp.hip): a slab is spread over the
- *   register files of a group of CUs, stays there between the min/max and the binning, and is refilled row by row
- *   with the group's next slab.  Needs >= 65 536 cells per slab, even nx, 16-byte aligned pointers, the in-kernel
- *   gradient and a slab that fits the chip (cfg2's 3600 x 1801 f64 just does); other shapes fall back to two-pass.
- *   Levels and counts are bit-identical to the two-pass path, sums agree to summation order.  A launch that cannot
- *   co-schedule its workgroups (another process holding CUs) gives up after 0.3 s with status[slab] == 2 for the slabs
- *   it did not finish; a slab whose levels are not equally spaced to a quarter of a bin (float32 contours of a tiny
- *   range, infinite extrema) is left out with status[slab] == 3.  Re-run such slabs with XC_KEFF_TWO_PASS
- *   (xcontour_amd.pipeline.KeffPlan.fetch does).
- * XC_KEFF_AUTO (default): two-pass.  Measured on MI355X the persistent kernel moves about half the bytes but loses
- *   ~13 us per cfg2 slab to grid-wide synchronisation and arrival skew (one slab in flight; a second does not fit on
- *   chip), so it is 10-15 % slower than the chained streaming schedule; XC_KEFF_PERSIST=1 in the environment makes
- *   AUTO pick it.  xc_last_keff_path: 1 persistent, 0 two-pass. */
-#define XC_KEFF_AUTO     0
-#define XC_KEFF_TWO_PASS 1
-#define XC_KEFF_PERSISTENT 2
-int xc_set_keff_mode(xc_ctx* ctx, int mode);
-int xc_last_keff_path(xc_ctx* ctx, int* out_path);
-/* Diagnostics: with a non-NULL device buffer of nslab * CUs * 8 uint64, the persistent kernel's thread 0 of every
- * workgroup stores the 100 MHz wall clock at the phase boundaries of every slab (tools/gpu_persist_check.py --stamps). */
-int xc_dbg_set_stamps(xc_ctx* ctx, void* dev_ptr);
 
 /* time of the dominant kernel (the histogram pass) of the last xc_keff_dev / xc_hist_dev
  * call, from HIP events recorded on the context's stream around that launch only.

@@ -71,6 +71,17 @@ int main(void)
             if (fabs(cdf[k][0][b] - run) > 1e-11 * (fabs(run) + 1.0)) { fprintf(stderr, "FAIL cdf slab %d bin %d\n", k, b); return 1; }
         }
     }
+    /* deterministic sums: two calls give the same bits, and agree with the default path to rounding */
+    {
+        static double c1[2][1][NLEV], c2[2][1][NLEV];
+        d.deterministic = 1; d.counts = NULL;
+        d.cdf = &c1[0][0][0]; if (xc_hist(ctx, &d) != XC_OK) return fail("xc_hist deterministic", ctx);
+        d.cdf = &c2[0][0][0]; if (xc_hist(ctx, &d) != XC_OK) return fail("xc_hist deterministic", ctx);
+        if (memcmp(c1, c2, sizeof c1) != 0) { fprintf(stderr, "FAIL: deterministic sums differ between two calls\n"); return 1; }
+        for (int k = 0; k < 2; ++k) for (int b = 0; b < NLEV; ++b)
+            if (fabs(c1[k][0][b] - cdf[k][0][b]) > 1e-11 * (fabs(cdf[k][0][b]) + 1.0)) { fprintf(stderr, "FAIL: deterministic cdf slab %d bin %d\n", k, b); return 1; }
+        d.deterministic = 0; d.cdf = &cdf[0][0][0]; d.counts = &counts[0][0];
+    }
     /* error path: non-ascending edges must be refused with a message, not crash */
     edges[0][5] = edges[0][4];
     if (xc_hist(ctx, &d) == XC_OK) { fprintf(stderr, "FAIL: bad edges accepted\n"); return 1; }

@@ -27,11 +27,26 @@ def test_library_exports_every_declared_symbol():
     assert sorted(nat.PROTOTYPES) == syms
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof of the two descriptor structs as gcc sees them in include/xcontour_hip.h == the ctypes mirrors"""
+    import subprocess
     from xcontour_amd import _native as nat
-    # natural alignment, no packing: sizes follow from the field lists in the header
-    assert C.sizeof(nat.HistDesc) == 8 + 8 + 24 + 8 + 8 + 8 + 8 + 8 + 8 + 16 + 8 + 8 + 8 + 8 + 8 + 24
-    assert C.sizeof(nat.KeffDesc) % 8 == 0 and nat.KeffDesc.q_next.offset == C.sizeof(nat.KeffDesc) - 16
+    fields = {'xc_hist_desc': [f[0] for f in nat.HistDesc._fields_], 'xc_keff_desc': [f[0] for f in nat.KeffDesc._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % os.path.join(ROOT, 'include', 'xcontour_hip.h'), 'int main(void){']
+    for st, fl in fields.items():
+        src.append('printf("%s %%zu\\n", sizeof(struct %s));' % (st, st))
+        for f in fl:
+            src.append('printf("%s.%s %%zu\\n", offsetof(struct %s, %s));' % (st, f, st, f))
+    src.append('return 0;}')
+    c = tmp_path / 'layout.c'
+    c.write_text('\n'.join(src))
+    exe = str(tmp_path / 'layout')
+    subprocess.run(['gcc', '-std=c99', '-o', exe, str(c)], check=True)
+    got = dict(line.split() for line in subprocess.run([exe], check=True, stdout=subprocess.PIPE, universal_newlines=True).stdout.splitlines())
+    for st, cls in (('xc_hist_desc', nat.HistDesc), ('xc_keff_desc', nat.KeffDesc)):
+        assert int(got[st]) == C.sizeof(cls), st
+        for f in fields[st]:
+            assert int(got['%s.%s' % (st, f)]) == getattr(cls, f).offset, '%s.%s' % (st, f)
     lib = nat.load()
     assert lib.xc_version().startswith(b'xcontour_hip')
 

@@ -505,121 +505,3 @@ def test_contexts_on_every_visible_device():
     finally:
         for c in ctxs:
             c.close()
-
-
-# ---------------------------------------------------------------- K3P: the persistent single-read Keff kernel (xc_keffp.hip)
-@pytest.mark.parametrize('dt,cd', [(np.float64, np.float64), (np.float32, np.float32), (np.float64, np.float32)])
-@pytest.mark.parametrize('dar', ['plane', 'row', 'slab', 'none'])
-def test_persistent_kernel_equals_two_pass_and_oracle(ctx, dt, cd, dar):
-    """xc_set_keff_mode(XC_KEFF_PERSISTENT): one launch, the tracer read once, a slab resident in registers between the
-    min/max and the binning.  Levels and counts bit-identical to the two-pass path and the oracle, sums to summation
-    order; several slabs per group (refill of the NEXT slab behind the rows being binned), NaN cells, both last-bin
-    rules, all (increase, lt), periodic and walled X, ragged chunks / strips (ny, nx not multiples of 18 / 124)."""
-    from xcontour_amd import _native as nat
-    from xcontour_amd.pipeline import KeffPlan
-    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included, cartesian_metrics
-    n = 0
-    try:
-        for (ny, nx, S) in ((301, 250, 9), (361, 722, 2), (181, 2000, 1)):
-            for periodic in (True, False):
-                n += 1
-                inc, lt = bool(n & 1), bool(n & 2)
-                rule = 'numpy' if n % 3 == 0 else 'xhistogram'
-                N = (201, 61, 500)[n % 3]
-                rng = np.random.default_rng(100 + n)
-                lat = np.linspace(-88, 88, ny); lon = np.arange(nx) * (360.0 / nx)
-                dA2 = cell_area(lat, lon) * (1 + 0.1 * rng.random((ny, nx)))
-                dA = {'none': None, 'row': dA2[:, 0].copy(), 'plane': dA2, 'slab': dA2[None] * (1 + 0.05 * rng.random((S, 1, 1)))}[dar]
-                q = (np.sin(np.deg2rad(lat))[None, :, None] * (1 + 0.3 * rng.random((S, 1, 1)))
-                     + 0.05 * rng.standard_normal((S, ny, nx))).astype(dt)
-                q[0, 5:9, 10:40] = np.nan
-                q[-1, :, 3] = np.nan
-                ylt = lt if inc else (not lt)
-                rows = (np.ones((ny, nx)) if dA is None else (dA2 if dar != 'row' else np.repeat(dA[:, None], nx, 1))).sum(1)
-                tbl = table_from_rowsums(rows, ylt, last_row_included(lat, rule))
-                kw = dict(dA=dA, tbl=tbl, tbl_coord=lat, increase=inc, lt=lt, right_edge=rule, periodic_x=periodic)
-                if periodic:
-                    kw.update(lat=lat, lon=lon)
-                else:
-                    rdx, rdy = cartesian_metrics(lat, 2.0)
-                    kw.update(rdx=rdx, rdy=rdy)
-                res = {}
-                for mode in (nat.XC_KEFF_PERSISTENT, nat.XC_KEFF_TWO_PASS):
-                    ctx.set_keff_mode(mode)
-                    plan = KeffPlan(ctx, S, ny, nx, N, dt, cd, **kw)
-                    plan.set_q(q); plan.run()
-                    res[mode] = plan.fetch()
-                    assert ctx.last_keff_path() == (1 if mode == nat.XC_KEFF_PERSISTENT else 0)
-                    plan.free()
-                a, b = res[nat.XC_KEFF_PERSISTENT], res[nat.XC_KEFF_TWO_PASS]
-                assert np.array_equal(a['ctr'], b['ctr']) and np.array_equal(a['counts'], b['counts'])
-                assert rel(a['area'], b['area']) < 1e-12 and rel(a['intgrdS'], b['intgrdS']) < 1e-11
-                for k in ('latEq', 'dqdA', 'dintSdA', 'Leq2'):
-                    assert rel(a[k], b[k]) < RTOL, k
-                if periodic and dar != 'none':
-                    s = S - 1
-                    dAs = dA if dar == 'plane' else (np.repeat(dA[:, None], nx, 1) if dar == 'row' else dA[s])
-                    r = O.keff_pipeline(q[s], dAs, lat, N, lon=lon, increase=inc, lt=lt, dtype=cd, right_edge=rule)
-                    assert np.array_equal(a['counts'][s].astype(np.int64), r['counts'])
-                    assert np.array_equal(a['ctr'][s], r['ctr'].astype(np.float64))
-                    assert rel(a['area'][s], r['area']) < TIGHT and rel(a['intgrdS'][s], r['intgrdS']) < 1e-10
-    finally:
-        ctx.set_keff_mode(nat.XC_KEFF_AUTO)
-
-
-def test_persistent_kernel_hands_odd_slabs_to_two_pass(ctx):
-    """slabs whose levels are not equally spaced to a quarter of a bin (float32 contours of a tiny range, an infinite
-    extremum) or whose field is all NaN: status 3 inside the persistent launch, replayed through the two-pass path by
-    KeffPlan.fetch -- same statuses, levels, counts and sums as a pure two-pass run; the mode is restored afterwards"""
-    from xcontour_amd import _native as nat
-    from xcontour_amd.pipeline import KeffPlan
-    from xcontour_amd.utils import cell_area, table_from_rowsums
-    ny, nx, N, S = 300, 400, 41, 4
-    lat = np.linspace(-80, 80, ny); lon = np.arange(nx) * 0.9
-    dA = cell_area(lat, lon); tbl = table_from_rowsums(dA.sum(1), True)
-    rng = np.random.default_rng(3)
-    q = np.sin(np.deg2rad(lat))[None, :, None] + 0.05 * rng.standard_normal((S, ny, nx))
-    q[1] = 300.0 + 1e-5 * q[1]
-    q[2, 5, 5] = np.inf
-    q[3] = np.nan
-    try:
-        for cd in (np.float32, np.float64):
-            res = []
-            for mode in (nat.XC_KEFF_PERSISTENT, nat.XC_KEFF_TWO_PASS):
-                ctx.set_keff_mode(mode)
-                plan = KeffPlan(ctx, S, ny, nx, N, np.float64, cd, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=True, lt=True)
-                plan.set_q(q); plan.run(); res.append(plan.fetch(check=False)); plan.free()
-                assert ctx._keff_mode == mode                                   # restored after the replay
-            a, b = res
-            assert np.array_equal(a['status'], b['status']) and (a['status'] < 2).all()
-            assert np.array_equal(a['ctr'], b['ctr'], equal_nan=True) and np.array_equal(a['counts'], b['counts'])
-            ok = a['status'] == 0
-            assert ok[0] and rel(a['area'][ok], b['area'][ok]) < 1e-12
-    finally:
-        ctx.set_keff_mode(nat.XC_KEFF_AUTO)
-
-
-def test_persistent_kernel_cfg2_full_size(ctx):
-    """BASELINE cfg2 at full size through the persistent kernel: 3 slabs (the slab fills the register files of the whole
-    chip; slab 2 and 3 arrive by refill), all nine vectors against the oracle"""
-    from xcontour_amd import _native as nat
-    from xcontour_amd.pipeline import KeffPlan
-    from xcontour_amd.utils import cell_area, table_from_rowsums
-    ny, nx, N, S = 1801, 3600, 201, 3
-    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 0.1
-    dA = cell_area(lat, lon)
-    tbl = table_from_rowsums(ctx.rowsum(None, dA, ny, nx), True)
-    try:
-        ctx.set_keff_mode(nat.XC_KEFF_PERSISTENT)
-        plan = KeffPlan(ctx, S, ny, nx, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=True, lt=True)
-        plan.synth(lat, lon, 77, 0)
-        plan.run()
-        out = plan.fetch()
-        assert ctx.last_keff_path() == 1
-        q = plan.download_q()
-        for s in range(S):
-            r = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float64)
-            check_nine(out, s, r)
-        plan.free()
-    finally:
-        ctx.set_keff_mode(nat.XC_KEFF_AUTO)

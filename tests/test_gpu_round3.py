@@ -1,0 +1,321 @@
+"""-m gpu, round 3: deterministic (order-free fixed-point) sums, and the N > 1 path with REAL pipeline output -- two
+processes sharing the one GPU of the test box, each running a KeffPlan over its block of a 1440 x 721 stack, one
+gloo all-gather, against the 1-rank run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import xcontour_oracle as O
+from test_gpu_parity import rel, RTOL, TIGHT
+from test_gpu_round2 import check_nine, NINE
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NY4, NX4, N4, SEED4 = 721, 1440, 201, 20241008
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def check_nine_det(out, s, r):
+    """check_nine for the fixed-point sums.  Lmin = 2 pi R cos(latEq) of a contour that encloses all but ~1e-13 of the sphere
+    is a 1e-4 m quantity on a 4e7 m scale whose value IS the rounding of the area sum (cos near 90 degrees): such contours
+    (Lmin below one metre) are compared through latEq only."""
+    assert np.array_equal(out['counts'][s].astype(np.int64), r['counts'])
+    assert np.array_equal(out['ctr'][s], r['ctr'].astype(np.float64))
+    assert rel(out['area'][s], r['area']) < TIGHT and rel(out['intgrdS'][s], r['intgrdS']) < TIGHT
+    for k in ('latEq', 'dqdA', 'dintSdA', 'Leq2'):
+        assert rel(out[k][s], r[k]) < RTOL, k
+    ok = r['Lmin'] > 1.0
+    assert rel(out['Lmin'][s][ok], r['Lmin'][ok]) < RTOL
+    assert rel(out['nkeff'][s][ok], r['nkeff'][ok]) < RTOL
+
+
+# ---------------------------------------------------------------- deterministic sums
+@pytest.mark.parametrize('dt,cd', [(np.float64, np.float64), (np.float32, np.float32)])
+def test_deterministic_pipeline_is_order_free(ctx, dt, cd):
+    """xc_keff_desc.deterministic: two runs, and launch sets of 1 / 2 / all slabs (different block geometry, different
+    partial layout), give the SAME bits in all nine vectors; levels and counts equal the default path's bits, sums agree
+    with it and with the oracle to rounding"""
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums
+    ny, nx, N, S = 181, 360, 101, 6
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 1.0
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(dA.sum(1), True)
+    kw = dict(dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=True, lt=True, nslots=4)
+    plain = KeffPlan(ctx, S, ny, nx, N, dt, cd, **kw)
+    plain.synth(lat, lon, 11, 0)
+    plain.run(0)
+    ref = plain.fetch(slot=0)
+    q = plain.download_q()
+    det = KeffPlan(ctx, S, ny, nx, N, dt, cd, deterministic=True, alloc_q=False, **kw)
+    det.set_q_device(plain._q_ptr)
+    outs = []
+    for slot, group in enumerate((None, None, 1, 2)):
+        det.run(slot, group, chain=(group == 2))                 # chain=True is ignored by the order-free passes
+        outs.append(det.fetch(slot=slot))
+    for o in outs[1:]:
+        for k in NINE:
+            assert np.array_equal(bits(o[k]), bits(outs[0][k])), k
+        assert np.array_equal(o['counts'], outs[0]['counts'])
+    d = outs[0]
+    assert np.array_equal(d['ctr'], ref['ctr']) and np.array_equal(d['counts'], ref['counts'])
+    assert rel(d['area'], ref['area']) < 1e-12 and rel(d['intgrdS'], ref['intgrdS']) < 1e-12
+    for s in range(S):
+        r = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=True, lt=True, dtype=cd)
+        check_nine_det(d, s, r)
+    det.free(); plain.free()
+
+
+def test_deterministic_hist_channels_and_odd_inputs(ctx):
+    """xc_hist_desc.deterministic through Context.hist: three channels (dA, a SIGNED integrand, |grad q|^2), NaN weights,
+    NaN tracer cells, odd nx, float32 tracer; splitting the stack changes the launch geometry, not one bit"""
+    rng = np.random.default_rng(5)
+    for (S, ny, nx, dt) in ((5, 90, 131, np.float32), (4, 64, 256, np.float64), (3, 33, 2, np.float64)):
+        q = rng.standard_normal((S, ny, nx)).astype(dt)
+        q[0, 3, 1] = np.nan
+        dA = rng.random((ny, nx)) + 0.1
+        dA[5, 0] = np.nan                                                 # fillna(0), core.py:449
+        g = rng.standard_normal((S, ny, nx)) * 10.0 ** rng.integers(-8, 8, (S, ny, nx))     # 16 decades, both signs
+        edges = np.linspace(-2.5, 2.5, 41)
+        rdx = rng.random(ny) + 0.5; rdy = rng.random(ny) + 0.5
+        kw = dict(dA=dA, integrands=[g], grad=(rdx, rdy, True), last_closed=False, lt=True, want=('pdf', 'counts', 'cdf'))
+        a = ctx.hist(q, edges, deterministic=True, **kw)
+        b = ctx.hist(q, edges, deterministic=True, **kw)
+        for k in ('pdf', 'cdf'):
+            assert np.array_equal(bits(a[k]), bits(b[k]))
+        parts = [ctx.hist(q[s:s + 1], edges, deterministic=True, **dict(kw, integrands=[g[s:s + 1]])) for s in range(S)]   # one slab per launch
+        assert np.array_equal(bits(np.concatenate([p['pdf'] for p in parts])), bits(a['pdf']))
+        plain = ctx.hist(q, edges, **kw)
+        assert np.array_equal(a['counts'], plain['counts'])
+        # against the default path on the scale of each channel's largest bin (a signed channel cancels inside a bin)
+        for ch in range(3):
+            scale = np.abs(plain['pdf'][:, ch]).max(axis=1, keepdims=True) + 1e-300
+            assert (np.abs(a['pdf'][:, ch] - plain['pdf'][:, ch]) / scale).max() < 1e-10, ch
+        # the area channel against numpy's histogram (no cell sits on the last edge, so the closed last bin is moot)
+        w = np.where(np.isnan(dA), 0.0, dA)
+        for s in range(S):
+            assert not (q[s] == edges[-1]).any()
+            ref, _ = np.histogram(q[s].astype(np.float64).ravel(), bins=edges, weights=w.ravel())
+            assert rel(a['pdf'][s, 0], ref) < 1e-12
+
+
+def test_deterministic_infinite_weight_reports_nan(ctx):
+    q = np.linspace(0.05, 0.95, 64 * 128).reshape(1, 64, 128)
+    dA = np.ones((64, 128)); dA[10, 7] = np.inf
+    edges = np.linspace(0, 1, 11)
+    a = ctx.hist(q, edges, dA=dA, deterministic=True, last_closed=False, want=('pdf', 'counts'))
+    k = int(np.digitize(q[0, 10, 7], edges) - 1)
+    assert np.isnan(a['pdf'][0, 0, k]) and np.isfinite(np.delete(a['pdf'][0, 0], k)).all()
+    assert a['counts'].sum() == 64 * 128
+
+
+def test_cfg2_full_size_deterministic(ctx):
+    """two runs at full cfg2 size give bit-identical area / intgrdS (and everything derived), equal to
+    the oracle within the same bars as the default path; a facade object with deterministic=True does the same"""
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
+    ny, nx, N = 1801, 3600, 201
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 0.1
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, ny, nx), True, last_row_included(lat))
+    plan = KeffPlan(ctx, 2, ny, nx, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                    increase=True, lt=True, deterministic=True, nslots=2)
+    plan.synth(lat, lon, 20241008, 0)
+    plan.run(0)
+    plan.run(1, group=1)
+    a, b = plan.fetch(slot=0), plan.fetch(slot=1)
+    for k in NINE:
+        assert np.array_equal(bits(a[k]), bits(b[k])), k
+    q = plan.download_q()
+    r = O.keff_pipeline(q[1], dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float64)
+    check_nine_det(a, 1, r)
+    plan.free()
+
+
+# ---------------------------------------------------------------- N > 1 with real pipeline output
+def _cfg4_block(ctx, lo, hi, chunk, det):
+    """this rank's (hi - lo, 9, N) block of the cfg4-shaped stack: chained launch sets of `chunk` slabs (ragged last set),
+    result slots -> slab-major block (the flow of bench.py's cfg4_strong / tools/bench_cfg4.py)"""
+    import ctypes as C
+    from xcontour_amd import _native as nat
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.distributed import chunks_to_slabs
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
+    lat = np.linspace(-90, 90, NY4); lon = np.arange(NX4) * 0.25
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, NY4, NX4), True, last_row_included(lat, 'xhistogram'))
+    n = hi - lo
+    if n == 0:
+        return np.empty((0, 9, N4))
+    Cn = min(chunk, n)
+    nchunk = -(-n // Cn)
+    sb = NY4 * NX4 * 8
+    qbuf = ctx.alloc(n * sb)
+    lat_b, lon_b = ctx.to_device(lat), ctx.to_device(lon)
+    for c0 in range(0, n, Cn):
+        m = min(Cn, n - c0)
+        ctx._check(ctx.lib.xc_synth_dev(ctx.handle, qbuf.ptr + c0 * sb, nat.XC_F64, m, NY4, NX4, lat_b.ptr, lon_b.ptr, SEED4 + lo + c0, 0))
+    ctx.sync()
+    plan = KeffPlan(ctx, Cn, NY4, NX4, N4, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                    increase=True, lt=True, nslots=nchunk, alloc_q=False, deterministic=det)
+    for ci in range(nchunk):
+        c0 = ci * Cn
+        m = min(Cn, n - c0)
+        plan.set_q_device(qbuf.ptr + c0 * sb)
+        nxt = ((ci + 1) % nchunk) * Cn
+        plan._point(ci, 0, m)
+        plan.desc.q_next = (qbuf.ptr + nxt * sb) if min(Cn, n - nxt) == m else None
+        ctx._check(ctx.lib.xc_keff_dev(ctx.handle, C.byref(plan.desc)))
+    ctx.sync()
+    res = plan.out_buf.download((nchunk * plan.slot_bytes // 8,), np.float64)
+    mine = chunks_to_slabs(res, plan.slot_bytes // 8, Cn, n, N4)
+    plan.free(); qbuf.free(); lat_b.free(); lon_b.free()
+    return mine
+
+
+def _gpu_rank(rank, world, port, S, chunk, det, outq):
+    """one rank = one fresh process with its own context on the (shared) GPU; gloo carries the one gather"""
+    try:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from xcontour_amd import _native as nat
+        from xcontour_amd.pipeline import shard_slabs
+        from xcontour_amd.distributed import all_gather_slabs
+        ctx = nat.Context(0)
+        lo, hi = shard_slabs(S, rank, world)
+        mine = _cfg4_block(ctx, lo, hi, chunk, det)
+        full = all_gather_slabs(torch.from_numpy(np.ascontiguousarray(mine)), S, rank, world)
+        dist.barrier()
+        outq.put((rank, full.numpy().copy(), None))
+        ctx.close()
+        dist.destroy_process_group()
+    except Exception as e:                      # noqa: BLE001 -- reported to the parent, which fails the test
+        import traceback
+        outq.put((rank, None, traceback.format_exc() + repr(e)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('det', [True, False])
+def test_two_ranks_share_one_gpu_real_pipeline(ctx, det):
+    """SURVEY 8(e) end to end on the hardware at hand: 2 spawned processes (never a re-exec of a process that touched the
+    GPU), each a real KeffPlan over its shard_slabs block of an 11-slab 1440 x 721 stack (ragged blocks 6 + 5, ragged
+    launch sets of 4), chunks_to_slabs -> all_gather_slabs over gloo.  Every rank must hold the 1-rank result: all nine
+    vectors bit for bit with deterministic sums; levels bit for bit and sums to 1e-12 with the default float64 atomics."""
+    import torch.multiprocessing as mp
+    S, chunk, world = 11, 4, 2
+    ref = _cfg4_block(ctx, 0, S, 5, det)                               # 1 rank, other launch-set size on purpose
+    mpc = mp.get_context('spawn')
+    outq = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_gpu_rank, args=(r, world, port, S, chunk, det, outq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, arr, err = outq.get(timeout=600)
+        assert err is None, 'rank %d failed:\n%s' % (r, err)
+        got[r] = arr
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ref.shape == (S, 9, N4)
+    ictr = NINE.index('ctr')
+    for r in range(world):
+        assert got[r].shape == ref.shape
+        assert np.array_equal(bits(got[r][:, ictr]), bits(ref[:, ictr]))
+        if det:
+            assert np.array_equal(bits(got[r]), bits(ref))             # all nine vectors, every slab, every rank
+        else:
+            for k in ('area', 'intgrdS', 'latEq'):
+                i = NINE.index(k)
+                assert rel(got[r][:, i], ref[:, i]) < 1e-12, k
+    assert np.array_equal(bits(got[0]), bits(got[1]))                   # the gather hands every rank the same bytes
+    # and the stack really is per-slab data in slab order: slab 7 against the oracle
+    from xcontour_amd import _native as nat
+    from xcontour_amd.utils import cell_area
+    lat = np.linspace(-90, 90, NY4); lon = np.arange(NX4) * 0.25
+    buf = ctx.alloc(NY4 * NX4 * 8)
+    lb_, lo_ = ctx.to_device(lat), ctx.to_device(lon)
+    ctx._check(ctx.lib.xc_synth_dev(ctx.handle, buf.ptr, nat.XC_F64, 1, NY4, NX4, lb_.ptr, lo_.ptr, SEED4 + 7, 0))
+    q7 = buf.download((NY4, NX4), np.float64)
+    r7 = O.keff_pipeline(q7, cell_area(lat, lon), lat, N4, lon=lon, increase=True, lt=True, dtype=np.float64)
+    assert np.array_equal(ref[7, ictr], r7['ctr'])
+    assert rel(ref[7, NINE.index('area')], r7['area']) < TIGHT and rel(ref[7, NINE.index('intgrdS')], r7['intgrdS']) < TIGHT
+    assert rel(ref[7, NINE.index('latEq')], r7['latEq']) < RTOL
+    buf.free(); lb_.free(); lo_.free()
+
+
+# ---------------------------------------------------------------- K8: three range-key passes + short-run repair
+def _sort_equals_oracle(ctx, q, dA=None, mask=None, negate=False):
+    r = ctx.sort_profile(q, dA=dA, mask=mask, want_sorted=True, want_acum=True, negate=negate)
+    _, xs, acum = O.sorted_profile(-q if negate else q, np.ones(q.shape) if dA is None else dA, [0.0], mask)
+    n = r['nvalid']
+    assert n == len(xs)
+    assert np.array_equal(r['q_sorted'][:n], xs)                            # exact order, ties included
+    assert rel(r['acum'][:n], acum) < 1e-12                                 # the payload travelled with its key (stable)
+    return ctx.last_sort_path()
+
+
+def test_sort_range_path_fields_ties_masks(ctx):
+    """float64 tracers: sorted by three passes over the 24-bit range key + repair of the short runs (path 1), the same
+    stable order as the oracle's argsort -- noise, heavy ties (stability decides the payload order), a land mask that
+    drops a third of the cells, NaNs, negated input, +-inf, a constant field, a two-cell plane"""
+    rng = np.random.default_rng(12)
+    ny, nx = 301, 700
+    dA = rng.random((ny, nx)) + 0.5
+    q = rng.standard_normal((ny, nx))
+    assert _sort_equals_oracle(ctx, q, dA) == 1
+    ties = rng.integers(0, 40, (ny, nx)).astype(np.float64)
+    assert _sort_equals_oracle(ctx, ties, dA) == 1                           # runs of ~5000 equal keys: already in order
+    mask = (rng.random((ny, nx)) > 0.33).astype(np.float64)
+    qn = q.copy(); qn[::7, ::5] = np.nan
+    assert _sort_equals_oracle(ctx, qn, dA, mask) == 1                       # dropped cells gather behind the maximum
+    assert _sort_equals_oracle(ctx, q, dA, negate=True) == 1
+    qi = q.copy(); qi[3, 4] = np.inf; qi[5, 6] = -np.inf
+    assert _sort_equals_oracle(ctx, qi, dA) in (1, 2)                        # an infinite range collapses the range key
+    assert _sort_equals_oracle(ctx, np.full((ny, nx), 2.5), dA) == 1
+    assert _sort_equals_oracle(ctx, np.array([[3.0, -1.0]])) == 1
+    # float32 tracers keep the four key passes
+    r = ctx.sort_profile(q.astype(np.float32), dA=dA, want_sorted=True)
+    assert ctx.last_sort_path() == 0 and np.array_equal(r['q_sorted'], np.sort(q.astype(np.float32).ravel()).astype(np.float64))
+
+
+def test_sort_range_path_spike_falls_back(ctx):
+    """distinct values packed into less than 2^-24 of the range (1e-12 noise around 1, two outliers): the runs of equal
+    range key are thousands of cells long and out of order -- the check fails, the eight key passes sort the stack (path 2)"""
+    rng = np.random.default_rng(13)
+    q = 1.0 + 1e-12 * rng.standard_normal((200, 512))
+    q[0, 0], q[1, 1] = -5.0, 7.0
+    dA = rng.random(q.shape) + 0.5
+    assert _sort_equals_oracle(ctx, q, dA) == 2
+    # the same spike in a stack next to a harmless plane: the batch falls back as a whole, every plane is right
+    st = np.stack([rng.standard_normal(q.shape), q])
+    r = ctx.sort_profile(st, dA=dA, want_sorted=True)
+    assert ctx.last_sort_path() == 2
+    for s in range(2):
+        assert np.array_equal(r['q_sorted'][s], np.sort(st[s].ravel()))
+    # runs just over / under the repair limit of 128: 120 distinct values inside one range-key bucket are repaired in LDS
+    base = np.linspace(0.0, 1.0, 4096 * 8).reshape(64, 512)
+    b2 = base.copy()
+    b2.ravel()[1000:1120] = base.ravel()[1000] + 1e-13 * rng.permutation(120)
+    assert _sort_equals_oracle(ctx, b2) == 1
+    b3 = base.copy()
+    b3.ravel()[1000:1400] = base.ravel()[1000] + 1e-13 * rng.permutation(400)
+    assert _sort_equals_oracle(ctx, b3) == 2

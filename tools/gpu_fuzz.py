@@ -83,20 +83,14 @@ def case_keff():
     tbl = table_from_rowsums(rows, ylt, last_row_included(lat, re_))          # the product's own table path (K2 + host rule)
     otbl, cs = O.cal_area_eqCoord_table_hist(np.ones((ny, nx)), dA, lat, inc, lt, re_)
     assert relerr(tbl, otbl) < 1e-12, 'keff table'
-    # a third of the cases through the persistent single-read kernel (it takes planes of >= 65 536 cells with even nx:
-    # XC_FUZZ_SCALE >= 3; smaller ones fall back to the two-pass path inside the library)
-    ctx.set_keff_mode(nat.XC_KEFF_PERSISTENT if rng.random() < 0.34 else nat.XC_KEFF_AUTO)
     plan = KeffPlan(ctx, S, ny, nx, N, dt, cdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=cs, increase=inc, lt=lt,
                     right_edge=re_)
     plan.set_q(q); plan.run()
     try:
         r = plan.fetch()
     except Exception:
-        plan.free(); ctx.set_keff_mode(nat.XC_KEFF_AUTO); return
-    if ctx.last_keff_path() == 1:
-        tick('keff_persistent')
+        plan.free(); return
     plan.free()
-    ctx.set_keff_mode(nat.XC_KEFF_AUTO)
     for s in range(S):
         o = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=inc, lt=lt, dtype=cdt, right_edge=re_)
         assert np.array_equal(r['ctr'][s], o['ctr'].astype(np.float64)), 'keff ctr'

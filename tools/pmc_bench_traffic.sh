@@ -1,29 +1,33 @@
 #!/bin/bash
 # tools/pmc_bench_traffic.sh (run on the GPU box via gpurun): fabric traffic of the bench's dominant kernel, FETCH_SIZE and
 # WRITE_SIZE in SEPARATE --pmc passes (the guide's rule), for every schedule bench.py can run:
-#   chain (default) | nochain | persistent, each with the shared dA plane and with per-slab dA (--slab-dA);
-# plus rocprofv3 --kernel-trace --stats summaries of the default command and of --no-chain / --persistent.
+#   chain (default) | nochain, each with the shared dA plane and with per-slab dA (--slab-dA);
+# plus rocprofv3 --kernel-trace --stats summaries of the default command and of --no-chain.
+# The JSON carries sha256(xc_hist.hip + xc_hist_kernel.h + xc_binning.h): bench.py quotes a figure only while that matches its tree.
 # Writes gpurun_out/hist_traffic.json (copy to profiles/) and gpurun_out/kt_<mode>/.
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && cd $R
 COMMIT=${1:-unknown}
-for mode in chain nochain persistent slab_chain slab_nochain slab_persistent; do
+for mode in chain nochain slab_chain slab_nochain; do
   arg=""
-  case $mode in *nochain) arg="--no-chain";; *persistent) arg="--persistent";; esac
+  case $mode in *nochain) arg="--no-chain";; esac
   case $mode in slab_*) arg="$arg --slab-dA";; esac
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb_${mode}_$c -- python3 bench.py --steps 12 --warmup 3 --no-cpu $arg > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb_${mode}_$c -- python3 bench.py --steps 12 --warmup 3 --no-cpu --no-extras --no-cfg4 $arg > /dev/null 2>&1
   done
 done
-for mode in chain nochain persistent; do
-  arg=""; [ $mode = nochain ] && arg="--no-chain"; [ $mode = persistent ] && arg="--persistent"
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_$mode -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu $arg > $R/gpurun_out/kt_$mode.log 2>&1
+for mode in chain nochain; do
+  arg=""; [ $mode = nochain ] && arg="--no-chain"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_$mode -o kt -- python3 bench.py --steps 100 --warmup 10 --no-cpu --no-extras --no-cfg4 $arg > $R/gpurun_out/kt_$mode.log 2>&1
 done
 python3 - <<PY
-import csv,glob,collections,json
+import csv,glob,collections,json,hashlib
 B, NY, NX = 64, 1801, 3600
-out = {'commit': '$COMMIT', 'slabs_per_launch': B,
+_h = hashlib.sha256()
+for _f in ('xc_hist.hip', 'xc_hist_kernel.h', 'xc_binning.h'):
+    _h.update(open('$R/xcontour_amd/csrc/' + _f, 'rb').read())
+out = {'commit': '$COMMIT', 'source_sha256': _h.hexdigest(), 'slabs_per_launch': B,
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over python3 bench.py --steps 12 --warmup 3 --no-cpu '
-                 '[--no-chain|--persistent] [--slab-dA]; median over the dispatches of the dominant kernel; FETCH_SIZE x 2 '
+                 '[--no-chain] [--slab-dA]; median over the dispatches of the dominant kernel; FETCH_SIZE x 2 '
                  '(gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md; calibrated on k_minmax_partial: '
                  'known bytes / reported KB) + WRITE_SIZE x 1; KB = 1024 B'}
 raw = collections.defaultdict(dict)
@@ -32,7 +36,7 @@ for f in sorted(glob.glob("$R/gpurun_out/pmcb_*/*/*counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        name = 'k_keff_persist' if 'k_keff_persist' in k else ('k_hist' if 'k_hist<' in k else ('k_minmax_partial' if 'k_minmax_partial' in k else None))
+        name = 'k_hist' if 'k_hist<' in k else ('k_minmax_partial' if 'k_minmax_partial' in k else None)
         if name:
             agg[(name, r['Counter_Name'])].append(float(r['Counter_Value']))
     for (name, ctr), v in agg.items():
@@ -43,7 +47,7 @@ if 'k_minmax_partial:FETCH_SIZE' in raw.get('nochain', {}):
     cal = known / raw['nochain']['k_minmax_partial:FETCH_SIZE']
     out['fetch_calibration'] = {'kernel': 'k_minmax_partial<double>', 'known_KB': known, 'FETCH_SIZE_KB_raw': raw['nochain']['k_minmax_partial:FETCH_SIZE'], 'factor': cal}
 for mode, d in raw.items():
-    dom = 'k_keff_persist' if 'persistent' in mode else 'k_hist'
+    dom = 'k_hist'
     if dom + ':FETCH_SIZE' not in d: continue
     slab = mode.startswith('slab_')
     cells = B * NY * NX

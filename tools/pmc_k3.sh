@@ -5,7 +5,7 @@ i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_BRANCH" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmck3_$i -- python3 bench.py --steps 6 --warmup 2 --no-cpu "$@" > /dev/null 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmck3_$i -- python3 bench.py --steps 6 --warmup 2 --no-cpu --no-extras --no-cfg4 "$@" > /dev/null 2>&1
 done
 python3 - <<PY
 import csv,glob,collections

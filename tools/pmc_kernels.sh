@@ -4,8 +4,8 @@
 # Prints, per kernel, the median counter value per launch; FETCH_SIZE is in units of 32 B... see profiles/r01_notes.md
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && cd $R
 for c in FETCH_SIZE WRITE_SIZE; do
-  XC_CPU=0 XC_VARIANT=2 XC_SLABS=8 timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmck_cross_$c -- python3 tools/gpu_cross_time.py > /dev/null 2>&1
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmck_sort_$c -- python3 tools/gpu_sort_time.py > /dev/null 2>&1
+  XC_CPU=0 XC_STRIDES=1 XC_SLABS=8 timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmck_cross_$c -- python3 tools/kernel_times.py cross > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmck_sort_$c -- python3 tools/kernel_times.py sort > /dev/null 2>&1
 done
 python3 - <<PY
 import csv,glob,collections

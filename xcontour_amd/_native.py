@@ -20,7 +20,6 @@ XC_F32, XC_F64 = 0, 1
 XC_DA_NONE, XC_DA_ROW, XC_DA_PLANE, XC_DA_SLAB = 0, 1, 2, 3
 XC_EDGE_NUMPY, XC_EDGE_XHISTOGRAM = 0, 1
 XC_MAX_INTEGRANDS = 2
-XC_KEFF_AUTO, XC_KEFF_TWO_PASS, XC_KEFF_PERSISTENT = 0, 1, 2
 MAX_SLABS_PER_LAUNCH = 65535
 XC_PAD_EDGE, XC_PAD_WRAP, XC_PAD_NAN, XC_PAD_REFLECT, XC_PAD_SYMMETRIC = 0, 1, 2, 3, 4
 PAD_MODES = {'edge': XC_PAD_EDGE, 'wrap': XC_PAD_WRAP, 'constant': XC_PAD_NAN, 'reflect': XC_PAD_REFLECT,
@@ -43,6 +42,7 @@ class HistDesc(C.Structure):
         ('periodic_x', _i32), ('lt', _i32),
         ('reverse', _i32), ('negate', _i32),
         ('pdf', _vp), ('counts', _vp), ('cdf', _vp),
+        ('deterministic', _i32), ('reserved0', _i32),
     ]
 
 
@@ -61,6 +61,7 @@ class KeffDesc(C.Structure):
         ('dqdA', _vp), ('dintSdA', _vp), ('Leq2', _vp), ('Lmin', _vp), ('nkeff', _vp),
         ('counts', _vp), ('interp', _vp), ('status', _vp), ('q_next', _vp),
         ('dA_pos_finite', _i32), ('q_gen', _i32),
+        ('deterministic', _i32), ('reserved0', _i32),
     ]
 
 
@@ -109,14 +110,12 @@ PROTOTYPES = {
                                             _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'xc_sort_profile_batch': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i64, _i64, _i64, C.c_int,
                                         _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'xc_last_sort_path': (C.c_int, [_vp, C.POINTER(C.c_int)]),
     'xc_keff_dev': (C.c_int, [_vp, C.POINTER(KeffDesc)]),
     'xc_keff_epilogue_dev': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int,
                                        C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xc_keff_epilogue': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int,
                                    C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'xc_set_keff_mode': (C.c_int, [_vp, C.c_int]),
-    'xc_last_keff_path': (C.c_int, [_vp, C.POINTER(C.c_int)]),
-    'xc_dbg_set_stamps': (C.c_int, [_vp, _vp]),
     'xc_set_kernel_timing': (C.c_int, [_vp, C.c_int]),
     'xc_last_hist_ms': (C.c_int, [_vp, C.POINTER(C.c_float)]),
     'xc_set_hist_events': (C.c_int, [_vp, _vp, _vp]),
@@ -270,15 +269,10 @@ class Context(object):
         self._check(self.lib.xc_event_elapsed_ms(self.handle, e0, e1, C.byref(ms)))
         return ms.value
 
-    def set_keff_mode(self, mode):
-        """XC_KEFF_AUTO (= two-pass unless XC_KEFF_PERSIST=1), XC_KEFF_TWO_PASS or XC_KEFF_PERSISTENT (single-read kernel
-        where the shape suits it; see include/xcontour_hip.h)"""
-        self._check(self.lib.xc_set_keff_mode(self.handle, int(mode)))
-        self._keff_mode = int(mode)
-
-    def last_keff_path(self):
+    def last_sort_path(self):
+        """K8, last call: 0 key passes only, 1 the three range-key passes sufficed, 2 they failed the check (re-sorted)"""
         p = C.c_int()
-        self._check(self.lib.xc_last_keff_path(self.handle, C.byref(p)))
+        self._check(self.lib.xc_last_sort_path(self.handle, C.byref(p)))
         return p.value
 
     def set_kernel_timing(self, on):
@@ -333,10 +327,11 @@ class Context(object):
         return ctr, edges, status
 
     def hist(self, q, edges, dA=None, integrands=(), grad=None, last_closed=True, lt=True,
-             reverse=False, prod_f32=False, negate=False, want=('pdf', 'counts', 'cdf')):
+             reverse=False, prod_f32=False, negate=False, want=('pdf', 'counts', 'cdf'), deterministic=False):
         """q: (nslab, ny, nx); edges: (nedge,) or (nslab, nedge) ascending f64.
         dA: None | (ny,) | (ny,nx) | (nslab,ny,nx) (converted to f64).
-        grad: None or (rdx, rdy, periodic_x).  Returns dict of requested outputs."""
+        grad: None or (rdx, rdy, periodic_x).  deterministic: order-free fixed-point sums (bit-reproducible).
+        Returns dict of requested outputs."""
         q = np.ascontiguousarray(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
@@ -348,7 +343,7 @@ class Context(object):
                 d3 = dA is not None and np.ndim(dA) == 3
                 parts.append(self.hist(q[sl], e[sl] if e.ndim == 2 else e, dA[sl] if d3 else dA,
                                        [np.asarray(v)[sl] for v in integrands], grad, last_closed, lt, reverse,
-                                       prod_f32, negate, want))
+                                       prod_f32, negate, want, deterministic))
             return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
         edges = np.ascontiguousarray(edges, dtype=np.float64)
         d = HistDesc()
@@ -391,6 +386,7 @@ class Context(object):
             keep += [rdx, rdy]
             d.grad, d.rdx, d.rdy, d.periodic_x = 1, _ptr(rdx), _ptr(rdy), 1 if grad[2] else 0
         d.lt, d.reverse, d.negate = 1 if lt else 0, 1 if reverse else 0, 1 if negate else 0
+        d.deterministic = 1 if deterministic else 0
         nch, nbin = 1 + d.nint + d.grad, d.nedge - 1
         out = {}
         if 'pdf' in want:

@@ -22,7 +22,9 @@ Extensions over the reference (all optional, defaults follow the snapshot):
     (the reference only supports a `time` loop, core.py:1259-1294);
   * `right_edge='xhistogram'|'numpy'` selects the last-bin rule: the default is what the reference
     runs (xhistogram: last edge + 1e-8 in the edge dtype, half-open), 'numpy' closes the last bin;
-  * `cal_squared_gradient`, `keff` (fused pipeline), `metric=` in cal_local_wave_activity.
+  * `cal_squared_gradient`, `keff` (fused pipeline), `metric=` in cal_local_wave_activity;
+  * `deterministic=True`: order-free fixed-point sums in every histogram pass (include/xcontour_hip.h, "Deterministic
+    sums"): bit-identical results between runs and shardings, like the reference's np.bincount, at ~2x the pass.
 """
 import numpy as np
 
@@ -44,7 +46,7 @@ class Contour2D(object):
 
     def __init__(self, trcr, dA, dims, dimEq, arakawa='A',
                  increase=True, lt=False, check_mono=False, dtype=np.float32,
-                 device=0, right_edge='xhistogram'):
+                 device=0, right_edge='xhistogram', deterministic=False):
         if len(dimEq) != 1:
             raise Exception('dimEq should be one dimension e.g., {"Y","lat"}')
 
@@ -68,6 +70,7 @@ class Contour2D(object):
         self.increase = increase
         self.right_edge = right_edge
         self.device = device
+        self.deterministic = bool(deterministic)     # order-free fixed-point sums (bit-reproducible; ~2x the histogram pass)
         if self.dimEqV not in self.dimVs:
             raise Exception('dimEq should be one of dims')
         self._xdim = [d for d in self.dimVs if d != self.dimEqV][0]
@@ -306,7 +309,7 @@ class Contour2D(object):
         b = self._contour_values(contour, nslab, list(lead), list(lshape))
         edges, binc, last_closed = _edges_from_levels(b, self.right_edge)
         out = self.ctx.hist(q, edges, dA=dA, integrands=integ, last_closed=last_closed, lt=self.lt,
-                            reverse=not binc, prod_f32=prod_f32, want=('cdf',))
+                            reverse=not binc, prod_f32=prod_f32, want=('cdf',), deterministic=self.deterministic)
         cdf = out['cdf'][:, 1 if integ else 0, :]
         N = b.shape[1]
         binNum = np.arange(N).astype(np.float32)                      # core.py:1255-1257
@@ -342,7 +345,7 @@ class Contour2D(object):
             e = np.stack([np.concatenate(([-np.inf], uniq[s])) for s in grp])
             res = self.ctx.hist(q[grp], e, dA=dA if dA.ndim < 3 else dA[grp],
                                 integrands=[g[grp] for g in integ], last_closed=False, lt=True,
-                                negate=not self.lt, prod_f32=prod_f32, want=('cdf',))
+                                negate=not self.lt, prod_f32=prod_f32, want=('cdf',), deterministic=self.deterministic)
             cdf = res['cdf'][:, 1 if integ else 0, :]
             for i, s in enumerate(grp):
                 out[s] = cdf[i][np.searchsorted(uniq[s], sgn * b[s])]
@@ -434,7 +437,7 @@ class Contour2D(object):
         b = self._contour_values(contour, nslab, list(lead), list(lshape))
         edges, binc, last_closed = _edges_from_levels(b, self.right_edge)
         out = self.ctx.hist(q, edges, dA=dA, integrands=gs, last_closed=last_closed, lt=self.lt,
-                            reverse=not binc, prod_f32=flags[0], want=('cdf',))
+                            reverse=not binc, prod_f32=flags[0], want=('cdf',), deterministic=self.deterministic)
         binNum = np.arange(b.shape[1]).astype(np.float32)                  # core.py:1255-1257
         name = 'histogram_%s' % lb.unwrap(self.tracer)[3]
         res = [self._wrap_contour(np.ascontiguousarray(out['cdf'][:, c, :]), lead, lshape, coords, name, self.tracer, binNum)
@@ -734,7 +737,7 @@ class Contour2D(object):
         # a per-slab dA travels with every batch (like the tracer): only its shape enters the key
         dkey = ('slab',) if slab_dA else (flat[::max(1, flat.size // 4096)].tobytes(), float(flat[0]), float(flat[-1]))
         key = (batch, ny, nx, int(N), q.dtype.str, np.dtype(self.dtype).str, None if g is None else g.dtype.str,
-               bool(periodic_x), float(nkeff_mask), bool(self.increase), bool(self.lt), self.right_edge, self.device,
+               bool(periodic_x), float(nkeff_mask), bool(self.increase), bool(self.lt), self.right_edge, self.device, self.deterministic,
                dA.shape[-2:] if slab_dA else dA.shape, dkey,
                small(tv), small(tcoords[table._dimEq]), small(preY), small(rdx), small(rdy))
         plans = self.__dict__.setdefault('_keff_plans', {})
@@ -745,7 +748,7 @@ class Contour2D(object):
                             increase=self.increase, lt=self.lt, right_edge=self.right_edge,
                             nkeff_mask=nkeff_mask, grdS_dtype=None if g is None else g.dtype,
                             prod_f32=bool(g is not None and g.dtype == np.float32 and dA_f32),
-                            detect_row_dA=not slab_dA)
+                            detect_row_dA=not slab_dA, deterministic=self.deterministic)
         if slab_dA:
             plan.desc.dA_pos_finite = int(bool(np.isfinite(dA).all() and (dA >= 0).all()))
         try:

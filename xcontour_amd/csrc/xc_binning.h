@@ -1,5 +1,4 @@
-// Device helpers shared by the histogram kernels (xc_hist.hip: streaming two-pass K3; xc_keffp.hip: persistent
-// single-read Keff kernel): exact contour-level / edge arithmetic, np.digitize-exact bin search, LDS atomics,
+// Device helpers of the histogram kernels (xc_hist.hip, K3): exact contour-level / edge arithmetic, np.digitize-exact bin search, LDS atomics,
 // cross-lane moves.  Included inside namespace xc { namespace { ... } } of each translation unit.
 #pragma once
 
@@ -138,6 +137,26 @@ __device__ __forceinline__ void lds_add(double* p, double v)
 __device__ __forceinline__ void lds_add(unsigned* p, unsigned v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add(unsigned long long* p, unsigned long long v)      // ds_add_u64: associative, order-free
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// rint(w * 2^k) as a two's-complement 64-bit integer, |w * 2^k| < 2^62 (the deterministic sums, xc_hist_det.hip).  gfx950 has
+// no f64 -> i64 conversion: split t = hi * 2^32 + lo with hi = floor(t / 2^32) (exact: a power-of-two scaling, a floor and an
+// FMA that cancels), 0 <= lo <= 2^32, and convert the halves.  A function of (w, k) alone: the same cell always
+// contributes the same integer.  (lo == 2^32 after rounding -- one case in 2^33 -- saturates to 2^32 - 1: one unit of
+// 2^-k, still the same integer every time.)
+__device__ __forceinline__ unsigned long long fixed_point(double w, int k)
+{
+    const double t = ldexp(w, k);
+    const double th = floor(t * 0x1p-32);
+    const double tl = rint(__builtin_fma(th, -0x1p32, t));
+    return ((unsigned long long)(long long)(int)th << 32) + (unsigned long long)(unsigned)tl;
+}
+__device__ __forceinline__ void lds_max(unsigned long long* p, unsigned long long v)      // ds_max_u64
+{
+    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // copy slot of a lane.  (Rotating the slot by the bin index to spread LDS banks was measured

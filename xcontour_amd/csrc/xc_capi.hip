@@ -4,6 +4,7 @@
 #include "xc_internal.h"
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <new>
 #include <mutex>
 #include <set>
@@ -141,6 +142,16 @@ int xc_create(int device_id, xc_ctx** out)
         delete ctx; return fail(nullptr, XC_ENODEV, m);
     }
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    {
+        // the only place the library reads the environment: K3 geometry knobs for experiments (xc_internal.h, HistKnobs)
+        auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        HistKnobs& k = ctx->knobs;
+        k.xcd_map = env_int("XC_HIST_XCDMAP", 1); k.tile_map = env_int("XC_HIST_TILEMAP", 1); k.vec4 = env_int("XC_HIST_VEC4", -1);
+        k.threads = env_int("XC_HIST_THREADS", 0); k.ncopy = env_int("XC_HIST_NCOPY", 0); k.rows = env_int("XC_HIST_ROWS", 0);
+        k.bps = env_int("XC_HIST_BPS", 0);
+        k.cross_ncopy = env_int("XC_CROSS_NCOPY", 0); k.cross_blocks = env_int("XC_CROSS_BLOCKS", 0);
+        k.sort_range = env_int("XC_SORT_RANGE", 1);
+    }
     ctx->cus = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         int rc = hipfail(nullptr, e, "hipStreamCreate"); delete ctx; return rc;
@@ -403,19 +414,36 @@ static int check_hist_desc(xc_ctx* ctx, const xc_hist_desc* d)
     return XC_OK;
 }
 
+// Deterministic sums: max pass, scales, fixed-point pass, exact integer reduction into f.red_h / f.red_c
+// (xc_hist_det.hip); launch_finalize then runs its second stage only.
+static int det_passes(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, HistArgs& a,
+                      int* scale, FinalArgs& f)
+{
+    a.q_next = nullptr; a.mm_next = nullptr; a.det_scale = nullptr;
+    XC_TRY(launch_hist_det(ctx, q_dtype, nint, grad, g, nslab, a, 1));
+    XC_TRY(launch_det_scales(ctx, nslab, g.bps, f.nch, f.nbin, a.part_h, a.part_c, scale, f.red_c));
+    a.det_scale = scale;
+    a.ctr_out = nullptr; a.edges_out = nullptr; a.status = nullptr;      // written by the first pass
+    XC_TRY(launch_hist_det(ctx, q_dtype, nint, grad, g, nslab, a, 2));
+    XC_TRY(launch_det_reduce(ctx, nslab, g.bps, f.nch, f.nbin, a.part_h, scale, f.red_h));
+    f.skip_reduce = 1;
+    return XC_OK;
+}
+
 int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
 {
     XC_CTX(ctx);
     XC_TRY(check_hist_desc(ctx, d));
     const int nbin = (int)(d->nedge - 1), nch = 1 + d->nint + (d->grad ? 1 : 0);
     HistGeom g;
+    const int det = d->deterministic ? 1 : 0;
     XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, nbin, nch,
-                         vec_align_bits(d->q, d->q_dtype, nullptr, d->dA, d->dA_rank, d->integrand, d->integrand_dtype, d->nint), &g));
+                         vec_align_bits(d->q, d->q_dtype, nullptr, d->dA, d->dA_rank, d->integrand, d->integrand_dtype, d->nint), &g, 0, det));
     const size_t ph = al((size_t)d->nslab * g.bps * nch * nbin * sizeof(double));
     const size_t pc = al((size_t)d->nslab * g.bps * nbin * sizeof(unsigned));
     const size_t rh = al((size_t)d->nslab * nch * nbin * sizeof(double));
     const size_t rc = al((size_t)d->nslab * nbin * sizeof(unsigned long long));
-    XC_TRY(ensure_scratch(ctx, ph + pc + rh + rc));
+    XC_TRY(ensure_scratch(ctx, ph + pc + rh + rc + (det ? rh : 0)));
     HistArgs a; memset(&a, 0, sizeof(a));
     a.q = d->q; a.dA = d->dA; a.dA_rank = d->dA_rank;
     if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); a.dA = ctx->ones; a.dA_rank = XC_DA_ROW; }
@@ -427,13 +455,18 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
     a.part_h = (double*)ctx->scratch; a.part_c = (unsigned*)((char*)ctx->scratch + ph);
-    XC_TRY(hist_ev_begin(ctx));
-    XC_TRY(launch_hist(ctx, d->q_dtype, d->nint, d->grad, g, d->nslab, a));
-    XC_TRY(hist_ev_end(ctx));
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = a.part_h; f.part_c = a.part_c; f.bps = g.bps; f.nch = nch; f.nbin = nbin;
     f.red_h = (double*)((char*)ctx->scratch + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + ph + pc + rh);
     f.lt = d->lt; f.reverse = d->reverse; f.pdf = d->pdf; f.counts = d->counts; f.cdf = d->cdf;
+    XC_TRY(hist_ev_begin(ctx));
+    if (det) {
+        int* scale = (int*)((char*)ctx->scratch + ph + pc + rh + rc);
+        XC_TRY(det_passes(ctx, d->q_dtype, d->nint, d->grad, g, d->nslab, a, scale, f));
+    } else {
+        XC_TRY(launch_hist(ctx, d->q_dtype, d->nint, d->grad, g, d->nslab, a));
+    }
+    XC_TRY(hist_ev_end(ctx));
     return launch_finalize(ctx, d->nslab, f);
 }
 
@@ -695,6 +728,13 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
                                  out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
 }
 
+int xc_last_sort_path(xc_ctx* ctx, int* out_path)
+{
+    if (!ctx || !out_path) return fail(ctx, XC_EBADARG, "xc_last_sort_path: bad arguments");
+    *out_path = ctx->last_sort_path;
+    return XC_OK;
+}
+
 // ------------------------------------------------------------------------------------ K5 / K6 alone
 int xc_keff_epilogue_dev(xc_ctx* ctx, const double* pdf, const double* ctr, int ctr_dtype, int64_t nslab, int N,
                          int increase, int lt, const double* tbl, const double* tbl_coord, int ntbl,
@@ -769,52 +809,8 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     if (d->grad ? (!d->rdx || !d->rdy) : !d->grdS) return fail(ctx, XC_EBADARG, "xc_keff: need rdx/rdy (grad=1) or grdS (grad=0)");
     if (d->npre < 0 || (d->npre > 0 && d->interp && !d->preY)) return fail(ctx, XC_EBADARG, "xc_keff: preY is NULL");
     const int N = d->N, nch = 2;
-    // ---- the persistent single-read kernel (xc_keffp.hip) when the shape suits it: in-kernel gradient, one tracer pass
-    PersistGeom pg;
-    const double* dA_eff = d->dA; int dA_rank_eff = d->dA_rank;
-    if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); dA_eff = ctx->ones; dA_rank_eff = XC_DA_ROW; }
-    if (d->grad && d->nslab <= 0x7fffffff &&
-        persist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, d->q, dA_eff, dA_rank_eff, &pg)) {
-        const size_t S = (size_t)d->nslab;
-        const size_t sync_b = al(S * 8 * sizeof(SyncShard) + 64);
-        const size_t ph = al(S * pg.G * nch * N * sizeof(double));
-        const size_t pc = al(S * pg.G * N * sizeof(unsigned));
-        const size_t rh = al(S * nch * N * sizeof(double));
-        const size_t rc = al(S * N * sizeof(unsigned long long));
-        XC_TRY(ensure_scratch(ctx, sync_b + ph + pc + rh + rc));
-        char* base = (char*)ctx->scratch;
-        XC_HIP(ctx, hipMemsetAsync(base, 0, sync_b, ctx->stream));
-        PersistArgs a; memset(&a, 0, sizeof(a));
-        a.q = d->q; a.dA = dA_eff; a.dA_rank = dA_rank_eff; a.rdx = d->rdx; a.rdy = d->rdy;
-        a.periodic_x = d->periodic_x; a.dA_pos_finite = (d->dA_rank == XC_DA_NONE) ? 1 : d->dA_pos_finite;
-        a.last_closed = d->right_edge == XC_EDGE_NUMPY;
-        a.ny = d->ny; a.nx = d->nx; a.nslab = (int)d->nslab; a.nbin = N; a.ncopy = pg.ncopy;
-        a.increase = d->increase; a.q_f32 = d->q_dtype == XC_F32; a.ctr_f32 = d->ctr_dtype == XC_F32;
-        a.right_edge = d->right_edge; a.inv_nm1 = 1.0 / (double)(N - 1); a.inv_n = 1.0 / (double)N;
-        a.G = pg.G; a.ngroups = pg.ngroups; a.nstrip = pg.nstrip; a.cps = pg.cps; a.rpc = pg.rpc;
-        a.slots = pg.slots; a.ngps = pg.ngps; a.cus = ctx->cus;
-        a.sync = (SyncShard*)base; a.abort = (unsigned*)(base + S * 8 * sizeof(SyncShard));
-        a.part_h = (double*)(base + sync_b); a.part_c = (unsigned*)(base + sync_b + ph);
-        a.ctr_out = d->ctr; a.status = d->status; a.stamps = ctx->dbg_stamps;
-        ctx->mm_valid = 0;
-        XC_TRY(hist_ev_begin(ctx));
-        XC_TRY(launch_keff_persist(ctx, d->q_dtype, a, pg));
-        XC_TRY(hist_ev_end(ctx));
-        ctx->last_keff_path = 1;
-        FinalArgs f; memset(&f, 0, sizeof(f));
-        f.part_h = a.part_h; f.part_c = a.part_c; f.bps = pg.G; f.nch = nch; f.nbin = N;
-        f.red_h = (double*)(base + sync_b + ph + pc); f.red_c = (unsigned long long*)(base + sync_b + ph + pc + rh);
-        f.lt = d->lt; f.reverse = !d->increase;
-        f.counts = d->counts;
-        f.keff = 1; f.ctr_f32 = a.ctr_f32; f.ctr = d->ctr;
-        f.tbl = d->tbl; f.tbl_coord = d->tbl_coord; f.ntbl = (int)d->ny;
-        f.preY = d->preY; f.npre = d->interp ? d->npre : 0;
-        f.nkeff_mask = d->nkeff_mask; f.lmin_scale = d->lmin_scale;
-        f.o_area = d->area; f.o_intS = d->intgrdS; f.o_latEq = d->latEq; f.o_dqdA = d->dqdA; f.o_dSdA = d->dintSdA;
-        f.o_Leq2 = d->Leq2; f.o_Lmin = d->Lmin; f.o_nkeff = d->nkeff; f.o_interp = d->interp;
-        return launch_finalize(ctx, d->nslab, f);
-    }
-    ctx->last_keff_path = 0;
+    const int det = d->deterministic ? 1 : 0;
+    const void* q_next = det ? nullptr : d->q_next;          // the order-free passes do not chain: K1 runs on its own
     HistGeom g;
     {
         const void* gi[1] = {d->grdS}; const int32_t gt[1] = {d->grdS_dtype};
@@ -825,14 +821,14 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
                                   reinterpret_cast<uintptr_t>(d->grdS) % 16 == 0;
         XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, nch,
                              vec_align_bits(d->q, d->q_dtype, d->q_next, d->dA, d->dA_rank, gi, gt, d->grad ? 0 : 1), &g,
-                             fast_layout ? 1 : (supplied_f32 ? 2 : 0)));
+                             fast_layout ? 1 : (supplied_f32 ? 2 : 0), det));
     }
     const size_t mb = al((size_t)d->nslab * kMinmaxBlocks * 2 * sizeof(double));
     const size_t ph = al((size_t)d->nslab * g.bps * nch * N * sizeof(double));
     const size_t pc = al((size_t)d->nslab * g.bps * N * sizeof(unsigned));
     const size_t rh = al((size_t)d->nslab * nch * N * sizeof(double));
     const size_t rc = al((size_t)d->nslab * N * sizeof(unsigned long long));
-    XC_TRY(ensure_scratch(ctx, mb + ph + pc + rh + rc));
+    XC_TRY(ensure_scratch(ctx, mb + ph + pc + rh + rc + (det ? rh : 0)));
     double* mmpart = (double*)ctx->scratch;
     double* part_h = (double*)((char*)ctx->scratch + mb);
     unsigned* part_c = (unsigned*)((char*)ctx->scratch + mb + ph);
@@ -847,7 +843,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     }
     ctx->mm_valid = 0;
     double* mm_next = nullptr;
-    if (d->q_next) {
+    if (q_next) {
         const int nb = 1 - ctx->mm_cur;
         XC_TRY(grow(ctx, (void**)&ctx->mmnext[nb], &ctx->mmnext_bytes[nb], al((size_t)d->nslab * g.bps * 2 * sizeof(double))));
         mm_next = ctx->mmnext[nb];
@@ -857,7 +853,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     a.q = d->q; a.dA = d->dA; a.dA_rank = d->dA_rank;
     if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); a.dA = ctx->ones; a.dA_rank = XC_DA_ROW; }
     if (!d->grad) { a.integ[0] = d->grdS; a.integ_f32[0] = d->grdS_dtype == XC_F32; }
-    a.q_next = d->q_next; a.mm_next = mm_next;
+    a.q_next = q_next; a.mm_next = mm_next;
     a.dA_pos_finite = (d->dA_rank == XC_DA_NONE) ? 1 : d->dA_pos_finite;
     a.mmpart = mmpart; a.P = mmP; a.levels_mode = 1; a.nbin = N;
     a.last_closed = d->right_edge == XC_EDGE_NUMPY;
@@ -867,18 +863,23 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
     a.part_h = part_h; a.part_c = part_c; a.ctr_out = d->ctr; a.status = d->status;
+    FinalArgs f; memset(&f, 0, sizeof(f));
+    f.part_h = part_h; f.part_c = part_c; f.bps = g.bps; f.nch = nch; f.nbin = N;
+    f.red_h = (double*)((char*)ctx->scratch + mb + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + mb + ph + pc + rh);
     XC_TRY(hist_ev_begin(ctx));
-    XC_TRY(launch_hist(ctx, d->q_dtype, d->grad ? 0 : 1, d->grad, g, d->nslab, a));
+    if (det) {
+        int* scale = (int*)((char*)ctx->scratch + mb + ph + pc + rh + rc);
+        XC_TRY(det_passes(ctx, d->q_dtype, d->grad ? 0 : 1, d->grad, g, d->nslab, a, scale, f));
+    } else {
+        XC_TRY(launch_hist(ctx, d->q_dtype, d->grad ? 0 : 1, d->grad, g, d->nslab, a));
+    }
     XC_TRY(hist_ev_end(ctx));
-    if (d->q_next) {
-        ctx->mm_cur = 1 - ctx->mm_cur; ctx->mm_valid = 1; ctx->mm_P = g.bps; ctx->mm_q = d->q_next;
+    if (q_next) {
+        ctx->mm_cur = 1 - ctx->mm_cur; ctx->mm_valid = 1; ctx->mm_P = g.bps; ctx->mm_q = q_next;
         ctx->mm_nslab = d->nslab; ctx->mm_ny = d->ny; ctx->mm_nx = d->nx; ctx->mm_dtype = d->q_dtype;
         ctx->mm_gen = d->q_gen;
     }
 
-    FinalArgs f; memset(&f, 0, sizeof(f));
-    f.part_h = part_h; f.part_c = part_c; f.bps = g.bps; f.nch = nch; f.nbin = N;
-    f.red_h = (double*)((char*)ctx->scratch + mb + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + mb + ph + pc + rh);
     f.lt = d->lt; f.reverse = !d->increase;       // decreasing levels -> flip to level order (core.py:454-455)
     f.counts = d->counts;
     f.keff = 1; f.ctr_f32 = a.ctr_f32; f.ctr = d->ctr;
@@ -888,29 +889,6 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     f.o_area = d->area; f.o_intS = d->intgrdS; f.o_latEq = d->latEq; f.o_dqdA = d->dqdA; f.o_dSdA = d->dintSdA;
     f.o_Leq2 = d->Leq2; f.o_Lmin = d->Lmin; f.o_nkeff = d->nkeff; f.o_interp = d->interp;
     return launch_finalize(ctx, d->nslab, f);
-}
-
-int xc_set_keff_mode(xc_ctx* ctx, int mode)
-{
-    if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
-    if (mode != XC_KEFF_AUTO && mode != XC_KEFF_TWO_PASS && mode != XC_KEFF_PERSISTENT)
-        return fail(ctx, XC_EBADARG, "xc_set_keff_mode: mode must be XC_KEFF_AUTO, XC_KEFF_TWO_PASS or XC_KEFF_PERSISTENT");
-    ctx->keff_mode = mode;
-    return XC_OK;
-}
-
-int xc_dbg_set_stamps(xc_ctx* ctx, void* dev_ptr)
-{
-    if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
-    ctx->dbg_stamps = (unsigned long long*)dev_ptr;
-    return XC_OK;
-}
-
-int xc_last_keff_path(xc_ctx* ctx, int* out_path)
-{
-    if (!ctx || !out_path) return fail(ctx, XC_EBADARG, "xc_last_keff_path: bad arguments");
-    *out_path = ctx->last_keff_path;
-    return XC_OK;
 }
 
 // ------------------------------------------------------------------------------------ synthetic slabs

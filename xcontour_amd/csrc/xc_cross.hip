@@ -545,7 +545,7 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
     if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_crossing: nslab too large");
     const int np = (N + 1) | 1;                           // N + 1 cells (the difference form writes at index N), odd row pitch: the copies of one contour fall in different banks
     int ncopy = 8;
-    if (const char* e = getenv("XC_CROSS_NCOPY")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ncopy = v; }
+    { const int v = ctx->knobs.cross_ncopy; if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) ncopy = v; }   // experiment knob (xc_create)
     while (ncopy > 1 && (size_t)(2 * N + 3) * 8 + (size_t)ncopy * np * 12 > 48 * 1024) ncopy >>= 1;   // several blocks per CU
     const size_t lds = (size_t)(2 * N + 3) * 8 + (size_t)ncopy * np * 12;
     if (lds > kLdsBudget) return fail(ctx, XC_EBADARG, "xc_crossing: too many contours for one pass");
@@ -567,7 +567,7 @@ int launch_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int6
     const int64_t tw = stride == 1 ? CROSS_W1 : CROSS_TPB;
     const int64_t ntj = (nbj + rbox - 1) / rbox;
     const int64_t nti = cols ? ((nbi + nbw - 1) / nbw + 3) / 4 : (nbi + tw - 1) / tw;
-    static const int env_blocks = [] { const char* e = getenv("XC_CROSS_BLOCKS"); return e ? atoi(e) : 0; }();     // experiment knob
+    const int env_blocks = ctx->knobs.cross_blocks;                                                                // experiment knob (xc_create)
     int64_t bps = (env_blocks > 0 ? env_blocks : 2048) / nslab; if (bps < 8) bps = 8; if (bps > ntj * nti) bps = ntj * nti;
     const size_t pl = (size_t)nslab * bps * N * 8, pc = (size_t)nslab * bps * N * 4;
     {

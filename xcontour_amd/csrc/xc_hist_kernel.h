@@ -1,0 +1,517 @@
+// K3 kernel body + its launcher template, shared by xc_hist.hip (the float64-atomics variants) and xc_hist_det.hip (the
+// order-free fixed-point variants, DET = 1 / 2).  Included INSIDE `namespace xc { namespace {` of each translation unit.
+#pragma once
+
+#ifndef XC_U
+#define XC_U 2
+#endif
+// Cache policy of the two tracer streams (bit 0: the binned batch, bit 1: the NEXT batch whose min / max rides along).
+// Measured on MI355X (bench.py, 64 slabs per launch): the non-temporal hint on the NEXT stream -- read once, used for
+// two compares, never needed again by this launch -- keeps the shared dA plane in the XCD L2s: 1.367 -> 1.285 ms per
+// launch; the same hint on the binned stream costs 9 % (its halo / neighbour re-reads want the line), on both 7 %.
+#ifndef XC_HIST_QNT
+#define XC_HIST_QNT 2
+#endif
+template <int VEC> struct RowsPerBatch { static constexpr int value = VEC >= 4 ? 1 : XC_U; };   // rows per prefetch batch (double-buffered): the same bytes in flight
+
+// Grid mapping (1-D grid).  Workgroups go round-robin to the 8 XCDs (workgroup id % 8), each XCD has its own
+// L2, and every slab of a launch reads the SAME dA rows in its block `bx`.  XCD-aware order (default): XCD x
+// takes the row groups bx = x, x+8, ... and runs each for ALL slabs back to back -- with one 1024-thread block
+// per CU the 32 CUs of an XCD hold one row group of 32 slabs at a time, so that part of the dA plane is
+// fetched into that L2 once per launch instead of once per XCD per slab group.  Plain order (xcd_map == 0):
+// slab fastest, blocks of one row group spread over all XCDs.
+#define XC_NBLK (a.bps)
+
+#include "xc_binning.h"
+
+template <int VEC, int NINT>
+struct RowBuf {
+    double q[VEC];          // GRAD: row (centre+1); else: the centre row itself
+    double h;               // GRAD: lane 0 = left halo of that row, lane 63 = right halo
+    double dA[VEC];
+    double in[NINT > 0 ? NINT : 1][VEC];
+    double qn[VEC];         // NEXT: the same cells of the next batch (min/max by-product)
+};
+
+// DA2D: dA is a [ny][nx] plane (vector loads); otherwise one value per row (scalar).
+// NEXT: also stream the same cells of a.q_next and emit its per-block min/max partials.
+// FAST (Keff layout only): periodic X and dA verified finite and >= 0 are COMPILE-time facts -- the wall selects and
+// the fillna selects vanish from the row body.
+// DET (deterministic sums, xc_hist_det.hip): 0 = float64 LDS atomics (sums depend on the order in which waves reach the
+// LDS: last bits vary from run to run); 1 = per-bin max |w| with ds_max_u64 on the bit patterns (exact, order-free);
+// 2 = fixed-point accumulation: every weight becomes the 64-bit integer rint(w * 2^k), k chosen per (bin, channel) from
+// pass 1's maximum and count so that the bin's sum stays below 2^62, and the integers are added with ds_add_u64 -- integer
+// addition is associative, so the per-bin sums do not depend on the order of arrival, the block geometry or the number of
+// slabs per launch.
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT, bool FAST = false, int DET = 0>
+__global__ __launch_bounds__(kHistThreads)
+void k_hist(const HistArgs a)
+{
+    constexpr int NCH = 1 + NINT + (GRAD ? 1 : 0);
+    constexpr int W = 64 * VEC;
+    constexpr int U = RowsPerBatch<VEC>::value;
+    extern __shared__ __align__(16) double smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction
+    const int nwave = blockDim.x >> 6;
+    int slab, bx;
+    {
+        const int L = (int)blockIdx.x;
+        if (a.xcd_map) { const int j = L >> 3; slab = j % a.nslab_grid; bx = (L & 7) + 8 * (j / a.nslab_grid); }
+        else { slab = L % a.nslab_grid; bx = L / a.nslab_grid; }
+        if (bx >= a.bps) return;                                  // padding blocks of the XCD-aware order
+    }
+    const int nbx = XC_NBLK;
+    const int N = a.nbin;
+    const int ncopy = a.ncopy;
+    const int epad = (N + 2) & ~1;
+    double*   s_red   = smem;                                   // 64 doubles
+    double*   s_edges = smem + 64;                              // N+1
+    // one CELL per (bin, copy): the NCH sums and the count side by side (count = low word of the last slot), so a cell's
+    // three adds share ONE address computation; bin N is a trash bin -- NaN, out-of-range and inactive cells add there
+    // unconditionally instead of branching around the adds (round 2: 86 -> 7x VALU instructions per 128-cell wave-row)
+    constexpr int CW = NCH + 1;
+    double*   s_cell  = s_edges + epad;                         // [(N + 1) * ncopy][CW]
+    const int hsz = (N + 1) * ncopy;
+    int*      s_scale = reinterpret_cast<int*>(s_cell + (size_t)CW * hsz);   // DET == 2: [(N + 1)][NCH] binary exponents k (w -> w * 2^k)
+
+    // ------------------------------------------------------------------ this wave's share of (strip,row) pairs
+    const int ny = (int)a.ny, nx = (int)a.nx;                    // host guarantees < 2^31
+    const int64_t total = (int64_t)a.nstrip * ny;
+    const int64_t nw = (int64_t)nbx * nwave;
+    const int64_t wg = (int64_t)bx * nwave + wave;
+    int64_t g0 = total * wg / nw;
+    int64_t g1 = total * (wg + 1) / nw;
+    if (a.nchunk > 0) {
+        // Strip-fastest order: the waves of a workgroup sweep the SAME rows of ADJACENT strips side by side, so the halo
+        // column a wave needs (one 128-byte line per row and side for 8 bytes) is a line its neighbour wave streams
+        // at the same moment -- an L2 hit instead of a fabric fetch (measured: ~1 GB of the 7.7 GB per 64-slab launch).
+        const int strip = (int)(wg % a.nstrip), chunk = (int)(wg / a.nstrip);
+        if (chunk < a.nchunk) {
+            g0 = (int64_t)strip * ny + (int64_t)ny * chunk / a.nchunk;
+            g1 = (int64_t)strip * ny + (int64_t)ny * (chunk + 1) / a.nchunk;
+        } else { g0 = 0; g1 = 0; }
+    }
+
+    const size_t slab_off = (size_t)slab * (size_t)ny * (size_t)nx;
+    const size_t rowq = (size_t)nx * sizeof(TQ), rowd = (size_t)nx * sizeof(double);
+    const TQ* __restrict__ qs = reinterpret_cast<const TQ*>(a.q) + slab_off;
+    const TQ* __restrict__ qnx = NEXT ? reinterpret_cast<const TQ*>(a.q_next) + slab_off : nullptr;
+    double nmn = dinf(), nmx = -dinf();
+    const double* __restrict__ dAp = (DA2D && a.dA_rank == XC_DA_SLAB) ? a.dA + slab_off : a.dA;
+    const double* __restrict__ rdxp = a.rdx;
+    const double* __restrict__ rdyp = a.rdy;
+    const int copy = lane & (ncopy - 1);
+    const int cshift = __builtin_ctz((unsigned)ncopy);            // ncopy is a power of two
+    const int periodic_x = FAST ? 1 : a.periodic_x;
+
+    // segment state (wave-uniform scalars + per-lane 32-bit byte offsets inside a row)
+    int y0 = 0, y1 = 0;
+    unsigned xo_q = 0, xo_h = 0, xo_d = 0, xo_f = 0;
+    bool active = false, full_strip = true;
+    unsigned long long inactive_mask = 0ull;                      // lanes beyond the row end (ragged last strip)
+    int rlane = 63;
+    double fx[VEC];
+
+    auto begin_segment = [&]() {
+        const int     s  = (int)(g0 / ny);
+        y0 = (int)(g0 - (int64_t)s * ny);
+        const int64_t rem = g1 - g0;
+        y1 = (y0 + rem < ny) ? (int)(y0 + rem) : ny;
+        g0 += (y1 - y0);
+        const int x0 = s * W;
+        const int x  = x0 + lane * VEC;
+        active = x < nx;
+        const int xend = (x0 + W < nx) ? x0 + W : nx;
+        rlane = (xend - x0) / VEC - 1;                                 // lane holding the strip's last valid cell
+        full_strip = rlane == 63;
+        inactive_mask = full_strip ? 0ull : (~0ull << (rlane + 1));
+        // inactive lanes load from a clamped (valid) address; in a ragged last strip of a periodic
+        // domain the first inactive lane loads columns 0.. so that its cell 0 IS the right halo
+        const int xld = active ? x : ((periodic_x && lane == rlane + 1) ? 0 : nx - VEC);
+        const int xl = (x0 == 0) ? (periodic_x ? nx - 1 : 0) : x0 - 1;
+        const int xr = (xend == nx) ? (periodic_x ? 0 : nx - 1) : xend;
+        const int xh = (lane == 0) ? xl : ((lane == 63) ? xr : xld);   // halo column (lanes 0 / 63 matter)
+        xo_q = (unsigned)xld * (unsigned)sizeof(TQ); xo_h = (unsigned)xh * (unsigned)sizeof(TQ);
+        xo_d = (unsigned)xld * 8u; xo_f = (unsigned)xld * 4u;
+        // one-sided x differences at the walls of a non-periodic domain use spacing dx, not 2dx
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+            fx[c] = (!periodic_x && (x + c == 0 || x + c == nx - 1)) ? 2.0 : 1.0;
+    };
+
+    // per-row gradient metrics, lane-distributed: lane i holds row ymet0 + i (64 rows per refill),
+    // read back with v_readlane -- 4 VGPRs per wave instead of 4 per buffered row
+    double rdxv = 0.0, rdyv = 0.0;
+    int ymet0 = 0;
+    auto load_metrics = [&](int yfirst) {
+        ymet0 = yfirst;
+        const int y = (yfirst + lane < ny) ? yfirst + lane : ny - 1;
+        rdxv = rdxp[y]; rdyv = rdyp[y];
+    };
+
+    // branch-free loads of one row: q row `yq` (+ halo), weights of row `yw`
+    const char* qbase = reinterpret_cast<const char*>(qs);
+    const char* nbase = reinterpret_cast<const char*>(qnx);
+    const char* dbase = reinterpret_cast<const char*>(dAp);
+    auto load_row = [&](RowBuf<VEC, NINT>& r, int yq, int yw) {
+        yq = yq < ny - 1 ? yq : ny - 1;
+        yw = yw < ny - 1 ? yw : ny - 1;
+        const char* qrow = qbase + (size_t)yq * rowq;                          // wave-uniform
+#if (XC_HIST_QNT & 1)
+        RowLoadNT<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
+#else
+        RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
+#endif
+        if (GRAD) r.h = (double)*reinterpret_cast<const TQ*>(qrow + xo_h);
+#if (XC_HIST_QNT & 2)
+        if (NEXT) RowLoadNT<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
+#else
+        if (NEXT) RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
+#endif
+        if (DA2D) {
+            RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(dbase + (size_t)yw * rowd + xo_d), r.dA);
+        } else {
+            const double v = dAp[yw];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) r.dA[c] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NINT; ++i) {
+            if (a.integ_f32[i])
+                RowLoad<float, VEC>::ld(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.integ[i]) +
+                                        (slab_off + (size_t)yw * nx) * 4 + xo_f), r.in[i]);
+            else
+                RowLoad<double, VEC>::ld(reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.integ[i]) +
+                                         (slab_off + (size_t)yw * nx) * 8 + xo_d), r.in[i]);
+        }
+    };
+    auto load_batch = [&](RowBuf<VEC, NINT> (&L)[U], int yb) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) load_row(L[i], GRAD ? yb + i + 1 : yb + i, yb + i);
+    };
+
+    // issue the first loads of this wave BEFORE the edge prologue so that their HBM latency
+    // overlaps the min/max reduction and the barriers below
+    RowBuf<VEC, NINT> A[U], B[U];
+    double qm[VEC], qcur[VEC], hcur = 0.0;
+    bool have = g0 < g1;
+    if (have) {
+        begin_segment();
+        if (GRAD) {
+            load_metrics(y0);
+            RowBuf<VEC, NINT> t;
+            load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) qm[c] = t.q[c];
+            load_row(t, y0, y0);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) qcur[c] = t.q[c];
+            hcur = t.h;
+        }
+        load_batch(A, y0);
+    }
+
+    for (int i = tid; i < CW * hsz; i += blockDim.x) s_cell[i] = 0.0;
+
+    // ------------------------------------------------------------------ edges -> LDS
+    if (a.levels_mode) {
+        // reduce the per-block partial min/max of K1 (fixed order: deterministic)
+        const double* mp = a.mmpart + (size_t)slab * a.P * 2;
+        double mn = dinf(), mx = -dinf();
+        for (int i = tid; i < a.P; i += blockDim.x) { mn = fmin(mn, mp[2 * i]); mx = fmax(mx, mp[2 * i + 1]); }
+        for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
+        if (lane == 0) { s_red[2 * wave] = mn; s_red[2 * wave + 1] = mx; }
+        __syncthreads();
+        mn = s_red[0]; mx = s_red[1];
+        for (int w = 1; w < nwave; ++w) { mn = fmin(mn, s_red[2 * w]); mx = fmax(mx, s_red[2 * w + 1]); }
+        if (mn == dinf() && mx == -dinf()) { mn = dnan(); mx = dnan(); }     // all-NaN slab
+        for (int k = tid; k < N; k += blockDim.x) {
+            const double c = level_value(mn, mx, k, a.increase, a.q_f32, a.ctr_f32, a.inv_nm1);
+            s_edges[a.increase ? k + 1 : N - k] = c;
+            if (bx == 0 && a.ctr_out) a.ctr_out[(size_t)slab * N + k] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double lo = s_edges[1], hi = s_edges[N];
+            s_edges[0] = dummy_edge(lo, hi, N, a.ctr_f32);
+            if (a.right_edge == XC_EDGE_XHISTOGRAM) s_edges[N] = bump_last_edge(hi, a.ctr_f32);
+        }
+        if (bx == 0 && a.status) {
+            // reference raises 'non monotonic bins' when two adjacent levels coincide (core.py:1233)
+            int bad = 0;
+            for (int k = tid + 1; k < N; k += blockDim.x) bad |= (s_edges[k] == s_edges[k + 1]);
+            bad = __syncthreads_or(bad);
+            if (tid == 0) a.status[slab] = bad ? 1 : 0;
+        }
+        __syncthreads();
+        if (bx == 0 && a.edges_out)
+            for (int k = tid; k <= N; k += blockDim.x) a.edges_out[(size_t)slab * (N + 1) + k] = s_edges[k];
+    } else {
+        const double* e = a.edges + (a.edges_per_slab ? (size_t)slab * (N + 1) : 0);
+        for (int k = tid; k <= N; k += blockDim.x) s_edges[k] = e[k];
+        __syncthreads();
+    }
+    const double e0 = s_edges[0], eN = s_edges[N];
+    const double inv = (double)N / (eN - e0);
+    const int last_closed = FAST ? 0 : a.last_closed;           // FAST: the half-open (xhistogram) rule is a compile-time fact
+    // Are the edges equally spaced to a quarter of a bin?  Then the NEAREST edge j = floor((v - e0) / h + 1/2) brackets v
+    // between e[j-1] and e[j+1], and ONE exact comparison against e[j] gives np.digitize's answer (one 8-byte LDS read
+    // and one compare per cell instead of two reads, two compares and a call on a miss).  Checked per slab, wave-uniform.
+    bool uni;
+    {
+        const double hstep = (eN - e0) / (double)N;
+        int bad = 0;
+        for (int k = tid; k <= N; k += blockDim.x) bad |= !(fabs(s_edges[k] - (e0 + (double)k * hstep)) <= 0.25 * hstep);
+        uni = !__syncthreads_or(bad);
+    }
+    const int negate = a.negate;
+    const bool wpos = FAST ? true : (a.dA_pos_finite != 0);
+    if (DET == 2) {
+        const int* sc = a.det_scale + (size_t)slab * NCH * N;                     // [NCH][N], written by k_det_scales
+        for (int i = tid; i < NCH * (N + 1); i += blockDim.x) {
+            const int b = i / NCH, ch = i - b * NCH;
+            s_scale[i] = b < N ? sc[(size_t)ch * N + b] : 0;                       // the trash bin takes any exponent
+        }
+        __syncthreads();
+    }
+
+    double   acc[NCH];
+    unsigned cnt = 0;
+    int      cur = -1;                   // wave-uniform: bin of the register accumulators
+    int      fp_skip = 0, fp_miss = 0;   // wave-uniform: rows left without the one-bin test / consecutive rows that failed it
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = 0.0;
+
+    auto flush = [&]() {
+        if (cnt) {
+            double* cp = s_cell + (unsigned)(cur * ncopy + copy) * (unsigned)CW;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) lds_add(cp + c, acc[c]);
+            lds_add(reinterpret_cast<unsigned*>(cp + NCH), cnt);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] = 0.0;
+        cnt = 0;
+    };
+
+    // one centre row: bins, weights, accumulate
+    auto do_row = [&](const double (&qc)[VEC], const double (&qS)[VEC], const double (&qN)[VEC],
+                      double hc, const double (&dAv)[VEC], const double (&inv_)[NINT > 0 ? NINT : 1][VEC],
+                      double rdx, double rdy) {
+        unsigned k[VEC];                 // bin, or N (the trash bin) for a dropped cell
+        double w[NCH][VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            const double vb = (!GRAD && negate) ? -qc[c] : qc[c];
+            int kb;
+            if (uni) {
+                int j = (int)__builtin_fma(vb - e0, inv, 0.5);                      // NaN -> 0
+                asm("v_med3_i32 %0, %1, 0, %2" : "=v"(j) : "v"(j), "s"(N));         // clamp to [0, N]
+                kb = (vb >= s_edges[j]) ? j : j - 1;                                // NaN -> -1; at or beyond the last edge -> N
+                if (last_closed && vb == eN) kb = N - 1;
+            } else {
+                kb = find_bin(vb, s_edges, N, e0, eN, inv, last_closed);            // -1 when dropped
+            }
+            unsigned ku = (unsigned)kb < (unsigned)N ? (unsigned)kb : (unsigned)N;  // v_min_u32: -1 and N both land in the trash bin
+            if (!full_strip) ku = active ? ku : (unsigned)N;                        // wave-uniform: selects only in a ragged strip
+            k[c] = ku;
+            const double dv = dAv[c];
+            w[0][c] = wpos ? dv : ((dv != dv) ? 0.0 : dv);                    // fillna(0), core.py:449 (wpos: host checked dA finite)
+#pragma unroll
+            for (int i = 0; i < NINT; ++i) {
+                double p = a.prod_f32 ? (double)__fmul_rn((float)inv_[i][c], (float)dv)
+                                      : __dmul_rn(inv_[i][c], dv);            // integrand * dA, core.py:444
+                w[1 + i][c] = (p != p) ? 0.0 : p;
+            }
+        }
+        if (GRAD) {
+            // x-neighbours: lane-1's last cell / lane+1's first cell; lane 0 keeps the left halo (hc of
+            // lane 0), lane 63 the right halo (hc of lane 63); a ragged strip's right halo sits in the
+            // first inactive lane's cell 0 (see begin_segment)
+            const double fromL = lane_shift_keep<DPP_WAVE_SHR1>(qc[VEC - 1], hc);
+            const double fromR = lane_shift_keep<DPP_WAVE_SHL1>(qc[0], hc);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                double qW = (c == 0) ? fromL : qc[c > 0 ? c - 1 : 0];
+                double qE = (c == VEC - 1) ? fromR : qc[c < VEC - 1 ? c + 1 : 0];
+                if (!periodic_x) {                                        // wave-uniform branch: walls are one-sided
+                    if (fx[c] == 2.0) { if (lane == 0 && c == 0) qW = qc[c]; else qE = qc[c]; }
+                }
+                double gx = __dmul_rn(__dsub_rn(qE, qW), rdx);
+                if (!periodic_x) gx = __dmul_rn(gx, fx[c]);
+                const double gy = __dmul_rn(__dsub_rn(qN[c], qS[c]), rdy);
+                const double g2 = __dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy));
+                const double p = __dmul_rn(g2, dAv[c]);
+                // NaN -> 0; with finite non-negative dA the product is >= 0 or NaN, so one v_max_f64 does it
+                w[NCH - 1][c] = wpos ? fmax(p, 0.0) : ((p != p) ? 0.0 : p);
+            }
+        }
+        // wave-uniform fast path: every valid cell of the row in one bin -> per-lane registers, no LDS traffic.  A field with
+        // grid-scale noise never takes it, and the test itself (readfirstlane, compares, ballot) is a tenth of the row: after 8
+        // consecutive failures the wave stops testing for 48 rows, then looks again (smooth fields never stop)
+        bool one_bin = false;
+        int rb = 0;
+        if (DET == 0 && fp_skip == 0) {                  // (the order-free variants always go through the LDS)
+            rb = __builtin_amdgcn_readfirstlane((int)k[0]);
+            bool match = true;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) match = match && ((int)k[c] == rb);
+            one_bin = rb < N && (__ballot(match) | inactive_mask) == ~0ull;
+            if (one_bin) fp_miss = 0;
+            else if (++fp_miss >= 8) { fp_skip = 48; fp_miss = 7; }
+        } else {
+            --fp_skip;
+        }
+        if (one_bin) {
+            if (rb != cur) { flush(); cur = rb; }
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) {
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) acc[ch] += w[ch][c];
+                }
+                cnt += VEC;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                double* cp = s_cell + ((k[c] << cshift) + (unsigned)XC_ROT(copy, k[c], ncopy)) * (unsigned)CW;      // 32-bit LDS offset
+                if (DET == 0) {
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) lds_add(cp + ch, w[ch][c]);
+                    lds_add(reinterpret_cast<unsigned*>(cp + NCH), 1u);
+                } else if (DET == 1) {
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch)
+                        lds_max(reinterpret_cast<unsigned long long*>(cp + ch), (unsigned long long)__double_as_longlong(fabs(w[ch][c])));
+                    lds_add(reinterpret_cast<unsigned*>(cp + NCH), 1u);
+                } else {
+                    const int* sp = s_scale + k[c] * (unsigned)NCH;
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch)
+                        lds_add(reinterpret_cast<unsigned long long*>(cp + ch), fixed_point(w[ch][c], sp[ch]));
+                }
+            }
+        }
+    };
+
+    // batch of U centre rows starting at yb; L holds (GRAD) q rows yb+1.. and weights rows yb..
+    auto process_batch = [&](RowBuf<VEC, NINT> (&L)[U], int yb) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            if (yb + i < y1) {
+                if (NEXT && active) {
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) {              // NaN never wins a compare: NaN-skipping
+                        const double v = L[i].qn[c];
+                        nmn = fmin(nmn, v); nmx = fmax(nmx, v);                  // fmin / fmax skip NaN
+                    }
+                }
+                if (GRAD) {
+                    if (yb + i - ymet0 >= 64) load_metrics(yb + i);               // wave-uniform, once per 64 rows
+                    do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in,
+                           lane_get(rdxv, yb + i - ymet0), lane_get(rdyv, yb + i - ymet0));
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) { qm[c] = qcur[c]; qcur[c] = L[i].q[c]; }
+                    hcur = L[i].h;
+                } else {
+                    do_row(L[i].q, L[i].q, L[i].q, 0.0, L[i].dA, L[i].in, 0.0, 0.0);
+                }
+            }
+        }
+    };
+
+    while (have) {
+        for (int yb = y0; yb < y1; yb += 2 * U) {
+            if (yb + U < y1) load_batch(B, yb + U);
+            process_batch(A, yb);
+            if (yb + U >= y1) break;
+            if (yb + 2 * U < y1) load_batch(A, yb + 2 * U);
+            process_batch(B, yb + U);
+        }
+        have = g0 < g1;
+        if (have) {                                   // next segment (the range crossed a strip boundary)
+            begin_segment();
+            if (GRAD) {
+                load_metrics(y0);
+                RowBuf<VEC, NINT> t;
+                load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) qm[c] = t.q[c];
+                load_row(t, y0, y0);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) qcur[c] = t.q[c];
+                hcur = t.h;
+            }
+            load_batch(A, y0);
+        }
+    }
+    flush();
+    if (NEXT) {
+        for (int o = 32; o > 0; o >>= 1) { nmn = fmin(nmn, __shfl_xor(nmn, o)); nmx = fmax(nmx, __shfl_xor(nmx, o)); }
+        if (lane == 0) { s_red[2 * wave] = nmn; s_red[2 * wave + 1] = nmx; }
+    }
+    __syncthreads();
+    if (NEXT && tid == 0) {
+        for (int w = 1; w < nwave; ++w) { nmn = fmin(nmn, s_red[2 * w]); nmx = fmax(nmx, s_red[2 * w + 1]); }
+        double* o = a.mm_next + ((size_t)slab * nbx + bx) * 2;
+        o[0] = nmn; o[1] = nmx;
+    }
+
+    // ------------------------------------------------------------------ per-block partials (plain stores)
+    const size_t pb = (size_t)slab * nbx + bx;
+    double* ph = a.part_h + pb * NCH * N;
+    // sum the lane-privatised copies; every thread starts at a rotated copy index so that the
+    // 64 lanes of a wave hit distinct LDS banks (a fixed, thread-determined order)
+    for (int i = tid; i < NCH * N; i += blockDim.x) {
+        const int ch = i / N, b = i - ch * N;
+        const double* src = s_cell + (size_t)b * ncopy * CW + ch;
+        if (DET == 0) {
+            double sum = 0.0;
+            for (int c = 0; c < ncopy; ++c) sum += src[(size_t)((c + tid) & (ncopy - 1)) * CW];
+            ph[i] = sum;
+        } else {                                      // bit patterns: the maximum (DET 1) or the wrapping sum (DET 2) of the copies
+            unsigned long long r = 0ull;
+            for (int c = 0; c < ncopy; ++c) {
+                const unsigned long long v = *reinterpret_cast<const unsigned long long*>(src + (size_t)c * CW);
+                r = DET == 1 ? (v > r ? v : r) : r + v;
+            }
+            reinterpret_cast<unsigned long long*>(ph)[i] = r;
+        }
+    }
+    unsigned* pc = a.part_c + pb * N;
+    if (DET != 2)                                     // the fixed-point pass takes the counts of the max pass
+    for (int b = tid; b < N; b += blockDim.x) {
+        unsigned sum = 0u;
+        for (int c = 0; c < ncopy; ++c)
+            sum += *reinterpret_cast<const unsigned*>(s_cell + (size_t)(b * ncopy + ((c + tid) & (ncopy - 1))) * CW + NCH);
+        pc[b] = sum;
+    }
+}
+
+
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT, bool FAST = false, int DET = 0>
+int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
+{
+    auto kern = k_hist<TQ, VEC, NINT, GRAD, DA2D, NEXT, FAST, DET>;
+    { const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(kern), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; }
+    HistArgs b = a;
+    // the XCD-aware order needs whole groups of 8 row groups, otherwise it would leave XCDs idle (bps = 1 with many
+    // small slabs would put every block on XCD 0): plain slab-fastest order then
+    b.bps = g.bps; b.nslab_grid = (int)nslab; b.xcd_map = (ctx->knobs.xcd_map && g.bps % 8 == 0) ? 1 : 0;
+    {
+        const int64_t nw = (int64_t)g.bps * (g.threads / 64);
+        const int64_t nchunk = nw / g.nstrip;
+        // needs at least one chunk, at least 8 rows per chunk (two halo rows are loaded per chunk) and no more than a tenth of
+        // the waves left without a chunk (waves beyond nchunk x nstrip idle; the even strip-major split uses them all)
+        b.nchunk = (ctx->knobs.tile_map && nchunk >= 1 && a.ny / nchunk >= 8 && (nw - nchunk * g.nstrip) * 10 <= nw) ? (int)nchunk : 0;
+    }
+    const int64_t nblk = b.xcd_map ? (int64_t)8 * ((g.bps + 7) / 8) * nslab : (int64_t)g.bps * nslab;
+    if (nblk > 0x7fffffff) return fail(ctx, XC_EBADARG, "xc_hist: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(g.threads), g.lds, ctx->stream, b);
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+

@@ -8,8 +8,23 @@
 #include <vector>
 #include "../../include/xcontour_hip.h"
 
+// Experiment knobs of the K3 geometry, read from the environment ONCE, in xc_create (contexts may be driven from several
+// threads; nothing reads the environment after that).  0 / -1 = the built-in choice.
+struct HistKnobs {
+    int xcd_map = 1;     // XC_HIST_XCDMAP   XCD-aware block order when blocks per slab is a multiple of 8
+    int tile_map = 1;    // XC_HIST_TILEMAP  strip-fastest wave order
+    int vec4 = -1;       // XC_HIST_VEC4     four cells per lane: -1 float32 tracers only, 0 never, 1 always
+    int threads = 0;     // XC_HIST_THREADS  threads per block
+    int ncopy = 0;       // XC_HIST_NCOPY    LDS histogram copies
+    int rows = 0;        // XC_HIST_ROWS     (strip, row) pairs per wave
+    int bps = 0;         // XC_HIST_BPS      blocks per slab
+    int cross_ncopy = 0, cross_blocks = 0;   // XC_CROSS_NCOPY, XC_CROSS_BLOCKS (K9)
+    int sort_range = 1;  // XC_SORT_RANGE    K8: three range-key passes + short-run repair for float64 tracers (0: always eight passes)
+};
+
 struct xc_ctx {
     int device = 0;
+    HistKnobs knobs;
     hipStream_t stream = nullptr;
     int cus = 0;
     char name[256] = {0};
@@ -29,9 +44,7 @@ struct xc_ctx {
     double* mmnext[2] = {nullptr, nullptr};  size_t mmnext_bytes[2] = {0, 0};
     int mm_cur = 0, mm_valid = 0, mm_P = 0, mm_dtype = 0;
     const void* mm_q = nullptr;  int64_t mm_nslab = 0, mm_ny = 0, mm_nx = 0;  int mm_gen = 0;
-    int keff_mode = 0;          // xc_set_keff_mode: XC_KEFF_AUTO / XC_KEFF_TWO_PASS / XC_KEFF_PERSISTENT
-    unsigned long long* dbg_stamps = nullptr;   // xc_dbg_set_stamps
-    int last_keff_path = 0;     // 1 = the last xc_keff_dev call ran the persistent kernel, 0 = two-pass
+    int last_sort_path = 0;     // K8, last call: 0 eight / four key passes, 1 three range-key passes sufficed, 2 they did not (re-sorted)
 };
 
 namespace xc {
@@ -105,6 +118,7 @@ struct HistArgs {
     double*       ctr_out;      // [nslab][nbin]   (levels mode, may be null)
     double*       edges_out;    // [nslab][nbin+1] (levels mode, may be null)
     int32_t*      status;       // [nslab]         (levels mode, may be null)
+    const int*    det_scale;    // [nslab][nch][nbin] binary exponents of the fixed-point pass (DET == 2), else null
 };
 
 struct FinalArgs {
@@ -114,6 +128,7 @@ struct FinalArgs {
     unsigned long long* red_c;// [nslab][nbin]
     int             bps, nch, nbin;
     int             lt, reverse;
+    int             skip_reduce;   // red_h / red_c are already filled (deterministic path): run stage 2 only
     double*         pdf;      // [nslab][nch][nbin] or null
     uint64_t*       counts;   // [nslab][nbin] or null
     double*         cdf;      // [nslab][nch][nbin] or null
@@ -128,58 +143,21 @@ struct FinalArgs {
     double *o_area, *o_intS, *o_latEq, *o_dqdA, *o_dSdA, *o_Leq2, *o_Lmin, *o_nkeff, *o_interp;
 };
 
-// ---------------------------------------------------------------- persistent single-read Keff kernel (xc_keffp.hip)
-constexpr int kPersistThreads = 768;  // 12 waves per workgroup, 3 per SIMD: 168 VGPRs each
-constexpr int kPersistRows = 18;      // rows of the slab a wave holds in registers (+ 2 halo rows)
-constexpr int kPersistLdsRows = 8;    // rows of the NEXT slab's tile that wait in LDS instead of being refilled late (float64 tracers)
-constexpr int kPersistCols = 124;     // computed columns of a wave's strip (62 lanes x 2 cells; lanes 0 / 63 are halos)
-
-struct PersistGeom {
-    int G, ngroups;          // workgroups per group, groups in all (G * ngroups = CUs * slots)
-    int slots, ngps;         // workgroups per CU (1 or 3: 768 / 256 threads each), groups per slot (ngroups = slots * ngps)
-    int nstrip, cps, rpc;    // strips of kPersistCols columns, chunks per strip, rows per chunk (<= kPersistRows)
-    int ncopy;               // LDS histogram copies
-    size_t lds;
-};
-
-struct SyncShard {            // one eighth of a slab's sync record, on its own 64 bytes
-    unsigned long long kmn, kmx;   // ~key(min), key(max) under atomic max
-    unsigned cnt;                  // arrivals in this shard
-    unsigned pad[11];
-};
-
-struct PersistArgs {
-    const void*   q;
-    const double* dA;  int dA_rank;
-    const double* rdx; const double* rdy;
-    int           periodic_x, dA_pos_finite, last_closed;
-    int64_t       ny, nx;
-    int           nslab, nbin, ncopy;
-    int           increase, q_f32, ctr_f32, right_edge;
-    double        inv_nm1, inv_n;
-    int           G, ngroups, nstrip, cps, rpc;
-    int           slots, ngps, cus;   // workgroups per CU, groups per slot, CUs (grid = cus * slots)
-    SyncShard*    sync;        // [nslab][8]  zeroed before the launch
-    unsigned*     abort;       // [1]         zeroed before the launch
-    double*       part_h;      // [nslab][G][2][nbin]
-    unsigned*     part_c;      // [nslab][G][nbin]
-    double*       ctr_out;     // [nslab][nbin]
-    int32_t*      status;      // [nslab]
-    unsigned long long* stamps;   // diagnostics: [nslab][blocks][8] wall-clock stamps, or null
-};
-
-bool persist_geometry(const xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int N,
-                      const void* q, const double* dA, int dA_rank, PersistGeom* g);
-int launch_keff_persist(xc_ctx* ctx, int q_dtype, const PersistArgs& a, const PersistGeom& g);
-
 // ---------------------------------------------------------------- launchers (defined in the .hip files)
 int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part);
 int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, int P, double* out);
 int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
                   int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status);
 int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int nbin, int nch,
-                  const void* q, HistGeom* g, int keff_fast_layout = 0);
+                  const void* q, HistGeom* g, int keff_fast_layout = 0, int det = 0);
 int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a);
+// deterministic sums (xc_hist_det.hip): pass 1 (det = 1, per-bin max |w| + counts), the scales, pass 2 (det = 2, fixed point),
+// and the exact integer reduction that fills FinalArgs.red_h / red_c (launch_finalize is then called with skip_reduce)
+int launch_hist_det(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a, int det);
+int launch_det_scales(xc_ctx* ctx, int64_t nslab, int bps, int nch, int nbin, const double* part_h, const unsigned* part_c,
+                      int* scale, unsigned long long* red_c);
+int launch_det_reduce(xc_ctx* ctx, int64_t nslab, int bps, int nch, int nbin, const double* part_h, const int* scale,
+                      double* red_h);
 int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a);
 int launch_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
                   int64_t ny, int64_t nx, int multiply, double* out_rows);

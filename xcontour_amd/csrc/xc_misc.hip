@@ -461,9 +461,11 @@ int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
     }
     const int nvh = a.nch * a.nbin;
     dim3 g1((unsigned)((nvh + a.nbin + 7) / 8), (unsigned)nslab);
-    hipLaunchKernelGGL(k_reduce_partials, g1, dim3(256), 0, ctx->stream, a.part_h, a.part_c, a.bps, nvh, a.nbin,
-                       a.red_h, a.red_c);
-    XC_HIP(ctx, hipGetLastError());
+    if (!a.skip_reduce) {
+        hipLaunchKernelGGL(k_reduce_partials, g1, dim3(256), 0, ctx->stream, a.part_h, a.part_c, a.bps, nvh, a.nbin,
+                           a.red_h, a.red_c);
+        XC_HIP(ctx, hipGetLastError());
+    }
     const int nthr = (a.keff && a.o_interp && a.npre > 256) ? 1024 : 256;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)nslab), dim3(nthr), lds, ctx->stream, a);
     XC_HIP(ctx, hipGetLastError());

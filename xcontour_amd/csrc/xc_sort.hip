@@ -9,6 +9,15 @@
 // Every kernel takes the slab from blockIdx.y (or blockIdx.x for the one-block-per-slab kernels): a stack of
 // planes is sorted by ONE set of launches (segmented sort: per-slab tile histograms, bases and scans).
 //
+// float64 tracers (round 3): THREE passes instead of eight.  The sort key of the passes is not the 64-bit pattern but
+// the 24-bit RANGE key  d = floor((v - min) * (2^24 - 1) / (max - min))  (min / max from K1; subtract, multiply by a positive
+// constant and floor are each monotone, so d never orders two values the wrong way; equal values share a d).  Three
+// stable LSD passes over the bytes of d leave the pairs sorted by d with the cells of one d in their original order; a
+// RUN of equal d holds 0.4 cells on average for 6.5 M pairs, so `k_fix_runs` finishes the job with a stable insertion
+// sort of every run that is out of order (in LDS, runs of <= 128), and `k_check_sorted` proves the result: one flag is
+// read back, and only if some run was longer and out of order (a spike of distinct values narrower than 2^-24 of the
+// range) the stack is sorted again by the full eight-pass path.  Ties of any length are already in order.
+//
 // Hand-written LSD radix sort, 8-bit digits, 64-bit order-preserving keys, f64 payload:
 // one block owns one tile of 4096 consecutive elements (4 waves x 1024); stable ranks come from wave
 // ballots (8 ballots give the peer mask of a lane's digit) + per-wave digit counters in LDS; the tile is
@@ -16,6 +25,9 @@
 // small kernels.  The key type is a template parameter: float32 tracers sort 32-bit keys in 4 passes
 // (4 B/elem histogram + 24 B/elem scatter), float64 tracers 64-bit keys in 8 passes (8 + 32 B/elem).
 #include "xc_internal.h"
+#include <type_traits>
+
+#define XC_TRY_(expr) do { int _rc = (expr); if (_rc != XC_OK) return _rc; } while (0)
 
 namespace xc {
 namespace {
@@ -73,7 +85,35 @@ __device__ __forceinline__ void make_pair(const TQ* __restrict__ q, const TM* __
 struct PairSrc {                 // where pass 0 finds its input (per-slab strides applied by the kernels)
     const void* q; const void* mask; const double* dA;
     int dA_rank, negate; int64_t nx, mask_stride, dA_stride;
+    const double* mm;            // [nslab][2] min / max of the tracer (K1): the range-key passes only
 };
+
+// ---- the 24-bit range key (MODE 1 of the passes).  Valid values map to [0, 2^24 - 2] monotonically, dropped cells
+// (key == invalid) to 2^24 - 1, so that they gather behind every valid value without sharing a run with the maximum.
+constexpr unsigned RANGE_INVALID = 0xFFFFFFu;
+struct RangeMap { double lo, scale; };
+__device__ __forceinline__ RangeMap range_map(const double* __restrict__ mm, int slab, int negate)
+{
+    const double mn = mm[2 * slab], mx = mm[2 * slab + 1];
+    RangeMap r;
+    r.lo = negate ? -mx : mn;
+    const double hi = negate ? -mn : mx, w = hi - r.lo;
+    r.scale = (w > 0.0 && w < __longlong_as_double(0x7ff0000000000000LL)) ? 16777215.0 / w : 0.0;   // constant / empty / infinite range: one run
+    return r;
+}
+template <typename K>
+__device__ __forceinline__ unsigned range_key(K key, const RangeMap& m)
+{
+    if (key == KeyTraits<K>::invalid()) return RANGE_INVALID;
+    const double x = (KeyTraits<K>::decode(key) - m.lo) * m.scale;      // monotone in the value; NaN (inf - inf, 0 * inf) -> 0 below
+    return (unsigned)fmin(fmax(x, 0.0), 16777214.0);
+}
+template <typename K, int MODE>
+__device__ __forceinline__ unsigned digit_of(K key, int shift, const RangeMap& m)
+{
+    if (MODE == 0) return (unsigned)((key >> shift) & (K)255);
+    return (range_key<K>(key, m) >> shift) & 255u;
+}
 
 // number of valid cells = position of the first KEY_INVALID in the sorted keys (one thread:
 // a per-wave atomic counter while building the keys serialised 100k atomics on one address = 1.1 ms)
@@ -103,13 +143,15 @@ __device__ __forceinline__ unsigned long long digit_peers(unsigned d, unsigned l
 // Counting needs no ranks: one returnless ds_add_u32 per key on per-wave counters (the ballot ranking
 // of the scatter costs ~60 VALU instructions per 64 keys and made this kernel ALU-bound); a round
 // whose 64 digits are all equal -- sorted or constant data -- is added once by one lane.
-template <typename K, bool FIRST = false, typename TQ = double, typename TM = double>
+template <typename K, bool FIRST = false, typename TQ = double, typename TM = double, int MODE = 0>
 __global__ __launch_bounds__(256)
 void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, unsigned* __restrict__ hist, const PairSrc src)
 {
     __shared__ unsigned s_cnt[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = blockIdx.x;
+    RangeMap rm = {0.0, 0.0};
+    if (MODE == 1) rm = range_map(src.mm, blockIdx.y, src.negate);
     keys += (size_t)blockIdx.y * n; hist += (size_t)blockIdx.y * 256 * ntiles;
     for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = 0;
     if constexpr (FIRST) {
@@ -129,7 +171,7 @@ void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, 
         for (int r = 0; r < TILE_ROUNDS; ++r) {
             const int64_t i = base + r * 64 + lane;
             const bool valid = i < n;
-            const unsigned d = (unsigned)((kreg[r] >> shift) & (K)255);
+            const unsigned d = digit_of<K, MODE>(kreg[r], shift, rm);
             const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
             if (base + TILE <= n && __ballot(d != d0) == 0ull) { if (lane == 0) atomicAdd(&s_cnt[wave][d0], 64u); }
             else if (valid) atomicAdd(&s_cnt[wave][d], 1u);
@@ -165,7 +207,7 @@ void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, 
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + (int64_t)((r / KPL) * 64 + lane) * KPL + (r % KPL);
         const bool valid = full || i < n;
-        const unsigned d = (unsigned)((kreg[r] >> shift) & (K)255);
+        const unsigned d = digit_of<K, MODE>(kreg[r], shift, rm);
         const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
         if (full && __ballot(d != d0) == 0ull) { if (lane == 0) atomicAdd(&s_cnt[wave][d0], 64u); }
         else if (valid) atomicAdd(&s_cnt[wave][d], 1u);
@@ -207,7 +249,7 @@ void k_radix_scan_rows(unsigned* __restrict__ hist, int ntiles, unsigned* __rest
 // (stable: wave-major, then round, then lane = element order), then written out position by position:
 // consecutive LDS positions with the same digit go to consecutive global addresses, so the stores
 // of a wave cover runs of ~BTILE/256 elements instead of 64 unrelated 8-byte targets.
-template <typename K, bool FIRST = false, typename TQ = double, typename TM = double>
+template <typename K, bool FIRST = false, typename TQ = double, typename TM = double, int MODE = 0>
 __global__ __launch_bounds__(256)
 void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
                      K* __restrict__ kout, double* __restrict__ vout, int64_t n, int shift,
@@ -222,6 +264,8 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
     unsigned* s_wsum = s_gbase + 256;                          // [8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x;
+    RangeMap rm = {0.0, 0.0};
+    if (MODE == 1) rm = range_map(src.mm, blockIdx.y, src.negate);
     { const size_t so = (size_t)blockIdx.y * n; kin += so; vin += so; kout += so; vout += so; }
     hist += (size_t)blockIdx.y * 256 * ntiles; totals += (size_t)blockIdx.y * 256;
     for (int d = lane; d < 256; d += 64) s_cnt[wave * 256 + d] = 0;
@@ -254,7 +298,7 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
         const bool valid = i < n;
-        const unsigned d = valid ? (unsigned)((kreg[r] >> shift) & (K)255) : 0u;
+        const unsigned d = valid ? digit_of<K, MODE>(kreg[r], shift, rm) : 0u;
         const unsigned long long peers = digit_peers(d, __ballot(valid));
         const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
         unsigned pos = 0;
@@ -290,7 +334,7 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
 #pragma unroll
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
-        const unsigned d = (unsigned)((kreg[r] >> shift) & (K)255);
+        const unsigned d = digit_of<K, MODE>(kreg[r], shift, rm);
         lrank[r] = (unsigned short)(s_cnt[wave * 256 + d] + lrank[r]);      // tile-local position
         if (i < n) s_k[lrank[r]] = kreg[r];
     }
@@ -303,7 +347,7 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
         const int p = r * 256 + tid;
         if (p < cnt) {
             const K key = s_k[p];
-            gpos[r] = s_gbase[(unsigned)((key >> shift) & (K)255)] + (unsigned)p;
+            gpos[r] = s_gbase[digit_of<K, MODE>(key, shift, rm)] + (unsigned)p;
             kout[gpos[r]] = key;
         }
     }
@@ -319,6 +363,64 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
         const int p = r * 256 + tid;
         if (p < cnt) vout[gpos[r]] = s_v[p];
     }
+}
+
+// ---- after the three range-key passes: finish every run of equal range key that is out of order.  A block owns the
+// runs whose HEAD lies in its FIX_C positions and sees FIX_H more; a head's thread walks its run, and if it found an
+// inversion and the run has at most FIX_MAXRUN cells inside the window it sorts the run by the full key with a stable
+// insertion sort in LDS and writes it back in place.  Runs are disjoint, so are the writes; a neighbouring block reading
+// a cell while it is being rewritten only derives its range key from it, which every cell of the run shares.
+constexpr int FIX_C = 2048, FIX_H = 128, FIX_MAXRUN = 128, FIX_W = FIX_C + FIX_H + 1;
+template <typename K>
+__global__ __launch_bounds__(256)
+void k_fix_runs(K* __restrict__ keys, double* __restrict__ vals, int64_t n, const PairSrc src)
+{
+    __shared__ K s_k[FIX_W];
+    __shared__ double s_v[FIX_W];
+    __shared__ unsigned s_d[FIX_W];
+    const int tid = threadIdx.x;
+    const RangeMap rm = range_map(src.mm, blockIdx.y, src.negate);
+    keys += (size_t)blockIdx.y * n; vals += (size_t)blockIdx.y * n;
+    const int64_t w0 = (int64_t)blockIdx.x * FIX_C - 1;             // window position i <-> cell w0 + i; cells w0+1 .. w0+FIX_C are owned
+    for (int i = tid; i < FIX_W; i += 256) {
+        const int64_t g = w0 + i;
+        if (g >= 0 && g < n) { const K k = keys[g]; s_k[i] = k; s_v[i] = vals[g]; s_d[i] = range_key<K>(k, rm); }
+        else s_d[i] = g < 0 ? 0xFFFFFFFFu : 0xFFFFFFFEu;           // no cell: never equal to a range key
+    }
+    __syncthreads();
+    for (int i = 1 + tid; i <= FIX_C; i += 256) {
+        if (w0 + i >= n) break;
+        const unsigned d = s_d[i];
+        if (d == s_d[i - 1]) continue;                              // not the head of a run
+        int L = 1;
+        bool inv = false;
+        while (i + L < FIX_W && L <= FIX_MAXRUN && s_d[i + L] == d) { inv |= s_k[i + L] < s_k[i + L - 1]; ++L; }
+        if (!inv) continue;
+        if (L > FIX_MAXRUN || i + L >= FIX_W) continue;             // longer than this kernel takes: k_check_sorted will see it
+        for (int x = i + 1; x < i + L; ++x) {                       // stable: an equal key never moves past its predecessor
+            const K kk = s_k[x]; const double vv = s_v[x];
+            int y = x - 1;
+            while (y >= i && s_k[y] > kk) { s_k[y + 1] = s_k[y]; s_v[y + 1] = s_v[y]; --y; }
+            s_k[y + 1] = kk; s_v[y + 1] = vv;
+        }
+        for (int x = i; x < i + L; ++x) { keys[w0 + x] = s_k[x]; vals[w0 + x] = s_v[x]; }
+    }
+}
+
+// is the stack sorted by the full key?  (equal keys are in their original order by construction of the stable passes)
+template <typename K>
+__global__ __launch_bounds__(256)
+void k_check_sorted(const K* __restrict__ keys, int64_t n, unsigned* __restrict__ flag)
+{
+    keys += (size_t)blockIdx.y * n;
+    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t i = base + c;
+        if (i >= 1 && i < n) bad |= keys[i] < keys[i - 1];
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 // ---- inclusive f64 scan (cumulative area of the sorted state): block sums, their exclusive scan, then
@@ -471,7 +573,8 @@ __global__ void k_sum_parts(const double* __restrict__ part, int n, double* __re
 
 }  // namespace
 
-// Workspace layout (device), every array with a leading slab dim: keys A/B, vals A/B, hist, totals, nvalid, bsums, bpe parts
+// Workspace layout (device), every array with a leading slab dim: keys A/B, vals A/B, hist, totals, nvalid, bsums, bpe parts,
+// K1 partials + min/max + the "not sorted" flag of the range-key path
 constexpr int BPE_BLOCKS = 256;
 size_t sort_workspace_bytes(int64_t n, int64_t nslab)
 {
@@ -479,11 +582,12 @@ size_t sort_workspace_bytes(int64_t n, int64_t nslab)
     const int64_t nb = (n + 2047) / 2048;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t S = (size_t)nslab;
-    return 4 * al(S * n * 8) + al(S * 256 * ntiles * 4) + al(S * 256 * 4) + al(S * 4) + al(S * nb * 8) + al(S * BPE_BLOCKS * 8);
+    return 4 * al(S * n * 8) + al(S * 256 * ntiles * 4) + al(S * 256 * 4) + al(S * 4) + al(S * nb * 8) + al(S * BPE_BLOCKS * 8) +
+           al(S * kMinmaxBlocks * 2 * 8) + al(S * 2 * 8) + 256;
 }
 
 template <typename TQ, typename K>
-static int sort_profile_typed(xc_ctx* ctx, const TQ* q, const void* mask, int mask_dtype, int mask_per_slab,
+static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
                               const double* dA, int dA_rank, int64_t nslab, int64_t ny, int64_t nx, int negate,
                               const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                               void* workspace, double* out_Q, double* out_qsorted, double* out_acum,
@@ -503,43 +607,78 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, const void* mask, int ma
     unsigned* totals = (unsigned*)w; w += al(S * 256 * 4);
     unsigned* nvalid = (unsigned*)w; w += al(S * 4);
     double* bsum = (double*)w; w += al(S * nb * 8);
-    double* parts = (double*)w;
+    double* parts = (double*)w; w += al(S * BPE_BLOCKS * 8);
+    double* mmpart = (double*)w; w += al(S * kMinmaxBlocks * 2 * 8);
+    double* mm = (double*)w; w += al(S * 2 * 8);
+    unsigned* flag = (unsigned*)w;
     const unsigned ns = (unsigned)nslab;
 
     const unsigned gb = (unsigned)((n + 255) / 256);
     // a per-slab dA plane is the PLANE case with a slab stride
     const int krank = dA_rank == XC_DA_SLAB ? XC_DA_PLANE : dA_rank;
     const int64_t dstride = dA_rank == XC_DA_SLAB ? n : 0, mstride = (mask && mask_per_slab) ? n : 0;
-    const PairSrc src = {q, mask, dA, krank, negate, nx, mstride, dstride};
+    const PairSrc src = {q, mask, dA, krank, negate, nx, mstride, dstride, mm};
     const unsigned gt = (unsigned)ntiles;
     const size_t sc_lds = (size_t)BTILE * 8 + (4 * 256 + 256 + 8) * sizeof(unsigned);
     const int inline_scan = ntiles <= 32 ? 1 : 0;       // measured: the O(ntiles) walk per block costs ~0.14 us per tile, the scan launch ~5 us
     K *kin = kA, *kout = kB;
     double *vin = vA, *vout = vB;
     const bool mf32 = mask && mask_dtype == XC_F32;
-    XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_scatter<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds));
-    if (mf32) XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_scatter<K, true, TQ, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds));
-    else XC_HIP(ctx, hipFuncSetAttribute((const void*)k_radix_scatter<K, true, TQ, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_lds));
-    for (int pass = 0; pass < KeyTraits<K>::passes; ++pass) {
-        const int shift = pass * 8;
-        // pass 0 reads the tracer itself (no k_sort_keys launch, the unsorted pairs never touch memory)
-        if (pass == 0) {
-            if (mf32) hipLaunchKernelGGL((k_radix_hist<K, true, TQ, float>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
-            else hipLaunchKernelGGL((k_radix_hist<K, true, TQ, double>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
-        } else hipLaunchKernelGGL(k_radix_hist<K>, dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
+
+    // one LSD pass (histogram, row scan, scatter); MODE 0: byte `shift / 8` of the key, MODE 1: of the 24-bit range key
+    auto big_lds = [&](const void* f) { return ensure_big_lds(ctx, f, (int)sc_lds); };
+    auto pass = [&](auto mode_tag, bool first, int shift) -> int {
+        constexpr int MODE = decltype(mode_tag)::value;
+        if (first) {            // reads the tracer itself (the unsorted pairs never touch memory)
+            if (mf32) {
+                XC_TRY_(big_lds((const void*)k_radix_scatter<K, true, TQ, float, MODE>));
+                hipLaunchKernelGGL((k_radix_hist<K, true, TQ, float, MODE>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
+            } else {
+                XC_TRY_(big_lds((const void*)k_radix_scatter<K, true, TQ, double, MODE>));
+                hipLaunchKernelGGL((k_radix_hist<K, true, TQ, double, MODE>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
+            }
+        } else {
+            XC_TRY_(big_lds((const void*)k_radix_scatter<K, false, double, double, MODE>));
+            hipLaunchKernelGGL((k_radix_hist<K, false, double, double, MODE>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
+        }
         if (!inline_scan) hipLaunchKernelGGL(k_radix_scan_rows, dim3(256, ns), dim3(1024), 0, ctx->stream, hist, (int)ntiles, totals);
-        if (pass == 0) {
-            if (mf32) hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, float>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+        if (first) {
+            if (mf32) hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, float, MODE>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
                                          (int)ntiles, hist, totals, inline_scan, src);
-            else hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, double>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+            else hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, double, MODE>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
                                     (int)ntiles, hist, totals, inline_scan, src);
-        } else hipLaunchKernelGGL(k_radix_scatter<K>, dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+        } else hipLaunchKernelGGL((k_radix_scatter<K, false, double, double, MODE>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
                                   (int)ntiles, hist, totals, inline_scan, src);
         XC_HIP(ctx, hipGetLastError());
         K* tk = kin; kin = kout; kout = tk;
         double* tv = vin; vin = vout; vout = tv;
+        return XC_OK;
+    };
+
+    bool sorted = false;
+    if constexpr (sizeof(K) == 8) {
+        if (ctx->knobs.sort_range) {
+            // ---- three passes over the 24-bit range key, then the short runs (see the head of this file)
+            XC_TRY_(launch_minmax_partial(ctx, q, q_dtype, nslab, n, mmpart));
+            XC_TRY_(launch_minmax_final(ctx, mmpart, nslab, minmax_blocks(n), mm));
+            XC_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream));
+            for (int p = 0; p < 3; ++p) XC_TRY_(pass(std::integral_constant<int, 1>(), p == 0, 8 * p));
+            hipLaunchKernelGGL(k_fix_runs<K>, dim3((unsigned)((n + FIX_C - 1) / FIX_C), ns), dim3(256), 0, ctx->stream, kin, vin, n, src);
+            hipLaunchKernelGGL(k_check_sorted<K>, dim3((unsigned)((n + 1023) / 1024), ns), dim3(256), 0, ctx->stream, kin, n, flag);
+            XC_HIP(ctx, hipGetLastError());
+            unsigned h_flag = 1;
+            XC_HIP(ctx, hipMemcpyAsync(&h_flag, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+            XC_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the one host round trip of the sort: did the short-run repair suffice?
+            sorted = h_flag == 0;
+            ctx->last_sort_path = sorted ? 1 : 2;
+            if (!sorted) { kin = kA; kout = kB; vin = vA; vout = vB; }
+        }
     }
-    // an even number of passes: the sorted data are back in kA / vA (= kin / vin)
+    if (!sorted) {
+        if (!(sizeof(K) == 8 && ctx->knobs.sort_range)) ctx->last_sort_path = 0;
+        for (int p = 0; p < KeyTraits<K>::passes; ++p) XC_TRY_(pass(std::integral_constant<int, 0>(), p == 0, 8 * p));
+    }
+    // the sorted pairs are in kin / vin
     hipLaunchKernelGGL(k_count_valid<K>, dim3(ns), dim3(64), 0, ctx->stream, kin, n, nvalid);
     double* acum = vout;                                   // reuse the idle payload buffer
     hipLaunchKernelGGL(k_scan_local<false>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
@@ -573,10 +712,10 @@ int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mas
     if (dA_rank < XC_DA_NONE || dA_rank > XC_DA_SLAB) return fail(ctx, XC_EBADARG, "xc_sort_profile: bad dA_rank");
     if (dA_rank != XC_DA_NONE && !dA) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA is NULL");
     if (q_dtype == XC_F64)
-        return sort_profile_typed<double, u64>(ctx, (const double*)q, mask, mask_dtype, mask_per_slab, dA, dA_rank, nslab, ny, nx, negate,
+        return sort_profile_typed<double, u64>(ctx, (const double*)q, q_dtype, mask, mask_dtype, mask_per_slab, dA, dA_rank, nslab, ny, nx, negate,
                                                targets, J, tbl, coord, ntbl, workspace, out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
     if (q_dtype == XC_F32)      // the order of floats is the order of their 32-bit keys: 4 passes of 4-byte keys
-        return sort_profile_typed<float, u32>(ctx, (const float*)q, mask, mask_dtype, mask_per_slab, dA, dA_rank, nslab, ny, nx, negate,
+        return sort_profile_typed<float, u32>(ctx, (const float*)q, q_dtype, mask, mask_dtype, mask_per_slab, dA, dA_rank, nslab, ny, nx, negate,
                                               targets, J, tbl, coord, ntbl, workspace, out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
     return fail(ctx, XC_EBADARG, "xc_sort_profile: q_dtype must be XC_F32 or XC_F64");
 }

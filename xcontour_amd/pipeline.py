@@ -38,7 +38,7 @@ class KeffPlan(object):
                  tbl=None, tbl_coord=None, preY=None, increase=True, lt=True,
                  right_edge='xhistogram', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
                  prod_f32=False, alloc_q=True, nslots=1, out_ptr=None, detect_row_dA=False,
-                 out_slabs=None, replicate_dA=False):
+                 out_slabs=None, replicate_dA=False, deterministic=False):
         """dA: None | (ny,) | (ny,nx) | (nslab,ny,nx) f64 (the last: weights that change with the leading
         (time, level) index, which the reference allows -- core.py:1271-1274).  Gradient metrics either `rdx, rdy`
         (per-row reciprocals) or derived from `lat, lon` (sphere).  If
@@ -50,7 +50,9 @@ class KeffPlan(object):
         `detect_row_dA`: a 2-D dA whose rows are constant (every regular lat-lon `rA`) is passed
         to the kernels as its first column (identical results, 8 B/cell less traffic).
         `replicate_dA`: store a (ny,nx) dA once PER SLAB on the device and run the per-slab-weights path
-        (XC_DA_SLAB) on it -- what a time-varying metric costs, without a (nslab,ny,nx) host array."""
+        (XC_DA_SLAB) on it -- what a time-varying metric costs, without a (nslab,ny,nx) host array.
+        `deterministic`: order-free fixed-point sums (xc_keff_desc.deterministic): area / intgrdS and everything derived
+        from them are bit-identical between runs, launch-set sizes and ranks; chaining (q_next) is ignored."""
         self.ctx = ctx
         self.nslab, self.ny, self.nx, self.N = int(nslab), int(ny), int(nx), int(N)
         self.q_dtype, self.ctr_dtype = np.dtype(q_dtype), np.dtype(ctr_dtype)
@@ -66,6 +68,7 @@ class KeffPlan(object):
         d.nslab, d.ny, d.nx, d.N = self.nslab, self.ny, self.nx, self.N
         d.increase, d.lt = int(bool(increase)), int(bool(lt))
         d.right_edge = nat.XC_EDGE_XHISTOGRAM if right_edge == 'xhistogram' else nat.XC_EDGE_NUMPY
+        d.deterministic = 1 if deterministic else 0
         if dA is None:
             d.dA, d.dA_rank = None, nat.XC_DA_NONE
         else:
@@ -148,7 +151,6 @@ class KeffPlan(object):
             self.out_buf = None
             self.out_ptr = int(out_ptr)
         self._point(0, 0, self.nslab)
-        self._log = []          # launch sets enqueued since the last fetch (replayed if the persistent kernel gave up)
 
     @staticmethod
     def out_bytes(nslab, N, npre=0):
@@ -231,7 +233,6 @@ class KeffPlan(object):
             ok = chain and min(g, self.nslab - nxt) == n          # same shape only
             self.desc.q_next = (self._q_ptr + nxt * esz) if ok else None
             self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
-            self._note(slot, s0, n, None)
 
     def run_range(self, slot, s0, n, next_s0=None, out_s0=None):
         """One launch set over slabs [s0, s0+n) into result slot `slot`; `next_s0`: first slab of
@@ -241,12 +242,6 @@ class KeffPlan(object):
         esz = self.ny * self.nx * self.q_dtype.itemsize
         self.desc.q_next = (self._q_ptr + next_s0 * esz) if next_s0 is not None else None
         self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
-        self._note(slot, s0, n, out_s0)
-
-    def _note(self, slot, s0, n, out_s0):
-        self._log.append((slot, s0, n, out_s0, self._q_ptr, self.out_ptr))
-        if len(self._log) > 4096:
-            del self._log[:2048]
 
     def unpack(self, raw):
         """one result slot (bytes as a uint8 ndarray) -> dict of arrays"""
@@ -268,29 +263,6 @@ class KeffPlan(object):
         self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, raw.ctypes.data,
                                                    self.out_ptr + slot * self.slot_bytes, self.slot_bytes))
         out = self.unpack(raw)
-        if (out['status'] >= 2).any():
-            # the persistent kernel left slabs to the two-pass path: status 2 = it could not co-schedule its workgroups
-            # (another process on the GPU) and gave up -- the context then stays in two-pass mode; status 3 = that slab's
-            # levels are not equally spaced to a quarter of a bin (float32 contours of a tiny range, infinite extrema).
-            # Replay everything enqueued since the last fetch through the two-pass path, once.
-            log, self._log = self._log, []
-            stay = bool((out['status'] == 2).any())
-            mode_before = getattr(self.ctx, '_keff_mode', nat.XC_KEFF_AUTO)
-            self.ctx.set_keff_mode(nat.XC_KEFF_TWO_PASS)
-            keep = (self._q_ptr, self.out_ptr)
-            for (sl, s0, n, o0, qp, op) in log:
-                self._q_ptr, self.out_ptr = qp, op
-                self._point(sl, s0, n, o0)
-                self.desc.q_next = None
-                self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
-            self._q_ptr, self.out_ptr = keep
-            if not stay:
-                self.ctx.set_keff_mode(mode_before)
-            self.ctx.sync()
-            self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, raw.ctypes.data,
-                                                       self.out_ptr + slot * self.slot_bytes, self.slot_bytes))
-            out = self.unpack(raw)
-        self._log = []
         if check and out['status'].any():
             raise Exception('non monotonic bins')          # reference core.py:1233-1251
         return out
