@@ -216,7 +216,7 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
                     double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
 
 /* float64 tracers take a three-pass path: a stable LSD sort on the 24-bit RANGE key floor((q - min) * (2^24 - 1) / (max - min))
- * (monotone in q), then a stable in-LDS insertion sort of every run of equal range key that is out of order, then a
+ * (monotone in q), then a stable in-LDS odd-even transposition sort of every run of equal range key that is out of order and a
  * sortedness check whose flag is read back -- the ONE host round trip these calls (also the _dev ones) make; a stack that
  * fails it (distinct values packed into less than 2^-24 of the range, more than 128 of them) is sorted again with the
  * eight key passes.  The result is the same stable sort either way.  xc_last_sort_path: 0 = key passes only (float32

@@ -292,6 +292,14 @@ def test_sort_range_path_fields_ties_masks(ctx):
     assert _sort_equals_oracle(ctx, qi, dA) in (1, 2)                        # an infinite range collapses the range key
     assert _sort_equals_oracle(ctx, np.full((ny, nx), 2.5), dA) == 1
     assert _sort_equals_oracle(ctx, np.array([[3.0, -1.0]])) == 1
+    # ties AND inversions inside one range-key run: few distinct values 1e-13 apart, payloads must follow the stable order
+    tq = 0.25 + 1e-13 * rng.integers(0, 4, (ny, nx))
+    tq[::3] = rng.standard_normal((len(range(0, ny, 3)), nx))
+    assert _sort_equals_oracle(ctx, tq, dA) in (1, 2)
+    tq2 = np.linspace(0, 1, ny * nx).reshape(ny, nx)
+    for off in range(500, ny * nx - 64, 9973):
+        tq2.ravel()[off:off + 40] = tq2.ravel()[off] + 1e-14 * rng.integers(0, 3, 40)
+    assert _sort_equals_oracle(ctx, tq2, dA) == 1
     # float32 tracers keep the four key passes
     r = ctx.sort_profile(q.astype(np.float32), dA=dA, want_sorted=True)
     assert ctx.last_sort_path() == 0 and np.array_equal(r['q_sorted'], np.sort(q.astype(np.float32).ravel()).astype(np.float64))
@@ -311,11 +319,12 @@ def test_sort_range_path_spike_falls_back(ctx):
     assert ctx.last_sort_path() == 2
     for s in range(2):
         assert np.array_equal(r['q_sorted'][s], np.sort(st[s].ravel()))
-    # runs just over / under the repair limit of 128: 120 distinct values inside one range-key bucket are repaired in LDS
+    # runs under / over the repair limit: 50 distinct values inside one range-key bucket are repaired in LDS, 400 are not
     base = np.linspace(0.0, 1.0, 4096 * 8).reshape(64, 512)
-    b2 = base.copy()
-    b2.ravel()[1000:1120] = base.ravel()[1000] + 1e-13 * rng.permutation(120)
-    assert _sort_equals_oracle(ctx, b2) == 1
+    for off in (1000, 2047, 2048 + 17, 4096 - 25):                       # also runs that straddle two repair blocks
+        b2 = base.copy()
+        b2.ravel()[off:off + 50] = base.ravel()[off] + 1e-13 * rng.permutation(50)
+        assert _sort_equals_oracle(ctx, b2) == 1
     b3 = base.copy()
     b3.ravel()[1000:1400] = base.ravel()[1000] + 1e-13 * rng.permutation(400)
     assert _sort_equals_oracle(ctx, b3) == 2

@@ -13,8 +13,8 @@
 // the 24-bit RANGE key  d = floor((v - min) * (2^24 - 1) / (max - min))  (min / max from K1; subtract, multiply by a positive
 // constant and floor are each monotone, so d never orders two values the wrong way; equal values share a d).  Three
 // stable LSD passes over the bytes of d leave the pairs sorted by d with the cells of one d in their original order; a
-// RUN of equal d holds 0.4 cells on average for 6.5 M pairs, so `k_fix_runs` finishes the job with a stable insertion
-// sort of every run that is out of order (in LDS, runs of <= 128), and `k_check_sorted` proves the result: one flag is
+// RUN of equal d holds 0.4 cells on average for 6.5 M pairs, so `k_fix_runs` finishes the job with a stable odd-even
+// transposition sort of every run that is out of order (in LDS, runs of <= 128) and proves the result: one flag is
 // read back, and only if some run was longer and out of order (a spike of distinct values narrower than 2^-24 of the
 // range) the stack is sorted again by the full eight-pass path.  Ties of any length are already in order.
 //
@@ -70,17 +70,44 @@ template <> struct KeyTraits<u32> {            // float32 tracers: the key of th
     }
 };
 
-// the (key, payload) pair of cell i, straight from the tracer / mask / dA: pass 0 of the sort builds its pairs
-// with this, so the unsorted pairs are never written and read back (24-32 B per cell; 0.60 -> 0.57 ms for 6.48 M pairs)
-template <typename TQ, typename TM, typename K>
-__device__ __forceinline__ void make_pair(const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA,
-                                          int dA_rank, int64_t nx, int negate, int64_t i, K& key, double& val)
+// the (key, payload) pairs of TILE_ROUNDS cells per lane, straight from the tracer / mask / dA: pass 0 of the sort builds its
+// pairs with this, so the unsorted pairs are never written and read back (24-32 B per cell).  Phases, not a per-cell
+// function: every load of a stream is issued before the first use (clamped addresses, wave-uniform branches only), and a
+// per-row dA divides in 32 bits (n < 2^31).
+template <typename TQ, typename TM, typename K, int R, bool VALS>
+__device__ __forceinline__ void load_pairs(const TQ* __restrict__ q, const TM* __restrict__ mask, const double* __restrict__ dA,
+                                           int dA_rank, int64_t nx, int negate, int64_t base, int lane, int64_t n,
+                                           K (&key)[R], double (&val)[R])
 {
-    const double v = negate ? -(double)q[i] : (double)q[i];
-    const bool ok = (v == v) && (!mask || mask[i] == (TM)1);
-    const double w = (dA_rank == XC_DA_ROW) ? dA[i / nx] : (dA_rank == XC_DA_PLANE ? dA[i] : 1.0);
-    key = ok ? KeyTraits<K>::encode(v) : KeyTraits<K>::invalid();       // invalid cells sort to the end
-    val = ok ? w : 0.0;
+    TQ qv[R];
+    TM mv[R];
+    unsigned idx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int64_t i = base + r * 64 + lane; idx[r] = (unsigned)(i < n ? i : n - 1); qv[r] = q[idx[r]]; }
+    if (mask) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) mv[r] = mask[idx[r]];
+    }
+    if (VALS) {
+        if (dA_rank == XC_DA_PLANE) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) val[r] = dA[idx[r]];
+        } else if (dA_rank == XC_DA_ROW) {
+            const unsigned unx = (unsigned)nx;
+#pragma unroll
+            for (int r = 0; r < R; ++r) val[r] = dA[idx[r] / unx];
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) val[r] = 1.0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double v = negate ? -(double)qv[r] : (double)qv[r];
+        const bool ok = (v == v) && (!mask || mv[r] == (TM)1) && (base + r * 64 + lane < n);
+        key[r] = ok ? KeyTraits<K>::encode(v) : KeyTraits<K>::invalid();       // dropped cells sort to the end
+        if (VALS) val[r] = ok ? val[r] : 0.0;
+    }
 }
 struct PairSrc {                 // where pass 0 finds its input (per-slab strides applied by the kernels)
     const void* q; const void* mask; const double* dA;
@@ -160,13 +187,8 @@ void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, 
         const TM* mask = src.mask ? (const TM*)src.mask + (size_t)blockIdx.y * src.mask_stride : nullptr;
         const int64_t base = t * BTILE + (int64_t)wave * TILE;
         K kreg[TILE_ROUNDS];
-#pragma unroll
-        for (int r = 0; r < TILE_ROUNDS; ++r) {
-            const int64_t i = base + r * 64 + lane;
-            double dummy;
-            if (i < n) make_pair<TQ, TM, K>(q, mask, nullptr, XC_DA_NONE, src.nx, src.negate, i, kreg[r], dummy);
-            else kreg[r] = (K)0;
-        }
+        double dummy[TILE_ROUNDS];
+        load_pairs<TQ, TM, K, TILE_ROUNDS, false>(q, mask, nullptr, XC_DA_NONE, src.nx, src.negate, base, lane, n, kreg, dummy);
 #pragma unroll
         for (int r = 0; r < TILE_ROUNDS; ++r) {
             const int64_t i = base + r * 64 + lane;
@@ -262,6 +284,7 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
     unsigned* s_cnt = (unsigned*)(s_dyn + BTILE);              // [4][256] per-wave digit counts -> start offsets
     unsigned* s_gbase = s_cnt + 4 * 256;                       // [256] global position minus tile-local position
     unsigned* s_wsum = s_gbase + 256;                          // [8]
+    unsigned char* s_dig = (unsigned char*)(s_wsum + 8);       // [BTILE] digit of the element at every tile-local position
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x;
     RangeMap rm = {0.0, 0.0};
@@ -274,17 +297,13 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
     K kreg[TILE_ROUNDS];                                       // the whole part's loads in flight at once
     double vreg[TILE_ROUNDS];
     unsigned short lrank[TILE_ROUNDS];
+    unsigned char dreg[TILE_ROUNDS];                           // the digit, computed once (the range key costs ~10 VALU operations)
     if constexpr (FIRST) {
         // pass 0 builds its pairs from the tracer / mask / dA (kin / vin do not exist yet; their slab offset above is harmless)
         const TQ* q = (const TQ*)src.q + (size_t)blockIdx.y * n;
         const TM* mask = src.mask ? (const TM*)src.mask + (size_t)blockIdx.y * src.mask_stride : nullptr;
         const double* dA = src.dA ? src.dA + (size_t)blockIdx.y * src.dA_stride : nullptr;
-#pragma unroll
-        for (int r = 0; r < TILE_ROUNDS; ++r) {
-            const int64_t i = base + r * 64 + lane;
-            if (i < n) make_pair<TQ, TM, K>(q, mask, dA, src.dA_rank, src.nx, src.negate, i, kreg[r], vreg[r]);
-            else { kreg[r] = (K)0; vreg[r] = 0.0; }
-        }
+        load_pairs<TQ, TM, K, TILE_ROUNDS, true>(q, mask, dA, src.dA_rank, src.nx, src.negate, base, lane, n, kreg, vreg);
     } else {
 #pragma unroll
         for (int r = 0; r < TILE_ROUNDS; ++r) {
@@ -299,6 +318,7 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
         const int64_t i = base + r * 64 + lane;
         const bool valid = i < n;
         const unsigned d = valid ? digit_of<K, MODE>(kreg[r], shift, rm) : 0u;
+        dreg[r] = (unsigned char)d;
         const unsigned long long peers = digit_peers(d, __ballot(valid));
         const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
         unsigned pos = 0;
@@ -334,9 +354,9 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
 #pragma unroll
     for (int r = 0; r < TILE_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
-        const unsigned d = digit_of<K, MODE>(kreg[r], shift, rm);
+        const unsigned d = dreg[r];
         lrank[r] = (unsigned short)(s_cnt[wave * 256 + d] + lrank[r]);      // tile-local position
-        if (i < n) s_k[lrank[r]] = kreg[r];
+        if (i < n) { s_k[lrank[r]] = kreg[r]; s_dig[lrank[r]] = dreg[r]; }
     }
     __syncthreads();
     const int64_t left = n - tbase;
@@ -347,7 +367,7 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
         const int p = r * 256 + tid;
         if (p < cnt) {
             const K key = s_k[p];
-            gpos[r] = s_gbase[digit_of<K, MODE>(key, shift, rm)] + (unsigned)p;
+            gpos[r] = s_gbase[s_dig[p]] + (unsigned)p;
             kout[gpos[r]] = key;
         }
     }
@@ -365,62 +385,114 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
     }
 }
 
-// ---- after the three range-key passes: finish every run of equal range key that is out of order.  A block owns the
-// runs whose HEAD lies in its FIX_C positions and sees FIX_H more; a head's thread walks its run, and if it found an
-// inversion and the run has at most FIX_MAXRUN cells inside the window it sorts the run by the full key with a stable
-// insertion sort in LDS and writes it back in place.  Runs are disjoint, so are the writes; a neighbouring block reading
-// a cell while it is being rewritten only derives its range key from it, which every cell of the run shares.
-constexpr int FIX_C = 2048, FIX_H = 128, FIX_MAXRUN = 128, FIX_W = FIX_C + FIX_H + 1;
+// ---- after the three range-key passes: finish every run of equal range key that is out of order, and count the valid
+// cells.  IN PLACE; one block per FIX_C consecutive positions [a, b) OWNS the runs whose first cell (head) lies there, to
+// their end -- so a run belongs to exactly one block, and the block's window is [a - 1, b + FIX_H).
+//   1. Every inversion (a cell whose full key is smaller than its left neighbour's inside one run) in the window looks
+//      for the ends of its run within FIX_RUN / 2 cells on either side; if one is missing the run may be longer than
+//      FIX_RUN and the flag sends the whole stack to the eight-pass path.  Otherwise every run that needs work has at
+//      most FIX_RUN <= FIX_H cells: a run headed in [a, b) lies wholly inside the window.
+//   2. Odd-even transposition rounds exchange ADJACENT cells of the SAME range key whose full keys are out of order --
+//      stable, branch-free, all lanes busy -- until a double round moves nothing (runs hold ~1.4 cells on average: three
+//      to five double rounds; a run of r cells needs at most r rounds).
+//   3. The block writes back the cells that moved, if they belong to a run it owns: everything from the first head at or
+//      after a to the first head at or after b.  Cells of a run headed in a neighbour's positions are that neighbour's;
+//      a block reading such a cell while it is rewritten only derives its range key from it, which the run shares.
+//   The step from the last valid key to the first dropped one (always a head) gives nvalid.
+constexpr int FIX_C = 1024, FIX_H = 128, FIX_RUN = 128, FIX_NL = (FIX_C + FIX_H + 1 + 255) / 256, FIX_W = FIX_NL * 256,
+              FIX_ROUNDS = FIX_RUN + 2;
 template <typename K>
 __global__ __launch_bounds__(256)
-void k_fix_runs(K* __restrict__ keys, double* __restrict__ vals, int64_t n, const PairSrc src)
+void k_fix_runs(K* __restrict__ keys, double* __restrict__ vals, int64_t n, unsigned* __restrict__ flag,
+                unsigned* __restrict__ nvalid, const PairSrc src)
 {
-    __shared__ K s_k[FIX_W];
+    __shared__ K s_k[FIX_W + FIX_RUN];                                       // (+ FIX_RUN: the run-end search may look past the window)
     __shared__ double s_v[FIX_W];
-    __shared__ unsigned s_d[FIX_W];
+    __shared__ unsigned s_d[FIX_W + FIX_RUN];
+    __shared__ int s_first[2];
     const int tid = threadIdx.x;
     const RangeMap rm = range_map(src.mm, blockIdx.y, src.negate);
     keys += (size_t)blockIdx.y * n; vals += (size_t)blockIdx.y * n;
-    const int64_t w0 = (int64_t)blockIdx.x * FIX_C - 1;             // window position i <-> cell w0 + i; cells w0+1 .. w0+FIX_C are owned
-    for (int i = tid; i < FIX_W; i += 256) {
+    const int64_t a = (int64_t)blockIdx.x * FIX_C, w0 = a - 1;               // window position i <-> cell w0 + i; owned heads: i in [1, FIX_C]
+    K kr[FIX_NL]; double vr[FIX_NL];                                          // every load issued before the first use
+#pragma unroll
+    for (int c = 0; c < FIX_NL; ++c) {
+        int64_t g = w0 + tid + 256 * c;
+        g = g < 0 ? 0 : (g < n ? g : n - 1);
+        kr[c] = keys[g]; vr[c] = vals[g];
+    }
+    if (tid < 2) s_first[tid] = FIX_W;
+    if (tid < FIX_RUN) s_d[FIX_W + tid] = 0xFFFFFFF0u + (unsigned)(tid & 1);
+#pragma unroll
+    for (int c = 0; c < FIX_NL; ++c) {
+        const int i = tid + 256 * c;
         const int64_t g = w0 + i;
-        if (g >= 0 && g < n) { const K k = keys[g]; s_k[i] = k; s_v[i] = vals[g]; s_d[i] = range_key<K>(k, rm); }
-        else s_d[i] = g < 0 ? 0xFFFFFFFFu : 0xFFFFFFFEu;           // no cell: never equal to a range key
+        const bool in = g >= 0 && g < n;
+        s_k[i] = in ? kr[c] : (K)0; s_v[i] = in ? vr[c] : 0.0;
+        s_d[i] = in ? range_key<K>(kr[c], rm) : 0xFFFFFFF0u + (unsigned)(i & 1);          // no cell: equal to no neighbour
     }
     __syncthreads();
-    for (int i = 1 + tid; i <= FIX_C; i += 256) {
-        if (w0 + i >= n) break;
-        const unsigned d = s_d[i];
-        if (d == s_d[i - 1]) continue;                              // not the head of a run
-        int L = 1;
-        bool inv = false;
-        while (i + L < FIX_W && L <= FIX_MAXRUN && s_d[i + L] == d) { inv |= s_k[i + L] < s_k[i + L - 1]; ++L; }
-        if (!inv) continue;
-        if (L > FIX_MAXRUN || i + L >= FIX_W) continue;             // longer than this kernel takes: k_check_sorted will see it
-        for (int x = i + 1; x < i + L; ++x) {                       // stable: an equal key never moves past its predecessor
-            const K kk = s_k[x]; const double vv = s_v[x];
-            int y = x - 1;
-            while (y >= i && s_k[y] > kk) { s_k[y + 1] = s_k[y]; s_v[y + 1] = s_v[y]; --y; }
-            s_k[y + 1] = kk; s_v[y + 1] = vv;
-        }
-        for (int x = i; x < i + L; ++x) { keys[w0 + x] = s_k[x]; vals[w0 + x] = s_v[x]; }
-    }
-}
-
-// is the stack sorted by the full key?  (equal keys are in their original order by construction of the stable passes)
-template <typename K>
-__global__ __launch_bounds__(256)
-void k_check_sorted(const K* __restrict__ keys, int64_t n, unsigned* __restrict__ flag)
-{
-    keys += (size_t)blockIdx.y * n;
-    const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     bool bad = false;
+    int h0 = FIX_W, h1 = FIX_W;                                                // first head at or after a / at or after b seen by this thread
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int64_t i = base + c;
-        if (i >= 1 && i < n) bad |= keys[i] < keys[i - 1];
+    for (int c = 0; c < FIX_NL; ++c) {
+        const int i = tid + 256 * c;
+        if (i == 0) continue;
+        const unsigned d = s_d[i];
+        if (d != s_d[i - 1]) {                                                 // a head: the first at or after a, the first at or after b
+            if (i <= FIX_C) h0 = i < h0 ? i : h0; else h1 = i < h1 ? i : h1;
+            if (d == RANGE_INVALID && i <= FIX_C && w0 + i < n) nvalid[blockIdx.y] = (unsigned)(w0 + i);
+            continue;
+        }
+        if (!(s_k[i] < s_k[i - 1]) || i > FIX_C + FIX_RUN) continue;          // not an inversion (or beyond any run this block may own)
+        bool left = false, right = false;                                      // the ends of the run within FIX_RUN / 2 cells?
+        for (int j = 2; j <= FIX_RUN / 2 && !left; ++j) left = i - j < 0 || s_d[i - j] != d;
+        for (int j = 1; j < FIX_RUN / 2 && !right; ++j) right = s_d[i + j] != d;
+        bad |= !(left && right);
     }
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    for (int o = 32; o > 0; o >>= 1) { const int x0 = __shfl_xor(h0, o), x1 = __shfl_xor(h1, o); h0 = x0 < h0 ? x0 : h0; h1 = x1 < h1 ? x1 : h1; }
+    if ((tid & 63) == 0) { atomicMin(&s_first[0], h0); atomicMin(&s_first[1], h1); }      // one LDS atomic per wave, not one per head
+    if (__syncthreads_or(bad)) {                                               // the stack goes to the eight-pass path: nothing else to do here
+        if (tid == 0) atomicOr(flag, 1u);
+        return;
+    }
+    if (blockIdx.x == 0 && tid == 0) {                                         // no dropped cell at all / only dropped cells
+        if (s_d[1] == RANGE_INVALID) nvalid[blockIdx.y] = 0u;
+    }
+    if (w0 + FIX_C >= n - 1 && tid == 0) {                                     // the block that holds the last cell
+        const int il = (int)(n - 1 - w0);
+        if (s_d[il] != RANGE_INVALID) nvalid[blockIdx.y] = (unsigned)n;
+    }
+    for (int round = 0; round < FIX_ROUNDS; round += 2) {
+        int moved = 0;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+#pragma unroll
+            for (int c = 0; c < FIX_NL / 2 + 1; ++c) {
+                const int i = 2 * tid + par + 512 * c;
+                if (i + 1 < FIX_W) {
+                    const K k0 = s_k[i], k1 = s_k[i + 1];
+                    if (s_d[i] == s_d[i + 1] && k1 < k0) {
+                        const double v0 = s_v[i];
+                        s_k[i] = k1; s_k[i + 1] = k0; s_v[i] = s_v[i + 1]; s_v[i + 1] = v0;
+                        moved = 1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(moved)) break;
+    }
+    const int f0 = s_first[0], f1 = s_first[1];                                // owned cells: window positions [f0, f1)
+#pragma unroll
+    for (int c = 0; c < FIX_NL; ++c) {
+        const int i = tid + 256 * c;
+        if (i >= f0 && i < f1 && w0 + i < n) {                                 // (padding positions behind the last cell are heads too)
+            const K k = s_k[i];
+            const double v = s_v[i];
+            if (k != kr[c] || v != vr[c]) { keys[w0 + i] = k; vals[w0 + i] = v; }   // (a cell may inherit an EQUAL key from a neighbour that moved: compare the payload too)
+        }
+    }
 }
 
 // ---- inclusive f64 scan (cumulative area of the sorted state): block sums, their exclusive scan, then
@@ -619,7 +691,7 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
     const int64_t dstride = dA_rank == XC_DA_SLAB ? n : 0, mstride = (mask && mask_per_slab) ? n : 0;
     const PairSrc src = {q, mask, dA, krank, negate, nx, mstride, dstride, mm};
     const unsigned gt = (unsigned)ntiles;
-    const size_t sc_lds = (size_t)BTILE * 8 + (4 * 256 + 256 + 8) * sizeof(unsigned);
+    const size_t sc_lds = (size_t)BTILE * 8 + (4 * 256 + 256 + 8) * sizeof(unsigned) + BTILE;
     const int inline_scan = ntiles <= 32 ? 1 : 0;       // measured: the O(ntiles) walk per block costs ~0.14 us per tile, the scan launch ~5 us
     K *kin = kA, *kout = kB;
     double *vin = vA, *vout = vB;
@@ -663,8 +735,7 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
             XC_TRY_(launch_minmax_final(ctx, mmpart, nslab, minmax_blocks(n), mm));
             XC_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream));
             for (int p = 0; p < 3; ++p) XC_TRY_(pass(std::integral_constant<int, 1>(), p == 0, 8 * p));
-            hipLaunchKernelGGL(k_fix_runs<K>, dim3((unsigned)((n + FIX_C - 1) / FIX_C), ns), dim3(256), 0, ctx->stream, kin, vin, n, src);
-            hipLaunchKernelGGL(k_check_sorted<K>, dim3((unsigned)((n + 1023) / 1024), ns), dim3(256), 0, ctx->stream, kin, n, flag);
+            hipLaunchKernelGGL(k_fix_runs<K>, dim3((unsigned)((n + FIX_C - 1) / FIX_C), ns), dim3(256), 0, ctx->stream, kin, vin, n, flag, nvalid, src);
             XC_HIP(ctx, hipGetLastError());
             unsigned h_flag = 1;
             XC_HIP(ctx, hipMemcpyAsync(&h_flag, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
@@ -678,8 +749,8 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
         if (!(sizeof(K) == 8 && ctx->knobs.sort_range)) ctx->last_sort_path = 0;
         for (int p = 0; p < KeyTraits<K>::passes; ++p) XC_TRY_(pass(std::integral_constant<int, 0>(), p == 0, 8 * p));
     }
-    // the sorted pairs are in kin / vin
-    hipLaunchKernelGGL(k_count_valid<K>, dim3(ns), dim3(64), 0, ctx->stream, kin, n, nvalid);
+    // the sorted pairs are in kin / vin (the range-key path has counted the valid cells already)
+    if (!sorted) hipLaunchKernelGGL(k_count_valid<K>, dim3(ns), dim3(64), 0, ctx->stream, kin, n, nvalid);
     double* acum = vout;                                   // reuse the idle payload buffer
     hipLaunchKernelGGL(k_scan_local<false>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
     hipLaunchKernelGGL(k_scan_bsums, dim3(ns), dim3(1024), 0, ctx->stream, bsum, nb);
