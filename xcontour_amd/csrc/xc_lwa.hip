@@ -16,6 +16,15 @@ namespace xc {
 namespace {
 
 
+// a value every lane of the wave holds: hand it to the scalar unit
+__device__ __forceinline__ double lane_uniform(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ int mask3(double qe, bool m, int increase)
 {
     // core.py:759-766
@@ -154,17 +163,23 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             if (yb + r >= ny) break;
-            const double qv = qv_[r], cy = cy_[r], mv = mv_[r];
+            const double qv = qv_[r], mv = mv_[r];
+            const double cy = lane_uniform(cy_[r]);                                     // the same value in every lane: keep the side test scalar
             const double wei = wv_[r];                                                  // dA / max(dA), core.py:724
 #pragma unroll
             for (int t = 0; t < JT; ++t) {
-                const double qe = V2 ? __dsub_rn(Qj[t], qv) : __dsub_rn(qv, Qj[t]);     // core.py:860 / 754
-                const bool m = coord_incre ? (cy >= cj[t]) : (cy <= cj[t]);             // core.py:757
-                const int mk = mask3(qe, m, inc_eff);
-                // (kept as a branch: for most (j, y') pairs the whole wave has mk == 0 and skips the products;
+                // mask3 (core.py:759-766 / 865-872) with the side m of row y' WAVE-UNIFORM:  mask3 != 0  <=>  u > 0 with
+                // u = -qe on the side where mask3 = +-1 needs qe < 0 and u = +qe on the other; qe * mask3 = -+u exactly
+                // (a - b and b - a are exact negations, as are x * (-1) and -x), so the term of core.py:789 is
+                // -+((u * wei) * M) bit for bit and only |term| is accumulated; the sign goes on at the end.
+                const bool m = coord_incre ? (cy >= cj[t]) : (cy <= cj[t]);             // core.py:757 (scalar)
+                if (keep != 0 && (keep > 0) != m) continue;                             // 'upper' / 'lower' keep one side (core.py:775-784)
+                const double a = V2 ? Qj[t] : qv, b = V2 ? qv : Qj[t];                  // qe = a - b, core.py:860 / 754
+                const double u = (m == (inc_eff != 0)) ? __dsub_rn(b, a) : __dsub_rn(a, b);
+                // (kept as a branch: for most (j, y') pairs no lane contributes and the wave skips the products;
                 //  a branch-free select version measured 89 vs 63 us on cfg3)
-                if (mk != 0 && (keep == 0 || (keep > 0) == (mk > 0))) {
-                    const double term = __dmul_rn(__dmul_rn(__dmul_rn(qe, (double)mk), wei), mv);
+                if (u > 0.0) {
+                    const double term = __dmul_rn(__dmul_rn(u, wei), mv);
                     if (term == term) acc[t] = __dadd_rn(acc[t], term);                 // nansum
                 }
             }
@@ -173,7 +188,7 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
     if (active) {
 #pragma unroll
         for (int t = 0; t < JT; ++t)
-            if (j0 + t < ny) out[so + (size_t)(j0 + t) * nx + x] = -acc[t];        // core.py:789
+            if (j0 + t < ny) out[so + (size_t)(j0 + t) * nx + x] = inc_eff ? (acc[t] == 0.0 ? -0.0 : acc[t]) : -acc[t];   // -(sum of terms), core.py:789 (an empty sum is -0.0 there)
     }
 }
 
@@ -226,7 +241,7 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
         hipLaunchKernelGGL(k_lwa_prep<float>, gp, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, nstrip, wei, rowinfo, stripmm);
     else return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
     if (M_rank == XC_DA_NONE) { M = dA; M_rank = dA_rank; }
-    const bool small = (double)ny * (double)ny * (double)nx * (double)nslab < 4.0e9;
+    const bool small = (double)ny * (double)ny * (double)nx * (double)nslab < 2.0e8;
     const int jt = small ? 1 : 4;
     dim3 grid((unsigned)((nx + 63) / 64), (unsigned)((ny + 4 * jt - 1) / (4 * jt)), (unsigned)nslab);
 #define XC_LWA2(T, V, J) hipLaunchKernelGGL((k_lwa<T, V, J>), grid, dim3(256), 0, ctx->stream, (const T*)q, Q, coord, wei, dA_rank, \
