@@ -85,6 +85,14 @@ int xc_free(xc_ctx* ctx, void* dptr);
 int xc_memcpy_h2d(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int xc_memcpy_d2h(xc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int xc_memset(xc_ctx* ctx, void* dptr, int value, size_t bytes);
+/* Uploads that overlap compute: xc_memcpy_h2d_async copies on the context's second (copy) stream and returns when the
+ * host buffer may be reused (pageable memory: when the copy is done; kernels enqueued earlier on the compute stream run
+ * meanwhile).  xc_stream_wait_copies makes everything enqueued on the compute stream AFTER the call wait for the copies
+ * issued so far; xc_copies_wait_stream makes later copies wait for the compute work enqueued so far (before a buffer that
+ * kernels still read is overwritten). */
+int xc_memcpy_h2d_async(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int xc_stream_wait_copies(xc_ctx* ctx);
+int xc_copies_wait_stream(xc_ctx* ctx);
 int xc_event_create(xc_ctx* ctx, void** out_event);
 int xc_event_destroy(xc_ctx* ctx, void* event);
 int xc_event_record(xc_ctx* ctx, void* event);

@@ -328,3 +328,50 @@ def test_sort_range_path_spike_falls_back(ctx):
     b3 = base.copy()
     b3.ravel()[1000:1400] = base.ravel()[1000] + 1e-13 * rng.permutation(400)
     assert _sort_equals_oracle(ctx, b3) == 2
+
+
+# ---------------------------------------------------------------- byte-bounded staging of the facade (missing #4)
+def test_facade_methods_stream_large_stacks_in_batches(ctx, baro):
+    """a stack larger than a deliberately small staging cap goes through the device in batches of whole slabs -- histogram
+    integrals, crossing, LWA, sorted profile, the fused keff() with its double-buffered uploads -- with the results of one
+    big launch (counts / levels / exact kernels bit for bit, float sums to rounding)"""
+    import xcontour_amd as xa
+    q0, lat, lon = baro
+    S = 7
+    rng = np.random.default_rng(4)
+    q = np.stack([q0 * (1 + 0.1 * s) + 1e-6 * rng.standard_normal(q0.shape).astype(np.float32) for s in range(S)])
+    c = {'time': np.arange(S), 'latitude': lat, 'longitude': lon}
+    tr = xa.DataArray(q, ('time', 'latitude', 'longitude'), c, 'absolute_vorticity')
+    dA = xa.DataArray(O.cell_area(lat, lon), ('latitude', 'longitude'), {'latitude': lat, 'longitude': lon}, 'rA')
+    mask = xa.DataArray(np.ones_like(q0), ('latitude', 'longitude'), {'latitude': lat, 'longitude': lon}, 'mask')
+    cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True)
+    table = cm.cal_area_eqCoord_table_hist(mask)
+    ctr = cm.cal_contours(41)
+    dy = np.gradient(np.deg2rad(lat.astype(np.float64))) * O.Rearth
+    Qeq = xa.DataArray(np.sort(q.mean(axis=2), axis=1), ('time', 'latitude'), {'time': np.arange(S), 'latitude': lat}, 'absolute_vorticity')
+
+    def everything(cap_keff):
+        return dict(area=cm.cal_integral_within_contours_hist(ctr).values,
+                    cross=cm.cal_contour_crossing(ctr, stride=[1, 2]),
+                    lwa=cm.cal_local_wave_activity(tr, Qeq, metric=dy).values,
+                    prof=cm.cal_sorted_profile(table).values,
+                    keff=cm.keff(41, table, lat=lat, lon=lon, max_batch_bytes=cap_keff))
+
+    cap = cm.ctx.max_batch_bytes
+    big = everything(8 << 30)
+    try:
+        cm.ctx.max_batch_bytes = 3 * q0.nbytes + 1000                 # room for one or two slabs' worth of staged bytes
+        assert len(cm.ctx._batches(S, q0.nbytes)) >= 3
+        small = everything(5 * q0.nbytes)                              # keff: two device halves of two slabs each, four batches
+    finally:
+        cm.ctx.max_batch_bytes = cap
+    assert rel(small['area'], big['area']) < 1e-12
+    for a, b in zip(small['cross'], big['cross']):
+        assert rel(a.values, b.values) < 1e-12
+    assert np.array_equal(small['lwa'], big['lwa'])                    # sequential sums: bit-identical
+    assert np.array_equal(small['prof'], big['prof'])
+    for k in ('ctr', 'area', 'intgrdS', 'latEq', 'nkeff'):
+        a, b = small['keff'][k].values, big['keff'][k].values
+        assert a.shape == (S, 41)
+        assert np.array_equal(a, b) if k == 'ctr' else rel(a, b) < 1e-9, k
+    cm.close()

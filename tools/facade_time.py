@@ -47,3 +47,42 @@ timed('keff (fused, grdS supplied)', lambda: cm.keff(N, table, grdS=g2))
 timed('keff (fused, in-kernel gradient)', lambda: cm.keff(N, table, lat=lat, lon=lon))
 rec['sum of the call sequence'] = sum(v for k, v in rec.items() if not k.startswith('keff'))
 print(json.dumps({'facade_ms_per_call_cfg2_slab': rec, 'kwargs': {k: str(v) for k, v in kw.items()}}))
+
+# ---- a long host stack through the fused keff(): uploads in batches on the copy stream while the previous batch computes.
+# Beside it: the bare hipMemcpy of the same bytes (pageable and pinned source), the floor of any host-side entry point.
+S = int(os.environ.get('XC_FACADE_STACK', '0'))
+if S:
+    import ctypes as C
+    from xcontour_amd import _native as nat
+    stack = np.empty((S, NY, NX))
+    for s in range(S):
+        stack[s] = q * (1.0 + 0.01 * s)
+    c3 = {'time': np.arange(S), 'lat': lat, 'lon': lon}
+    tr3 = xa.DataArray(stack, ('time', 'lat', 'lon'), c3, 'pv')
+    cm3 = xa.Contour2D(tr3, dA, **kw)
+    cap = int(float(os.environ.get('XC_FACADE_CAP_GB', '4')) * (1 << 30))
+    cm3.keff(N, table, lat=lat, lon=lon, max_batch_bytes=cap)                       # plan + buffers
+    t = time.perf_counter()
+    out = cm3.keff(N, table, lat=lat, lon=lon, max_batch_bytes=cap)
+    t_keff = time.perf_counter() - t
+    ctx = cm3.ctx
+    dev = ctx.alloc(min(stack.nbytes, cap))
+    hip = C.CDLL('libamdhip64.so')
+    chunk = dev.nbytes // (NY * NX * 8)
+
+    def bare(src):
+        t0 = time.perf_counter()
+        for s0 in range(0, S, chunk):
+            m = min(chunk, S - s0)
+            ctx._check(ctx.lib.xc_memcpy_h2d(ctx.handle, dev.ptr, src[s0:s0 + m].ctypes.data, m * NY * NX * 8))
+        return time.perf_counter() - t0
+    bare(stack)
+    t_page = bare(stack)
+    rc = hip.hipHostRegister(C.c_void_p(stack.ctypes.data), C.c_size_t(stack.nbytes), 0)
+    t_pin = bare(stack) if rc == 0 else None
+    if rc == 0:
+        hip.hipHostUnregister(C.c_void_p(stack.ctypes.data))
+    print(json.dumps({'facade_keff_stack': {'slabs': S, 'GB': stack.nbytes / 1e9, 'batch_cap_GB': cap / 2 ** 30, 'keff_s': t_keff,
+                                            'keff_GBps': stack.nbytes / t_keff / 1e9, 'ms_per_slab': t_keff / S * 1e3,
+                                            'bare_h2d_pageable_s': t_page, 'bare_h2d_pinned_s': t_pin,
+                                            'keff_over_pinned_copy': None if not t_pin else t_keff / t_pin}}))

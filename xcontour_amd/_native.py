@@ -80,6 +80,9 @@ PROTOTYPES = {
     'xc_memcpy_h2d': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     'xc_memcpy_d2h': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     'xc_memset': (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
+    'xc_memcpy_h2d_async': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    'xc_stream_wait_copies': (C.c_int, [_vp]),
+    'xc_copies_wait_stream': (C.c_int, [_vp]),
     'xc_event_create': (C.c_int, [_vp, C.POINTER(_vp)]),
     'xc_event_destroy': (C.c_int, [_vp, _vp]),
     'xc_event_record': (C.c_int, [_vp, _vp]),
@@ -191,6 +194,13 @@ class DeviceBuffer(object):
         self.ctx._check(self.ctx.lib.xc_memcpy_h2d(self.ctx.handle, self.ptr, _ptr(arr), arr.nbytes))
         return self
 
+    def upload_async(self, arr, offset_bytes=0):
+        """copy on the context's copy stream (overlaps kernels already enqueued); pair with Context.stream_wait_copies()"""
+        arr = np.ascontiguousarray(arr)
+        assert offset_bytes + arr.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.xc_memcpy_h2d_async(self.ctx.handle, self.ptr + offset_bytes, _ptr(arr), arr.nbytes))
+        return self
+
     def download(self, shape, dtype, offset_bytes=0):
         out = np.empty(shape, dtype=dtype)
         assert offset_bytes + out.nbytes <= self.nbytes
@@ -217,6 +227,10 @@ class Context(object):
         self.handle = h
         self.device = int(device)
         self._buffers = []
+        # host-pointer entry points stage at most this many bytes of per-slab data (tracer, integrands, per-slab weights,
+        # per-slab outputs) on the device at once: larger stacks go through in batches of whole slabs (the reference's
+        # histogram path is lazy / dask-friendly, core.py:158-160, 241-246)
+        self.max_batch_bytes = int(os.environ.get('XC_MAX_BATCH_BYTES', 8 << 30))
 
     # -- plumbing
     def _check(self, rc):
@@ -238,6 +252,12 @@ class Context(object):
 
     def sync(self):
         self._check(self.lib.xc_sync(self.handle))
+
+    def stream_wait_copies(self):
+        self._check(self.lib.xc_stream_wait_copies(self.handle))
+
+    def copies_wait_stream(self):
+        self._check(self.lib.xc_copies_wait_stream(self.handle))
 
     def device_name(self):
         buf = C.create_string_buffer(256)
@@ -303,13 +323,19 @@ class Context(object):
         self._check(self.lib.xc_comm_finalize(self.handle))
 
     # -- host-pointer compute entry points (numpy in, numpy out)
+    def _batches(self, nslab, per_slab_bytes):
+        """[(s0, s1), ...]: the slab axis cut into equal batches of whole slabs whose staged bytes stay below
+        `max_batch_bytes` (and below the 65535 slabs one launch takes); one batch if everything fits"""
+        b = max(1, min(int(nslab), MAX_SLABS_PER_LAUNCH, int(self.max_batch_bytes) // max(1, int(per_slab_bytes))))
+        return [(s0, min(int(nslab), s0 + b)) for s0 in range(0, int(nslab), b)]
+
     def minmax(self, q):
         """q: (nslab, ny, nx) or (nslab, ncell) f32/f64 -> (nslab, 2) f64"""
         q = np.ascontiguousarray(q)
         nslab = q.shape[0]
-        if nslab > MAX_SLABS_PER_LAUNCH:
-            return np.concatenate([self.minmax(q[s0:s0 + MAX_SLABS_PER_LAUNCH])
-                                   for s0 in range(0, nslab, MAX_SLABS_PER_LAUNCH)])
+        bt = self._batches(nslab, q.nbytes // max(1, nslab))
+        if len(bt) > 1:
+            return np.concatenate([self.minmax(q[s0:s1]) for s0, s1 in bt])
         out = np.empty((nslab, 2), dtype=np.float64)
         self._check(self.lib.xc_minmax(self.handle, _ptr(q), dtype_code(q.dtype), nslab,
                                        int(q.size // nslab), _ptr(out)))
@@ -335,10 +361,12 @@ class Context(object):
         q = np.ascontiguousarray(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
-        if nslab > MAX_SLABS_PER_LAUNCH:                     # the library launches at most 65535 slabs at once
+        per = ny * nx * (q.dtype.itemsize + sum(np.asarray(v).dtype.itemsize for v in integrands) + (8 if dA is not None and np.ndim(dA) == 3 else 0))
+        bt = self._batches(nslab, per)
+        if len(bt) > 1:                                      # more than one launch / one arena takes: batches of whole slabs
             parts = []
-            for s0 in range(0, nslab, MAX_SLABS_PER_LAUNCH):
-                sl = slice(s0, s0 + MAX_SLABS_PER_LAUNCH)
+            for s0, s1 in bt:
+                sl = slice(s0, s1)
                 e = np.asarray(edges)
                 d3 = dA is not None and np.ndim(dA) == 3
                 parts.append(self.hist(q[sl], e[sl] if e.ndim == 2 else e, dA[sl] if d3 else dA,
@@ -442,6 +470,9 @@ class Context(object):
         q = np.ascontiguousarray(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
+        bt = self._batches(nslab, ny * nx * (q.dtype.itemsize + 8))
+        if len(bt) > 1:
+            return np.concatenate([self.grad2(q[s0:s1], rdx, rdy, periodic_x) for s0, s1 in bt])
         rdx = np.ascontiguousarray(rdx, dtype=np.float64)
         rdy = np.ascontiguousarray(rdy, dtype=np.float64)
         out = np.empty(q.shape, dtype=np.float64)
@@ -468,6 +499,13 @@ class Context(object):
         if pad_mode not in PAD_MODES:
             raise XContourHipError(XC_EBADARG, 'pad mode must be one of %s' % sorted(PAD_MODES))
         N = contours.shape[-1]
+        bt = self._batches(nslab, ny * nx * (q.dtype.itemsize + (area.dtype.itemsize if area.ndim == 3 else 0)))
+        if len(bt) > 1:
+            parts = [self.crossing(q[s0:s1], contours[s0:s1] if per_slab else contours, area[s0:s1] if area.ndim == 3 else area,
+                                   stride, pad_x, pad_mode, full_width) for s0, s1 in bt]
+            if np.ndim(stride) > 0:
+                return [(np.concatenate([p[i][0] for p in parts]), np.concatenate([p[i][1] for p in parts])) for i in range(len(parts[0]))]
+            return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
         if np.ndim(stride) > 0:
             # several strides on the same padded slab: one upload, one device call per stride
             # (`stride` may be a list; returns lists of results in the same order)
@@ -505,6 +543,11 @@ class Context(object):
         assert q.ndim == 3
         nslab, ny, nx = q.shape
         Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(nslab, ny)
+        bt = self._batches(nslab, ny * nx * (q.dtype.itemsize + 8 + (0 if mask_idx is None else len(mask_idx))))
+        if len(bt) > 1:
+            parts = [self.lwa(q[s0:s1], Q[s0:s1], coord, dA, dA_max, M, increase, part, mask_idx, variant) for s0, s1 in bt]
+            return (np.concatenate([p[0] for p in parts]),
+                    None if parts[0][1] is None else np.concatenate([p[1] for p in parts]))
         coord = np.ascontiguousarray(coord, dtype=np.float64)
         dA = np.ascontiguousarray(dA, dtype=np.float64)
         dr = XC_DA_ROW if dA.shape == (ny,) else XC_DA_PLANE
@@ -537,6 +580,15 @@ class Context(object):
             q = q[None]
         assert q.ndim == 3
         nslab, ny, nx = q.shape
+        # staged per slab: the tracer, per-slab mask / dA, the requested full-length outputs and the sort's own four work arrays
+        per = ny * nx * (q.dtype.itemsize + 32 + (8 if want_sorted else 0) + (8 if want_acum else 0) +
+                         (8 if dA is not None and np.ndim(dA) == 3 else 0) + (8 if mask is not None and np.ndim(mask) == 3 else 0))
+        bt = self._batches(nslab, per)
+        if len(bt) > 1:
+            parts = [self.sort_profile(q[s0:s1], dA[s0:s1] if dA is not None and np.ndim(dA) == 3 else dA,
+                                       mask[s0:s1] if mask is not None and np.ndim(mask) == 3 else mask,
+                                       targets, tbl, coord, want_sorted, want_acum, negate) for s0, s1 in bt]
+            return {k: np.concatenate([np.atleast_1d(p[k]) for p in parts]) for k in parts[0]}
         rank = XC_DA_NONE
         if dA is not None:
             dA = np.ascontiguousarray(dA, dtype=np.float64)

@@ -733,40 +733,63 @@ class Contour2D(object):
             return None if a is None else np.ascontiguousarray(a, dtype=np.float64).tobytes()
         per_slab = ny * nx * (q.dtype.itemsize + (0 if g is None else g.dtype.itemsize) + (8 if slab_dA else 0))
         batch = int(min(nslab, max(1, int(max_batch_bytes) // per_slab), 65535))
+        # more than one batch: the device holds TWO (half the budget each), the upload of batch k + 1 runs on the copy
+        # stream while batch k computes
+        nbuf = 1
+        if batch < nslab:
+            nbuf = 2
+            batch = int(min(nslab, max(1, int(max_batch_bytes) // (2 * per_slab)), 65535))
         flat = dA.reshape(-1)
         # a per-slab dA travels with every batch (like the tracer): only its shape enters the key
         dkey = ('slab',) if slab_dA else (flat[::max(1, flat.size // 4096)].tobytes(), float(flat[0]), float(flat[-1]))
-        key = (batch, ny, nx, int(N), q.dtype.str, np.dtype(self.dtype).str, None if g is None else g.dtype.str,
+        key = (batch, nbuf, ny, nx, int(N), q.dtype.str, np.dtype(self.dtype).str, None if g is None else g.dtype.str,
                bool(periodic_x), float(nkeff_mask), bool(self.increase), bool(self.lt), self.right_edge, self.device, self.deterministic,
                dA.shape[-2:] if slab_dA else dA.shape, dkey,
                small(tv), small(tcoords[table._dimEq]), small(preY), small(rdx), small(rdy))
         plans = self.__dict__.setdefault('_keff_plans', {})
         plan = plans.pop(key, None)
         if plan is None:
-            plan = KeffPlan(self.ctx, batch, ny, nx, N, q.dtype, self.dtype, dA=dA[:batch] if slab_dA else dA, rdx=rdx, rdy=rdy,
+            plan = KeffPlan(self.ctx, nbuf * batch, ny, nx, N, q.dtype, self.dtype, dA=dA[:min(nslab, nbuf * batch)] if slab_dA else dA,
+                            rdx=rdx, rdy=rdy,
                             periodic_x=periodic_x, tbl=tv, tbl_coord=tcoords[table._dimEq], preY=preY,
                             increase=self.increase, lt=self.lt, right_edge=self.right_edge,
                             nkeff_mask=nkeff_mask, grdS_dtype=None if g is None else g.dtype,
                             prod_f32=bool(g is not None and g.dtype == np.float32 and dA_f32),
-                            detect_row_dA=not slab_dA, deterministic=self.deterministic)
+                            detect_row_dA=not slab_dA, deterministic=self.deterministic, out_slabs=batch, nslots=nbuf)
         if slab_dA:
             plan.desc.dA_pos_finite = int(bool(np.isfinite(dA).all() and (dA >= 0).all()))
+        ctx = self.ctx
+        qb, gb, db = ny * nx * q.dtype.itemsize, 0 if g is None else ny * nx * g.dtype.itemsize, ny * nx * 8
+
+        def upload(k):
+            """batch k -> half k % nbuf of the device buffers, on the copy stream"""
+            s0 = k * batch
+            m = min(batch, nslab - s0)
+            off = (k % nbuf) * batch
+            plan.q_buf.upload_async(q[s0:s0 + m], off * qb)
+            if slab_dA:
+                plan.dA_buf.upload_async(dA[s0:s0 + m], off * db)
+            if g is not None:
+                plan.grdS_buf.upload_async(g[s0:s0 + m], off * gb)
+
         try:
             parts = []
-            for s0 in range(0, nslab, batch):
-                m = min(batch, nslab - s0)
-                plan.q_buf.upload(q[s0:s0 + m])
+            nb = -(-nslab // batch)
+            upload(0)
+            for k in range(nb):
+                h = k % nbuf
+                m = min(batch, nslab - k * batch)
+                ctx.stream_wait_copies()                              # the kernels of batch k wait for its upload
                 plan.touch()
-                if slab_dA:
-                    plan.dA_buf.upload(dA[s0:s0 + m])
-                if g is not None:
-                    plan.grdS_buf.upload(g[s0:s0 + m])
-                plan.run_range(0, 0, m)
-                r = plan.fetch(check=False)
+                plan.run_range(h, h * batch, m, None, out_s0=0)
+                if k + 1 < nb:
+                    upload(k + 1)                                     # overlaps the kernels just enqueued (the other half is free:
+                                                                      # batch k - 1 was fetched, i.e. synchronised, last turn)
+                r = plan.fetch(check=False, slot=h)
                 if r['status'][:m].any():
                     raise Exception('non monotonic bins')          # reference core.py:1233-1251
-                parts.append({k: np.array(v[:m]) for k, v in r.items()})
-            res = parts[0] if len(parts) == 1 else {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+                parts.append({k_: np.array(v[:m]) for k_, v in r.items()})
+            res = parts[0] if len(parts) == 1 else {k_: np.concatenate([p[k_] for p in parts]) for k_ in parts[0]}
         except Exception:
             plan.free()
             raise

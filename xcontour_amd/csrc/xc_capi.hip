@@ -156,6 +156,11 @@ int xc_create(int device_id, xc_ctx** out)
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         int rc = hipfail(nullptr, e, "hipStreamCreate"); delete ctx; return rc;
     }
+    if ((e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->ev_compute, hipEventDisableTiming)) != hipSuccess) {
+        int rc = hipfail(nullptr, e, "hipStreamCreate(copy)"); delete ctx; return rc;
+    }
     if ((e = hipEventCreate(&ctx->ev_hist0)) != hipSuccess || (e = hipEventCreate(&ctx->ev_hist1)) != hipSuccess) {
         int rc = hipfail(nullptr, e, "hipEventCreate"); delete ctx; return rc;
     }
@@ -168,7 +173,11 @@ int xc_destroy(xc_ctx* ctx)
     if (!ctx) return XC_OK;
     (void)hipSetDevice(ctx->device);
     (void)xc_comm_finalize(ctx);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+    if (ctx->ev_compute) (void)hipEventDestroy(ctx->ev_compute);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->big) (void)hipFree(ctx->big);
@@ -213,6 +222,7 @@ int xc_free(xc_ctx* ctx, void* dptr)
     XC_CTX(ctx);
     if (!dptr) return XC_OK;
     mm_touch(ctx, dptr, (size_t)1 << 62);         // an allocation that starts at or below the cached batch may contain it
+    XC_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     XC_HIP(ctx, hipFree(dptr));
     return XC_OK;
@@ -225,6 +235,31 @@ int xc_memcpy_h2d(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes
     mm_touch(ctx, dst_dev, bytes);
     XC_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return XC_OK;
+}
+
+int xc_memcpy_h2d_async(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
+{
+    XC_CTX(ctx);
+    if (bytes && (!dst_dev || !src_host)) return fail(ctx, XC_EBADARG, "xc_memcpy_h2d_async: NULL pointer");
+    mm_touch(ctx, dst_dev, bytes);
+    XC_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    return XC_OK;
+}
+
+int xc_stream_wait_copies(xc_ctx* ctx)
+{
+    XC_CTX(ctx);
+    XC_HIP(ctx, hipEventRecord(ctx->ev_copy, ctx->copy_stream));
+    XC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0));
+    return XC_OK;
+}
+
+int xc_copies_wait_stream(xc_ctx* ctx)
+{
+    XC_CTX(ctx);
+    XC_HIP(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));
+    XC_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compute, 0));
     return XC_OK;
 }
 

@@ -26,6 +26,8 @@ struct xc_ctx {
     int device = 0;
     HistKnobs knobs;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;            // uploads that overlap compute (xc_memcpy_h2d_async)
+    hipEvent_t ev_copy = nullptr, ev_compute = nullptr;
     int cus = 0;
     char name[256] = {0};
     std::string err;

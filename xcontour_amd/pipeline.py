@@ -81,14 +81,16 @@ class KeffPlan(object):
                 d.dA_rank = nat.XC_DA_SLAB
             elif dA.shape == (self.ny, self.nx):
                 d.dA_rank = nat.XC_DA_PLANE
-            elif dA.shape == (self.nslab, self.ny, self.nx):
-                d.dA_rank = nat.XC_DA_SLAB
+            elif dA.ndim == 3 and dA.shape[1:] == (self.ny, self.nx) and 1 <= dA.shape[0] <= self.nslab:
+                d.dA_rank = nat.XC_DA_SLAB                         # (fewer planes than slabs: the rest is uploaded later, batch by batch)
             else:
                 raise Exception('dA must be (ny,), (ny,nx) or (nslab,ny,nx)')
             if d.dA_rank == nat.XC_DA_SLAB and dA.ndim == 2:
                 self.dA_buf = ctx.alloc(self.nslab * dA.nbytes)
                 for s_ in range(self.nslab):
                     ctx._check(ctx.lib.xc_memcpy_h2d(ctx.handle, self.dA_buf.ptr + s_ * dA.nbytes, dA.ctypes.data, dA.nbytes))
+            elif d.dA_rank == nat.XC_DA_SLAB:
+                self.dA_buf = ctx.alloc(self.nslab * self.ny * self.nx * 8).upload(dA)
             else:
                 self.dA_buf = ctx.to_device(dA)
             self._dA_ptr = self.dA_buf.ptr
