@@ -375,3 +375,45 @@ def test_facade_methods_stream_large_stacks_in_batches(ctx, baro):
         assert a.shape == (S, 41)
         assert np.array_equal(a, b) if k == 'ctr' else rel(a, b) < 1e-9, k
     cm.close()
+
+
+def test_crossing_uncrossed_interior_levels_are_exact_zeros(ctx):
+    """two regions of the plane separated by NaN columns hold values in [0, 0.3] and [0.7, 1]; no box has corners in
+    both, so the levels in between are crossed by nothing and must come out as the exact 0 of the reference's per-contour
+    loop (the difference-array accumulation used to leave ~1e-16-of-the-mass residues there), and nothing is negative"""
+    rng = np.random.default_rng(8)
+    ny, nx = 96, 260
+    q = np.empty((2, ny, nx))
+    q[:, :, :128] = 0.3 * rng.random((2, ny, 128))
+    q[:, :, 128:132] = np.nan
+    q[:, :, 132:] = 0.7 + 0.3 * rng.random((2, ny, nx - 132))
+    area = 1e9 * (1 + rng.random((ny, nx)))
+    ctr = np.linspace(0.0, 1.0, 101)
+    lens, cnts = ctx.crossing(q, ctr, area, stride=1, full_width=True)
+    mid = (ctr > 0.305) & (ctr < 0.695)
+    assert (cnts[:, mid] == 0).all() and (cnts[:, (ctr > 0.05) & (ctr < 0.25)] > 0).all() and (cnts[:, (ctr > 0.75) & (ctr < 0.95)] > 0).all()
+    assert (lens[:, mid] == 0.0).all()
+    assert (lens >= 0).all()
+    for s in range(2):
+        ol, oc = O.contour_crossing(q[s], ctr, area, 1, True)
+        assert np.array_equal(cnts[s].astype(np.int64), oc) and rel(lens[s], ol) < 1e-13
+
+
+def test_hist_all_nan_rows_and_land_mask(ctx):
+    """rows that are entirely NaN (land in an ocean field) are skipped as a whole by K3; counts and sums
+    are those of the oracle's histogram"""
+    rng = np.random.default_rng(9)
+    ny, nx = 120, 384
+    q = rng.standard_normal((3, ny, nx))
+    q[:, 10:40, :] = np.nan                                   # whole rows
+    q[:, 60:90, 100:300] = np.nan                             # a continent
+    q[1] = np.nan                                             # a slab with no ocean at all
+    dA = rng.random((ny, nx)) + 0.5
+    edges = np.linspace(-3, 3, 61)
+    out = ctx.hist(q, edges, dA=dA, last_closed=True, want=('pdf', 'counts'))
+    for s in range(3):
+        ok = ~np.isnan(q[s])
+        rc, _ = np.histogram(q[s][ok], bins=edges)
+        rw, _ = np.histogram(q[s][ok], bins=edges, weights=dA[ok])
+        assert np.array_equal(out['counts'][s].astype(np.int64), rc)
+        assert rel(out['pdf'][s, 0], rw) < 1e-12

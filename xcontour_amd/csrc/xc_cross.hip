@@ -496,7 +496,11 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
     __syncthreads();
     const size_t pb = ((size_t)slab * bps + blockIdx.x) * N;
     for (int k = tid; k < N; k += CROSS_TPB) {
-        part_len[pb + k] = s_len[k] + s_dir[k];
+        // the difference form leaves, at a level none of this block's boxes crosses, the residue of cancelling sums (~1e-16 of
+        // the mass on that side, either sign); the box count is exact, so with it such a level is written as the exact 0 the
+        // reference's per-contour loop gives.  (Lengths without counts, out_cnt == NULL: agreement to ~1e-15 of the largest level.)
+        const double l = s_len[k] + s_dir[k];
+        part_len[pb + k] = (CNT && s_cnt[k] == 0u) ? 0.0 : l;
         if (CNT) part_cnt[pb + k] = s_cnt[k];
     }
 }

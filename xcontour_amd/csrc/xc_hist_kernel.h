@@ -351,20 +351,24 @@ void k_hist(const HistArgs a)
         // wave-uniform fast path: every valid cell of the row in one bin -> per-lane registers, no LDS traffic.  A field with
         // grid-scale noise never takes it, and the test itself (readfirstlane, compares, ballot) is a tenth of the row: after 8
         // consecutive failures the wave stops testing for 48 rows, then looks again (smooth fields never stop)
-        bool one_bin = false;
+        bool one_bin = false, all_dropped = false;
         int rb = 0;
         if (DET == 0 && fp_skip == 0) {                  // (the order-free variants always go through the LDS)
             rb = __builtin_amdgcn_readfirstlane((int)k[0]);
             bool match = true;
 #pragma unroll
             for (int c = 0; c < VEC; ++c) match = match && ((int)k[c] == rb);
-            one_bin = rb < N && (__ballot(match) | inactive_mask) == ~0ull;
-            if (one_bin) fp_miss = 0;
+            const bool same = (__ballot(match) | inactive_mask) == ~0ull;
+            one_bin = rb < N && same;
+            all_dropped = rb >= N && same;                // a row of NaN / out-of-range cells (land in ocean fields): nothing to add at all
+            if (one_bin || all_dropped) fp_miss = 0;
             else if (++fp_miss >= 8) { fp_skip = 48; fp_miss = 7; }
         } else {
             --fp_skip;
         }
-        if (one_bin) {
+        if (all_dropped) {
+            // (without this the 64 * VEC cells of such a row each did their LDS adds on the `ncopy` addresses of the trash bin)
+        } else if (one_bin) {
             if (rb != cur) { flush(); cur = rb; }
             if (active) {
 #pragma unroll
