@@ -387,30 +387,28 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
 
 // ---- after the three range-key passes: finish every run of equal range key that is out of order, and count the valid
 // cells.  IN PLACE; one block per FIX_C consecutive positions [a, b) OWNS the runs whose first cell (head) lies there, to
-// their end -- so a run belongs to exactly one block, and the block's window is [a - 1, b + FIX_H).
-//   1. Every inversion (a cell whose full key is smaller than its left neighbour's inside one run) in the window looks
-//      for the ends of its run within FIX_RUN / 2 cells on either side; if one is missing the run may be longer than
-//      FIX_RUN and the flag sends the whole stack to the eight-pass path.  Otherwise every run that needs work has at
-//      most FIX_RUN <= FIX_H cells: a run headed in [a, b) lies wholly inside the window.
-//   2. Odd-even transposition rounds exchange ADJACENT cells of the SAME range key whose full keys are out of order --
-//      stable, branch-free, all lanes busy -- until a double round moves nothing (runs hold ~1.4 cells on average: three
-//      to five double rounds; a run of r cells needs at most r rounds).
-//   3. The block writes back the cells that moved, if they belong to a run it owns: everything from the first head at or
-//      after a to the first head at or after b.  Cells of a run headed in a neighbour's positions are that neighbour's;
-//      a block reading such a cell while it is rewritten only derives its range key from it, which the run shares.
+// their end -- a run belongs to exactly one block; the block's window is [a - 1, a - 1 + FIX_W).
+//   1. head[i] / end[i] of the run of every window cell: a prefix-max / suffix-min scan over the head positions.
+//   2. Every inversion (a cell whose full key is smaller than its left neighbour's inside one run) marks its run dirty;
+//      if that run is owned and longer than FIX_RUN the flag sends the whole stack to the eight-pass path.  Runs without
+//      an inversion -- ties of any length -- are never touched.
+//   3. Every cell of a dirty owned run counts the cells of its run that sort before it (smaller key, or equal key and
+//      earlier position: a stable rank, at most FIX_RUN reads, ~2 on average) and, if its place changes, writes ITSELF
+//      (key and payload from its registers) to head + rank.  The writes of a run are a permutation of the run; a
+//      neighbouring block reading such a cell meanwhile only derives its range key from it, which the run shares.
 //   The step from the last valid key to the first dropped one (always a head) gives nvalid.
-constexpr int FIX_C = 1024, FIX_H = 128, FIX_RUN = 128, FIX_NL = (FIX_C + FIX_H + 1 + 255) / 256, FIX_W = FIX_NL * 256,
-              FIX_ROUNDS = FIX_RUN + 2;
+constexpr int FIX_C = 1024, FIX_RUN = 128, FIX_NL = 5, FIX_W = FIX_NL * 256;      // window = 1 + FIX_C + 255 cells
 template <typename K>
 __global__ __launch_bounds__(256)
 void k_fix_runs(K* __restrict__ keys, double* __restrict__ vals, int64_t n, unsigned* __restrict__ flag,
                 unsigned* __restrict__ nvalid, const PairSrc src)
 {
-    __shared__ K s_k[FIX_W + FIX_RUN];                                       // (+ FIX_RUN: the run-end search may look past the window)
-    __shared__ double s_v[FIX_W];
-    __shared__ unsigned s_d[FIX_W + FIX_RUN];
-    __shared__ int s_first[2];
-    const int tid = threadIdx.x;
+    __shared__ K s_k[FIX_W];
+    __shared__ unsigned s_d[FIX_W];
+    __shared__ unsigned short s_h[FIX_W], s_e[FIX_W];
+    __shared__ unsigned char s_dirty[FIX_W];
+    __shared__ int s_wh[4], s_we[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RangeMap rm = range_map(src.mm, blockIdx.y, src.negate);
     keys += (size_t)blockIdx.y * n; vals += (size_t)blockIdx.y * n;
     const int64_t a = (int64_t)blockIdx.x * FIX_C, w0 = a - 1;               // window position i <-> cell w0 + i; owned heads: i in [1, FIX_C]
@@ -421,77 +419,90 @@ void k_fix_runs(K* __restrict__ keys, double* __restrict__ vals, int64_t n, unsi
         g = g < 0 ? 0 : (g < n ? g : n - 1);
         kr[c] = keys[g]; vr[c] = vals[g];
     }
-    if (tid < 2) s_first[tid] = FIX_W;
-    if (tid < FIX_RUN) s_d[FIX_W + tid] = 0xFFFFFFF0u + (unsigned)(tid & 1);
 #pragma unroll
     for (int c = 0; c < FIX_NL; ++c) {
         const int i = tid + 256 * c;
         const int64_t g = w0 + i;
         const bool in = g >= 0 && g < n;
-        s_k[i] = in ? kr[c] : (K)0; s_v[i] = in ? vr[c] : 0.0;
+        s_k[i] = in ? kr[c] : (K)0;
         s_d[i] = in ? range_key<K>(kr[c], rm) : 0xFFFFFFF0u + (unsigned)(i & 1);          // no cell: equal to no neighbour
+        s_dirty[i] = 0;
     }
     __syncthreads();
+    // ---- 1. heads: thread t scans the cells [5t, 5t + 5); last head at or before i (0: the run began before the window),
+    //         first head after i (FIX_W: the run leaves the window)
+    {
+        const int i0 = FIX_NL * tid;
+        bool hd[FIX_NL];
+        int lastl = -1, firstl = FIX_W;
+#pragma unroll
+        for (int c = 0; c < FIX_NL; ++c) {
+            const int i = i0 + c;
+            hd[c] = i > 0 && s_d[i] != s_d[i - 1];
+            if (hd[c]) { lastl = i; if (firstl == FIX_W) firstl = i; }
+        }
+        int pm = lastl, sm = firstl;                                          // inclusive prefix max / suffix min over the lanes
+        for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_up(pm, o), y = __shfl_down(sm, o);
+            if (lane >= o) pm = x > pm ? x : pm;
+            if (lane + o < 64) sm = y < sm ? y : sm;
+        }
+        if (lane == 63) s_wh[wave] = pm;
+        if (lane == 0) s_we[wave] = sm;
+        __syncthreads();
+        int before = __shfl_up(pm, 1), after = __shfl_down(sm, 1);            // exclusive: heads in earlier / later lanes
+        if (lane == 0) before = -1;
+        if (lane == 63) after = FIX_W;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) before = s_wh[w] > before ? s_wh[w] : before;
+            if (w > wave) after = s_we[w] < after ? s_we[w] : after;
+        }
+        int run_h = before < 0 ? 0 : before;
+#pragma unroll
+        for (int c = 0; c < FIX_NL; ++c) { if (hd[c]) run_h = i0 + c; s_h[i0 + c] = (unsigned short)run_h; }
+        int run_e = after;
+#pragma unroll
+        for (int c = FIX_NL - 1; c >= 0; --c) { s_e[i0 + c] = (unsigned short)run_e; if (hd[c]) run_e = i0 + c; }
+    }
+    __syncthreads();
+    // ---- 2. inversions mark their run; an owned run longer than FIX_RUN cannot be repaired here
     bool bad = false;
-    int h0 = FIX_W, h1 = FIX_W;                                                // first head at or after a / at or after b seen by this thread
 #pragma unroll
     for (int c = 0; c < FIX_NL; ++c) {
         const int i = tid + 256 * c;
         if (i == 0) continue;
-        const unsigned d = s_d[i];
-        if (d != s_d[i - 1]) {                                                 // a head: the first at or after a, the first at or after b
-            if (i <= FIX_C) h0 = i < h0 ? i : h0; else h1 = i < h1 ? i : h1;
-            if (d == RANGE_INVALID && i <= FIX_C && w0 + i < n) nvalid[blockIdx.y] = (unsigned)(w0 + i);
+        const int h = s_h[i];
+        if (h == i) {                                                          // a head
+            if (s_d[i] == RANGE_INVALID && i <= FIX_C && w0 + i < n) nvalid[blockIdx.y] = (unsigned)(w0 + i);
             continue;
         }
-        if (!(s_k[i] < s_k[i - 1]) || i > FIX_C + FIX_RUN) continue;          // not an inversion (or beyond any run this block may own)
-        bool left = false, right = false;                                      // the ends of the run within FIX_RUN / 2 cells?
-        for (int j = 2; j <= FIX_RUN / 2 && !left; ++j) left = i - j < 0 || s_d[i - j] != d;
-        for (int j = 1; j < FIX_RUN / 2 && !right; ++j) right = s_d[i + j] != d;
-        bad |= !(left && right);
+        if (!(s_k[i] < s_k[i - 1]) || h > FIX_C) continue;                    // no inversion, or the run is the right neighbour's
+        if (h < 1) {                                                           // the run began before the window: the left neighbour's, who sees this
+            if (i >= FIX_RUN) bad = true;                                      // cell only if the run is short -- and this far in, it is not
+            continue;
+        }
+        if ((int)s_e[i] - h > FIX_RUN) bad = true; else s_dirty[h] = 1;
     }
-    for (int o = 32; o > 0; o >>= 1) { const int x0 = __shfl_xor(h0, o), x1 = __shfl_xor(h1, o); h0 = x0 < h0 ? x0 : h0; h1 = x1 < h1 ? x1 : h1; }
-    if ((tid & 63) == 0) { atomicMin(&s_first[0], h0); atomicMin(&s_first[1], h1); }      // one LDS atomic per wave, not one per head
+    if (blockIdx.x == 0 && tid == 0 && s_d[1] == RANGE_INVALID) nvalid[blockIdx.y] = 0u;       // only dropped cells
+    if (w0 + FIX_C >= n - 1 && tid == 0) {                                     // the block that holds the last cell: no dropped cell at all
+        const int il = (int)(n - 1 - w0);
+        if (s_d[il] != RANGE_INVALID) nvalid[blockIdx.y] = (unsigned)n;
+    }
     if (__syncthreads_or(bad)) {                                               // the stack goes to the eight-pass path: nothing else to do here
         if (tid == 0) atomicOr(flag, 1u);
         return;
     }
-    if (blockIdx.x == 0 && tid == 0) {                                         // no dropped cell at all / only dropped cells
-        if (s_d[1] == RANGE_INVALID) nvalid[blockIdx.y] = 0u;
-    }
-    if (w0 + FIX_C >= n - 1 && tid == 0) {                                     // the block that holds the last cell
-        const int il = (int)(n - 1 - w0);
-        if (s_d[il] != RANGE_INVALID) nvalid[blockIdx.y] = (unsigned)n;
-    }
-    for (int round = 0; round < FIX_ROUNDS; round += 2) {
-        int moved = 0;
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-#pragma unroll
-            for (int c = 0; c < FIX_NL / 2 + 1; ++c) {
-                const int i = 2 * tid + par + 512 * c;
-                if (i + 1 < FIX_W) {
-                    const K k0 = s_k[i], k1 = s_k[i + 1];
-                    if (s_d[i] == s_d[i + 1] && k1 < k0) {
-                        const double v0 = s_v[i];
-                        s_k[i] = k1; s_k[i + 1] = k0; s_v[i] = s_v[i + 1]; s_v[i + 1] = v0;
-                        moved = 1;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (!__syncthreads_or(moved)) break;
-    }
-    const int f0 = s_first[0], f1 = s_first[1];                                // owned cells: window positions [f0, f1)
+    // ---- 3. stable rank inside the run; a cell whose place changes writes itself there
 #pragma unroll
     for (int c = 0; c < FIX_NL; ++c) {
         const int i = tid + 256 * c;
-        if (i >= f0 && i < f1 && w0 + i < n) {                                 // (padding positions behind the last cell are heads too)
-            const K k = s_k[i];
-            const double v = s_v[i];
-            if (k != kr[c] || v != vr[c]) { keys[w0 + i] = k; vals[w0 + i] = v; }   // (a cell may inherit an EQUAL key from a neighbour that moved: compare the payload too)
-        }
+        const int h = s_h[i];
+        if (h < 1 || h > FIX_C || !s_dirty[h] || w0 + i >= n) continue;
+        const int e = s_e[i];
+        const K k = kr[c];
+        int rank = 0;
+        for (int j = h; j < e; ++j) { const K kj = s_k[j]; rank += (kj < k) || (kj == k && j < i); }
+        if (h + rank != i) { keys[w0 + h + rank] = k; vals[w0 + h + rank] = vr[c]; }
     }
 }
 
@@ -727,49 +738,52 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
         return XC_OK;
     };
 
-    bool sorted = false;
+    // everything after the sort: cumulative area, profile, BPE, copies of the requested arrays
+    auto tail = [&](bool count_valid) -> int {
+        if (count_valid) hipLaunchKernelGGL(k_count_valid<K>, dim3(ns), dim3(64), 0, ctx->stream, kin, n, nvalid);
+        double* acum = vout;                                   // reuse the idle payload buffer
+        hipLaunchKernelGGL(k_scan_local<false>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
+        hipLaunchKernelGGL(k_scan_bsums, dim3(ns), dim3(1024), 0, ctx->stream, bsum, nb);
+        hipLaunchKernelGGL(k_scan_local<true>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
+        XC_HIP(ctx, hipGetLastError());
+        if (out_Q && J > 0) {
+            if (!targets) return fail(ctx, XC_EBADARG, "xc_sort_profile: targets is NULL");
+            hipLaunchKernelGGL(k_profile<K>, dim3((J + 255) / 256, ns), dim3(256), 0, ctx->stream, kin, acum, nvalid, targets, J, out_Q, n);
+        }
+        if (out_bpe) {
+            if (!tbl || !coord || ntbl < 2) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
+            hipLaunchKernelGGL(k_bpe<K>, dim3(BPE_BLOCKS, ns), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts, n);
+            hipLaunchKernelGGL(k_sum_parts, dim3(ns), dim3(64), 0, ctx->stream, parts, BPE_BLOCKS, out_bpe);
+        }
+        if (out_qsorted) hipLaunchKernelGGL(k_unkey<K>, dim3(gb, ns), dim3(256), 0, ctx->stream, kin, n, out_qsorted);
+        if (out_acum) XC_HIP(ctx, hipMemcpyAsync(out_acum, acum, S * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (out_nvalid) XC_HIP(ctx, hipMemcpyAsync(out_nvalid, nvalid, S * sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
+        XC_HIP(ctx, hipGetLastError());
+        return XC_OK;
+    };
+
     if constexpr (sizeof(K) == 8) {
         if (ctx->knobs.sort_range) {
             // ---- three passes over the 24-bit range key, then the short runs (see the head of this file)
             XC_TRY_(launch_minmax_partial(ctx, q, q_dtype, nslab, n, mmpart));
-            XC_TRY_(launch_minmax_final(ctx, mmpart, nslab, minmax_blocks(n), mm));
             XC_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream));
+            XC_TRY_(launch_minmax_final(ctx, mmpart, nslab, minmax_blocks(n), mm));
             for (int p = 0; p < 3; ++p) XC_TRY_(pass(std::integral_constant<int, 1>(), p == 0, 8 * p));
             hipLaunchKernelGGL(k_fix_runs<K>, dim3((unsigned)((n + FIX_C - 1) / FIX_C), ns), dim3(256), 0, ctx->stream, kin, vin, n, flag, nvalid, src);
             XC_HIP(ctx, hipGetLastError());
             unsigned h_flag = 1;
             XC_HIP(ctx, hipMemcpyAsync(&h_flag, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-            XC_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the one host round trip of the sort: did the short-run repair suffice?
-            sorted = h_flag == 0;
-            ctx->last_sort_path = sorted ? 1 : 2;
-            if (!sorted) { kin = kA; kout = kB; vin = vA; vout = vB; }
-        }
-    }
-    if (!sorted) {
-        if (!(sizeof(K) == 8 && ctx->knobs.sort_range)) ctx->last_sort_path = 0;
-        for (int p = 0; p < KeyTraits<K>::passes; ++p) XC_TRY_(pass(std::integral_constant<int, 0>(), p == 0, 8 * p));
-    }
-    // the sorted pairs are in kin / vin (the range-key path has counted the valid cells already)
-    if (!sorted) hipLaunchKernelGGL(k_count_valid<K>, dim3(ns), dim3(64), 0, ctx->stream, kin, n, nvalid);
-    double* acum = vout;                                   // reuse the idle payload buffer
-    hipLaunchKernelGGL(k_scan_local<false>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
-    hipLaunchKernelGGL(k_scan_bsums, dim3(ns), dim3(1024), 0, ctx->stream, bsum, nb);
-    hipLaunchKernelGGL(k_scan_local<true>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
-    XC_HIP(ctx, hipGetLastError());
-    if (out_Q && J > 0) {
-        if (!targets) return fail(ctx, XC_EBADARG, "xc_sort_profile: targets is NULL");
-        hipLaunchKernelGGL(k_profile<K>, dim3((J + 255) / 256, ns), dim3(256), 0, ctx->stream, kin, acum, nvalid, targets, J, out_Q, n);
-    }
-    if (out_bpe) {
-        if (!tbl || !coord || ntbl < 2) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
-        hipLaunchKernelGGL(k_bpe<K>, dim3(BPE_BLOCKS, ns), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts, n);
-        hipLaunchKernelGGL(k_sum_parts, dim3(ns), dim3(64), 0, ctx->stream, parts, BPE_BLOCKS, out_bpe);
-    }
-    if (out_qsorted) hipLaunchKernelGGL(k_unkey<K>, dim3(gb, ns), dim3(256), 0, ctx->stream, kin, n, out_qsorted);
-    if (out_acum) XC_HIP(ctx, hipMemcpyAsync(out_acum, acum, S * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    if (out_nvalid) XC_HIP(ctx, hipMemcpyAsync(out_nvalid, nvalid, S * sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
-    XC_HIP(ctx, hipGetLastError());
-    return XC_OK;
+            // the rest is enqueued as if the repair had sufficed -- it nearly always has -- so that the GPU does not idle through
+            // the one host round trip of the sort; a stack that failed the check is sorted again below and the rest redone
+            XC_TRY_(tail(false));
+            XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->last_sort_path = h_flag == 0 ? 1 : 2;
+            if (h_flag == 0) return XC_OK;
+            kin = kA; kout = kB; vin = vA; vout = vB;
+        } else ctx->last_sort_path = 0;
+    } else ctx->last_sort_path = 0;
+    for (int p = 0; p < KeyTraits<K>::passes; ++p) XC_TRY_(pass(std::integral_constant<int, 0>(), p == 0, 8 * p));
+    return tail(true);
 }
 
 int launch_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, int mask_dtype, int mask_per_slab,
