@@ -113,33 +113,123 @@ struct PairSrc {                 // where pass 0 finds its input (per-slab strid
     const void* q; const void* mask; const double* dA;
     int dA_rank, negate; int64_t nx, mask_stride, dA_stride;
     const double* mm;            // [nslab][2] min / max of the tracer (K1): the range-key passes only
+    const unsigned* rtab;        // [nslab][2 * RANGE_NB] first range key and number of range keys of every coarse bin
 };
 
 // ---- the 24-bit range key (MODE 1 of the passes).  Valid values map to [0, 2^24 - 2] monotonically, dropped cells
 // (key == invalid) to 2^24 - 1, so that they gather behind every valid value without sharing a run with the maximum.
+// The map is piecewise linear: the value range is cut into RANGE_NB equal coarse bins and every bin gets a share of the 2^24
+// range keys proportional to its POPULATION (histogram equalisation: k_range_hist counts, k_range_table divides), so a
+// plateau that holds a third of the cells inside a thousandth of the range -- a well-mixed layer, a saturating tanh profile --
+// is still resolved to ~2^-30 of the range and its runs of equal range key stay short.  Monotone: x = (v - lo) * S is
+// monotone in v, so are b = floor(x) and, inside a bin, x - b (exact) and floor((x - b) * width); bins do not overlap.
 constexpr unsigned RANGE_INVALID = 0xFFFFFFu;
-struct RangeMap { double lo, scale; };
-__device__ __forceinline__ RangeMap range_map(const double* __restrict__ mm, int slab, int negate)
+constexpr int RANGE_NB = 256;
+constexpr int RANGE_SAMPLE = 16;       // k_range_hist looks at one 2048-cell chunk in 16: any positive widths give a monotone map, the
+                                        // populations only have to be roughly right for the runs to come out short
+struct RangeMap { double lo, scale; const unsigned* tab; };      // tab: the slab's table, staged in LDS by the kernel
+__device__ __forceinline__ void range_lo_scale(const double* __restrict__ mm, int slab, int negate, double& lo, double& scale)
 {
     const double mn = mm[2 * slab], mx = mm[2 * slab + 1];
+    lo = negate ? -mx : mn;
+    const double hi = negate ? -mn : mx, w = hi - lo;
+    scale = (w > 0.0 && w < __longlong_as_double(0x7ff0000000000000LL)) ? (double)RANGE_NB / w : 0.0;   // constant / empty / infinite range: one bin
+}
+__device__ __forceinline__ int range_bin(double v, double lo, double scale, double& x)
+{
+    x = (v - lo) * scale;                                               // NaN (inf - inf, 0 * inf) -> bin 0 below
+    int b = (int)fmin(fmax(x, 0.0), (double)(RANGE_NB - 1));
+    return b;
+}
+// stage the slab's table in LDS (2 * RANGE_NB words); the caller synchronises before the first range_key
+__device__ __forceinline__ RangeMap range_map(const PairSrc& src, int slab, unsigned* s_tab)
+{
     RangeMap r;
-    r.lo = negate ? -mx : mn;
-    const double hi = negate ? -mn : mx, w = hi - r.lo;
-    r.scale = (w > 0.0 && w < __longlong_as_double(0x7ff0000000000000LL)) ? 16777215.0 / w : 0.0;   // constant / empty / infinite range: one run
+    range_lo_scale(src.mm, slab, src.negate, r.lo, r.scale);
+    const unsigned* g = src.rtab + (size_t)slab * 2 * RANGE_NB;
+    for (int i = threadIdx.x; i < 2 * RANGE_NB; i += blockDim.x) s_tab[i] = g[i];
+    r.tab = s_tab;
     return r;
 }
 template <typename K>
 __device__ __forceinline__ unsigned range_key(K key, const RangeMap& m)
 {
     if (key == KeyTraits<K>::invalid()) return RANGE_INVALID;
-    const double x = (KeyTraits<K>::decode(key) - m.lo) * m.scale;      // monotone in the value; NaN (inf - inf, 0 * inf) -> 0 below
-    return (unsigned)fmin(fmax(x, 0.0), 16777214.0);
+    double x;
+    const int b = range_bin(KeyTraits<K>::decode(key), m.lo, m.scale, x);
+    const unsigned first = m.tab[2 * b], width = m.tab[2 * b + 1];
+    const double f = fmin(fmax(x - (double)b, 0.0), 1.0) * (double)width;      // (clamped at the ends of the range)
+    const unsigned off = (unsigned)f;
+    return first + (off < width ? off : width - 1u);
 }
 template <typename K, int MODE>
 __device__ __forceinline__ unsigned digit_of(K key, int shift, const RangeMap& m)
 {
     if (MODE == 0) return (unsigned)((key >> shift) & (K)255);
     return (range_key<K>(key, m) >> shift) & 255u;
+}
+
+// population of the RANGE_NB coarse bins (valid cells only, the validity rule of load_pairs); hist zeroed by the caller
+template <typename TQ, typename TM>
+__global__ __launch_bounds__(256)
+void k_range_hist(int64_t n, const PairSrc src, unsigned* __restrict__ hist)
+{
+    __shared__ unsigned s_h[RANGE_NB];
+    for (int i = threadIdx.x; i < RANGE_NB; i += 256) s_h[i] = 0;
+    double lo, scale;
+    range_lo_scale(src.mm, blockIdx.y, src.negate, lo, scale);
+    const TQ* q = (const TQ*)src.q + (size_t)blockIdx.y * n;
+    const TM* mask = src.mask ? (const TM*)src.mask + (size_t)blockIdx.y * src.mask_stride : nullptr;
+    __syncthreads();
+    constexpr int U = 8;
+    const int64_t samp = n > (int64_t)256 * RANGE_SAMPLE * 64 ? RANGE_SAMPLE : 1;             // small planes: every cell
+    const int64_t nseg = (n + 256 * samp - 1) / (256 * samp);                                 // the first 256 cells of every 256 * samp
+    for (int64_t s0 = (int64_t)blockIdx.x * U; s0 < nseg; s0 += (int64_t)gridDim.x * U) {
+        TQ qv[U]; TM mv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int64_t i = (s0 + u) * 256 * samp + threadIdx.x; qv[u] = q[i < n ? i : n - 1]; }
+        if (mask) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int64_t i = (s0 + u) * 256 * samp + threadIdx.x; mv[u] = mask[i < n ? i : n - 1]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = (s0 + u) * 256 * samp + threadIdx.x;
+            const double v = src.negate ? -(double)qv[u] : (double)qv[u];
+            if (s0 + u < nseg && i < n && v == v && (!mask || mv[u] == (TM)1)) { double x; atomicAdd(&s_h[range_bin(v, lo, scale, x)], 1u); }
+        }
+    }
+    __syncthreads();
+    unsigned* h = hist + (size_t)blockIdx.y * RANGE_NB;
+    for (int i = threadIdx.x; i < RANGE_NB; i += 256) if (s_h[i]) atomicAdd(&h[i], s_h[i]);
+}
+
+// counts -> (first range key, number of range keys) per coarse bin: HALF of the 2^24 - 1 keys are dealt out evenly (a bin the
+// sample missed still resolves 2^-23 of the range), the other half in proportion to the sampled counts (rounded down: the
+// last key used is at most 2^24 - 2)
+__global__ __launch_bounds__(RANGE_NB)
+void k_range_table(const unsigned* __restrict__ hist, unsigned* __restrict__ rtab)
+{
+    __shared__ unsigned s_w[(RANGE_NB + 63) / 64];
+    __shared__ unsigned long long s_tot;
+    const int b = threadIdx.x, lane = b & 63, wave = b >> 6;
+    const unsigned c = hist[(size_t)blockIdx.x * RANGE_NB + b];
+    unsigned long long t = c;
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (b == 0) s_tot = 0ull;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&s_tot, t);
+    __syncthreads();
+    const unsigned long long tot = s_tot, even = 8388608ull / RANGE_NB, budget = 16777215ull - even * RANGE_NB;
+    const unsigned width = (unsigned)even + (tot ? (unsigned)((unsigned long long)c * budget / tot) : 0u);
+    unsigned x = width;                                                 // exclusive scan of the widths
+    for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    unsigned first = x - width;
+    for (int w = 0; w < wave; ++w) first += s_w[w];
+    rtab[((size_t)blockIdx.x * RANGE_NB + b) * 2] = first;
+    rtab[((size_t)blockIdx.x * RANGE_NB + b) * 2 + 1] = width;
 }
 
 // number of valid cells = position of the first KEY_INVALID in the sorted keys (one thread:
@@ -177,10 +267,12 @@ void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, 
     __shared__ unsigned s_cnt[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = blockIdx.x;
-    RangeMap rm = {0.0, 0.0};
-    if (MODE == 1) rm = range_map(src.mm, blockIdx.y, src.negate);
+    __shared__ unsigned s_rt[MODE == 1 ? 2 * RANGE_NB : 1];
+    RangeMap rm = {0.0, 0.0, nullptr};
+    if (MODE == 1) rm = range_map(src, blockIdx.y, s_rt);
     keys += (size_t)blockIdx.y * n; hist += (size_t)blockIdx.y * 256 * ntiles;
     for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = 0;
+    if (MODE == 1) __syncthreads();
     if constexpr (FIRST) {
         // pass 0: the keys do not exist yet -- encode them from the tracer (the order inside the tile is irrelevant here)
         const TQ* q = (const TQ*)src.q + (size_t)blockIdx.y * n;
@@ -287,8 +379,9 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
     unsigned char* s_dig = (unsigned char*)(s_wsum + 8);       // [BTILE] digit of the element at every tile-local position
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x;
-    RangeMap rm = {0.0, 0.0};
-    if (MODE == 1) rm = range_map(src.mm, blockIdx.y, src.negate);
+    __shared__ unsigned s_rt[MODE == 1 ? 2 * RANGE_NB : 1];
+    RangeMap rm = {0.0, 0.0, nullptr};
+    if (MODE == 1) { rm = range_map(src, blockIdx.y, s_rt); __syncthreads(); }
     { const size_t so = (size_t)blockIdx.y * n; kin += so; vin += so; kout += so; vout += so; }
     hist += (size_t)blockIdx.y * 256 * ntiles; totals += (size_t)blockIdx.y * 256;
     for (int d = lane; d < 256; d += 64) s_cnt[wave * 256 + d] = 0;
@@ -409,7 +502,8 @@ void k_fix_runs(K* __restrict__ keys, double* __restrict__ vals, int64_t n, unsi
     __shared__ unsigned char s_dirty[FIX_W];
     __shared__ int s_wh[4], s_we[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const RangeMap rm = range_map(src.mm, blockIdx.y, src.negate);
+    __shared__ unsigned s_rt[2 * RANGE_NB];
+    const RangeMap rm = range_map(src, blockIdx.y, s_rt);
     keys += (size_t)blockIdx.y * n; vals += (size_t)blockIdx.y * n;
     const int64_t a = (int64_t)blockIdx.x * FIX_C, w0 = a - 1;               // window position i <-> cell w0 + i; owned heads: i in [1, FIX_C]
     K kr[FIX_NL]; double vr[FIX_NL];                                          // every load issued before the first use
@@ -419,6 +513,7 @@ void k_fix_runs(K* __restrict__ keys, double* __restrict__ vals, int64_t n, unsi
         g = g < 0 ? 0 : (g < n ? g : n - 1);
         kr[c] = keys[g]; vr[c] = vals[g];
     }
+    __syncthreads();                                                           // the range table is in LDS
 #pragma unroll
     for (int c = 0; c < FIX_NL; ++c) {
         const int i = tid + 256 * c;
@@ -666,7 +761,7 @@ size_t sort_workspace_bytes(int64_t n, int64_t nslab)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t S = (size_t)nslab;
     return 4 * al(S * n * 8) + al(S * 256 * ntiles * 4) + al(S * 256 * 4) + al(S * 4) + al(S * nb * 8) + al(S * BPE_BLOCKS * 8) +
-           al(S * kMinmaxBlocks * 2 * 8) + al(S * 2 * 8) + 256;
+           al(S * kMinmaxBlocks * 2 * 8) + al(S * 2 * 8) + 256 + al(S * RANGE_NB * 4) + al(S * RANGE_NB * 8);
 }
 
 template <typename TQ, typename K>
@@ -693,14 +788,16 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
     double* parts = (double*)w; w += al(S * BPE_BLOCKS * 8);
     double* mmpart = (double*)w; w += al(S * kMinmaxBlocks * 2 * 8);
     double* mm = (double*)w; w += al(S * 2 * 8);
-    unsigned* flag = (unsigned*)w;
+    unsigned* flag = (unsigned*)w; w += 256;
+    unsigned* rhist = (unsigned*)w; w += al(S * RANGE_NB * 4);
+    unsigned* rtab = (unsigned*)w;
     const unsigned ns = (unsigned)nslab;
 
     const unsigned gb = (unsigned)((n + 255) / 256);
     // a per-slab dA plane is the PLANE case with a slab stride
     const int krank = dA_rank == XC_DA_SLAB ? XC_DA_PLANE : dA_rank;
     const int64_t dstride = dA_rank == XC_DA_SLAB ? n : 0, mstride = (mask && mask_per_slab) ? n : 0;
-    const PairSrc src = {q, mask, dA, krank, negate, nx, mstride, dstride, mm};
+    const PairSrc src = {q, mask, dA, krank, negate, nx, mstride, dstride, mm, rtab};
     const unsigned gt = (unsigned)ntiles;
     const size_t sc_lds = (size_t)BTILE * 8 + (4 * 256 + 256 + 8) * sizeof(unsigned) + BTILE;
     const int inline_scan = ntiles <= 32 ? 1 : 0;       // measured: the O(ntiles) walk per block costs ~0.14 us per tile, the scan launch ~5 us
@@ -766,8 +863,18 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
         if (ctx->knobs.sort_range) {
             // ---- three passes over the 24-bit range key, then the short runs (see the head of this file)
             XC_TRY_(launch_minmax_partial(ctx, q, q_dtype, nslab, n, mmpart));
-            XC_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream));
+            XC_HIP(ctx, hipMemsetAsync(flag, 0, 256 + S * RANGE_NB * 4, ctx->stream));      // the flag and the coarse histogram behind it
             XC_TRY_(launch_minmax_final(ctx, mmpart, nslab, minmax_blocks(n), mm));
+            {
+                const int64_t samp = n > (int64_t)256 * RANGE_SAMPLE * 64 ? RANGE_SAMPLE : 1;
+                int64_t hb = ((n + 256 * samp - 1) / (256 * samp) + 7) / 8;                  // eight 256-cell segments per block and round
+                if (hb > 1024) hb = 1024;
+                if (hb < 1) hb = 1;
+                if (mf32) hipLaunchKernelGGL((k_range_hist<TQ, float>), dim3((unsigned)hb, ns), dim3(256), 0, ctx->stream, n, src, rhist);
+                else hipLaunchKernelGGL((k_range_hist<TQ, double>), dim3((unsigned)hb, ns), dim3(256), 0, ctx->stream, n, src, rhist);
+                hipLaunchKernelGGL(k_range_table, dim3(ns), dim3(RANGE_NB), 0, ctx->stream, rhist, rtab);
+                XC_HIP(ctx, hipGetLastError());
+            }
             for (int p = 0; p < 3; ++p) XC_TRY_(pass(std::integral_constant<int, 1>(), p == 0, 8 * p));
             hipLaunchKernelGGL(k_fix_runs<K>, dim3((unsigned)((n + FIX_C - 1) / FIX_C), ns), dim3(256), 0, ctx->stream, kin, vin, n, flag, nvalid, src);
             XC_HIP(ctx, hipGetLastError());
