@@ -52,7 +52,19 @@ def case_hist():
     if rng.random() < 0.3:
         dA[rng.integers(ny), rng.integers(nx)] = np.nan
     last = bool(rng.random() < 0.7)
-    out = ctx.hist(q, ed, dA=dA, last_closed=last, lt=bool(rng.random() < 0.5), want=('counts', 'pdf'))
+    det = bool(rng.random() < 0.4)
+    cap = ctx.max_batch_bytes
+    if rng.random() < 0.3:
+        ctx.max_batch_bytes = max(1, int(q[0].nbytes * rng.uniform(0.5, 2.5)))      # the stack goes through in batches of one or two slabs
+    try:
+        out = ctx.hist(q, ed, dA=dA, last_closed=last, lt=bool(rng.random() < 0.5), want=('counts', 'pdf'), deterministic=det)
+        if det:                                                     # order-free sums: the same bits again, whatever the batching
+            ctx.max_batch_bytes = cap if rng.random() < 0.5 else max(1, q[0].nbytes)
+            again = ctx.hist(q, ed, dA=dA, last_closed=last, lt=True, want=('pdf',), deterministic=True)
+            assert np.array_equal(again['pdf'].view(np.int64), out['pdf'].view(np.int64)), 'deterministic pdf bits'
+            tick('hist_deterministic')
+    finally:
+        ctx.max_batch_bytes = cap
     for s in range(S):
         x = q[s].astype(np.float64).ravel(); w = np.nan_to_num(dA.ravel(), nan=0.0)
         if last:
@@ -83,13 +95,20 @@ def case_keff():
     tbl = table_from_rowsums(rows, ylt, last_row_included(lat, re_))          # the product's own table path (K2 + host rule)
     otbl, cs = O.cal_area_eqCoord_table_hist(np.ones((ny, nx)), dA, lat, inc, lt, re_)
     assert relerr(tbl, otbl) < 1e-12, 'keff table'
+    det = bool(rng.random() < 0.4)
     plan = KeffPlan(ctx, S, ny, nx, N, dt, cdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=cs, increase=inc, lt=lt,
-                    right_edge=re_)
-    plan.set_q(q); plan.run()
+                    right_edge=re_, deterministic=det, nslots=2)
+    plan.set_q(q); plan.run(0)
     try:
-        r = plan.fetch()
+        r = plan.fetch(slot=0)
     except Exception:
         plan.free(); return
+    if det:                                                         # one slab per launch: other geometry, same bits
+        plan.run(1, group=1)
+        r2 = plan.fetch(check=False, slot=1)
+        for k in ('area', 'intgrdS', 'latEq', 'nkeff'):
+            assert np.array_equal(r[k].view(np.int64), r2[k].view(np.int64)), 'deterministic keff bits ' + k
+        tick('keff_deterministic')
     plan.free()
     for s in range(S):
         o = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=inc, lt=lt, dtype=cdt, right_edge=re_)
@@ -150,12 +169,20 @@ def case_sort():
     q = field(S, ny, nx, dt)
     if rng.random() < 0.3:
         q = np.round(q, 1)                                  # many ties
+    if rng.random() < 0.3:                                  # plateaus and clusters far below the range-key resolution
+        q = np.where(rng.random(q.shape) < 0.5, q, (q[0, 0, 0] if np.isfinite(q[0, 0, 0]) else 0.5) +
+                     rng.choice([1e-15, 1e-11, 1e-7]) * rng.integers(0, 50, q.shape)).astype(dt)
     dA = rng.random((ny, nx)) + 0.1
-    r = ctx.sort_profile(q, dA=dA, want_sorted=True, negate=bool(rng.random() < 0.3))
+    neg = bool(rng.random() < 0.3)
+    r = ctx.sort_profile(q, dA=dA, want_sorted=True, want_acum=True, negate=neg)
+    tick('sort_path_%d' % ctx.last_sort_path())
     for s in range(S):
         x = q[s].astype(np.float64).ravel(); x = x[~np.isnan(x)]
         n = int(r['nvalid'][s])
         assert n == len(x), 'sort nvalid'
+        _, oxs, oac = O.sorted_profile(-q[s] if neg else q[s], dA, [0.0])
+        assert np.array_equal(r['q_sorted'][s][:n], oxs.astype(np.float64)), 'sort order'
+        assert n == 0 or relerr(r['acum'][s][:n], oac) < 1e-12, 'sort payload order (stability)'
         got = r['q_sorted'][s][:n]
         want = np.sort(x) if np.array_equal(got, np.sort(got)) and not np.array_equal(got, -np.sort(-x)[::-1]) else None
         assert np.array_equal(np.sort(got), got), 'sortedness'
