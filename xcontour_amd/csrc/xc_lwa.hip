@@ -192,6 +192,186 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
     }
 }
 
+// ---- small planes (the reference's own 256 x 512 field, X-Z sections): ONE launch, no prologue kernel.  A 1024-thread
+// workgroup owns a 64-column strip and `tper` target rows, 16 at a time (one per wave, lanes along X):
+//   (a) the whole strip of the tracer goes into LDS (row pitch 65: a thread can walk a row without bank conflicts), with the
+//       (coord, Q) pairs and the per-row weights;  (b) 256 threads take the NaN-skipping extrema of the strip's rows;
+//   (c) every wave finds the band of rows that can contribute to its target from those (as k_lwa does) and the workgroup takes
+//       the union;  (d) wei = dA / max(dA) and a 2-D metric are staged for the union band only, `wchunk` rows at a time -- the
+//       f64 divisions are done for the rows that matter, once per workgroup;  (e) the waves walk their bands out of LDS.
+// Same arithmetic and order as k_lwa (bit-identical).  k_lwa_prep + k_lwa remain for planes whose strip does not fit the LDS.
+constexpr int LWA_SW = 16;                      // waves per workgroup
+__host__ __device__ inline size_t lwa_strip_lds(int64_t ny, size_t tsize, bool wplane, bool mplane, int wchunk)
+{
+    size_t b = (size_t)ny * 6 * 8;                                            // coord, Q, min, max, row wei, row M
+    if (wplane) b += (size_t)wchunk * 64 * 8;
+    if (mplane) b += (size_t)wchunk * 64 * 8;
+    b += (size_t)ny * 65 * tsize + 64;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <typename T, bool V2>
+__global__ __launch_bounds__(64 * LWA_SW)
+void k_lwa_strip(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
+                 const double* __restrict__ dA, int dA_rank, double dA_max, const double* __restrict__ M, int M_rank,
+                 int64_t ny_, int64_t nx_, int increase, int part, int tper, int wchunk, double* __restrict__ out)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int ny = (int)ny_, nx = (int)nx_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool wplane = dA_rank == XC_DA_PLANE, mplane = M_rank == XC_DA_PLANE;
+    double* s_c = sm;                 double* s_Q = s_c + ny;      double* s_mn = s_Q + ny;   double* s_mx = s_mn + ny;
+    double* s_wr = s_mx + ny;         double* s_Mr = s_wr + ny;
+    double* s_wei = s_Mr + ny;        double* s_Mp = s_wei + (wplane ? (size_t)wchunk * 64 : 0);
+    int* s_band = reinterpret_cast<int*>(s_Mp + (mplane ? (size_t)wchunk * 64 : 0));           // [2] + padding to 64 bytes
+    T* s_q = reinterpret_cast<T*>(reinterpret_cast<char*>(s_band) + 64);
+    const size_t so = (size_t)blockIdx.z * ny * nx;
+    const T* qs = q + so;
+    const double* Qs = Q + (size_t)blockIdx.z * ny;
+    const int x0 = blockIdx.x * 64, x = x0 + lane;
+    const bool active = x < nx;
+    const int xl = active ? x : nx - 1;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL), nan = __longlong_as_double(0x7ff8000000000000LL);
+
+    // (a) the strip: wave w takes rows w, w + 16, ...; sixteen loads in flight per lane
+    for (int yb = wave; yb < ny; yb += LWA_SW * 16) {
+        T r[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int y = yb + LWA_SW * k; r[k] = qs[(size_t)(y < ny ? y : ny - 1) * nx + xl]; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int y = yb + LWA_SW * k; if (y < ny) s_q[y * 65 + lane] = active ? r[k] : (T)nan; }   // beyond the plane: NaN -> no contribution
+    }
+    for (int y = tid; y < ny; y += 64 * LWA_SW) {
+        s_c[y] = coord[y]; s_Q[y] = Qs[y];
+        s_wr[y] = wplane ? 0.0 : __ddiv_rn(dA[y], dA_max);                    // core.py:723-724 (row weights: once per row)
+        s_Mr[y] = mplane ? 0.0 : M[y];
+    }
+    __syncthreads();
+    // (b) NaN-skipping extrema of the strip's rows
+    for (int y = tid; y < ny; y += 64 * LWA_SW) {
+        double mn[4] = {inf, inf, inf, inf}, mx[4] = {-inf, -inf, -inf, -inf};   // four independent chains: the LDS reads pipeline
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const double v = (double)s_q[y * 65 + c + k]; mn[k] = fmin(mn[k], v); mx[k] = fmax(mx[k], v); }
+        }
+        s_mn[y] = fmin(fmin(mn[0], mn[1]), fmin(mn[2], mn[3])); s_mx[y] = fmax(fmax(mx[0], mx[1]), fmax(mx[2], mx[3]));
+    }
+    __syncthreads();
+
+    const int coord_incre = !(s_c[ny - 1] < s_c[0]);                           // core.py:736-738
+    const int inc_eff = V2 ? !increase : increase;                             // core.py:865-872 vs 759-766
+    const int keep = (part == 0) ? 0 : (((part == 1) == (increase != 0)) ? 1 : -1);   // core.py:775-784
+    const int jlo = blockIdx.y * tper, jhi = (jlo + tper < ny) ? jlo + tper : ny;
+    for (int jb = jlo; jb < jhi; jb += LWA_SW) {
+        const int j = jb + wave;                                               // this wave's target row (idle beyond jhi, but it joins the barriers)
+        const bool live = j < jhi;
+        const int jc = live ? j : ny - 1;
+        // (c) the band of rows that can contribute to target j (lanes spread over y')
+        int y0 = ny, y1 = 0;
+        const double tlo = V2 ? s_mn[jc] : s_Q[jc], thi = V2 ? s_mx[jc] : s_Q[jc], cj = s_c[jc];
+        for (int yy = 0; yy < ny && live; yy += 64) {
+            const int y = (yy + lane < ny) ? yy + lane : ny - 1;
+            const double rmin = s_mn[y], rmax = s_mx[y], cyr = s_c[y], Qy = s_Q[y];
+            const bool anypos = V2 ? (thi > Qy) : (rmax > thi);
+            const bool anyneg = V2 ? (tlo < Qy) : (rmin < tlo);
+            const bool m = coord_incre ? (cyr >= cj) : (cyr <= cj);
+            bool nd = m ? (inc_eff ? anyneg : anypos) : (inc_eff ? anypos : anyneg);
+            if (keep != 0 && (keep > 0) != m) nd = false;                      // 'upper' / 'lower': one side only
+            const unsigned long long hit = __ballot(nd && yy + lane < ny);
+            if (hit) {
+                const int first = yy + (__ffsll((long long)hit) - 1), last = yy + 63 - __clzll((long long)hit);
+                y0 = first < y0 ? first : y0; y1 = last + 1 > y1 ? last + 1 : y1;
+            }
+        }
+        const double Qj = V2 ? (double)s_q[jc * 65 + lane] : s_Q[jc];
+        double acc = 0.0;
+        // (d) plane weights: the union band of the 16 targets, staged `wchunk` rows at a time; row weights: nothing to stage,
+        //     one "chunk" = the wave's own band, no barriers
+        const bool staged = wplane || mplane;                                  // workgroup-uniform
+        int Y0 = y0, Y1 = y1;
+        if (staged) {
+            if (tid == 0) { s_band[0] = ny; s_band[1] = 0; }
+            __syncthreads();
+            if (lane == 0 && live && y0 < y1) { atomicMin(&s_band[0], y0); atomicMax(&s_band[1], y1); }
+            __syncthreads();
+            Y0 = s_band[0]; Y1 = s_band[1];
+        }
+        const int step = staged ? wchunk : (Y1 > Y0 ? Y1 - Y0 : 1);
+        for (int yc = Y0; yc < Y1; yc += step) {
+            const int nr = (Y1 - yc < step) ? Y1 - yc : step;
+            if (staged) {
+                for (int i0 = tid; i0 < nr * 64; i0 += 64 * LWA_SW * 4) {
+                    double dr[4], mr[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = i0 + 64 * LWA_SW * k;
+                        const int r = (i < nr * 64 ? i : nr * 64 - 1) >> 6, c = i & 63;
+                        const size_t g = (size_t)(yc + r) * nx + (x0 + c < nx ? x0 + c : nx - 1);
+                        dr[k] = wplane ? dA[g] : 0.0; mr[k] = mplane ? M[g] : 0.0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = i0 + 64 * LWA_SW * k;
+                        if (i < nr * 64) {
+                            if (wplane) s_wei[i] = __ddiv_rn(dr[k], dA_max);    // core.py:723-724, for the rows that matter
+                            if (mplane) s_Mp[i] = mr[k];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            // (e) this wave's rows of the chunk, in y' order -- only the rows whose extrema allow a contribution (the test of (c),
+            //     a ballot per 64 rows; the span between the first and the last such row is mostly rows that cannot contribute)
+            const int ya = y0 > yc ? y0 : yc, yb_ = y1 < yc + nr ? y1 : yc + nr;
+            for (int yy = ya & ~63; yy < yb_ && live; yy += 64) {
+                const int yl = yy + lane;
+                const int y = yl < ny ? yl : ny - 1;
+                const double rmin = s_mn[y], rmax = s_mx[y], cyr = s_c[y], Qy = s_Q[y];
+                const bool anypos = V2 ? (thi > Qy) : (rmax > thi);
+                const bool anyneg = V2 ? (tlo < Qy) : (rmin < tlo);
+                const bool ml = coord_incre ? (cyr >= cj) : (cyr <= cj);
+                bool nd = ml ? (inc_eff ? anyneg : anypos) : (inc_eff ? anypos : anyneg);
+                if (keep != 0 && (keep > 0) != ml) nd = false;
+                unsigned long long hit = __ballot(nd && yl >= ya && yl < yb_);
+                while (hit) {
+                    // four contributing rows per turn: their LDS reads are issued together, the arithmetic follows in row order
+                    int yr[4]; bool on[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        on[k] = hit != 0ull;
+                        yr[k] = on[k] ? yy + (__ffsll((long long)hit) - 1) : yr[k > 0 ? k - 1 : 0];
+                        if (k == 0 && !on[0]) yr[0] = yy;
+                        hit &= hit - (on[k] ? 1ull : 0ull);
+                    }
+                    double cy[4], qv[4], wv[4], mv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        cy[k] = s_c[yr[k]];
+                        qv[k] = V2 ? s_Q[yr[k]] : (double)s_q[yr[k] * 65 + lane];
+                        wv[k] = wplane ? s_wei[(yr[k] - yc) * 64 + lane] : s_wr[yr[k]];
+                        mv[k] = mplane ? s_Mp[(yr[k] - yc) * 64 + lane] : s_Mr[yr[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (on[k]) {
+                            const bool m = coord_incre ? (cy[k] >= cj) : (cy[k] <= cj);      // core.py:757 (wave-uniform)
+                            const double a = V2 ? Qj : qv[k], b = V2 ? qv[k] : Qj;           // qe = a - b (core.py:860 / 754); see k_lwa for the sign algebra
+                            const double u = (m == (inc_eff != 0)) ? __dsub_rn(b, a) : __dsub_rn(a, b);
+                            if (u > 0.0) {
+                                const double term = __dmul_rn(__dmul_rn(u, wv[k]), mv[k]);
+                                if (term == term) acc = __dadd_rn(acc, term);                 // nansum
+                            }
+                        }
+                    }
+                }
+            }
+            if (staged) __syncthreads();
+        }
+        if (live && active) out[so + (size_t)j * nx + x] = inc_eff ? (acc == 0.0 ? -0.0 : acc) : -acc;   // core.py:789
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_lwa_masks(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
@@ -225,6 +405,42 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     if (part < 0 || part > 2) return fail(ctx, XC_EBADARG, "xc_lwa: part must be 0 (all), 1 (upper) or 2 (lower)");
     if (nmask < 0 || (nmask > 0 && (!mask_idx || !out_masks))) return fail(ctx, XC_EBADARG, "xc_lwa: mask arguments");
     if (ny > 65535 || nslab * (nmask > 0 ? nmask : 1) > 65535) return fail(ctx, XC_EBADARG, "xc_lwa: ny / nslab too large");
+    if (variant != 0 && variant != 1) return fail(ctx, XC_EBADARG, "xc_lwa: variant must be 0 or 1");
+    if (q_dtype != XC_F32 && q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
+    {
+        // ---- one launch with the 64-column strip of the tracer in LDS when it fits
+        const double* Mt = M_rank == XC_DA_NONE ? dA : M;
+        const int Mr = M_rank == XC_DA_NONE ? dA_rank : M_rank;
+        const size_t tsz = q_dtype == XC_F32 ? 4 : 8;
+        const bool wpl = dA_rank == XC_DA_PLANE, mpl = Mr == XC_DA_PLANE;
+        int wchunk = 0;
+        for (int c : {64, 32, 16})
+            if (!wchunk && lwa_strip_lds(ny, tsz, wpl, mpl, c) <= kLdsBudget) wchunk = c;
+        if (wchunk && ctx->knobs.lwa_strip && ny <= 0x7fff && nx <= 0x7fffffff / ny) {
+            const int64_t nstrip = (nx + 63) / 64;
+            const int64_t nb16 = (ny + LWA_SW - 1) / LWA_SW;                  // workgroups per strip with 16 targets each
+            // ~2 workgroups per CU; more target rows per workgroup when there is more work than that (the strip is staged once per workgroup)
+            // measured on MI355X: this kernel wins while its grid does not fill the chip twice (cfg3 alone: 13 us against 5 + 19 for
+            // prologue + streaming kernel); stacks that do are VALU-bound either way and the streaming kernel's four targets per
+            // thread win (64 slabs: 226 against 272 us)
+            const bool few = nstrip * nslab * nb16 <= 2 * (ctx->cus > 0 ? ctx->cus : 256) || ctx->knobs.lwa_strip > 1;
+            const int64_t tper = LWA_SW, ts = nb16;
+            if (few && nstrip <= 0x7fffffff && ts <= 65535 && nslab <= 65535) {
+                const size_t lds = lwa_strip_lds(ny, tsz, wpl, mpl, wchunk);
+                const dim3 grid((unsigned)nstrip, (unsigned)ts, (unsigned)nslab);
+#define XC_LWAS(T, V) do { \
+                    const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(k_lwa_strip<T, V>), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; \
+                    hipLaunchKernelGGL((k_lwa_strip<T, V>), grid, dim3(64 * LWA_SW), lds, ctx->stream, (const T*)q, Q, coord, dA, dA_rank, dA_max, \
+                                       Mt, Mr, ny, nx, increase, part, (int)tper, wchunk, out_lwa); } while (0)
+                if (q_dtype == XC_F64) { if (variant) XC_LWAS(double, true); else XC_LWAS(double, false); }
+                else { if (variant) XC_LWAS(float, true); else XC_LWAS(float, false); }
+#undef XC_LWAS
+                XC_HIP(ctx, hipGetLastError());
+                goto masks;
+            }
+        }
+    }
+    {
     // small problems: one target row per thread so that the whole chip is busy
     // scratch: wei (same rank as dA) and the per-row tracer extrema; M defaults to dA itself (core.py:789 as written)
     const int64_t nw = dA_rank == XC_DA_ROW ? ny : ny * nx;
@@ -247,13 +463,13 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
 #define XC_LWA2(T, V, J) hipLaunchKernelGGL((k_lwa<T, V, J>), grid, dim3(256), 0, ctx->stream, (const T*)q, Q, coord, wei, dA_rank, \
                            M, M_rank, rowinfo, stripmm, ny, nx, increase, part, out_lwa)
 #define XC_LWA(T, V) do { if (small) XC_LWA2(T, V, 1); else XC_LWA2(T, V, 4); } while (0)
-    if (variant != 0 && variant != 1) return fail(ctx, XC_EBADARG, "xc_lwa: variant must be 0 or 1");
     if (q_dtype == XC_F64) { if (variant) XC_LWA(double, true); else XC_LWA(double, false); }
-    else if (q_dtype == XC_F32) { if (variant) XC_LWA(float, true); else XC_LWA(float, false); }
-    else return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
+    else { if (variant) XC_LWA(float, true); else XC_LWA(float, false); }
 #undef XC_LWA
 #undef XC_LWA2
     XC_HIP(ctx, hipGetLastError());
+    }
+masks:
     if (nmask > 0) {
         dim3 g2((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)(nslab * nmask));
         if (q_dtype == XC_F64)
