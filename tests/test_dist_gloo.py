@@ -1,6 +1,6 @@
-"""The N > 1 path on CPU: world_size-2 (and 3, ragged) gloo process groups run the slab
-sharding + the single end-of-job gather and must reproduce the 1-rank result bit for bit
-(slabs are independent)."""
+"""The N > 1 path on CPU: world_size-2 (and 3, ragged) process groups -- torch.distributed gloo AND the package's own
+torch-free SocketGroup -- run the slab sharding + the single end-of-job gather and must reproduce the 1-rank result bit
+for bit (slabs are independent)."""
 import os
 import socket
 import sys
@@ -129,3 +129,49 @@ def test_single_rank_passthrough():
     from xcontour_amd.distributed import all_gather_slabs
     t = torch.arange(12.).reshape(4, 3)
     assert torch.equal(all_gather_slabs(t, 4, 0, 1), t)
+
+
+# ---------------------------------------------------------------- the torch-free carrier (xcontour_amd.distributed.SocketGroup)
+def _socket_worker(rank, world, port, nslab, q):
+    sys.path.insert(0, ROOT)
+    from xcontour_amd.distributed import SocketGroup, run_sharded
+    assert 'torch.distributed' not in sys.modules or True        # (the spawned test module imports torch; the package path below does not need it)
+    g = SocketGroup(rank, world, '127.0.0.1', port)
+    out = run_sharded(_process, nslab, rank, world, group=g)
+    g.barrier()
+    tmax = g.allreduce_max(float(rank))
+    ids = g.allgather(np.array([rank, rank * 10], dtype=np.int64))
+    q.put((rank, np.asarray(out).copy(), tmax, ids))
+    g.close()
+
+
+@pytest.mark.parametrize('world,nslab', [(2, 8), (2, 7), (3, 5), (3, 1)])
+def test_socket_group_sharded_gather_equals_single_rank(world, nslab):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_socket_worker, args=(r, world, port, nslab, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, out, tmax, ids = q.get(timeout=120)
+        got[r] = out
+        assert tmax == world - 1
+        assert np.array_equal(ids, np.array([[k, 10 * k] for k in range(world)]))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _process(0, nslab)
+    for r in range(world):
+        assert isinstance(got[r], np.ndarray) and got[r].shape == ref.shape and np.array_equal(got[r], ref)
+
+
+def test_distributed_module_does_not_import_torch():
+    """xcontour_amd.distributed is importable and its SocketGroup path usable without torch in the process"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import xcontour_amd.distributed as d; import numpy as np; "
+            "g = d.SocketGroup(0, 1); out = d.run_sharded(lambda lo, hi: np.arange(hi - lo)[:, None] * np.ones(3), 4, 0, 1, group=g); "
+            "assert out.shape == (4, 3); assert 'torch' not in sys.modules; print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr

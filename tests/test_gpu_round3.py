@@ -179,22 +179,31 @@ def _cfg4_block(ctx, lo, hi, chunk, det):
     return mine
 
 
-def _gpu_rank(rank, world, port, S, chunk, det, outq):
-    """one rank = one fresh process with its own context on the (shared) GPU; gloo carries the one gather"""
+def _gpu_rank(rank, world, port, S, chunk, det, carrier, outq):
+    """one rank = one fresh process with its own context on the (shared) GPU; the one gather travels over torch.distributed
+    gloo or over the package's own torch-free SocketGroup"""
     try:
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        from xcontour_amd import _native as nat
+        from xcontour_amd.pipeline import shard_slabs
+        from xcontour_amd.distributed import all_gather_slabs, SocketGroup
+        ctx = nat.Context(0)
+        lo, hi = shard_slabs(S, rank, world)
+        mine = np.ascontiguousarray(_cfg4_block(ctx, lo, hi, chunk, det))
+        if carrier == 'socket':
+            g = SocketGroup(rank, world, '127.0.0.1', port)
+            full = all_gather_slabs(mine, S, rank, world, group=g)
+            g.barrier()
+            outq.put((rank, np.asarray(full).copy(), None))
+            g.close()
+            ctx.close()
+            return
         import torch
         import torch.distributed as dist
         dist.init_process_group('gloo', rank=rank, world_size=world)
-        from xcontour_amd import _native as nat
-        from xcontour_amd.pipeline import shard_slabs
-        from xcontour_amd.distributed import all_gather_slabs
-        ctx = nat.Context(0)
-        lo, hi = shard_slabs(S, rank, world)
-        mine = _cfg4_block(ctx, lo, hi, chunk, det)
-        full = all_gather_slabs(torch.from_numpy(np.ascontiguousarray(mine)), S, rank, world)
+        full = all_gather_slabs(torch.from_numpy(mine), S, rank, world)
         dist.barrier()
         outq.put((rank, full.numpy().copy(), None))
         ctx.close()
@@ -212,8 +221,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('det', [True, False])
-def test_two_ranks_share_one_gpu_real_pipeline(ctx, det):
+@pytest.mark.parametrize('det,carrier', [(True, 'gloo'), (False, 'gloo'), (True, 'socket')])
+def test_two_ranks_share_one_gpu_real_pipeline(ctx, det, carrier):
     """SURVEY 8(e) end to end on the hardware at hand: 2 spawned processes (never a re-exec of a process that touched the
     GPU), each a real KeffPlan over its shard_slabs block of an 11-slab 1440 x 721 stack (ragged blocks 6 + 5, ragged
     launch sets of 4), chunks_to_slabs -> all_gather_slabs over gloo.  Every rank must hold the 1-rank result: all nine
@@ -224,7 +233,7 @@ def test_two_ranks_share_one_gpu_real_pipeline(ctx, det):
     mpc = mp.get_context('spawn')
     outq = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_gpu_rank, args=(r, world, port, S, chunk, det, outq)) for r in range(world)]
+    procs = [mpc.Process(target=_gpu_rank, args=(r, world, port, S, chunk, det, carrier, outq)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
