@@ -5,6 +5,7 @@
     python tools/kernel_times.py lwa             K7: cfg3 (barotropic 256x512, J = 256), stacks of it, one cfg2-sized slab
     python tools/kernel_times.py cross           K9: cfg2-sized slabs, strides, field variants
     python tools/kernel_times.py pipe            Keff pipeline: tracer / contour dtypes, supplied grdS, chained or not, deterministic
+    python tools/kernel_times.py land            Keff pipeline on ocean-like slabs: ~30 % of the cells NaN (whole rows + a continent)
     python tools/kernel_times.py ncontours       Keff pipeline time per cfg2 slab against the number of contours
     python tools/kernel_times.py shapes          every kernel on awkward shapes (per-cell cost; catches pathological regimes)
     python tools/kernel_times.py single          every operator on ONE cfg2 slab next to its per-slab time in a 16-slab launch
@@ -214,6 +215,32 @@ def cmd_pipe(ctx, T):
                          deterministic=det, chained=chain, slabs_per_launch=B, us_per_slab=pipe_time(ctx, T, B, chain, **kw))
 
 
+def cmd_land(ctx, T):
+    """rows that are entirely NaN used to send 64 * VEC cells x 3 LDS adds onto the few addresses of the trash bin"""
+    lat, lon, dA = grid()
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, NY, NX), True)
+    B = 8
+    rng = np.random.default_rng(2)
+    base = np.sin(np.deg2rad(lat))[:, None] + 0.25 * np.cos(3 * np.deg2rad(lon))[None, :] * np.cos(np.deg2rad(lat))[:, None] ** 2
+    for frac_name, land in (('no land', None), ('30 % land (500 whole rows + a 600 x 1000 continent)', True)):
+        q = np.stack([base + 0.02 * rng.standard_normal((NY, NX)) for _ in range(2 * B)])
+        if land:
+            q[:, 100:600, :] = np.nan
+            q[:, 900:1500, 1000:2000] = np.nan
+        plan = KeffPlan(ctx, 2 * B, NY, NX, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=True, lt=True, out_slabs=B)
+        plan.set_q(q)
+        for chain in (False, True):
+            k = [0]
+
+            def step():
+                s0 = (k[0] % 2) * B
+                plan.run_range(0, s0, B, ((k[0] + 1) % 2) * B if chain else None, out_s0=0)
+                k[0] += 1
+            emit(kernel='Keff pipeline', field=frac_name, nan_fraction=float(np.isnan(q).mean()), chained=chain, slabs_per_launch=B,
+                 us_per_slab=T.ms(step, reps=10, warm=4) / B * 1e3)
+        plan.free()
+
+
 def cmd_ncontours(ctx, T):
     lat, lon, dA = grid()
     tbl = table_from_rowsums(ctx.rowsum(None, dA, NY, NX), True)
@@ -289,7 +316,7 @@ def cmd_single(ctx, T):
         emit(operator=name, one_slab_us=out[name, 1] * 1e3, per_slab_of_16_us=out[name, 16] / 16 * 1e3)
 
 
-CMDS = {'sort': cmd_sort, 'lwa': cmd_lwa, 'cross': cmd_cross, 'pipe': cmd_pipe, 'ncontours': cmd_ncontours, 'shapes': cmd_shapes, 'single': cmd_single}
+CMDS = {'sort': cmd_sort, 'lwa': cmd_lwa, 'cross': cmd_cross, 'pipe': cmd_pipe, 'land': cmd_land, 'ncontours': cmd_ncontours, 'shapes': cmd_shapes, 'single': cmd_single}
 
 if __name__ == '__main__':
     if len(sys.argv) < 2 or any(c not in CMDS for c in sys.argv[1:]):
