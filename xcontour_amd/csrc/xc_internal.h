@@ -132,6 +132,7 @@ struct FinalArgs {
     int             bps, nch, nbin;
     int             lt, reverse;
     int             skip_reduce;   // red_h / red_c are already filled (deterministic path): run stage 2 only
+    int             fuse_reduce;   // set by launch_finalize: stage 1 folded into stage 2 (few partials per slab)
     double*         pdf;      // [nslab][nch][nbin] or null
     uint64_t*       counts;   // [nslab][nbin] or null
     double*         cdf;      // [nslab][nch][nbin] or null

@@ -223,11 +223,45 @@ void k_finalize(const FinalArgs a)
     double* s_cdf = sm + (size_t)NCH * N; // [NCH][N] in LEVEL order (after optional reversal)
     double* s_x   = s_cdf + (size_t)NCH * N;   // 7*N scratch for the epilogue
 
-    const double* ph = a.red_h + (size_t)slab * NCH * N;
-    for (int i = tid; i < NCH * N; i += nthr) s_pdf[i] = ph[i];
-    if (a.counts) {
-        const unsigned long long* pc = a.red_c + (size_t)slab * N;
-        for (int i = tid; i < N; i += nthr) a.counts[(size_t)slab * N + (a.reverse ? N - 1 - i : i)] = pc[i];
+    // the A(Yeq) table goes into LDS for the look-ups of the epilogue: its loads are issued FIRST, eight pairs per thread at a
+    // time, so that their latency runs under the reduction and the cumulative sums (they used to be a loop of dependent
+    // round trips in the middle of the kernel: 7 of its 20 us per launch)
+    constexpr int TB = 8;
+    double tb_t[TB], tb_c[TB];
+    const bool tbl_regs = a.keff && a.tbl_in_lds && a.ntbl <= TB * nthr;
+    if (tbl_regs) {
+#pragma unroll
+        for (int u = 0; u < TB; ++u) { const int i = tid + u * nthr; const int ic = i < a.ntbl ? i : a.ntbl - 1; tb_t[u] = a.tbl[ic]; tb_c[u] = a.tbl_coord[ic]; }
+    }
+    if (a.fuse_reduce) {
+        // stage 1 folded in: the per-block partials of this slab summed in block order (fixed: deterministic), four loads in flight
+        const int nvh = NCH * N;
+        const double* pp = a.part_h + (size_t)slab * a.bps * nvh;
+        for (int i = tid; i < nvh; i += nthr) {
+            double sum = 0.0;
+            int b = 0;
+            for (; b + 4 <= a.bps; b += 4) {
+                const double v0 = pp[(size_t)b * nvh + i], v1 = pp[(size_t)(b + 1) * nvh + i], v2 = pp[(size_t)(b + 2) * nvh + i], v3 = pp[(size_t)(b + 3) * nvh + i];
+                sum = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(sum, v0), v1), v2), v3);
+            }
+            for (; b < a.bps; ++b) sum = __dadd_rn(sum, pp[(size_t)b * nvh + i]);
+            s_pdf[i] = sum;
+        }
+        if (a.counts) {
+            const unsigned* pc = a.part_c + (size_t)slab * a.bps * N;
+            for (int i = tid; i < N; i += nthr) {
+                unsigned long long c = 0;
+                for (int b = 0; b < a.bps; ++b) c += pc[(size_t)b * N + i];
+                a.counts[(size_t)slab * N + (a.reverse ? N - 1 - i : i)] = c;
+            }
+        }
+    } else {
+        const double* ph = a.red_h + (size_t)slab * NCH * N;
+        for (int i = tid; i < NCH * N; i += nthr) s_pdf[i] = ph[i];
+        if (a.counts) {
+            const unsigned long long* pc = a.red_c + (size_t)slab * N;
+            for (int i = tid; i < N; i += nthr) a.counts[(size_t)slab * N + (a.reverse ? N - 1 - i : i)] = pc[i];
+        }
     }
     __syncthreads();
     if (tid < NCH) {                      // np.cumsum order (core.py:1320)
@@ -259,7 +293,12 @@ void k_finalize(const FinalArgs a)
     const double* tblp = a.tbl; const double* crdp = a.tbl_coord;
     if (a.tbl_in_lds) {
         double* s_tbl = s_x + 7 * (size_t)N;
-        for (int i = tid; i < a.ntbl; i += nthr) { s_tbl[i] = a.tbl[i]; s_tbl[a.ntbl + i] = a.tbl_coord[i]; }
+        if (tbl_regs) {
+#pragma unroll
+            for (int u = 0; u < TB; ++u) { const int i = tid + u * nthr; if (i < a.ntbl) { s_tbl[i] = tb_t[u]; s_tbl[a.ntbl + i] = tb_c[u]; } }
+        } else {
+            for (int i = tid; i < a.ntbl; i += nthr) { s_tbl[i] = a.tbl[i]; s_tbl[a.ntbl + i] = a.tbl_coord[i]; }
+        }
         __syncthreads();
         tblp = s_tbl; crdp = s_tbl + a.ntbl;
     }
@@ -461,7 +500,9 @@ int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
     }
     const int nvh = a.nch * a.nbin;
     dim3 g1((unsigned)((nvh + a.nbin + 7) / 8), (unsigned)nslab);
-    if (!a.skip_reduce) {
+    // few partials per slab (the Keff pipeline: ~20): stage 1 runs inside stage 2's workgroup, one launch less
+    a.fuse_reduce = (!a.skip_reduce && a.bps <= 64 && !a.big) ? 1 : 0;
+    if (!a.skip_reduce && !a.fuse_reduce) {
         hipLaunchKernelGGL(k_reduce_partials, g1, dim3(256), 0, ctx->stream, a.part_h, a.part_c, a.bps, nvh, a.nbin,
                            a.red_h, a.red_c);
         XC_HIP(ctx, hipGetLastError());
