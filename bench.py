@@ -58,7 +58,8 @@ CHECK_NAMES = ('ctr', 'area', 'intgrdS', 'latEq', 'dqdA', 'dintSdA', 'Leq2', 'Lm
 
 def _cpu_keff_worker(args):
     """One slab through the oracle's Keff call sequence (runs in a spawned process)."""
-    path, idx, want = args
+    path, idx, want = args[:3]
+    cdt = np.dtype(args[3]) if len(args) > 3 else np.float64
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import xcontour_oracle as O
     q = np.load(path, mmap_mode='r')[idx]
@@ -66,7 +67,7 @@ def _cpu_keff_worker(args):
     lon = np.arange(NX) * 0.1
     dA = O.cell_area(lat, lon)
     t = time.perf_counter()
-    r = O.keff_pipeline(np.asarray(q), dA, lat, NCONT, lon=lon, increase=True, lt=True, dtype=np.float64)
+    r = O.keff_pipeline(np.asarray(q), dA, lat, NCONT, lon=lon, increase=True, lt=True, dtype=cdt)
     dt = time.perf_counter() - t
     if not want:
         return dt, None
@@ -109,7 +110,7 @@ def _compare_with_oracle(gpu, ref, s):
         raise RuntimeError('bench parity check against the oracle FAILED for slab %d: %s' % (s, ', '.join(bad)))
 
 
-def cpu_baseline(q_host, gpu_out, ncheck):
+def cpu_baseline(q_host, gpu_out, ncheck, cdt='float64'):
     """Oracle on a bounded sample: single-thread time per slab, then every logical core of the host in parallel
     (bounded by memory: ~1.2 GB of numpy temporaries per worker).  The first `ncheck` slabs' vectors are compared
     with the GPU's (`gpu_out`, same slabs) -- the CPU leg is the checker of the timed GPU result, not only a clock."""
@@ -129,14 +130,14 @@ def cpu_baseline(q_host, gpu_out, ncheck):
     try:
         path = os.path.join(tmp, 'q.npy')
         np.save(path, q_host)
-        t1, r0 = _cpu_keff_worker((path, 0, True))                   # single thread, in-process
+        t1, r0 = _cpu_keff_worker((path, 0, True, cdt))              # single thread, in-process
         _compare_with_oracle(gpu_out, r0, 0)
         ctx = mp.get_context('spawn')
         with ctx.Pool(workers) as pool:
-            pool.map(_cpu_keff_worker, [(path, 0, False)] * workers, chunksize=1)     # warm the workers (imports, page cache)
+            pool.map(_cpu_keff_worker, [(path, 0, False, cdt)] * workers, chunksize=1)     # warm the workers (imports, page cache)
             for w in tries:                                          # w tasks in flight on w idle workers
                 t = time.perf_counter()
-                res = pool.map(_cpu_keff_worker, [(path, i % nd, i < ncheck) for i in range(w)], chunksize=1)
+                res = pool.map(_cpu_keff_worker, [(path, i % nd, i < ncheck, cdt) for i in range(w)], chunksize=1)
                 rates[w] = (w, time.perf_counter() - t)
                 for i in range(min(ncheck, w)):                      # ten 201-vectors per checked slab: not a timing factor
                     _compare_with_oracle(gpu_out, res[i][1], i % nd)
@@ -162,11 +163,11 @@ def cpu_baseline(q_host, gpu_out, ncheck):
         'value': n * work / wall, 'unit': 'cells*contours/s', 'cores': best, 'kind': 'port',
         'single_thread_value': work / t1, 'parity_checked_slabs': max(1, nchecked),
         'by_workers': {str(w): rates[w][0] * work / rates[w][1] for w in tries},
-        'sample': '%d slabs (%d distinct) of %dx%d f64, %d contours, numpy oracle (port of the reference xarray/'
+        'sample': '%d slabs (%d distinct) of %dx%d %s, %d contours, numpy oracle (port of the reference xarray/'
                   'xhistogram Keff call sequence) in %d concurrent processes (best of %s): %.2f s wall; single thread %.2f s/slab '
                   '= %.3e cells*contours/s; host: %s, %d logical / %d physical cores; %d slabs compared with the GPU vectors '
                   '(counts + levels bit-exact, sums 1e-11, derived 1e-6)'
-                  % (n, nd, NX, NY, NCONT, best, tries, wall, t1, work / t1, model, cores, len(phys) or cores, max(1, nchecked)),
+                  % (n, nd, NX, NY, q_host.dtype.name, NCONT, best, tries, wall, t1, work / t1, model, cores, len(phys) or cores, max(1, nchecked)),
     }
 
 
@@ -381,6 +382,9 @@ def main():
     ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
                     help="BASELINE.json configuration: cfg2 (default, the headline metric's), or one of the secondary ones as "
                          'a bench line of the same contract (tools/bench_configs.py; single GPU; --steps / --warmup apply)')
+    ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'],
+                    help='tracer dtype: f64 (default: the headline configuration BASELINE.json names) or f32 -- float32 tracer AND float32 '
+                         'contours, the dtype of the files the reference ships and its default `dtype` (core.py:21); algorithmic bytes 4 + 8 per cell')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-slabs', type=int, default=0, help='distinct slabs in the CPU sample, all parity-checked (0: 8)')
     ap.add_argument('--no-extras', action='store_true', help='skip variants / long_run / unchained after the timed region')
@@ -436,6 +440,8 @@ def main():
         ctx.close()
         return
     B, K, W = a.batch, a.steps, a.warmup
+    qdt = np.dtype(np.float32 if a.dtype == 'f32' else np.float64)
+    bpc = qdt.itemsize + 8                                        # algorithmic bytes per cell: tracer once + 2-D f64 dA once
     lat = np.linspace(-90, 90, NY)
     lon = np.arange(NX) * 0.1
     dA = cell_area(lat, lon)
@@ -450,7 +456,7 @@ def main():
     slot = KeffPlan.out_bytes(B, NCONT)
     res = torch.empty(slot * K // 8, dtype=torch.float64, device='cuda')
     wres = torch.empty(slot // 8, dtype=torch.float64, device='cuda')        # warm-up slot
-    plan = KeffPlan(ctx, NB * B, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl,
+    plan = KeffPlan(ctx, NB * B, NY, NX, NCONT, qdt, qdt, dA=dA, lat=lat, lon=lon, tbl=tbl,
                     tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.data_ptr(), detect_row_dA=a.row_dA,
                     out_slabs=B, replicate_dA=a.slab_dA, right_edge='xhistogram', deterministic=a.deterministic)
     plan.synth(lat, lon, SEED + rank * NB * B, a.variant)         # slab s of rank r: seed + r*2B + s
@@ -527,10 +533,10 @@ def main():
             'metric': 'lat-lon cells*contours/s, full Keff pipeline', 'value': work_step * K / el,
             'unit': 'cells*contours/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': el / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'cfg2: synthetic %dx%d float64 PV-like slabs, 2-D f64 dA, %d contours, '
+            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': 'cfg2: synthetic %dx%d %s PV-like slabs, 2-D f64 dA, %d contours, '
                                    'full Keff (min/max + histogram with in-kernel |grad q|^2 + CDF + epilogue)'
-                                   % (NX, NY, NCONT),
+                                   % (NX, NY, qdt.name, NCONT),
                        'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant, 'dA': dA_kind,
                        'minmax': 'folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass',
                        'sums': 'order-free fixed point (deterministic)' if a.deterministic else 'float64 LDS atomics',
@@ -538,21 +544,21 @@ def main():
                        'device': ctx.device_name()},
         }
         cells = B * NY * NX
-        alg = cells * (8 if a.row_dA else BYTES_PER_CELL)              # tracer once + dA once per slab
+        alg = cells * (qdt.itemsize if a.row_dA else bpc)              # tracer once + dA once per slab
 
         def uniq_bytes(slab_dA):
             # bytes that MUST cross HBM once per launch: this batch's tracer + the weights that are not shared
             # (a dA plane shared by the B slabs of a launch is fetched once; per-slab dA planes B times; a per-row vector ~0)
-            return cells * 8 + (cells * 8 if slab_dA else (NY * 8 if a.row_dA else NY * NX * 8))
+            return cells * qdt.itemsize + (cells * 8 if slab_dA else (NY * 8 if a.row_dA else NY * NX * 8))
 
         def kernel_name(slab_dA, ch):
-            return 'k_hist<double,%s,%s>' % ('DA_SLAB' if slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'), 'NEXT' if ch else 'plain')
+            return ('k_hist<double,%s,%s>' if a.dtype == 'f64' else 'k_hist<float,%s,%s>') % ('DA_SLAB' if slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'), 'NEXT' if ch else 'plain')
 
         if group == B:
             ms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in ev])
             ach = alg / (ms.mean() * 1e-3) / 1e9
             uniq = uniq_bytes(a.slab_dA)
-            traffic, tsrc = (None, 'not measured for this variant') if (a.row_dA or a.variant != 0 or a.deterministic) else \
+            traffic, tsrc = (None, 'not measured for this variant') if (a.row_dA or a.variant != 0 or a.deterministic or a.dtype != 'f64') else \
                 stored_traffic(('slab_' if a.slab_dA else '') + ('chain' if chain else 'nochain'), B)
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': ach / HBM_PEAK_GBS,
@@ -562,16 +568,19 @@ def main():
                                 'launch_ms': float(ms.mean()), 'launch_ms_std': float(ms.std()),
                                 'algorithmic_bytes_per_launch': alg,
                                 'hbm_unique_bytes_per_launch': uniq,
-                                'streamed_bytes_per_launch': alg + (cells * 8 if chain else 0),
+                                'streamed_bytes_per_launch': alg + (cells * qdt.itemsize if chain else 0),
                                 'pipeline_frac': (alg * K / el / 1e9) / HBM_PEAK_GBS,
                                 'pipeline_hbm_unique_frac': (uniq * K / el / 1e9) / HBM_PEAK_GBS,
-                                'note': 'frac = 16 B/cell (SURVEY 8d) / launch time / 8 TB/s; its numerator counts the dA plane once per '
+                                'note': 'frac = ' + str(bpc) + ' B/cell (SURVEY 8d) / launch time / 8 TB/s; its numerator counts the dA plane once per '
                                         'slab although the %d slabs of a launch share it (cache-served after the first fetch) -- '
                                         'hbm_unique_frac counts only bytes that must come from HBM.  variants.slab_dA is the '
                                         'configuration where the two coincide' % B}
         # self-check of the last step: every cell lands in exactly one bin (xhistogram rule: last edge + 1e-8 keeps the max cell)
         out = plan.fetch(slot=K - 1)
-        if not (out['counts'].sum(axis=1).astype(np.int64) == NY * NX).all() or out['status'].any():
+        # (float32 contours: the last level is the float32 rounding of the maximum and `+ 1e-8` is below its resolution, so the
+        #  maximum cell itself may fall outside the last edge -- reference behaviour; the oracle check below is exact)
+        csum = out['counts'].sum(axis=1).astype(np.int64)
+        if not ((csum == NY * NX).all() if a.dtype == 'f64' else ((csum <= NY * NX) & (csum >= NY * NX - 4)).all()) or out['status'].any():
             raise RuntimeError('bench self-check failed: counts %r status %r' % (out['counts'].sum(axis=1), out['status']))
         extras = world == 1 and group == B and not a.no_extras
         if extras and chain:
@@ -620,7 +629,7 @@ def main():
             # batches, same chained schedule; its vectors are compared with the main leg's (same dA values -> same answers)
             p2 = None
             try:
-                p2 = KeffPlan(ctx, NB * B, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                p2 = KeffPlan(ctx, NB * B, NY, NX, NCONT, qdt, qdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
                               increase=True, lt=True, nslots=1, out_slabs=B, replicate_dA=True, right_edge='xhistogram',
                               alloc_q=False, deterministic=a.deterministic)
                 p2.set_q_device(plan._q_ptr)
@@ -643,7 +652,7 @@ def main():
                 if bad or vo['status'].any():
                     raise RuntimeError('variants.slab_dA: results differ from the main leg: %s' % bad)
                 ub = uniq_bytes(True)
-                vt, vsrc = stored_traffic('slab_chain' if chain else 'slab_nochain', B) if (a.variant == 0 and not a.deterministic) else (None, 'not measured')
+                vt, vsrc = stored_traffic('slab_chain' if chain else 'slab_nochain', B) if (a.variant == 0 and not a.deterministic and a.dtype == 'f64') else (None, 'not measured')
                 line['variants'] = {'slab_dA': {
                     'steps': KV, 'ms_per_step': el4 / KV * 1e3, 'value': work_step * KV / el4, 'kernel': kernel_name(True, chain),
                     'launch_ms': float(vms.mean()), 'launch_ms_std': float(vms.std()),
@@ -663,15 +672,15 @@ def main():
             # the oracle on slabs of the LAST timed step's batch; their vectors are compared with that step's GPU result
             nd = max(1, min(a.cpu_slabs or 8, B))
             s0 = ((K - 1) % NB) * B
-            esz = NY * NX * 8
-            qh = np.empty((nd, NY, NX), dtype=np.float64)
+            esz = NY * NX * qdt.itemsize
+            qh = np.empty((nd, NY, NX), dtype=qdt)
             ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, plan._q_ptr + s0 * esz, nd * esz))
-            line['cpu_baseline'] = cpu_baseline(qh, out, nd)
+            line['cpu_baseline'] = cpu_baseline(qh, out, nd, qdt.name)
     # ---- cfg4 strong scaling: every rank takes part (its own timed region, after the cfg2 buffers are gone)
     plan.free()
     del res, wres, gathered
     torch.cuda.empty_cache()
-    if not a.no_cfg4:
+    if not a.no_cfg4 and a.dtype == 'f64':
         blk = cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev)
         if rank == 0:
             line['cfg4_strong'] = blk

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; cd $R; RD=${1:-r03}; COMMIT=${2:-unknown}; O=$R/gpurun_out
 echo "== bench default"; timeout -k 10 500 python3 bench.py > $O/${RD}_bench_n1.json 2> $O/${RD}_bench_n1.err || exit 1
 echo "== bench variants"
 : > $O/${RD}_bench_variants.jsonl
-for a in "--no-chain" "--slab-dA" "--row-dA" "--deterministic" "--variant 1" "--variant 2"; do
+for a in "--no-chain" "--slab-dA" "--row-dA" "--deterministic" "--variant 1" "--variant 2" "--dtype f32" "--dtype f32 --no-chain"; do
   timeout -k 10 300 python3 bench.py --no-cpu --no-cfg4 --no-extras $a 2>/dev/null | grep '^{' >> $O/${RD}_bench_variants.jsonl || exit 1
 done
 echo "== secondary configs"

@@ -15,7 +15,7 @@ for f in sorted(glob.glob("$R/gpurun_out/pmck3_*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
         if 'k_hist<' in k:
-            agg[('chain' if 'true, true, true, true' in k else 'nochain', r['Counter_Name'])].append(float(r['Counter_Value']))
+            agg[(('f32 ' if 'k_hist<float' in k else '') + ('chain' if 'true, true, true, true' in k else 'nochain'), r['Counter_Name'])].append(float(r['Counter_Value']))
     for k,v in sorted(agg.items()):
         v=sorted(v); m=v[len(v)//2]; print(k[0], k[1], '%.4g' % m, 'per cell %.4f' % (m / cells))
 PY
