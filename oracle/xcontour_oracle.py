@@ -134,7 +134,7 @@ def hist_edges(b):
     return edges, bincrease
 
 
-def weighted_histogram(x, edges, weights=None, right_edge='xhistogram'):
+def weighted_histogram(x, edges, weights=None, right_edge='xhistogram', deterministic=False):
     """N-bin histogram of `x` over ascending `edges` (xhistogram semantics).
 
     bin k = [edges[k], edges[k+1]); NaN and out-of-range values dropped;
@@ -159,11 +159,43 @@ def weighted_histogram(x, edges, weights=None, right_edge='xhistogram'):
     if weights is None:
         return counts.astype(np.float64), counts
     w = np.asarray(weights, dtype=np.float64).ravel()
+    if deterministic:
+        return deterministic_bin_sums(idx, w, nb), counts
     sums = np.bincount(idx, weights=w, minlength=nb + 2)[1:nb + 1]
     return sums, counts
 
 
-def histogram_cdf(q, b, weights, lt, right_edge='xhistogram'):
+def deterministic_bin_sums(idx, w, nb):
+    """Order-free per-bin sums (BUILD-DEFINED: the `deterministic` mode of the HIP histogram pass, include/xcontour_hip.h
+    "Deterministic sums"; the reference itself sums with np.bincount).  For every bin: M = max |w|, c = count,
+    k = 62 - ceil(log2 c) - (ilogb(M) + 1); every weight becomes the integer rint(w * 2^k) (round half to even, one
+    rounding per cell), the integers are added exactly (int64) and the total is converted once: float(n) * 2^-k.
+    Because integer addition is associative the result does not depend on the order of the cells -- the GPU must
+    reproduce it BIT FOR BIT.  A bin that holds an infinite weight yields NaN.  idx: bin of every cell in 1..nb
+    (np.digitize convention; everything else is dropped)."""
+    idx = np.asarray(idx); w = np.asarray(w, dtype=np.float64)
+    ok = (idx >= 1) & (idx <= nb)
+    b, v = idx[ok] - 1, w[ok]
+    out = np.zeros(nb, dtype=np.float64)
+    cnt = np.bincount(b, minlength=nb)
+    mx = np.zeros(nb, dtype=np.float64)
+    np.maximum.at(mx, b, np.abs(v))
+    for j in range(nb):
+        if cnt[j] == 0 or mx[j] == 0.0:
+            continue
+        if not np.isfinite(mx[j]):
+            out[j] = np.nan
+            continue
+        e = int(np.frexp(mx[j])[1])                  # mx < 2^e  (frexp: mx = m * 2^e with 0.5 <= m < 1), = ilogb + 1
+        L = int(cnt[j] - 1).bit_length() if cnt[j] > 1 else 0
+        k = 62 - L - e
+        t = np.ldexp(v[b == j], k)                   # exact scaling (|t| < 2^62 / c)
+        n = int(np.rint(t).astype(np.int64).sum(dtype=np.int64))      # np.rint: half to even; |sum| < 2^63
+        out[j] = np.ldexp(np.float64(n), -k)         # float(n): one rounding to 53 bits
+    return out
+
+
+def histogram_cdf(q, b, weights, lt, right_edge='xhistogram', deterministic=False):
     """`_histogram(var, bins, dim, weights, lt)` for one slab (core.py:1296-1325).
 
     Result is in ASCENDING-VALUE order (position i <-> i-th smallest level),
@@ -173,7 +205,7 @@ def histogram_cdf(q, b, weights, lt, right_edge='xhistogram'):
     edges, bincrease = hist_edges(b)
     q = np.asarray(q)
     w = np.broadcast_to(np.asarray(weights), q.shape)
-    pdf, counts = weighted_histogram(q, edges, w, right_edge)
+    pdf, counts = weighted_histogram(q, edges, w, right_edge, deterministic)
     cdf = np.cumsum(pdf)                                     # core.py:1320
     if not lt:
         cdf = cdf[-1] - cdf                                  # core.py:1322-1323
@@ -195,11 +227,11 @@ def _weights(dA, integrand, shape):
 
 
 def cal_integral_within_contours_hist(q, ctr, dA, integrand=None, lt=False,
-                                      right_edge='xhistogram', return_counts=False):
+                                      right_edge='xhistogram', return_counts=False, deterministic=False):
     """core.py:412-460 for one slab: out[k] <-> ctr[k] whatever the direction."""
     q = np.asarray(q)
     wei = _weights(dA, integrand, q.shape)
-    cdf, pdf, counts, binc = histogram_cdf(q, ctr, wei, lt, right_edge)
+    cdf, pdf, counts, binc = histogram_cdf(q, ctr, wei, lt, right_edge, deterministic)
     if not binc:                                             # core.py:454-455
         cdf, pdf, counts = cdf[::-1], pdf[::-1], counts[::-1]
     if return_counts:
@@ -701,7 +733,7 @@ def cal_contour_crossing(tracer, ctr, dA, stride=1, mode='edge', has_x=True, dty
 # ---------------------------------------------------------------------------
 def keff_pipeline(q, dA, lat, N, grdS=None, lon=None, mask=None, increase=True,
                   lt=True, dtype=np.float32, preLats=None, right_edge='xhistogram',
-                  nkeff_mask=1e5):
+                  nkeff_mask=1e5, deterministic=False):
     """One slab, hist API, steps 1-10 of SURVEY 3.1.  Returns a dict of
     ndarrays on the contour dim (+ '<name>_eq' on preLats if given)."""
     q = np.asarray(q)
@@ -712,8 +744,8 @@ def keff_pipeline(q, dA, lat, N, grdS=None, lon=None, mask=None, increase=True,
     tbl, cs = cal_area_eqCoord_table_hist(mask, dA, lat, increase, lt, right_edge)
     ctr = cal_contours(q, N, increase, dtype)
     area, counts = cal_integral_within_contours_hist(q, ctr, dA, None, lt,
-                                                     right_edge, return_counts=True)
-    intgrdS = cal_integral_within_contours_hist(q, ctr, dA, grdS, lt, right_edge)
+                                                     right_edge, return_counts=True, deterministic=deterministic)
+    intgrdS = cal_integral_within_contours_hist(q, ctr, dA, grdS, lt, right_edge, deterministic=deterministic)
     latEq = lookup_coordinates(area, tbl, cs)
     Lmin = latitude_lengths_at(latEq)
     dintSdA = cal_gradient_wrt_area(intgrdS, area)

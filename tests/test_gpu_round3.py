@@ -69,6 +69,9 @@ def test_deterministic_pipeline_is_order_free(ctx, dt, cd):
     for s in range(S):
         r = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=True, lt=True, dtype=cd)
         check_nine_det(d, s, r)
+        # the oracle's own restatement of the fixed-point rule (deterministic_bin_sums): the SAME BITS, sums included
+        rd = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=True, lt=True, dtype=cd, deterministic=True)
+        assert np.array_equal(bits(d['area'][s]), bits(rd['area'])) and np.array_equal(bits(d['intgrdS'][s]), bits(rd['intgrdS']))
     det.free(); plain.free()
 
 
@@ -97,12 +100,18 @@ def test_deterministic_hist_channels_and_odd_inputs(ctx):
         for ch in range(3):
             scale = np.abs(plain['pdf'][:, ch]).max(axis=1, keepdims=True) + 1e-300
             assert (np.abs(a['pdf'][:, ch] - plain['pdf'][:, ch]) / scale).max() < 1e-10, ch
-        # the area channel against numpy's histogram (no cell sits on the last edge, so the closed last bin is moot)
+        # the area channel against numpy's histogram (no cell sits on the last edge, so the closed last bin is moot), and the
+        # area + SIGNED integrand channels bit for bit against the oracle's restatement of the fixed-point rule
         w = np.where(np.isnan(dA), 0.0, dA)
         for s in range(S):
             assert not (q[s] == edges[-1]).any()
             ref, _ = np.histogram(q[s].astype(np.float64).ravel(), bins=edges, weights=w.ravel())
             assert rel(a['pdf'][s, 0], ref) < 1e-12
+            od, _ = O.weighted_histogram(q[s].astype(np.float64), edges, w, 'numpy', deterministic=True)
+            assert np.array_equal(bits(a['pdf'][s, 0]), bits(od))
+            wg = g[s] * dA
+            oi, _ = O.weighted_histogram(q[s].astype(np.float64), edges, np.where(np.isnan(wg), 0.0, wg), 'numpy', deterministic=True)
+            assert np.array_equal(bits(a['pdf'][s, 1]), bits(oi))
 
 
 def test_deterministic_infinite_weight_reports_nan(ctx):
@@ -135,6 +144,8 @@ def test_cfg2_full_size_deterministic(ctx):
     q = plan.download_q()
     r = O.keff_pipeline(q[1], dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float64)
     check_nine_det(a, 1, r)
+    rd = O.keff_pipeline(q[1], dA, lat, N, lon=lon, increase=True, lt=True, dtype=np.float64, deterministic=True)
+    assert np.array_equal(bits(a['area'][1]), bits(rd['area'])) and np.array_equal(bits(a['intgrdS'][1]), bits(rd['intgrdS']))   # 6.5 M cells, bit for bit
     plan.free()
 
 

@@ -251,3 +251,27 @@ def test_levels_against_the_reference_notebook_printout():
         st = np.float32(1.0 / (N - 1)) * (mx - mn)
         return (st * np.arange(N, dtype=np.float32) + mn).astype(np.float32)
     assert any(len(nb1_max_candidates(f, l, N, all_f32)) == 0 for f, l in rows.values())
+
+
+def test_deterministic_bin_sums_rule():
+    """the build-defined order-free summation rule (oracle.deterministic_bin_sums; the GPU reproduces it bit for bit in
+    tests/test_gpu_round3.py): independent of the order of the cells, within a few ulp of np.bincount on benign weights,
+    exact on integers, NaN for a bin with an infinite weight"""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal(50000)
+    w = rng.standard_normal(50000) * 10.0 ** rng.integers(-6, 6, 50000)
+    e = np.linspace(-3, 3, 41)
+    a, c = O.weighted_histogram(x, e, w, 'numpy', deterministic=True)
+    for _ in range(3):
+        p = rng.permutation(len(x))
+        b, c2 = O.weighted_histogram(x[p], e, w[p], 'numpy', deterministic=True)
+        assert np.array_equal(a.view(np.int64), b.view(np.int64)) and np.array_equal(c, c2)
+    f, _ = O.weighted_histogram(x, e, w, 'numpy')
+    scale = np.array([np.abs(w[(x >= e[k]) & (x < e[k + 1])]).sum() for k in range(40)])
+    assert (np.abs(a - f) <= 1e-14 * scale).all()
+    wi = rng.integers(-1000, 1000, 50000).astype(np.float64)
+    ai, _ = O.weighted_histogram(x, e, wi, 'numpy', deterministic=True)
+    assert np.array_equal(ai, np.array([wi[(x >= e[k]) & (x < e[k + 1])].sum() for k in range(40)]))
+    w2 = np.abs(w); w2[np.argmin(np.abs(x))] = np.inf
+    an, _ = O.weighted_histogram(x, e, w2, 'numpy', deterministic=True)
+    assert np.isnan(an).sum() == 1 and np.isfinite(np.delete(an, np.argmax(np.isnan(an)))).all()

@@ -142,17 +142,18 @@ __device__ __forceinline__ void lds_add(unsigned long long* p, unsigned long lon
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// rint(w * 2^k) as a two's-complement 64-bit integer, |w * 2^k| < 2^62 (the deterministic sums, xc_hist_det.hip).  gfx950 has
-// no f64 -> i64 conversion: split t = hi * 2^32 + lo with hi = floor(t / 2^32) (exact: a power-of-two scaling, a floor and an
-// FMA that cancels), 0 <= lo <= 2^32, and convert the halves.  A function of (w, k) alone: the same cell always
-// contributes the same integer.  (lo == 2^32 after rounding -- one case in 2^33 -- saturates to 2^32 - 1: one unit of
-// 2^-k, still the same integer every time.)
+// rint(w * 2^k) (half to even) as a two's-complement 64-bit integer, |w * 2^k| < 2^62 (the deterministic sums,
+// xc_hist_det.hip; the oracle's deterministic_bin_sums is np.rint(np.ldexp(w, k)).astype(int64)).  gfx950 has no f64 -> i64
+// conversion: split t = hi * 2^32 + lo with hi = floor(t / 2^32) (exact: a power-of-two scaling, a floor and an FMA that
+// cancels), 0 <= lo < 2^32, round lo -- the fraction and the parity of t are those of lo, so rint(lo) completes rint(t) --
+// and convert the halves; rint(lo) == 2^32 saturates the 32-bit conversion and is carried into the high half.
 __device__ __forceinline__ unsigned long long fixed_point(double w, int k)
 {
     const double t = ldexp(w, k);
     const double th = floor(t * 0x1p-32);
     const double tl = rint(__builtin_fma(th, -0x1p32, t));
-    return ((unsigned long long)(long long)(int)th << 32) + (unsigned long long)(unsigned)tl;
+    const unsigned long long lo = (unsigned long long)(unsigned)tl + (tl >= 0x1p32 ? 1ull : 0ull);
+    return ((unsigned long long)(long long)(int)th << 32) + lo;
 }
 __device__ __forceinline__ void lds_max(unsigned long long* p, unsigned long long v)      // ds_max_u64
 {
