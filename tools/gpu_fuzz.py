@@ -76,6 +76,10 @@ def case_hist():
         if last:
             assert np.array_equal(oc, c), 'oracle counts'
             assert relerr(out['pdf'][s, 0], p) < 1e-12, 'hist pdf'
+            if det:                                                 # the fixed-point rule restated in numpy: the same bits
+                pd_, _ = O.weighted_histogram(x, ed, w, 'numpy', deterministic=True)
+                assert np.array_equal(out['pdf'][s, 0].view(np.int64), pd_.view(np.int64)), 'deterministic pdf vs oracle bits'
+                tick('hist_deterministic_oracle_bits')
             tick('hist')
 
 
