@@ -200,7 +200,7 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
 //       the union;  (d) wei = dA / max(dA) and a 2-D metric are staged for the union band only, `wchunk` rows at a time -- the
 //       f64 divisions are done for the rows that matter, once per workgroup;  (e) the waves walk their bands out of LDS.
 // Same arithmetic and order as k_lwa (bit-identical).  k_lwa_prep + k_lwa remain for planes whose strip does not fit the LDS.
-constexpr int LWA_SW = 16;                      // waves per workgroup
+constexpr int LWA_SW = 8;                       // waves per workgroup = target rows in flight per workgroup (cfg3: 256 workgroups, one per CU)
 __host__ __device__ inline size_t lwa_strip_lds(int64_t ny, size_t tsize, bool wplane, bool mplane, int wchunk)
 {
     size_t b = (size_t)ny * 6 * 8;                                            // coord, Q, min, max, row wei, row M
@@ -418,7 +418,7 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
             if (!wchunk && lwa_strip_lds(ny, tsz, wpl, mpl, c) <= kLdsBudget) wchunk = c;
         if (wchunk && ctx->knobs.lwa_strip && ny <= 0x7fff && nx <= 0x7fffffff / ny) {
             const int64_t nstrip = (nx + 63) / 64;
-            const int64_t nb16 = (ny + LWA_SW - 1) / LWA_SW;                  // workgroups per strip with 16 targets each
+            const int64_t nb16 = (ny + LWA_SW - 1) / LWA_SW;                  // workgroups per strip with LWA_SW targets each
             // ~2 workgroups per CU; more target rows per workgroup when there is more work than that (the strip is staged once per workgroup)
             // measured on MI355X: this kernel wins while its grid does not fill the chip twice (cfg3 alone: 13 us against 5 + 19 for
             // prologue + streaming kernel); stacks that do are VALU-bound either way and the streaming kernel's four targets per
