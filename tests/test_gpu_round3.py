@@ -437,3 +437,37 @@ def test_hist_all_nan_rows_and_land_mask(ctx):
         rw, _ = np.histogram(q[s][ok], bins=edges, weights=dA[ok])
         assert np.array_equal(out['counts'][s].astype(np.int64), rc)
         assert rel(out['pdf'][s, 0], rw) < 1e-12
+
+
+def test_keff_double_buffered_batches_with_supplied_grdS_and_per_slab_dA(ctx, baro):
+    """the multi-batch path of Contour2D.keff (two device halves, uploads on the copy stream) with everything that travels per
+    slab -- the tracer, a supplied squared gradient, time-varying weights -- against the single-batch result and the oracle"""
+    import xcontour_amd as xa
+    q0, lat, lon = baro
+    S = 5
+    rng = np.random.default_rng(14)
+    q = np.stack([q0 * (1 + 0.05 * s) for s in range(S)])
+    g = (rng.random(q.shape) * 1e-16).astype(np.float32)
+    dA0 = O.cell_area(lat, lon)
+    dA3 = np.stack([dA0 * (1 + 0.01 * s) for s in range(S)])
+    c3 = {'time': np.arange(S), 'latitude': lat, 'longitude': lon}
+    c2 = {'latitude': lat, 'longitude': lon}
+    tr = xa.DataArray(q, ('time', 'latitude', 'longitude'), c3, 'absolute_vorticity')
+    gs = xa.DataArray(g, ('time', 'latitude', 'longitude'), c3, 'grdS')
+    mask = xa.DataArray(np.ones_like(q0), ('latitude', 'longitude'), c2, 'mask')
+    for dA in (xa.DataArray(dA0, ('latitude', 'longitude'), c2, 'rA'), xa.DataArray(dA3, ('time', 'latitude', 'longitude'), c3, 'rA')):
+        cm = xa.Contour2D(tr, dA, dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True)
+        table = xa.Contour2D(tr, xa.DataArray(dA0, ('latitude', 'longitude'), c2, 'rA'), dims={'X': 'longitude', 'Y': 'latitude'},
+                             dimEq={'Y': 'latitude'}, increase=True, lt=True).cal_area_eqCoord_table_hist(mask)
+        one = cm.keff(31, table, grdS=gs)
+        per = q0.nbytes + g[0].nbytes + (dA0.nbytes if dA.values.ndim == 3 else 0)
+        many = cm.keff(31, table, grdS=gs, max_batch_bytes=2 * per * 2 + 100)          # two slabs per half: batches 2 + 2 + 1
+        for k in ('ctr', 'area', 'intgrdS', 'latEq', 'nkeff'):
+            a, b = many[k].values, one[k].values
+            assert np.array_equal(a, b) if k == 'ctr' else rel(a, b) < 1e-9, k
+        for s in (0, S - 1):
+            w = dA.values if dA.values.ndim == 2 else dA.values[s]
+            r = O.keff_pipeline(q[s], w, lat, 31, grdS=g[s], increase=True, lt=True, dtype=np.float32)
+            assert np.array_equal(many['ctr'].values[s], r['ctr'].astype(np.float64))
+            assert rel(many['area'].values[s], r['area']) < TIGHT and rel(many['intgrdS'].values[s], r['intgrdS']) < 1e-6
+        cm.close()
