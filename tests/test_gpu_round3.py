@@ -152,7 +152,7 @@ def test_cfg2_full_size_deterministic(ctx):
 # ---------------------------------------------------------------- N > 1 with real pipeline output
 def _cfg4_block(ctx, lo, hi, chunk, det):
     """this rank's (hi - lo, 9, N) block of the cfg4-shaped stack: chained launch sets of `chunk` slabs (ragged last set),
-    result slots -> slab-major block (the flow of bench.py's cfg4_strong / tools/bench_cfg4.py)"""
+    result slots -> slab-major block (the flow of bench.py's cfg4_strong)"""
     import ctypes as C
     from xcontour_amd import _native as nat
     from xcontour_amd.pipeline import KeffPlan

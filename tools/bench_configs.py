@@ -138,7 +138,7 @@ def run_cfg5(ctx, steps, warmup):
 
 
 def run_cfg4(ctx, steps, warmup, slabs=2048, chunk=256):
-    """one GPU: `slabs` of the 18 944 slabs of cfg4 (the multi-GPU driver is tools/bench_cfg4.py: static slab partition +
+    """one GPU: `slabs` of the 18 944 slabs of cfg4 (the multi-GPU job is bench.py's cfg4_strong block: static slab partition +
     one RCCL gather; here the single-GPU rate with the histogram pass timed launch by launch)"""
     import ctypes as C
     from xcontour_amd import _native as nat
