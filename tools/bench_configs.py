@@ -76,10 +76,11 @@ def run_cfg3(ctx, steps, warmup):
         'config': {'workload': 'cfg3: barotropic_vorticity 256x512 f32, sorted state from 121 contours, J = 256 target latitudes, '
                                'cal_local_wave_activity part=all, legacy dy metric', 'device': ctx.device_name()},
         'roofline': {'bound': 'hbm', 'achieved': alg / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_lwa (+ k_lwa_prep)', 'launch_ms': ms,
+                     'frac': alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_lwa_strip (one launch)', 'launch_ms': ms,
                      'algorithmic_bytes_per_launch': alg,
-                     'note': 'compulsory bytes are 2.6 MB for 33.5 M (target row, cell) pairs: the kernel is bound by the latency of its '
-                             'widest contributing band and by f64 VALU, not by HBM; the fraction is reported as the contract asks'},
+                     'note': 'compulsory bytes are 2.6 MB for 33.5 M (target row, cell) pairs: the kernel is a chain of dependent round '
+                             'trips (strip load, extrema, band, weights, band walk) and VALU-bound inside a CU, not by HBM; the fraction is '
+                             'reported as the contract asks'},
         'cpu_baseline': {'value': work / tc, 'unit': 'cell-rows/s', 'cores': 1, 'kind': 'port',
                          'sample': 'the whole cfg3 workload once through the numpy oracle (the reference\'s 256-iteration python loop, '
                                    'core.py:752-791): %.3f s; bit-identical to the GPU result; host: %s' % (tc, _host())},
@@ -117,8 +118,10 @@ def run_cfg5(ctx, steps, warmup):
         raise RuntimeError('cfg5 parity check against the oracle FAILED (BPE rel err %g)' % err)
     nvalid = int(maskC.sum())
     cells = S * nz * nxx
-    passes = 8                                                 # 64-bit keys, 8-bit digits
-    alg = S * nvalid * (passes * (8 + 2 * 16) + 8 + 8)         # per pass: key read for the histogram + (key, payload) read and written
+    path = ctx.last_sort_path()                                # 1: three passes over the 24-bit range key + run repair; else 8 key passes
+    passes = 3 if path == 1 else (11 if path == 2 else 8)
+    # per pass: key read for the histogram + (key, payload) read and written; range path: + the repair pass (read 16, rare writes); + the scan
+    alg = S * nvalid * (passes * (8 + 2 * 16) + (16 if path == 1 else 0) + 8 + 8)
     return {
         'metric': 'exact adiabatic sort + Q(z*) + BPE: cells / s (cfg5 stand-in)', 'value': cells / (ms * 1e-3), 'unit': 'cells/s',
         'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
@@ -127,10 +130,12 @@ def run_cfg5(ctx, steps, warmup):
                                'sort of (buoyancy, area) pairs + cumulative area + Q at %d levels + BPE integral' % (S, nz, nxx, nz),
                    'device': ctx.device_name()},
         'roofline': {'bound': 'hbm', 'achieved': alg / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'k_radix_hist + k_radix_scan_rows + k_radix_scatter x 8 passes',
-                     'launch_ms': ms, 'algorithmic_bytes_per_launch': alg,
-                     'note': 'pass traffic of an 8-pass LSD radix sort (40 B per valid pair and pass); at 0.4 M pairs per section the '
-                             '~25 dependent launches are latency-bound, the 6.48 M-pair sort of a cfg2 slab reaches ~3.5 TB/s (profiles/)'},
+                     'frac': alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                     'kernel': '(k_radix_hist + k_radix_scan_rows + k_radix_scatter) x %d passes%s' % (passes, ' over the range key + k_fix_runs' if path == 1 else ''),
+                     'launch_ms': ms, 'algorithmic_bytes_per_launch': alg, 'sort_path': path,
+                     'note': 'pass traffic of the LSD radix sort (40 B per valid pair and pass; float64 tracers: three passes over a monotone '
+                             '24-bit range key, in-LDS repair of the short runs, eight key passes only as the fallback); at 0.4 M pairs per '
+                             'section the ~20 dependent launches are latency-bound, the 6.48 M-pair sort of a cfg2 slab moves ~2.5 TB/s (profiles/)'},
         'cpu_baseline': {'value': cells / tc, 'unit': 'cells/s', 'cores': 1, 'kind': 'port',
                          'sample': 'the %d sections once through the numpy oracle (stable argsort + cumsum + interp + sum): %.3f s; '
                                    'BPE relative difference %.1e; host: %s' % (S, tc, err, _host())},
