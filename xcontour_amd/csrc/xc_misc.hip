@@ -184,6 +184,23 @@ __device__ __forceinline__ double grad_f32(const double* f, int k, int N)
     return (double)__fdiv_rn(__fsub_rn((float)f[k + 1], (float)f[k - 1]), 2.0f);
 }
 
+// lane i <- lane i - 1 (DPP wave_shr:1, off the LDS pipe); lane 0 keeps `old`
+__device__ __forceinline__ double lane_shr1_keep(double v, double old)
+{
+    const unsigned long long u = __double_as_longlong(v), o = __double_as_longlong(old);
+    const unsigned lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffu), (int)(u & 0xffffffffu), 0x138, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(u >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// the value lane `idx` holds (idx wave-uniform)
+__device__ __forceinline__ double lane_value(double v, int idx)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffu), idx);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(u >> 32), idx);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 // Stage 1: sum the per-block partial histograms of K3 in a fixed order.  8 values per
 // 256-thread block, 32 lanes per value (each lane owns partials l, l+32, ...), then a
 // fixed xor-shuffle tree: deterministic, fully parallel (no serial latency chain).
@@ -234,25 +251,37 @@ void k_finalize(const FinalArgs a)
         for (int u = 0; u < TB; ++u) { const int i = tid + u * nthr; const int ic = i < a.ntbl ? i : a.ntbl - 1; tb_t[u] = a.tbl[ic]; tb_c[u] = a.tbl_coord[ic]; }
     }
     if (a.fuse_reduce) {
-        // stage 1 folded in: the per-block partials of this slab summed in block order (fixed: deterministic), four loads in flight
-        const int nvh = NCH * N;
-        const double* pp = a.part_h + (size_t)slab * a.bps * nvh;
-        for (int i = tid; i < nvh; i += nthr) {
-            double sum = 0.0;
-            int b = 0;
-            for (; b + 4 <= a.bps; b += 4) {
-                const double v0 = pp[(size_t)b * nvh + i], v1 = pp[(size_t)(b + 1) * nvh + i], v2 = pp[(size_t)(b + 2) * nvh + i], v3 = pp[(size_t)(b + 3) * nvh + i];
-                sum = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(sum, v0), v1), v2), v3);
-            }
-            for (; b < a.bps; ++b) sum = __dadd_rn(sum, pp[(size_t)b * nvh + i]);
-            s_pdf[i] = sum;
-        }
-        if (a.counts) {
-            const unsigned* pc = a.part_c + (size_t)slab * a.bps * N;
-            for (int i = tid; i < N; i += nthr) {
+        // stage 1 folded in: the per-block partials of this slab summed in block order (fixed: deterministic).  The partials were
+        // written by other XCDs a moment ago: every load is a ~1 us round trip to the fabric, so what matters is how many are in
+        // flight -- RB blocks per thread and round (cfg2: 20 blocks per slab, five dependent rounds of four loads, two elements
+        // one after the other, took 12 of this kernel's 25 us; now one round)
+        constexpr int RB = 20;
+        const int nvh = NCH * N, bps = a.bps, nel = nvh + (a.counts ? N : 0);
+        const double* pp = a.part_h + (size_t)slab * bps * nvh;
+        const unsigned* pc = a.part_c + (size_t)slab * bps * N;
+        // one element per thread (launch_finalize sizes the workgroup for it): the weighted sums first, the counts behind them
+        for (int i = tid; i < nel; i += nthr) {
+            if (i < nvh) {
+                double sum = 0.0;
+                for (int b = 0; b < bps; b += RB) {
+                    double v[RB];
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) v[u] = pp[(size_t)(b + u < bps ? b + u : bps - 1) * nvh + i];
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) if (b + u < bps) sum = __dadd_rn(sum, v[u]);
+                }
+                s_pdf[i] = sum;
+            } else {
+                const int k = i - nvh;
                 unsigned long long c = 0;
-                for (int b = 0; b < a.bps; ++b) c += pc[(size_t)b * N + i];
-                a.counts[(size_t)slab * N + (a.reverse ? N - 1 - i : i)] = c;
+                for (int b = 0; b < bps; b += RB) {
+                    unsigned v[RB];
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) v[u] = pc[(size_t)(b + u < bps ? b + u : bps - 1) * N + k];
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) if (b + u < bps) c += v[u];
+                }
+                a.counts[(size_t)slab * N + (a.reverse ? N - 1 - k : k)] = c;
             }
         }
     } else {
@@ -264,15 +293,40 @@ void k_finalize(const FinalArgs a)
         }
     }
     __syncthreads();
-    if (tid < NCH) {                      // np.cumsum order (core.py:1320)
-        const double* p = s_pdf + (size_t)tid * N;
-        double* c = s_cdf + (size_t)tid * N;
-        double run = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < N; ++k) { run = __dadd_rn(run, p[k]); c[k] = run; }
-        if (!a.lt) { const double tot = c[N - 1]; for (int k = 0; k < N; ++k) c[k] = __dsub_rn(tot, c[k]); }   // core.py:1322-1323
-        if (a.reverse)                    // core.py:454-455
-            for (int k = 0; k < N / 2; ++k) { const double t = c[k]; c[k] = c[N - 1 - k]; c[N - 1 - k] = t; }
+    {
+        // np.cumsum order (core.py:1320), strictly left to right, one WAVE per channel.  A chain of N dependent adds is all the
+        // arithmetic there is; one thread walking the LDS paid ~85 cycles per element (load, add, store, loop: 7 us for 201
+        // bins).  Systolic instead: lane l holds elements 4l .. 4l + 3 of a 256-element chunk, every step is
+        // r0 = (r3 of lane l - 1; lane 0: the carry) + x0, r1 = r0 + x1, ... on all lanes -- two DPP moves and four adds.  After
+        // step t lanes 0..t hold their final sums (a lane past its step recomputes the same values from a neighbour that no longer
+        // changes), so 64 steps finish a chunk, in exactly the order ((p0 + p1) + p2) + ...
+        const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+        for (int ch = wave; ch < NCH; ch += nw) {
+            const double* p = s_pdf + (size_t)ch * N;
+            double* c = s_cdf + (size_t)ch * N;
+            double carry = 0.0;
+            for (int k0 = 0; k0 < N; k0 += 256) {
+                const int k = k0 + 4 * lane;
+                double x[4], r[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = k + e < N ? p[k + e] : 0.0;      // (past N: + 0.0, the running sum stays)
+#pragma unroll 4
+                for (int t = 0; t < 64; ++t) {
+                    r[0] = __dadd_rn(lane_shr1_keep(r[3], carry), x[0]);
+                    r[1] = __dadd_rn(r[0], x[1]); r[2] = __dadd_rn(r[1], x[2]); r[3] = __dadd_rn(r[2], x[3]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (k + e < N) c[a.reverse ? N - 1 - k - e : k + e] = r[e];   // level order (core.py:454-455)
+                carry = lane_value(r[3], 63);
+            }
+            if (!a.lt)                                                // core.py:1322-1323; every lane revisits its own elements
+                for (int k0 = 0; k0 < N; k0 += 256)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = k0 + 4 * lane + e;
+                        if (k < N) { const int o = a.reverse ? N - 1 - k : k; c[o] = __dsub_rn(carry, c[o]); }
+                    }
+        }
     }
     __syncthreads();
     for (int i = tid; i < NCH * N; i += nthr) {
@@ -483,6 +537,7 @@ int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab,
 int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
 {
     FinalArgs a = a_in;
+    hipStream_t st = ctx->stream;
     size_t lds = ((size_t)2 * a.nch * a.nbin + (a.keff ? 7 * (size_t)a.nbin : 0)) * sizeof(double);
     a.big = nullptr; a.big_stride = 0;
     if (lds > kLdsBudget) {               // work arrays in global memory instead
@@ -503,12 +558,16 @@ int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
     // few partials per slab (the Keff pipeline: ~20): stage 1 runs inside stage 2's workgroup, one launch less
     a.fuse_reduce = (!a.skip_reduce && a.bps <= 64 && !a.big) ? 1 : 0;
     if (!a.skip_reduce && !a.fuse_reduce) {
-        hipLaunchKernelGGL(k_reduce_partials, g1, dim3(256), 0, ctx->stream, a.part_h, a.part_c, a.bps, nvh, a.nbin,
+        hipLaunchKernelGGL(k_reduce_partials, g1, dim3(256), 0, st, a.part_h, a.part_c, a.bps, nvh, a.nbin,
                            a.red_h, a.red_c);
         XC_HIP(ctx, hipGetLastError());
     }
-    const int nthr = (a.keff && a.o_interp && a.npre > 256) ? 1024 : 256;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)nslab), dim3(nthr), lds, ctx->stream, a);
+    int nthr = (a.keff && a.o_interp && a.npre > 256) ? 1024 : 256;
+    if (a.fuse_reduce) {                 // one thread per partial sum to reduce: all loads of the reduction in flight at once
+        const int want = ((nvh + (a.counts ? a.nbin : 0) + 63) / 64) * 64;
+        nthr = want > 1024 ? 1024 : (want > nthr ? want : nthr);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)nslab), dim3(nthr), lds, st, a);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
 }
