@@ -391,7 +391,7 @@ def main():
     ap.add_argument('--long-run-s', type=float, default=0.5, help='seconds of extra steps with per-launch events (long_run)')
     ap.add_argument('--no-cfg4', action='store_true', help='skip the cfg4 strong-scaling block')
     ap.add_argument('--cfg4-slabs', type=int, default=512 * 37)
-    ap.add_argument('--cfg4-chunk', type=int, default=256, help='slabs per launch set of the cfg4 sweep')
+    ap.add_argument('--cfg4-chunk', type=int, default=512, help='slabs per launch set of the cfg4 sweep')
     ap.add_argument('--cfg4-reps', type=int, default=2, help='timed cfg4 jobs (sweep + gather)')
     a = ap.parse_args()
 

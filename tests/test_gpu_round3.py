@@ -471,3 +471,37 @@ def test_keff_double_buffered_batches_with_supplied_grdS_and_per_slab_dA(ctx, ba
             assert np.array_equal(many['ctr'].values[s], r['ctr'].astype(np.float64))
             assert rel(many['area'].values[s], r['area']) < TIGHT and rel(many['intgrdS'].values[s], r['intgrdS']) < 1e-6
         cm.close()
+
+
+# ---------------------------------------------------------------- K5: the cumulative sums keep np.cumsum's order
+@pytest.mark.parametrize('nint', [0, 2])
+def test_cdf_is_the_sequential_cumsum_of_the_pdf_bit_for_bit(ctx, nint):
+    """k_finalize takes the cumulative sums systolically (lanes hold four elements each, 256 per chunk): for bin counts
+    around the lane / chunk boundaries, for thousands of bins (work arrays in LDS and, with three channels, in global
+    memory), for `lt` or not and both level orders, cdf is bit-identical to np.cumsum of the returned pdf (core.py:1320-1323)"""
+    rng = np.random.default_rng(5)
+    ny, nx = 40, 96
+    q = rng.standard_normal((2, ny, nx))
+    dA = rng.random((ny, nx)) + 0.1
+    integ = [rng.standard_normal((2, ny, nx)) for _ in range(nint)]
+    for nb in (1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 300, 513, 1023, 4000 if nint == 0 else 3500):
+        edges = np.linspace(-3.0, 3.0, nb + 1)
+        for lt in (True, False):
+            for reverse in (False, True):
+                out = ctx.hist(q, edges, dA, integ, lt=lt, reverse=reverse)
+                pdf = out['pdf'][..., ::-1] if reverse else out['pdf']             # ascending-value order
+                c = np.cumsum(pdf, axis=-1)
+                if not lt:
+                    c = c[..., -1:] - c
+                if reverse:
+                    c = c[..., ::-1]
+                assert np.array_equal(bits(out['cdf']), bits(c)), (nb, lt, reverse)
+                assert out['counts'].sum() <= 2 * ny * nx
+    # and against the oracle's weighted histogram for one of them
+    edges = np.linspace(-3.0, 3.0, 258)
+    out = ctx.hist(q, edges, dA, integ, lt=True)
+    for s in range(2):
+        for ch, w in enumerate([dA] + [v[s] * dA for v in integ]):
+            ref, cnt = O.weighted_histogram(q[s], edges, w, right_edge='numpy')
+            assert np.array_equal(out['counts'][s].astype(np.int64), cnt)
+            assert rel(out['pdf'][s].reshape(1 + nint, -1)[ch], ref) < TIGHT
