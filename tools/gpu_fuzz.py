@@ -43,7 +43,7 @@ def case_hist():
     S, ny, nx = int(rng.integers(1, 5)), int(rng.integers(1, 90 * SC)), int(rng.integers(1, 300 * SC))
     dt = rng.choice([np.float32, np.float64])
     q = field(S, ny, nx, dt)
-    nb = int(rng.integers(1, 80))
+    nb = int(rng.integers(1, 80)) if rng.random() < 0.85 else int(rng.integers(80, 700))     # (past 256 bins: several chunks of the in-order scan)
     lo, hi = np.nanmin(q) if np.isfinite(q).any() else 0.0, np.nanmax(q) if np.isfinite(q).any() else 1.0
     ed = np.sort(rng.uniform(lo - 0.1, hi + 0.1, nb + 1)) if rng.random() < 0.5 else np.linspace(lo, hi + 1e-9, nb + 1)
     if len(np.unique(ed)) != len(ed):
@@ -92,7 +92,7 @@ def case_keff():
     # row drops out of the A(Yeq) table (the reference's own barotropic_vorticity.nc has float32 latitudes)
     lat = np.linspace(-80, 80, ny).astype(rng.choice([np.float32, np.float64])); lon = np.arange(nx) * (360.0 / nx)
     dA = O.cell_area(lat, lon)
-    N = int(rng.integers(3, 60)); inc = bool(rng.random() < 0.5); lt = bool(rng.random() < 0.5)
+    N = int(rng.integers(3, 60)) if rng.random() < 0.85 else int(rng.integers(60, 400)); inc = bool(rng.random() < 0.5); lt = bool(rng.random() < 0.5)
     re_ = str(rng.choice(['numpy', 'xhistogram']))
     ylt = lt if inc else (not lt)
     rows = ctx.rowsum(None, dA, ny, nx)
