@@ -306,7 +306,7 @@ typedef struct xc_keff_desc {
     int32_t       dA_pos_finite;/* caller verified that every dA value is finite and >= 0: the kernel then skips the
                                    fillna(0) selects on the dA channel (optional speed-up; 0 is always safe) */
     int32_t       q_gen;        /* generation of the tracer buffers (see q_next): any change invalidates chained min/max */
-    int32_t       deterministic;/* != 0: order-free fixed-point sums (below); q_next is then ignored (stand-alone K1 pass) */
+    int32_t       deterministic;/* != 0: order-free fixed-point sums (below); q_next rides in their second pass */
     int32_t       reserved0;
 } xc_keff_desc;
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);

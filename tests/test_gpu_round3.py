@@ -57,7 +57,7 @@ def test_deterministic_pipeline_is_order_free(ctx, dt, cd):
     det.set_q_device(plain._q_ptr)
     outs = []
     for slot, group in enumerate((None, None, 1, 2)):
-        det.run(slot, group, chain=(group == 2))                 # chain=True is ignored by the order-free passes
+        det.run(slot, group, chain=(group == 2))                 # chained min / max (q_next) ride in the fixed-point pass
         outs.append(det.fetch(slot=slot))
     for o in outs[1:]:
         for k in NINE:

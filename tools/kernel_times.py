@@ -210,7 +210,7 @@ def cmd_pipe(ctx, T):
                     kw['grdS_dtype'] = dt
                 else:
                     kw.update(lat=lat, lon=lon)
-                for chain in ((False,) if det else (False, True)):
+                for chain in (False, True):
                     emit(kernel='Keff pipeline', tracer=np.dtype(dt).name, contours=np.dtype(cd).name, gradient='supplied grdS' if supplied else 'in-kernel',
                          deterministic=det, chained=chain, slabs_per_launch=B, us_per_slab=pipe_time(ctx, T, B, chain, **kw))
 

@@ -454,11 +454,13 @@ static int check_hist_desc(xc_ctx* ctx, const xc_hist_desc* d)
 static int det_passes(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, HistArgs& a,
                       int* scale, FinalArgs& f)
 {
+    const void* q_next = a.q_next; double* mm_next = a.mm_next;          // the NEXT batch's min / max ride in the second pass
     a.q_next = nullptr; a.mm_next = nullptr; a.det_scale = nullptr;
     XC_TRY(launch_hist_det(ctx, q_dtype, nint, grad, g, nslab, a, 1));
     XC_TRY(launch_det_scales(ctx, nslab, g.bps, f.nch, f.nbin, a.part_h, a.part_c, scale, f.red_c));
     a.det_scale = scale;
     a.ctr_out = nullptr; a.edges_out = nullptr; a.status = nullptr;      // written by the first pass
+    a.q_next = q_next; a.mm_next = mm_next;
     XC_TRY(launch_hist_det(ctx, q_dtype, nint, grad, g, nslab, a, 2));
     XC_TRY(launch_det_reduce(ctx, nslab, g.bps, f.nch, f.nbin, a.part_h, scale, f.red_h));
     f.skip_reduce = 1;
@@ -845,7 +847,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     if (d->npre < 0 || (d->npre > 0 && d->interp && !d->preY)) return fail(ctx, XC_EBADARG, "xc_keff: preY is NULL");
     const int N = d->N, nch = 2;
     const int det = d->deterministic ? 1 : 0;
-    const void* q_next = det ? nullptr : d->q_next;          // the order-free passes do not chain: K1 runs on its own
+    const void* q_next = d->q_next;                          // (deterministic sums: carried by the fixed-point pass)
     HistGeom g;
     {
         const void* gi[1] = {d->grdS}; const int32_t gt[1] = {d->grdS_dtype};

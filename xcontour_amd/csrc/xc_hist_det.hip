@@ -34,6 +34,14 @@ int det_two(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a, in
     if (det == 1)
         return da2d ? launch_three<TQ, VEC, NINT, GRAD, true, false, false, 1>(ctx, g, nslab, a)
                     : launch_three<TQ, VEC, NINT, GRAD, false, false, false, 1>(ctx, g, nslab, a);
+    // the fixed-point pass of the two Keff layouts (in-kernel gradient; one supplied integrand) can carry the NEXT batch's
+    // min / max like the default kernel does (xc_keff_desc.q_next): the stand-alone K1 pass of the next call disappears
+    if constexpr ((GRAD && NINT == 0) || (!GRAD && NINT == 1)) {
+        if (a.q_next)
+            return da2d ? launch_three<TQ, VEC, NINT, GRAD, true, true, false, 2>(ctx, g, nslab, a)
+                        : launch_three<TQ, VEC, NINT, GRAD, false, true, false, 2>(ctx, g, nslab, a);
+    }
+    if (a.q_next) return fail(ctx, XC_EBADARG, "xc_hist: q_next rides in the Keff layouts only");
     return da2d ? launch_three<TQ, VEC, NINT, GRAD, true, false, false, 2>(ctx, g, nslab, a)
                 : launch_three<TQ, VEC, NINT, GRAD, false, false, false, 2>(ctx, g, nslab, a);
 }
@@ -120,7 +128,7 @@ int launch_hist_det(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom
 {
     if (det != 1 && det != 2) return fail(ctx, XC_EBADARG, "xc_hist: det must be 1 or 2");
     if (det == 2 && !a.det_scale) return fail(ctx, XC_EBADARG, "xc_hist: the fixed-point pass needs its exponents");
-    if (a.q_next) return fail(ctx, XC_EBADARG, "xc_hist: q_next is not available with deterministic sums");
+    if (a.q_next && (det != 2 || !a.mm_next)) return fail(ctx, XC_EBADARG, "xc_hist: q_next rides in the fixed-point pass only");
     if (g.vec == 4) return fail(ctx, XC_EBADARG, "xc_hist: no four-cell variant with deterministic sums");
     if (q_dtype == XC_F64)
         return g.vec == 2 ? det_one<double, 2>(ctx, nint, grad, g, nslab, a, det) : det_one<double, 1>(ctx, nint, grad, g, nslab, a, det);

@@ -52,7 +52,7 @@ class KeffPlan(object):
         `replicate_dA`: store a (ny,nx) dA once PER SLAB on the device and run the per-slab-weights path
         (XC_DA_SLAB) on it -- what a time-varying metric costs, without a (nslab,ny,nx) host array.
         `deterministic`: order-free fixed-point sums (xc_keff_desc.deterministic): area / intgrdS and everything derived
-        from them are bit-identical between runs, launch-set sizes and ranks; chaining (q_next) is ignored."""
+        from them are bit-identical between runs, launch-set sizes and ranks, chained (q_next) or not."""
         self.ctx = ctx
         self.nslab, self.ny, self.nx, self.N = int(nslab), int(ny), int(nx), int(N)
         self.q_dtype, self.ctr_dtype = np.dtype(q_dtype), np.dtype(ctr_dtype)
