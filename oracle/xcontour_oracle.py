@@ -592,6 +592,8 @@ def sorted_profile(q, dA, tbl_targets, mask=None):
     order = np.argsort(x, kind='stable')
     xs, ws = x[order], w[order]
     acum = np.cumsum(ws)
+    if len(xs) == 0:                             # nothing valid (an all-NaN / fully masked plane): no state to look up
+        return np.full(np.shape(tbl_targets), np.nan), xs, acum
     idx = np.searchsorted(acum, np.asarray(tbl_targets, dtype=np.float64), side='right')
     idx = np.minimum(idx, len(xs) - 1)
     return xs[idx], xs, acum

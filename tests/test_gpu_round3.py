@@ -505,3 +505,22 @@ def test_cdf_is_the_sequential_cumsum_of_the_pdf_bit_for_bit(ctx, nint):
             ref, cnt = O.weighted_histogram(q[s], edges, w, right_edge='numpy')
             assert np.array_equal(out['counts'][s].astype(np.int64), cnt)
             assert rel(out['pdf'][s].reshape(1 + nint, -1)[ch], ref) < TIGHT
+
+
+def test_sort_profile_of_planes_without_valid_cells(ctx):
+    """an all-NaN plane inside a stack: nvalid 0 and NaN for every target on that plane (the oracle's rule), the other planes
+    unaffected; both sort paths"""
+    rng = np.random.default_rng(3)
+    ny, nx = 37, 130
+    dA = rng.random((ny, nx)) + 0.1
+    tg = np.linspace(0.0, dA.sum(), 7)
+    for dt in (np.float64, np.float32):
+        q = rng.standard_normal((3, ny, nx)).astype(dt)
+        q[1] = np.nan
+        r = ctx.sort_profile(q, dA=dA, targets=tg, want_sorted=True, want_acum=True)
+        assert list(r['nvalid']) == [ny * nx, 0, ny * nx]
+        for s in range(3):
+            Q, xs, acum = O.sorted_profile(q[s], dA, tg)
+            assert np.array_equal(r['Q'][s], Q.astype(np.float64), equal_nan=True)
+            n = int(r['nvalid'][s])
+            assert np.array_equal(r['q_sorted'][s][:n], xs.astype(np.float64))

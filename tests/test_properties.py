@@ -78,6 +78,15 @@ def test_sorted_profile_property(q):
     assert abs(acum[-1] - dA.sum()) <= 1e-12 * dA.sum() and Q[0] == xs[0] and Q[-1] == xs[-1]
 
 
+def test_sorted_profile_of_a_plane_without_valid_cells():
+    """an all-NaN (or fully masked) plane has no sorted state: NaN for every target, empty sorted arrays"""
+    q = np.full((3, 4), np.nan)
+    Q, xs, acum = O.sorted_profile(q, np.ones((3, 4)), [0.0, 1.0])
+    assert np.isnan(Q).all() and Q.shape == (2,) and len(xs) == 0 and len(acum) == 0
+    Q, xs, acum = O.sorted_profile(np.arange(12.0).reshape(3, 4), np.ones((3, 4)), [0.0], mask=np.zeros((3, 4)))
+    assert np.isnan(Q).all() and len(xs) == 0
+
+
 @settings(max_examples=40, deadline=None)
 @given(st.integers(1, 20000), st.integers(1, 16))
 def test_shard_slabs_property(S, G):
