@@ -524,3 +524,31 @@ def test_sort_profile_of_planes_without_valid_cells(ctx):
             assert np.array_equal(r['Q'][s], Q.astype(np.float64), equal_nan=True)
             n = int(r['nvalid'][s])
             assert np.array_equal(r['q_sorted'][s][:n], xs.astype(np.float64))
+
+
+# ---------------------------------------------------------------- K4 on odd shapes
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+def test_grad2_shapes_and_walls_bit_identical(ctx, dt):
+    """K4 gives the bits of the normative order of operations (oracle.grad2_sphere) for widths around the 256-column
+    workgroup boundary, one or a few rows, NaN cells, periodic or walled (one-sided differences at the walls)"""
+    rng = np.random.default_rng(8)
+    for ny, nx in ((1, 4), (2, 6), (17, 126), (33, 128), (40, 130), (5, 254), (35, 256), (16, 258), (31, 510), (32, 512), (3, 514),
+                   (9, 1026), (7, 129), (19, 257)):
+        q = rng.standard_normal((2, ny, nx)).astype(dt)
+        q[1, ny // 2, nx // 3] = np.nan
+        rdx = rng.random(ny) + 0.5
+        rdy = rng.random(ny) + 0.5
+        for periodic in (True, False):
+            got = ctx.grad2(q, rdx, rdy, periodic)
+            x = q.astype(np.float64)
+            if periodic:
+                gx = (np.roll(x, -1, axis=2) - np.roll(x, 1, axis=2)) * rdx[None, :, None]
+            else:
+                e = np.concatenate((x[:, :, 1:], x[:, :, -1:]), axis=2)
+                w = np.concatenate((x[:, :, :1], x[:, :, :-1]), axis=2)
+                f = np.ones(nx); f[0] = 2.0; f[-1] = 2.0
+                gx = ((e - w) * rdx[None, :, None]) * f[None, None, :]
+            jn = np.minimum(np.arange(ny) + 1, ny - 1); js = np.maximum(np.arange(ny) - 1, 0)
+            gy = (x[:, jn, :] - x[:, js, :]) * rdy[None, :, None]
+            want = gx * gx + gy * gy
+            assert np.array_equal(got, want, equal_nan=True), (ny, nx, periodic)

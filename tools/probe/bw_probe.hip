@@ -48,6 +48,26 @@ __global__ void k_chunk(const double2* __restrict__ p, size_t n16, double* __res
     if (s == 12345.678) out[blockIdx.x] = s;
 }
 
+// copy: 16-byte loads and stores, U in flight (read + write traffic counted)
+template <int U, bool NT>
+__global__ void k_copy(const double2* __restrict__ p, double2* __restrict__ o, size_t n16)
+{
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        d2v v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p + i + u * stride)) : *reinterpret_cast<const d2v*>(p + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NT) __builtin_nontemporal_store(v[u], reinterpret_cast<d2v*>(o + i + u * stride));
+            else *reinterpret_cast<d2v*>(o + i + u * stride) = v[u];
+        }
+    }
+    for (; i < n16; i += stride) o[i] = p[i];
+}
+
 template <typename F>
 static double time_ms(F launch, int reps)
 {
@@ -88,6 +108,16 @@ int main()
         }
     for (int mult : {64, 256, 1024})
         row("stride_u4", cus * mult, 256, 4, time_ms([&] { hipLaunchKernelGGL((k_stride<4, false>), dim3(cus * mult), dim3(256), 0, 0, p, n16, out); }, 5));
+    {   // copy of half the buffer into the other half: bytes moved = read + written
+        const size_t h16 = n16 / 2;
+        for (int mult : {1, 4, 16, 64}) {
+            const int blocks = cus * mult;
+            const double ms0 = time_ms([&] { hipLaunchKernelGGL((k_copy<4, false>), dim3(blocks), dim3(256), 0, 0, p, p + h16, h16); }, 5);
+            printf(",\n {\"kernel\": \"copy_u4\", \"blocks\": %d, \"threads\": 256, \"loads_in_flight_per_lane\": 4, \"ms\": %.4f, \"TBps\": %.3f}", blocks, ms0, 2.0 * h16 * 16 / ms0 / 1e9);
+            const double ms1 = time_ms([&] { hipLaunchKernelGGL((k_copy<4, true>), dim3(blocks), dim3(256), 0, 0, p, p + h16, h16); }, 5);
+            printf(",\n {\"kernel\": \"copy_u4_nt\", \"blocks\": %d, \"threads\": 256, \"loads_in_flight_per_lane\": 4, \"ms\": %.4f, \"TBps\": %.3f}", blocks, ms1, 2.0 * h16 * 16 / ms1 / 1e9);
+        }
+    }
     printf("\n]}\n");
     CK(hipFree(p)); CK(hipFree(out));
     return 0;
