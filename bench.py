@@ -200,6 +200,17 @@ def stored_traffic(key, B):
         return None, 'profiles/hist_traffic.json unreadable: %s' % ex
 
 
+def stream_ceilings():
+    """what pure streams reach on this part (tools/probe/bw_probe.hip, stored in profiles/): context for `frac`, not its denominator"""
+    try:
+        rows = json.load(open(os.path.join(ROOT, 'profiles', 'r03_bw_probe.json')))['rows']
+        best = lambda pred: max((r['TBps'] for r in rows if pred(r['kernel'])), default=None)
+        return {'read_plain_TBps': best(lambda k: k in ('stride_u4', 'stride_u8', 'chunk_u8')), 'read_nontemporal_TBps': best(lambda k: k == 'stride_u8_nt'),
+                'copy_TBps': best(lambda k: k.startswith('copy')), 'source': 'profiles/r03_bw_probe.json (tools/probe/bw_probe.hip; best of each family, not re-measured in this run)'}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     if not np.array_equal(np.isnan(a), np.isnan(b)):
@@ -574,6 +585,7 @@ def main():
                                 'streamed_bytes_per_launch': alg + (cells * qdt.itemsize if chain else 0),
                                 'pipeline_frac': (alg * K / el / 1e9) / HBM_PEAK_GBS,
                                 'pipeline_hbm_unique_frac': (uniq * K / el / 1e9) / HBM_PEAK_GBS,
+                                'measured_stream_ceilings': stream_ceilings(),
                                 'note': 'frac = ' + str(bpc) + ' B/cell (SURVEY 8d) / launch time / 8 TB/s; its numerator counts the dA plane once per '
                                         'slab although the %d slabs of a launch share it (cache-served after the first fetch) -- '
                                         'hbm_unique_frac counts only bytes that must come from HBM.  variants.slab_dA is the '
