@@ -175,6 +175,7 @@ int xc_destroy(xc_ctx* ctx)
     (void)xc_comm_finalize(ctx);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pinned_flag) (void)hipHostFree(ctx->pinned_flag);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ev_compute) (void)hipEventDestroy(ctx->ev_compute);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

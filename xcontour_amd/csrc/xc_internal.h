@@ -29,6 +29,7 @@ struct xc_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;            // uploads that overlap compute (xc_memcpy_h2d_async)
     hipEvent_t ev_copy = nullptr, ev_compute = nullptr;
+    unsigned* pinned_flag = nullptr;   // 64 bytes of pinned host memory: the sort's one read-back
     int cus = 0;
     char name[256] = {0};
     std::string err;

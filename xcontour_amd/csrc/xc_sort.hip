@@ -721,22 +721,33 @@ void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
     { const size_t so = (size_t)blockIdx.y * ncell; keys += so; vals += so; acum += so; }
     part += (size_t)blockIdx.y * gridDim.x;
     const int64_t n = nvalid[blockIdx.y];
+    // the table goes into LDS when it fits (nz or ny entries): the bracket search is a chain of ~log2(ntbl) dependent reads per
+    // cell, ~1 us each from global memory (20 us per launch on the cfg5 stand-in), ~0.1 us from LDS
+    constexpr int BPE_TBL = 2048;
+    __shared__ double s_tbl[2 * BPE_TBL];
+    const bool in_lds = ntbl <= BPE_TBL;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < ntbl; i += 256) { s_tbl[i] = tbl[i]; s_tbl[BPE_TBL + i] = coord[i]; }
+        __syncthreads();
+    }
     const bool tinc = tbl[ntbl - 1] > tbl[0];
     double sum = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double a = acum[i] - 0.5 * vals[i];
-        auto X = [&](int k) { return tinc ? tbl[k] : tbl[ntbl - 1 - k]; };
-        auto F = [&](int k) { return tinc ? coord[k] : coord[ntbl - 1 - k]; };
-        double z;
-        if (a >= X(ntbl - 1)) z = F(ntbl - 1);
-        else if (a <= X(0)) z = F(0);
-        else {
-            int lo = 0, hi = ntbl - 1;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a >= X(mid)) lo = mid; else hi = mid; }
-            z = F(lo) + (F(lo + 1) - F(lo)) * (a - X(lo)) / (X(lo + 1) - X(lo));
+    auto walk = [&](auto X, auto F) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            const double a = acum[i] - 0.5 * vals[i];
+            double z;
+            if (a >= X(ntbl - 1)) z = F(ntbl - 1);
+            else if (a <= X(0)) z = F(0);
+            else {
+                int lo = 0, hi = ntbl - 1;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a >= X(mid)) lo = mid; else hi = mid; }
+                z = F(lo) + (F(lo + 1) - F(lo)) * (a - X(lo)) / (X(lo + 1) - X(lo));
+            }
+            sum += KeyTraits<K>::decode(keys[i]) * z * vals[i];
         }
-        sum += KeyTraits<K>::decode(keys[i]) * z * vals[i];
-    }
+    };
+    if (in_lds) walk([&](int k) { return s_tbl[tinc ? k : ntbl - 1 - k]; }, [&](int k) { return s_tbl[BPE_TBL + (tinc ? k : ntbl - 1 - k)]; });
+    else walk([&](int k) { return tinc ? tbl[k] : tbl[ntbl - 1 - k]; }, [&](int k) { return tinc ? coord[k] : coord[ntbl - 1 - k]; });
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     __shared__ double s[4];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sum;
@@ -744,9 +755,17 @@ void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
     if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-__global__ void k_sum_parts(const double* __restrict__ part, int n, double* __restrict__ out)
+// one wave per plane: lane l sums its contiguous share of the block partials, then a fixed xor tree (deterministic; the loop of
+// one thread over 256 dependent loads it replaces took 17 us)
+__global__ __launch_bounds__(64)
+void k_sum_parts(const double* __restrict__ part, int n, double* __restrict__ out)
 {
-    if (threadIdx.x == 0) { part += (size_t)blockIdx.x * n; double s = 0.0; for (int i = 0; i < n; ++i) s += part[i]; out[blockIdx.x] = s; }
+    part += (size_t)blockIdx.x * n;
+    const int per = (n + 63) / 64, i0 = threadIdx.x * per;
+    double s = 0.0;
+    for (int i = i0; i < i0 + per && i < n; ++i) s += part[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 }  // namespace
@@ -878,8 +897,11 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
             for (int p = 0; p < 3; ++p) XC_TRY_(pass(std::integral_constant<int, 1>(), p == 0, 8 * p));
             hipLaunchKernelGGL(k_fix_runs<K>, dim3((unsigned)((n + FIX_C - 1) / FIX_C), ns), dim3(256), 0, ctx->stream, kin, vin, n, flag, nvalid, src);
             XC_HIP(ctx, hipGetLastError());
-            unsigned h_flag = 1;
-            XC_HIP(ctx, hipMemcpyAsync(&h_flag, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+            // (read back into pinned memory: a copy to pageable memory holds the stream -- the kernels behind it waited 18 us)
+            if (!ctx->pinned_flag) XC_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_flag, 64, hipHostMallocDefault));
+            volatile unsigned& h_flag = *ctx->pinned_flag;
+            h_flag = 1;
+            XC_HIP(ctx, hipMemcpyAsync(ctx->pinned_flag, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
             // the rest is enqueued as if the repair had sufficed -- it nearly always has -- so that the GPU does not idle through
             // the one host round trip of the sort; a stack that failed the check is sorted again below and the rest redone
             XC_TRY_(tail(false));
