@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Kernel timeline of a rocprofv3 --kernel-trace run: per kernel name the average duration, and for the dominant kernel the
 idle time between the end of one launch and the start of the next (what the epilogue / launch overhead costs per step).
-usage: timeline_gaps.py <dir with *_kernel_trace.csv> [dominant-kernel substring, default k_hist]"""
+usage: timeline_gaps.py <dir with *_kernel_trace.csv> [dominant-kernel substring, default k_hist]
+       timeline_gaps.py <dir> --seq <kernel substring>    every launch between the last two launches of that kernel, with the idle
+                                                          time in front of each (one call of a multi-kernel operator, e.g. the sort)"""
 import csv
 import glob
 import sys
@@ -16,6 +18,17 @@ for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
         for r in csv.DictReader(fh):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Stream_Id', r.get('Queue_Id', ''))))
 rows.sort()
+if len(sys.argv) > 3 and sys.argv[2] == '--seq':
+    short = lambda n: n.replace('(anonymous namespace)::', '').replace('xc::', '').split('(')[0][:56]
+    idx = [i for i, r in enumerate(rows) if sys.argv[3] in r[2]]
+    if len(idx) < 2:
+        sys.exit('fewer than two launches of ' + sys.argv[3])
+    prev = None
+    for s_, e_, n_, q_ in rows[idx[-2]:idx[-1] + 1]:
+        print('%-58s %8.1f us   idle before %6.1f us' % (short(n_), (e_ - s_) / 1e3, (s_ - prev) / 1e3 if prev else 0.0))
+        prev = e_
+    print('start -> start: %.1f us' % ((rows[idx[-1]][0] - rows[idx[-2]][0]) / 1e3))
+    sys.exit(0)
 names = {}
 for s, e, n, q in rows:
     names.setdefault(n.replace('(anonymous namespace)::', '').replace('xc::', '').split('(')[0][:60], []).append(e - s)
