@@ -232,14 +232,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('det,carrier', [(True, 'gloo'), (False, 'gloo'), (True, 'socket')])
-def test_two_ranks_share_one_gpu_real_pipeline(ctx, det, carrier):
-    """SURVEY 8(e) end to end on the hardware at hand: 2 spawned processes (never a re-exec of a process that touched the
-    GPU), each a real KeffPlan over its shard_slabs block of an 11-slab 1440 x 721 stack (ragged blocks 6 + 5, ragged
-    launch sets of 4), chunks_to_slabs -> all_gather_slabs over gloo.  Every rank must hold the 1-rank result: all nine
-    vectors bit for bit with deterministic sums; levels bit for bit and sums to 1e-12 with the default float64 atomics."""
+@pytest.mark.parametrize('det,carrier,world,S', [(True, 'gloo', 2, 11), (False, 'gloo', 2, 11), (True, 'socket', 2, 11),
+                                                 (True, 'gloo', 3, 11), (True, 'socket', 4, 9)])
+def test_two_ranks_share_one_gpu_real_pipeline(ctx, det, carrier, world, S):
+    """SURVEY 8(e) end to end on the hardware at hand: 2 - 4 spawned processes (never a re-exec of a process that touched the
+    GPU), each a real KeffPlan over its shard_slabs block of a small 1440 x 721 stack (ragged blocks: 6 + 5, 4 + 4 + 3, and
+    3 + 3 + 3 + 0 -- a rank WITHOUT slabs; ragged launch sets of 4), chunks_to_slabs -> all_gather_slabs over gloo or the
+    package's own sockets.  Every rank must hold the 1-rank result: all nine vectors bit for bit with deterministic sums;
+    levels bit for bit and sums to 1e-12 with the default float64 atomics."""
     import torch.multiprocessing as mp
-    S, chunk, world = 11, 4, 2
+    chunk = 4
     ref = _cfg4_block(ctx, 0, S, 5, det)                               # 1 rank, other launch-set size on purpose
     mpc = mp.get_context('spawn')
     outq = mpc.Queue()
@@ -266,7 +268,7 @@ def test_two_ranks_share_one_gpu_real_pipeline(ctx, det, carrier):
             for k in ('area', 'intgrdS', 'latEq'):
                 i = NINE.index(k)
                 assert rel(got[r][:, i], ref[:, i]) < 1e-12, k
-    assert np.array_equal(bits(got[0]), bits(got[1]))                   # the gather hands every rank the same bytes
+    assert all(np.array_equal(bits(got[0]), bits(got[r])) for r in range(1, world))   # the gather hands every rank the same bytes
     # and the stack really is per-slab data in slab order: slab 7 against the oracle
     from xcontour_amd import _native as nat
     from xcontour_amd.utils import cell_area
