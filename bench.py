@@ -220,6 +220,23 @@ def rel_err(a, b):
 
 
 # ----------------------------------------------------------------------------- cfg4: strong scaling over the ranks
+def cfg4_launch_set(n, cus=256, blocks_per_slab=3):
+    """Slabs per launch set for a rank's block of `n` cfg4 slabs.  A set that TILES the block keeps every set chained (a ragged
+    last set and the set after it run a stand-alone min/max pass: 2 368 slabs per rank, the N = 8 block, 7.67 ms with sets of 256
+    + 64 against 7.32 ms with 4 x 592); the histogram grid is three workgroups per slab on 256 CUs, so a set should fill whole
+    rounds (296 slabs = 3.47 rounds: 8.12 ms); larger sets amortise the per-launch epilogue (N = 1: 512 -> 56.1 ms, 592 -> 56.5,
+    256 -> 57.5).  Among the divisors of n up to 640: best round efficiency minus a small bonus for size; no good divisor: 256, ragged."""
+    best, score = None, 0.0
+    for d in range(128, 641):
+        if n % d:
+            continue
+        rounds = blocks_per_slab * d / float(cus)
+        sc = rounds / np.ceil(rounds) - 0.02 * 256.0 / d
+        if sc > score:
+            best, score = d, sc
+    return best if best is not None and score >= 0.96 else 256
+
+
 def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
     """BASELINE.json configs[3]: `--cfg4-slabs` (18 944 = 512 x 37) slabs of 1440 x 721 float64, Keff per slab with per-slab
     levels; the flattened (time, level) index is cut into contiguous blocks of ceil(S/G) slabs (pipeline.shard_slabs), every
@@ -237,10 +254,7 @@ def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
     tbl = table_from_rowsums(ctx.rowsum(None, dA, NY4, NX4), True, last_row_included(lat, 'xhistogram'))
     lo, hi = shard_slabs(S, rank, world)
     n = hi - lo
-    # launch sets of 512 slabs when they tile the block (N = 1: 37 sets, measured 56.5 against 57.5 ms per job with 256), else 256
-    # (a ragged last set and the set after it cannot chain their min/max: the smaller the sets, the fewer slabs pay for that)
-    want = int(a.cfg4_chunk) if a.cfg4_chunk > 0 else (512 if n % 512 == 0 else 256)
-    Cn = min(want, max(n, 1))
+    Cn = min(int(a.cfg4_chunk) if a.cfg4_chunk > 0 else cfg4_launch_set(n), max(n, 1))
     nchunk = -(-n // Cn) if n else 0
     slab_bytes = NY4 * NX4 * 8
     qbuf, err = None, ''
@@ -405,7 +419,7 @@ def main():
     ap.add_argument('--long-run-s', type=float, default=4.0, help='seconds of extra steps with per-launch events (long_run)')
     ap.add_argument('--no-cfg4', action='store_true', help='skip the cfg4 strong-scaling block')
     ap.add_argument('--cfg4-slabs', type=int, default=512 * 37)
-    ap.add_argument('--cfg4-chunk', type=int, default=0, help='slabs per launch set of the cfg4 sweep (0: 512 when that tiles the rank\'s block, else 256)')
+    ap.add_argument('--cfg4-chunk', type=int, default=0, help='slabs per launch set of the cfg4 sweep (0: chosen by cfg4_launch_set: a size that tiles the rank\'s block and fills whole rounds of workgroups)')
     ap.add_argument('--cfg4-reps', type=int, default=2, help='timed cfg4 jobs (sweep + gather)')
     a = ap.parse_args()
 
