@@ -313,6 +313,12 @@ def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
         tt = torch.tensor([el], dtype=torch.float64, device=gdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+    # where a job's time goes (one extra job, host clock around each stage with a sync behind it; every rank takes part)
+    stages = {}
+    ts = time.perf_counter(); sweep(); ctx.sync(); stages['sweep_ms'] = (time.perf_counter() - ts) * 1e3
+    ts = time.perf_counter(); mine = chunks_to_slabs(res, slot // 8, Cn, n, NCONT); torch.cuda.synchronize(); stages['pack_ms'] = (time.perf_counter() - ts) * 1e3
+    ts = time.perf_counter(); full = all_gather_slabs(mine if gdev == 'cuda' else mine.cpu(), S, rank, world); torch.cuda.synchronize()
+    stages['gather_ms'] = (time.perf_counter() - ts) * 1e3
     block = None
     if rank == 0:
         assert tuple(full.shape) == (S, 9, NCONT)
@@ -357,6 +363,7 @@ def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
             'unit': 'cells*contours/s', 'n_gpus': world, 'scaling': 'strong', 'jobs_timed': R, 'ms_per_job': el / R * 1e3,
             'slabs': S, 'slab_shape': [NY4, NX4], 'slabs_per_gpu': -(-S // world), 'slabs_per_launch': Cn,
             'us_per_slab_per_gpu': el / R / max(1, -(-S // world)) * 1e6,
+            'job_stages_rank0': stages,
             'gathered_bytes': int(S * 9 * NCONT * 8), 'gather': ('torch.distributed all_gather_into_tensor, backend %s' % a.backend) if world > 1 else 'single rank (no collective)',
             'algorithmic_bytes': int(S * NY4 * NX4 * BYTES_PER_CELL), 'pipeline_frac': (S * NY4 * NX4 * BYTES_PER_CELL * R / el / 1e9) / HBM_PEAK_GBS / world,
             'checks': {'rank0_block_bit_identical': True, 'first_slab_of_each_rank_recomputed': checked,
