@@ -223,11 +223,11 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
                     const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                     double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
 
-/* float64 tracers take a three-pass path: a stable LSD sort on the 24-bit RANGE key floor((q - min) * (2^24 - 1) / (max - min))
- * (monotone in q), then a stable in-LDS odd-even transposition sort of every run of equal range key that is out of order and a
- * sortedness check whose flag is read back -- the ONE host round trip these calls (also the _dev ones) make; a stack that
- * fails it (distinct values packed into less than 2^-24 of the range, more than 128 of them) is sorted again with the
- * eight key passes.  The result is the same stable sort either way.  xc_last_sort_path: 0 = key passes only (float32
+/* float64 tracers take a three-pass path: a stable LSD sort on a 24-bit RANGE key -- a monotone, piecewise-linear map of
+ * (q - min) / (max - min) onto [0, 2^24 - 2] that gives densely populated parts of the range more keys (sampled histogram
+ * equalisation) -- then a repair pass that puts every run of equal range key into exact order (stable rank inside the run, in
+ * LDS) and proves the result sorted; its flag is read back -- the ONE host round trip these calls (also the _dev ones) make;
+ * a stack that fails it (more than 128 distinct values inside one range key) is sorted again with the eight key passes.  The result is the same stable sort either way.  xc_last_sort_path: 0 = key passes only (float32
  * tracers, or XC_SORT_RANGE=0 in the environment at xc_create), 1 = range-key path, 2 = range-key path failed the check. */
 int xc_last_sort_path(xc_ctx* ctx, int* out_path);
 
