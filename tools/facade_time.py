@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time of the facade (numpy in / numpy out, host entry points, PCIe included) on one cfg2-sized
-slab: the reference's Keff call sequence (tests/test_Keff_atmos.py:75-92) call by call, and the fused
+slab (and, with XC_FACADE_SMALL=1, on the 15 x 241 x 480 float32 stack of the reference's own demo size, cfg1): the reference's Keff call sequence (tests/test_Keff_atmos.py:75-92) call by call, and the fused
 `Contour2D.keff`.  Prints a JSON line."""
 import json
 import os
@@ -86,3 +86,34 @@ if S:
                                             'keff_GBps': stack.nbytes / t_keff / 1e9, 'ms_per_slab': t_keff / S * 1e3,
                                             'bare_h2d_pageable_s': t_page, 'bare_h2d_pinned_s': t_pin,
                                             'keff_over_pinned_copy': None if not t_pin else t_keff / t_pin}}))
+
+# ---- the reference's own problem size (cfg1: 15 levels of 241 x 480 float32): per-call latency, where fixed costs rule
+if os.environ.get('XC_FACADE_SMALL'):
+    def small():
+        rec = {}
+        def timed(name, fn, reps=20):
+            fn(); fn()
+            t = time.perf_counter()
+            for _ in range(reps):
+                out = fn()
+            rec[name] = (time.perf_counter() - t) / reps * 1e6
+            return out
+        NL1, NY1, NX1, N1 = 15, 241, 480, 201
+        lat = np.linspace(-90, 90, NY1).astype(np.float32); lon = (np.arange(NX1) * 0.75).astype(np.float32); lev = np.arange(NL1, dtype=np.float32)
+        rng = np.random.default_rng(0)
+        q = (np.sin(np.deg2rad(lat))[None, :, None] * (1 + 0.1 * lev[:, None, None]) + 0.05 * rng.standard_normal((NL1, NY1, NX1))).astype(np.float32)
+        c3 = {'lev': lev, 'lat': lat, 'lon': lon}; c2 = {'lat': lat, 'lon': lon}
+        tr = xa.DataArray(q, ('lev', 'lat', 'lon'), c3, 'pv')
+        dA = xa.DataArray(xa.cell_area(lat.astype(np.float64), lon.astype(np.float64)).astype(np.float32), ('lat', 'lon'), c2, 'dA')
+        g2 = xa.DataArray(rng.random(q.shape).astype(np.float32), ('lev', 'lat', 'lon'), c3, 'grdS')
+        mask = xa.DataArray(np.ones((NY1, NX1), np.float32), ('lat', 'lon'), c2, 'mask')
+        cm = xa.Contour2D(tr, dA, dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'}, increase=True, lt=True)
+        table = timed('cal_area_eqCoord_table_hist', lambda: cm.cal_area_eqCoord_table_hist(mask))
+        ctr = timed('cal_contours', lambda: cm.cal_contours(N1))
+        area = timed('integral_hist(area)', lambda: cm.cal_integral_within_contours_hist(ctr))
+        intS = timed('integral_hist(grdS)', lambda: cm.cal_integral_within_contours_hist(ctr, integrand=g2))
+        latEq = timed('lookup_coordinates', lambda: table.lookup_coordinates(area))
+        dq = timed('gradient_wrt_area x2', lambda: (cm.cal_gradient_wrt_area(ctr, area), cm.cal_gradient_wrt_area(intS, area)))
+        timed('keff fused (grdS supplied)', lambda: cm.keff(N1, table, grdS=g2))
+        print(json.dumps({'facade_us_per_call_cfg1_stack_15x241x480_f32': rec}))
+    small()
