@@ -85,6 +85,17 @@ int xc_free(xc_ctx* ctx, void* dptr);
 int xc_memcpy_h2d(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int xc_memcpy_d2h(xc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int xc_memset(xc_ctx* ctx, void* dptr, int value, size_t bytes);
+/* Resident inputs (no reference call site: the reference keeps everything in host memory).  The reference's Keff sequence hands
+ * the SAME tracer to cal_contours and twice to cal_integral_within_contours_hist, the same weights to every call; the host-form
+ * entry points upload their inputs on every call (~1 ms per 52 MB cfg2 slab over PCIe).  xc_keep_resident uploads `bytes` at
+ * `host_ptr` once into memory the library owns; from then on any host-form entry point whose input lies inside
+ * [host_ptr, host_ptr + bytes) -- the array itself or whole slabs of it -- copies from that mirror on the device instead.
+ * The caller must not modify (or free) the host array while it is registered; calling xc_keep_resident on the same pointer
+ * again refreshes the mirror; xc_release_resident(ctx, host_ptr) drops one entry, xc_release_resident(ctx, NULL) all.
+ * Python: Contour2D(..., resident=True). */
+int xc_keep_resident(xc_ctx* ctx, const void* host_ptr, size_t bytes);
+int xc_release_resident(xc_ctx* ctx, const void* host_ptr);
+
 /* Uploads that overlap compute: xc_memcpy_h2d_async copies on the context's second (copy) stream and returns when the
  * host buffer may be reused (pageable memory: when the copy is done; kernels enqueued earlier on the compute stream run
  * meanwhile).  xc_stream_wait_copies makes everything enqueued on the compute stream AFTER the call wait for the copies

@@ -554,3 +554,53 @@ def test_grad2_shapes_and_walls_bit_identical(ctx, dt):
             gy = (x[:, jn, :] - x[:, js, :]) * rdy[None, :, None]
             want = gx * gx + gy * gy
             assert np.array_equal(got, want, equal_nan=True), (ny, nx, periodic)
+
+
+# ---------------------------------------------------------------- resident inputs (xc_keep_resident)
+def test_resident_inputs_give_the_same_results(ctx, baro):
+    """Contour2D(resident=True): tracer and weights are uploaded once and the host-form calls copy from the device mirror --
+    same bits as without, for the reference's Keff call sequence on a stack, also when the stack goes through in batches of
+    whole slabs (slices of the registered array) and after touch() following an in-place change"""
+    import xcontour_amd as xa
+    q0, lat, lon = baro
+    S = 4
+    q = np.stack([q0 * (1 + 0.1 * s) for s in range(S)])
+    c3 = {'time': np.arange(S), 'latitude': lat, 'longitude': lon}
+    c2 = {'latitude': lat, 'longitude': lon}
+    tr = xa.DataArray(q, ('time', 'latitude', 'longitude'), c3, 'absolute_vorticity')
+    dA = xa.DataArray(O.cell_area(lat, lon), ('latitude', 'longitude'), c2, 'rA')
+    g = xa.DataArray(np.random.default_rng(2).random(q.shape).astype(np.float32), ('time', 'latitude', 'longitude'), c3, 'grdS')
+    mask = xa.DataArray(np.ones_like(q0), ('latitude', 'longitude'), c2, 'mask')
+    kw = dict(dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True, deterministic=True)
+
+    def sequence(cm):
+        table = cm.cal_area_eqCoord_table_hist(mask)
+        ctr = cm.cal_contours(61)
+        area = cm.cal_integral_within_contours_hist(ctr)
+        intS = cm.cal_integral_within_contours_hist(ctr, integrand=g)
+        return [table.lookup_coordinates(area).values, ctr.values, area.values, intS.values]
+
+    plain = xa.Contour2D(tr, dA, **kw)
+    ref = sequence(plain)
+    res = xa.Contour2D(tr, dA, resident=True, **kw)
+    n0 = len(res.ctx._resident)
+    got = sequence(res)
+    assert len(res.ctx._resident) == n0 + 2                         # the tracer stack and the float64 weights, once each
+    for a, b in zip(got, ref):
+        assert np.array_equal(bits(a), bits(b))
+    old = res.ctx.max_batch_bytes
+    try:
+        res.ctx.max_batch_bytes = 2 * q0.nbytes + 100                # two slabs per batch: slices of the registered stack
+        for a, b in zip(sequence(res), ref):
+            assert np.array_equal(bits(a), bits(b))
+    finally:
+        res.ctx.max_batch_bytes = old
+    q[1] = np.roll(q[1], 9, axis=0)                                 # in place (rows meet other weights): the mirror is stale until touch()
+    res.touch()
+    again = sequence(res)
+    fresh = sequence(xa.Contour2D(tr, dA, **kw))
+    for a, b in zip(again, fresh):
+        assert np.array_equal(bits(a), bits(b))
+    assert not np.array_equal(bits(again[2]), bits(ref[2]))
+    res.close(); plain.close()
+    assert len(res.ctx._resident) == n0

@@ -15,6 +15,7 @@ timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2
 echo "== kernel timings"
 timeout -k 10 500 python3 tools/kernel_times.py sort lwa cross pipe land single > $O/${RD}_kernel_times.jsonl 2>&1 || exit 1
 XC_FACADE_STACK=128 XC_FACADE_SMALL=1 timeout -k 10 300 python3 tools/facade_time.py 2>/dev/null | grep '^{' > $O/${RD}_facade_time.jsonl || exit 1
+XC_FACADE_KW='{"resident": true}' XC_FACADE_SMALL=1 timeout -k 10 300 python3 tools/facade_time.py 2>/dev/null | grep '^{' >> $O/${RD}_facade_time.jsonl || exit 1
 echo "== rocprofv3 kernel stats + PMC"
 cd /tmp && export TMPDIR=/tmp && cd $R
 bash tools/pmc_bench_traffic.sh $COMMIT > $O/${RD}_pmc_traffic.log 2>&1 || exit 1

@@ -107,7 +107,7 @@ if os.environ.get('XC_FACADE_SMALL'):
         dA = xa.DataArray(xa.cell_area(lat.astype(np.float64), lon.astype(np.float64)).astype(np.float32), ('lat', 'lon'), c2, 'dA')
         g2 = xa.DataArray(rng.random(q.shape).astype(np.float32), ('lev', 'lat', 'lon'), c3, 'grdS')
         mask = xa.DataArray(np.ones((NY1, NX1), np.float32), ('lat', 'lon'), c2, 'mask')
-        cm = xa.Contour2D(tr, dA, dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'}, increase=True, lt=True)
+        cm = xa.Contour2D(tr, dA, dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'}, increase=True, lt=True, resident=bool(kw.get('resident', False)))
         table = timed('cal_area_eqCoord_table_hist', lambda: cm.cal_area_eqCoord_table_hist(mask))
         ctr = timed('cal_contours', lambda: cm.cal_contours(N1))
         area = timed('integral_hist(area)', lambda: cm.cal_integral_within_contours_hist(ctr))
@@ -115,5 +115,5 @@ if os.environ.get('XC_FACADE_SMALL'):
         latEq = timed('lookup_coordinates', lambda: table.lookup_coordinates(area))
         dq = timed('gradient_wrt_area x2', lambda: (cm.cal_gradient_wrt_area(ctr, area), cm.cal_gradient_wrt_area(intS, area)))
         timed('keff fused (grdS supplied)', lambda: cm.keff(N1, table, grdS=g2))
-        print(json.dumps({'facade_us_per_call_cfg1_stack_15x241x480_f32': rec}))
+        print(json.dumps({'facade_us_per_call_cfg1_stack_15x241x480_f32': rec, 'resident': bool(kw.get('resident', False))}))
     small()

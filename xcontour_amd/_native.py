@@ -82,6 +82,8 @@ PROTOTYPES = {
     'xc_memset': (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
     'xc_memcpy_h2d_async': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     'xc_stream_wait_copies': (C.c_int, [_vp]),
+    'xc_keep_resident': (C.c_int, [_vp, _vp, C.c_size_t]),
+    'xc_release_resident': (C.c_int, [_vp, _vp]),
     'xc_copies_wait_stream': (C.c_int, [_vp]),
     'xc_event_create': (C.c_int, [_vp, C.POINTER(_vp)]),
     'xc_event_destroy': (C.c_int, [_vp, _vp]),
@@ -227,6 +229,7 @@ class Context(object):
         self.handle = h
         self.device = int(device)
         self._buffers = []
+        self._resident = {}          # data pointer -> ndarray registered with xc_keep_resident (kept alive here)
         # host-pointer entry points stage at most this many bytes of per-slab data (tracer, integrands, per-slab weights,
         # per-slab outputs) on the device at once: larger stacks go through in batches of whole slabs (the reference's
         # histogram path is lazy / dask-friendly, core.py:158-160, 241-246)
@@ -255,6 +258,26 @@ class Context(object):
 
     def stream_wait_copies(self):
         self._check(self.lib.xc_stream_wait_copies(self.handle))
+
+    # -- resident inputs: host arrays with a device mirror (xc_keep_resident)
+    def keep_resident(self, arr):
+        """upload `arr` (C-contiguous ndarray) once; host-form calls whose input is this array -- or whole leading-index slices of
+        it -- read the device mirror from now on.  The context keeps a reference to `arr` while it is registered (its memory
+        cannot be recycled under the mirror); do not modify it in place without calling keep_resident again."""
+        assert isinstance(arr, np.ndarray) and arr.flags['C_CONTIGUOUS']
+        self._check(self.lib.xc_keep_resident(self.handle, _ptr(arr), arr.nbytes))
+        self._resident[arr.ctypes.data] = arr
+        return arr
+
+    def release_resident(self, arr=None):
+        if not getattr(self, 'handle', None):
+            return
+        if arr is None:
+            self._check(self.lib.xc_release_resident(self.handle, None))
+            self._resident.clear()
+        elif arr.ctypes.data in self._resident:
+            self._check(self.lib.xc_release_resident(self.handle, _ptr(arr)))
+            del self._resident[arr.ctypes.data]
 
     def copies_wait_stream(self):
         self._check(self.lib.xc_copies_wait_stream(self.handle))

@@ -46,7 +46,7 @@ class Contour2D(object):
 
     def __init__(self, trcr, dA, dims, dimEq, arakawa='A',
                  increase=True, lt=False, check_mono=False, dtype=np.float32,
-                 device=0, right_edge='xhistogram', deterministic=False):
+                 device=0, right_edge='xhistogram', deterministic=False, resident=False):
         if len(dimEq) != 1:
             raise Exception('dimEq should be one dimension e.g., {"Y","lat"}')
 
@@ -71,13 +71,37 @@ class Contour2D(object):
         self.right_edge = right_edge
         self.device = device
         self.deterministic = bool(deterministic)     # order-free fixed-point sums (bit-reproducible; ~2x the histogram pass)
+        # resident=True: the tracer and the weights of THIS object are uploaded once and stay on the device between calls (the
+        # reference's Keff sequence passes them to four calls in a row; every call used to cross PCIe again).  Do not modify
+        # them in place afterwards without calling touch().
+        self.resident = bool(resident)
+        self._memo = {}
         if self.dimEqV not in self.dimVs:
             raise Exception('dimEq should be one of dims')
         self._xdim = [d for d in self.dimVs if d != self.dimEqV][0]
 
     # ------------------------------------------------------------------ plumbing
+    def touch(self):
+        """resident=True: the tracer / weights were modified in place -- forget the device mirrors (the next call uploads again)"""
+        for v in self.__dict__.get('_memo', {}).values():
+            try:
+                self.ctx.release_resident(v[0])
+            except Exception:
+                pass
+        self._memo = {}
+
+    def _keep(self, key, make):
+        """memoised (array, ...) tuple whose first element stays registered as a resident input of the context"""
+        if key not in self._memo:
+            t = make()
+            self.ctx.keep_resident(t[0])
+            self._memo[key] = t
+        return self._memo[key]
+
     def close(self):
         """Release the device buffers kept between keff() calls (also done when the object is collected)."""
+        if self.__dict__.get('_memo'):
+            self.touch()
         for plan in self.__dict__.pop('_keff_plans', {}).values():
             try:
                 plan.free()
@@ -93,6 +117,14 @@ class Contour2D(object):
 
     def _plane(self, arr):
         """labelled array -> (values (S, ny, nx) C-contiguous, lead dims, lead shape, coords)"""
+        if self.resident and arr is self.tracer:
+            def make():
+                v, lead, lshape, coords = self._plane_of(arr)
+                return np.ascontiguousarray(self._float(v)), lead, lshape, coords
+            return self._keep('tracer', make)
+        return self._plane_of(arr)
+
+    def _plane_of(self, arr):
         v, dims, coords, _ = lb.unwrap(arr)
         if self.dimEqV not in dims or self._xdim not in dims:
             raise Exception('array should have the dims %s' % self.dimVs)
@@ -109,6 +141,11 @@ class Contour2D(object):
 
     def _dA_array(self, ny, nx, nslab):
         """self.dA -> (float64 ndarray of shape (ny,), (ny,nx) or (nslab,ny,nx), was_f32)"""
+        if self.resident:
+            return self._keep(('dA', ny, nx, nslab), lambda: self._dA_array_of(ny, nx, nslab))
+        return self._dA_array_of(ny, nx, nslab)
+
+    def _dA_array_of(self, ny, nx, nslab):
         if lb.is_labeled(self.dA):
             v, dims, _, _ = lb.unwrap(self.dA)
             keep = [i for i, n in enumerate(v.shape) if not (n == 1 and dims[i] not in self.dimVs)]

@@ -30,6 +30,8 @@ struct xc_ctx {
     hipStream_t copy_stream = nullptr;            // uploads that overlap compute (xc_memcpy_h2d_async)
     hipEvent_t ev_copy = nullptr, ev_compute = nullptr;
     unsigned* pinned_flag = nullptr;   // 64 bytes of pinned host memory: the sort's one read-back
+    struct Resident { const char* host; size_t bytes; void* dev; };
+    std::vector<Resident> resident;    // host arrays with a device mirror (xc_keep_resident): the host-form entry points copy from the mirror
     int cus = 0;
     char name[256] = {0};
     std::string err;
