@@ -51,6 +51,22 @@ def test_struct_layouts_match_header(tmp_path):
     assert lib.xc_version().startswith(b'xcontour_hip')
 
 
+def test_integration_stub_struct_matches_the_library():
+    """the ctypes struct INTEGRATION.md shows a maintainer of the reference (the `_HistDesc` of the stub) has the fields, order and
+    size of the binding's own mirror of xc_hist_desc -- a stub that lags the header would let the library read past its end"""
+    from xcontour_amd import _native as nat
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    body = text[text.index('class _HistDesc(C.Structure):'):]
+    body = body[body.index('_fields_ = ['):body.index(']', body.index("('reserved0'")) + 1]
+    ns = {'C': C, '_vp': C.c_void_p, '_i32': C.c_int32, '_i64': C.c_int64}
+    exec(body.replace('_fields_', 'fields'), ns)
+    stub = type('Stub', (C.Structure,), {'_fields_': ns['fields']})
+    assert [f[0] for f in ns['fields']] == [f[0] for f in nat.HistDesc._fields_]
+    assert C.sizeof(stub) == C.sizeof(nat.HistDesc)
+    for name, _ in [(f[0], f[1]) for f in ns['fields']]:
+        assert getattr(stub, name).offset == getattr(nat.HistDesc, name).offset, name
+
+
 def test_no_cpu_fallback_without_device():
     """Without a GPU the product path must fail loudly, never fall back."""
     import torch

@@ -604,3 +604,32 @@ def test_resident_inputs_give_the_same_results(ctx, baro):
     assert not np.array_equal(bits(again[2]), bits(ref[2]))
     res.close(); plain.close()
     assert len(res.ctx._resident) == n0
+
+
+# ---------------------------------------------------------------- the stub of INTEGRATION.md, executed as printed
+def test_integration_md_stub_runs_as_printed(baro):
+    """the two python blocks INTEGRATION.md shows a maintainer of the reference (ctypes binding of xc_hist and xc_crossing) are
+    executed verbatim against the built library: histogram_cdf == the oracle's _histogram restatement (counts-exact levels,
+    sums to rounding), contour_crossing == the oracle's box counting"""
+    import re
+    from xcontour_amd import _native as nat
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    stub = next(b for b in blocks if 'class _HistDesc' in b)
+    cross = next(b for b in blocks if 'def contour_crossing' in b)
+    ns = {}
+    exec(stub.replace("C.CDLL('libxcontour_hip.so')", 'C.CDLL(%r)' % nat.LIB_PATH), ns)
+    exec(cross, ns)
+    q, lat, lon = baro
+    dA = O.cell_area(lat, lon)
+    for inc in (True, False):
+        ctr = O.cal_contours(q, 61, inc, np.float32)
+        for lt in (True, False):
+            got = ns['histogram_cdf'](q[None], ctr, dA, lt)
+            want = O.histogram_cdf(q, ctr, dA, lt)                 # ascending-value order like _histogram's return
+            want = want[0] if isinstance(want, tuple) else want
+            assert rel(got[0], np.asarray(want, dtype=np.float64)) < TIGHT, (inc, lt)
+    levels = np.sort(np.linspace(float(np.nanmin(q)), float(np.nanmax(q)), 9)[1:-1]).astype(np.float64)
+    got = ns['contour_crossing'](q[None].astype(np.float64), levels[None], dA, 2, 2, 'edge')      # stride 2, padded by max_stride = 2 columns
+    want, _ = O.contour_crossing(O.pad_x(q.astype(np.float64), 2, 'edge'), levels, O.pad_x(dA, 2, 'edge'), 2)
+    assert rel(got[0], np.asarray(want)) < 1e-12
