@@ -114,6 +114,16 @@ static int h2d(xc_ctx* ctx, void* d, const void* h, size_t n)
     XC_HIP(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream));
     return XC_OK;
 }
+// the big read-only inputs of the Keff sequence skip even that copy: the kernel reads the mirror itself (`slot`: the arena bytes
+// reserved for the upload, unused then)
+static int stage_in(xc_ctx* ctx, void* slot, const void* h, size_t n, const void** dev)
+{
+    if (!ctx->resident.empty())
+        if (const void* m = resident_lookup(ctx, h, n)) { *dev = m; return XC_OK; }
+    *dev = slot;
+    XC_HIP(ctx, hipMemcpyAsync(slot, h, n, hipMemcpyHostToDevice, ctx->stream));
+    return XC_OK;
+}
 static int d2h(xc_ctx* ctx, void* h, const void* d, size_t n)
 {
     XC_HIP(ctx, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -430,8 +440,9 @@ int xc_minmax(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t nc
     const size_t qb = (size_t)nslab * ncell * esize(q_dtype), ob = (size_t)nslab * 2 * sizeof(double);
     XC_TRY(ensure_arena(ctx, al(qb) + al(ob)));
     Stage st(ctx);
-    void* dq = st.take(qb); double* dout = (double*)st.take(ob);
-    XC_TRY(h2d(ctx, dq, q, qb));
+    const void* dq; double* dout;
+    XC_TRY(stage_in(ctx, st.take(qb), q, qb, &dq));
+    dout = (double*)st.take(ob);
     XC_TRY(xc_minmax_dev(ctx, dq, q_dtype, nslab, ncell, dout));
     XC_TRY(d2h(ctx, out_minmax, dout, ob));
     return xc_sync(ctx);
@@ -588,10 +599,10 @@ int xc_hist(xc_ctx* ctx, const xc_hist_desc* hd)
     XC_TRY(ensure_arena(ctx, al(qb) + al(eb) + al(dab) + al(ib[0]) + al(ib[1]) + 2 * al(rb) + 2 * al(pb) + al(cb)));
     Stage st(ctx);
     xc_hist_desc d = *hd;
-    void* dq = st.take(qb); XC_TRY(h2d(ctx, dq, hd->q, qb)); d.q = dq;
+    XC_TRY(stage_in(ctx, st.take(qb), hd->q, qb, &d.q));
     double* de = (double*)st.take(eb); XC_TRY(h2d(ctx, de, hd->edges, eb)); d.edges = de;
-    if (dab) { double* p = (double*)st.take(dab); XC_TRY(h2d(ctx, p, hd->dA, dab)); d.dA = p; }
-    for (int i = 0; i < hd->nint; ++i) { void* p = st.take(ib[i]); XC_TRY(h2d(ctx, p, hd->integrand[i], ib[i])); d.integrand[i] = p; }
+    if (dab) { const void* p; XC_TRY(stage_in(ctx, st.take(dab), hd->dA, dab, &p)); d.dA = (const double*)p; }
+    for (int i = 0; i < hd->nint; ++i) XC_TRY(stage_in(ctx, st.take(ib[i]), hd->integrand[i], ib[i], &d.integrand[i]));
     if (hd->grad) {
         double* p = (double*)st.take(rb); XC_TRY(h2d(ctx, p, hd->rdx, rb)); d.rdx = p;
         p = (double*)st.take(rb); XC_TRY(h2d(ctx, p, hd->rdy, rb)); d.rdy = p;
