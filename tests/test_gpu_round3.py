@@ -578,7 +578,8 @@ def test_resident_inputs_give_the_same_results(ctx, baro):
         ctr = cm.cal_contours(61)
         area = cm.cal_integral_within_contours_hist(ctr)
         intS = cm.cal_integral_within_contours_hist(ctr, integrand=g)
-        return [table.lookup_coordinates(area).values, ctr.values, area.values, intS.values]
+        ds = cm.keff(61, table, lat=lat, lon=lon)                    # the fused pipeline uploads through xc_memcpy_h2d_async: mirror-aware too
+        return [table.lookup_coordinates(area).values, ctr.values, area.values, intS.values, ds['area'].values, ds['nkeff'].values]
 
     plain = xa.Contour2D(tr, dA, **kw)
     ref = sequence(plain)

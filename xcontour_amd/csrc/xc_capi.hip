@@ -297,7 +297,8 @@ int xc_memcpy_h2d(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes
     XC_CTX(ctx);
     if (bytes && (!dst_dev || !src_host)) return fail(ctx, XC_EBADARG, "xc_memcpy_h2d: NULL pointer");
     mm_touch(ctx, dst_dev, bytes);
-    XC_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const void* m = ctx->resident.empty() ? nullptr : resident_lookup(ctx, src_host, bytes);   // a registered array: from its device mirror
+    XC_HIP(ctx, hipMemcpyAsync(dst_dev, m ? m : src_host, bytes, m ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return XC_OK;
 }
@@ -307,7 +308,8 @@ int xc_memcpy_h2d_async(xc_ctx* ctx, void* dst_dev, const void* src_host, size_t
     XC_CTX(ctx);
     if (bytes && (!dst_dev || !src_host)) return fail(ctx, XC_EBADARG, "xc_memcpy_h2d_async: NULL pointer");
     mm_touch(ctx, dst_dev, bytes);
-    XC_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    const void* m = ctx->resident.empty() ? nullptr : resident_lookup(ctx, src_host, bytes);
+    XC_HIP(ctx, hipMemcpyAsync(dst_dev, m ? m : src_host, bytes, m ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->copy_stream));
     return XC_OK;
 }
 
