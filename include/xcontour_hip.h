@@ -89,7 +89,8 @@ int xc_memset(xc_ctx* ctx, void* dptr, int value, size_t bytes);
  * the SAME tracer to cal_contours and twice to cal_integral_within_contours_hist, the same weights to every call; the host-form
  * entry points upload their inputs on every call (~1 ms per 52 MB cfg2 slab over PCIe).  xc_keep_resident uploads `bytes` at
  * `host_ptr` once into memory the library owns; from then on any host-form entry point whose input lies inside
- * [host_ptr, host_ptr + bytes) -- the array itself or whole slabs of it -- copies from that mirror on the device instead.
+ * [host_ptr, host_ptr + bytes) -- the array itself or whole slabs of it -- takes it from that mirror on the device instead
+ * (xc_minmax / xc_hist read the mirror in place; the others, and xc_memcpy_h2d[_async] from such a source, copy device to device).
  * The caller must not modify (or free) the host array while it is registered; calling xc_keep_resident on the same pointer
  * again refreshes the mirror; xc_release_resident(ctx, host_ptr) drops one entry, xc_release_resident(ctx, NULL) all.
  * Python: Contour2D(..., resident=True). */
