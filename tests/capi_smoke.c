@@ -82,6 +82,22 @@ int main(void)
             if (fabs(c1[k][0][b] - cdf[k][0][b]) > 1e-11 * (fabs(cdf[k][0][b]) + 1.0)) { fprintf(stderr, "FAIL: deterministic cdf slab %d bin %d\n", k, b); return 1; }
         d.deterministic = 0; d.cdf = &cdf[0][0][0]; d.counts = &counts[0][0];
     }
+    /* resident inputs: with the tracer and the weights registered the same call reads their device mirrors -- same bits
+       (deterministic sums); a slab inside the registered array is found too; after a release the call uploads again */
+    {
+        static double c1[2][1][NLEV], c2[2][1][NLEV], mm2[2];
+        d.deterministic = 1; d.counts = NULL;
+        d.cdf = &c1[0][0][0]; if (xc_hist(ctx, &d) != XC_OK) return fail("xc_hist before xc_keep_resident", ctx);
+        if (xc_keep_resident(ctx, q, sizeof q) != XC_OK || xc_keep_resident(ctx, dA, sizeof dA) != XC_OK) return fail("xc_keep_resident", ctx);
+        d.cdf = &c2[0][0][0]; if (xc_hist(ctx, &d) != XC_OK) return fail("xc_hist with resident inputs", ctx);
+        if (memcmp(c1, c2, sizeof c1) != 0) { fprintf(stderr, "FAIL: resident inputs change the result\n"); return 1; }
+        if (xc_minmax(ctx, &q[1][0][0], XC_F32, 1, (int64_t)NY * NX, mm2) != XC_OK) return fail("xc_minmax on a slab of a resident array", ctx);
+        if (mm2[0] != mm[1][0] || mm2[1] != mm[1][1]) { fprintf(stderr, "FAIL: min/max of the second slab through its mirror\n"); return 1; }
+        if (xc_release_resident(ctx, NULL) != XC_OK) return fail("xc_release_resident", ctx);
+        d.cdf = &c2[0][0][0]; if (xc_hist(ctx, &d) != XC_OK) return fail("xc_hist after xc_release_resident", ctx);
+        if (memcmp(c1, c2, sizeof c1) != 0) { fprintf(stderr, "FAIL: result after release differs\n"); return 1; }
+        d.deterministic = 0; d.cdf = &cdf[0][0][0]; d.counts = &counts[0][0];
+    }
     /* error path: non-ascending edges must be refused with a message, not crash */
     edges[0][5] = edges[0][4];
     if (xc_hist(ctx, &d) == XC_OK) { fprintf(stderr, "FAIL: bad edges accepted\n"); return 1; }
