@@ -2,7 +2,6 @@
 # tools/collect_profiles.sh ROUND COMMIT  (run on the GPU box via gpurun, ~10 min): everything profiles/ holds for a round,
 # re-taken at one commit.  Writes gpurun_out/rNN_*; copy what should be judged into profiles/.
 R=$GRAFT_REPO_ROOT; cd $R; RD=${1:-r03}; COMMIT=${2:-unknown}; O=$R/gpurun_out
-echo "== bench default"; timeout -k 10 500 python3 bench.py > $O/${RD}_bench_n1.json 2> $O/${RD}_bench_n1.err || exit 1
 echo "== bench variants"
 : > $O/${RD}_bench_variants.jsonl
 for a in "--no-chain" "--slab-dA" "--row-dA" "--deterministic" "--variant 1" "--variant 2" "--dtype f32" "--dtype f32 --no-chain"; do
@@ -25,4 +24,7 @@ bash tools/pmc_k3.sh > $O/${RD}_pmc_k3_instruction_mix.txt 2>&1 || exit 1
 bash tools/pmc_lwa.sh > $O/${RD}_pmc_k7_instruction_mix.txt 2>&1 || exit 1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_sort -o kt -- python3 tools/kernel_times.py sort > /dev/null 2>&1
 cp $O/kt_sort/*/kt_kernel_stats.csv $O/${RD}_k8_sort_kernel_stats.csv 2>/dev/null || cp $O/kt_sort/kt_kernel_stats.csv $O/${RD}_k8_sort_kernel_stats.csv
+echo "== bench default (last: it quotes the PMC traffic just measured)"
+cp $O/hist_traffic.json $R/profiles/hist_traffic.json
+timeout -k 10 500 python3 bench.py > $O/${RD}_bench_n1.json 2> $O/${RD}_bench_n1.err || exit 1
 echo "== done"; ls -la $O/${RD}_*
