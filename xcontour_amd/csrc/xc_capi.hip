@@ -249,6 +249,7 @@ int xc_keep_resident(xc_ctx* ctx, const void* host_ptr, size_t bytes)
 {
     XC_CTX(ctx);
     if (!host_ptr || bytes == 0) return fail(ctx, XC_EBADARG, "xc_keep_resident: bad arguments");
+    XC_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& e : ctx->resident)
         if (e.host == (const char*)host_ptr) {                      // registered before: refresh (the caller changed the array)
@@ -271,6 +272,7 @@ int xc_keep_resident(xc_ctx* ctx, const void* host_ptr, size_t bytes)
 int xc_release_resident(xc_ctx* ctx, const void* host_ptr)
 {
     XC_CTX(ctx);
+    XC_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));        // an asynchronous upload may still be reading a mirror
     XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < ctx->resident.size();) {
         if (!host_ptr || ctx->resident[i].host == (const char*)host_ptr) {
