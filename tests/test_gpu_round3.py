@@ -634,3 +634,41 @@ def test_integration_md_stub_runs_as_printed(baro):
     got = ns['contour_crossing'](q[None].astype(np.float64), levels[None], dA, 2, 2, 'edge')      # stride 2, padded by max_stride = 2 columns
     want, _ = O.contour_crossing(O.pad_x(q.astype(np.float64), 2, 'edge'), levels, O.pad_x(dA, 2, 'edge'), 2)
     assert rel(got[0], np.asarray(want)) < 1e-12
+
+
+def test_facade_cycles_do_not_leak_device_memory(ctx):
+    """create / use / close Contour2D objects over and over (resident or not, deterministic or not, every operator): the
+    free device memory settles -- plans, resident mirrors and work buffers are returned"""
+    import ctypes as C
+    import xcontour_amd as xa
+    hip = C.CDLL('libamdhip64.so')
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+    ny, nx, S = 91, 180, 4
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 2.0
+    rng = np.random.default_rng(0)
+    c3 = {'t': np.arange(S), 'lat': lat, 'lon': lon}; c2 = {'lat': lat, 'lon': lon}
+    dA = xa.DataArray(O.cell_area(lat, lon), ('lat', 'lon'), c2, 'dA')
+    mask = xa.DataArray(np.ones((ny, nx)), ('lat', 'lon'), c2, 'mask')
+    base = None
+    for it in range(45):
+        q = np.sin(np.deg2rad(lat))[None, :, None] + 0.05 * rng.standard_normal((S, ny, nx))
+        tr = xa.DataArray(q, ('t', 'lat', 'lon'), c3, 'pv')
+        cm = xa.Contour2D(tr, dA, dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'}, increase=True, lt=True,
+                          resident=(it % 2 == 0), deterministic=(it % 3 == 0))
+        table = cm.cal_area_eqCoord_table_hist(mask)
+        ctr = cm.cal_contours(31)
+        cm.cal_integral_within_contours_hist(ctr)
+        ds = cm.keff(31, table, preY=lat, lat=lat, lon=lon)
+        if it % 5 == 0:
+            cm.cal_local_wave_activity(tr, ds['ctr_eq'].rename({'new': 'lat'}))
+            cm.cal_sorted_profile(table)
+            cm.cal_contour_crossing(ctr, stride=[1, 2])
+        cm.close()
+        del cm
+        if it == 14:
+            base = free_bytes()
+    assert base - free_bytes() < (1 << 20), 'device memory keeps shrinking: %d bytes since iteration 14' % (base - free_bytes())
