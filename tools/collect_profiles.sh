@@ -22,6 +22,7 @@ cp $O/kt_chain/*/kt_kernel_stats.csv $O/${RD}_bench_kernel_stats_chain.csv 2>/de
 cp $O/kt_nochain/*/kt_kernel_stats.csv $O/${RD}_bench_kernel_stats_nochain.csv 2>/dev/null || cp $O/kt_nochain/kt_kernel_stats.csv $O/${RD}_bench_kernel_stats_nochain.csv
 bash tools/pmc_k3.sh > $O/${RD}_pmc_k3_instruction_mix.txt 2>&1 || exit 1
 bash tools/pmc_lwa.sh > $O/${RD}_pmc_k7_instruction_mix.txt 2>&1 || exit 1
+bash tools/pmc_cross.sh > $O/${RD}_pmc_k9_instruction_mix.txt 2>&1 || exit 1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_sort -o kt -- python3 tools/kernel_times.py sort > /dev/null 2>&1
 cp $O/kt_sort/*/kt_kernel_stats.csv $O/${RD}_k8_sort_kernel_stats.csv 2>/dev/null || cp $O/kt_sort/kt_kernel_stats.csv $O/${RD}_k8_sort_kernel_stats.csv
 echo "== bench default (last: it quotes the PMC traffic just measured)"
