@@ -638,7 +638,7 @@ def main():
         if extras and a.long_run_s > 0:
             # the timed region above is K steps (tens of ms at the default K); the same steps for >= long_run_s seconds, every
             # histogram launch between its own pair of HIP events: a steadier twin of the headline (results go to the warm-up slot)
-            nlr = int(min(4000, max(K, np.ceil(a.long_run_s / (el / K)))))
+            nlr = int(min(100000, max(K, np.ceil(a.long_run_s / (el / K)))))
             lev = [(ctx.event(), ctx.event()) for _ in range(nlr)]
             plan.out_ptr = wres.data_ptr()
             for k in range(-2, 0):
