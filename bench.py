@@ -593,8 +593,8 @@ def main():
             ms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in ev])
             ach = alg / (ms.mean() * 1e-3) / 1e9
             uniq = uniq_bytes(a.slab_dA)
-            traffic, tsrc = (None, 'not measured for this variant') if (a.row_dA or a.variant != 0 or a.deterministic or a.dtype != 'f64') else \
-                stored_traffic(('slab_' if a.slab_dA else '') + ('chain' if chain else 'nochain'), B)
+            traffic, tsrc = (None, 'not measured for this variant') if (a.row_dA or a.variant != 0 or a.deterministic or (a.dtype != 'f64' and a.slab_dA)) else \
+                stored_traffic(('f32_' if a.dtype == 'f32' else '') + ('slab_' if a.slab_dA else '') + ('chain' if chain else 'nochain'), B)
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': ach / HBM_PEAK_GBS,
                                 'hbm_unique_frac': uniq / (ms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,

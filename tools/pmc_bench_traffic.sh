@@ -1,16 +1,17 @@
 #!/bin/bash
 # tools/pmc_bench_traffic.sh (run on the GPU box via gpurun): fabric traffic of the bench's dominant kernel, FETCH_SIZE and
 # WRITE_SIZE in SEPARATE --pmc passes (the guide's rule), for every schedule bench.py can run:
-#   chain (default) | nochain, each with the shared dA plane and with per-slab dA (--slab-dA);
+#   chain (default) | nochain, each with the shared dA plane and with per-slab dA (--slab-dA), and for float32 tracers (--dtype f32);
 # plus rocprofv3 --kernel-trace --stats summaries of the default command and of --no-chain.
 # The JSON carries sha256(xc_hist.hip + xc_hist_kernel.h + xc_binning.h): bench.py quotes a figure only while that matches its tree.
 # Writes gpurun_out/hist_traffic.json (copy to profiles/) and gpurun_out/kt_<mode>/.
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && cd $R
 COMMIT=${1:-unknown}
-for mode in chain nochain slab_chain slab_nochain; do
+for mode in chain nochain slab_chain slab_nochain f32_chain f32_nochain; do
   arg=""
   case $mode in *nochain) arg="--no-chain";; esac
   case $mode in slab_*) arg="$arg --slab-dA";; esac
+  case $mode in f32_*) arg="$arg --dtype f32";; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb_${mode}_$c -- python3 bench.py --steps 12 --warmup 3 --no-cpu --no-extras --no-cfg4 $arg > /dev/null 2>&1
   done
@@ -50,11 +51,12 @@ for mode, d in raw.items():
     dom = 'k_hist'
     if dom + ':FETCH_SIZE' not in d: continue
     slab = mode.startswith('slab_')
+    f32 = mode.startswith('f32_')
     cells = B * NY * NX
     out[mode] = {'kernel': dom, 'slabs_per_launch': B, 'commit': '$COMMIT', 'FETCH_SIZE_KB_raw': d[dom + ':FETCH_SIZE'], 'WRITE_SIZE_KB': d.get(dom + ':WRITE_SIZE'),
                  'hbm_bytes_per_launch': (d[dom + ':FETCH_SIZE'] * 2 + d.get(dom + ':WRITE_SIZE', 0.0)) * 1024,
-                 'algorithmic_bytes_per_launch': cells * 16,
-                 'hbm_unique_bytes_per_launch': cells * 8 + (cells * 8 if slab else NY * NX * 8)}
+                 'algorithmic_bytes_per_launch': cells * (12 if f32 else 16),
+                 'hbm_unique_bytes_per_launch': cells * (4 if f32 else 8) + (cells * 8 if slab else NY * NX * 8)}
 json.dump(out, open("$R/gpurun_out/hist_traffic.json", 'w'), indent=1)
 print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if kk in ('hbm_bytes_per_launch', 'FETCH_SIZE_KB_raw', 'factor')}) for k, v in out.items() if k != 'method'}, indent=1))
 PY
