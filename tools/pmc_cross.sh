@@ -2,6 +2,7 @@
 # tools/pmc_cross.sh (on the GPU box): instruction mix of K9 (k_crossing, stride 1) on the noisy PV-like cfg2 field and on the smooth one:
 # what holds the noisy case at 4.5 TB/s?  SQ counters in their own --pmc passes.
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && cd $R
+rm -rf $R/gpurun_out/pmccross_*
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAVES" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \

@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/pmc_k3.sh [bench args]: instruction mix of the bench's histogram kernels (chained and unchained variants separately)
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && cd $R
+rm -rf $R/gpurun_out/pmck3_*
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_BRANCH" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do

@@ -2,6 +2,7 @@
 # tools/pmc_lwa.sh (run on the GPU box via gpurun): instruction mix of K7 (k_lwa) on cfg3 and on a 64-slab stack of it:
 # is it VALU-bound?  SQ_INSTS_VALU / SQ_BUSY_CYCLES etc. in their own --pmc passes (no trace domains alongside).
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && cd $R
+rm -rf $R/gpurun_out/pmclwa_*
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_BRANCH SQ_WAVES" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
