@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: labelled arrays, edge construction, table rules,
 O(N) contour-space algebra of the facade against the oracle, slab sharding."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,8 @@ import xcontour_amd as xa
 from xcontour_amd import core
 from xcontour_amd.utils import table_from_rowsums, cell_area, grad_metrics
 from xcontour_amd.pipeline import shard_slabs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_public_api_surface():
@@ -155,3 +159,19 @@ def test_metrics_helpers():
     rdx, rdy = grad_metrics(lat, lon)
     ox, oy = O.grad_metrics(lat, lon)
     assert np.array_equal(rdx, ox) and np.array_equal(rdy, oy)
+
+
+def test_cfg4_launch_sets_tile_the_blocks_of_every_rank_count():
+    """bench.cfg4_launch_set: the launch-set size for a rank's block of the 18 944-slab stack tiles the block (every set chains
+    its min/max) and fills whole rounds of workgroups, for the rank counts the driver runs; odd blocks fall back to 256"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for world, want in ((1, 512), (2, 592), (4, 592), (8, 592)):
+        n = 18944 // world
+        d = m.cfg4_launch_set(n)
+        assert d == want and n % d == 0
+        rounds = 3 * d / 256.0
+        assert rounds / np.ceil(rounds) > 0.98
+    assert m.cfg4_launch_set(11) == 256 and m.cfg4_launch_set(3157) == 256       # no divisor that fills the rounds: ragged sets of 256
