@@ -25,6 +25,8 @@ bash tools/pmc_lwa.sh > $O/${RD}_pmc_k7_instruction_mix.txt 2>&1 || exit 1
 bash tools/pmc_cross.sh > $O/${RD}_pmc_k9_instruction_mix.txt 2>&1 || exit 1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_sort -o kt -- python3 tools/kernel_times.py sort > /dev/null 2>&1
 cp $O/kt_sort/*/kt_kernel_stats.csv $O/${RD}_k8_sort_kernel_stats.csv 2>/dev/null || cp $O/kt_sort/kt_kernel_stats.csv $O/${RD}_k8_sort_kernel_stats.csv
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg4 -o kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras > /dev/null 2>&1
+cp $O/kt_cfg4/*/kt_kernel_stats.csv $O/${RD}_bench_cfg4_strong_kernel_stats.csv 2>/dev/null || cp $O/kt_cfg4/kt_kernel_stats.csv $O/${RD}_bench_cfg4_strong_kernel_stats.csv
 echo "== bench default (last: it quotes the PMC traffic just measured)"
 cp $O/hist_traffic.json $R/profiles/hist_traffic.json
 timeout -k 10 500 python3 bench.py > $O/${RD}_bench_n1.json 2> $O/${RD}_bench_n1.err || exit 1
