@@ -256,8 +256,8 @@ int xc_keep_resident(xc_ctx* ctx, const void* host_ptr, size_t bytes)
             if (bytes > e.bytes) {
                 XC_HIP(ctx, hipFree(e.dev)); e.dev = nullptr; e.bytes = 0;
                 XC_HIP(ctx, hipMalloc(&e.dev, bytes));
-                e.bytes = bytes;
             }
+            e.bytes = bytes;                                        // (a shorter array now: the tail of the old mirror is no longer valid)
             XC_HIP(ctx, hipMemcpy(e.dev, host_ptr, bytes, hipMemcpyHostToDevice));
             return XC_OK;
         }
