@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """
-bench.py -- headline benchmark of the contour-coordinate hot path on MI355X.
+bench.py -- headline benchmark of the contour-coordinate hot path on MI355X.  No PyTorch anywhere in this file: device
+memory, streams, events and the one collective come from libxcontour_hip.so (ctypes), the rendezvous from
+xcontour_amd.distributed.SocketGroup (TCP on MASTER_ADDR / MASTER_PORT + 1).
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N ...            # N > 1 without WORLD_SIZE in the environment: this process only LAUNCHES N fresh
+                                            # rank processes (one per GPU, before anything touches the GPU) and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W       # any launcher that exports RANK / WORLD_SIZE / MASTER_* works
 
 Workload (BASELINE.json configs[1]): synthetic 3600 x 1801 float64 PV-like slabs, 2-D
 float64 cell areas, 201 contours, the FULL Keff pipeline per slab (min/max -> levels ->
@@ -14,8 +18,9 @@ distinct slabs resident in HBM; two such batches alternate (each larger than the
 Infinity Cache, so every step really reads its tracer from HBM, and the batch whose min/max is
 folded into a histogram pass is different data).  Metric: lat-lon cells x contours per second,
 whole job.  N > 1: every rank owns its own batch of independent slabs (weak scaling), no
-data-path collective during compute, ONE RCCL all-gather of all per-slab result vectors at
-the end of the timed region.
+data-path collective during compute, ONE RCCL all-gather (the library's own communicator, xc_comm_*, over xGMI) of all
+per-slab result vectors at the end of the timed region.  `--backend gloo` carries that one gather through the
+host (sockets) instead: for rehearsing the N > 1 path on a box with fewer GPUs than ranks.
 
 Steady-state schedule (default, `--chain`): the stack is processed as a software pipeline -- the
 histogram pass of step k also streams the batch of step k+1 and leaves its min/max partials
@@ -27,10 +32,13 @@ the stand-alone min/max launch merely disappears.  `--no-chain` runs K1 then K3 
 After the timed region rank 0's line also carries (all outside the timed region, all parity-checked):
   * `variants.slab_dA` -- the same chained schedule with per-slab (time-varying) weights: every byte of the 16 B/cell
     numerator is then unique HBM traffic, so `frac == hbm_unique_frac` is a genuine HBM fraction;
+  * `variants.f32` -- the same schedule on float32 tracers and float32 contours (the dtype of every file the reference ships
+    and its default `dtype`, core.py:21), two of its slabs checked against the oracle;
   * `long_run` -- >= 0.5 s of the same steps with HIP events around every histogram launch (mean / spread);
   * `cfg4_strong` -- BASELINE.json configs[3]: 18 944 slabs of 1440 x 721 float64 partitioned contiguously over the
-    ranks (strong scaling: total work fixed), Keff per slab, ONE gather of all nine result vectors inside its own
-    timed region (barrier + sync on both sides, max over ranks).
+    ranks (strong scaling: total work fixed), Keff per slab, results written slab-major so that the rank's block IS the
+    send buffer, ONE gather of all nine result vectors inside its own timed region (barrier + sync on both sides, max over
+    ranks) and a `budget` of where each rank's job time goes.
 
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel = the histogram pass, timed
 with HIP events on its own stream around every launch of the timed region) and, at N=1,
@@ -219,6 +227,94 @@ def rel_err(a, b):
     return float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m]))) if m.any() else 0.0
 
 
+# ----------------------------------------------------------------------------- launcher + the ranks' process group
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh rank processes (one per GPU), each a
+    new interpreter running this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, and return the
+    worst exit code.  This process imports nothing that can touch the GPU and never execs: the ranks are children.
+    Rank 0's JSON line goes to this process's stdout (inherited); a rank that dies takes the others down with it."""
+    import secrets
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:      # a free port pair: P for a launcher's store (unused here), P + 1 for SocketGroup
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    port = port - 1 if port > 1024 else port
+    env = dict(os.environ)
+    env.update({'WORLD_SIZE': str(n), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'XC_DIST_TOKEN': secrets.token_hex(16),
+                'HSA_ENABLE_IPC_MODE_LEGACY': env.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), 'XC_BENCH_LAUNCHED': '1'})
+    procs = []
+    for r in range(n):
+        e = dict(env)
+        e.update({'RANK': str(r), 'LOCAL_RANK': str(r)})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+    rc, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            c = p.poll()
+            if c is None:
+                continue
+            alive.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                for q in alive:                                        # exactly the processes started above, by PID
+                    q.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
+class Gather(object):
+    """The one collective of a job: an all-gather of equal device blocks.  Carrier 'rccl': the library's own RCCL communicator
+    (xc_comm_*, ncclAllGather over xGMI on the context's stream).  Carrier 'host': device -> host, SocketGroup.allgather,
+    the result stays on the host (`--backend gloo`; also what a job falls back to -- loudly, in the JSON line -- if the
+    communicator cannot be created, e.g. more ranks than GPUs)."""
+
+    def __init__(self, ctx, group, backend):
+        self.ctx, self.group, self.note = ctx, group, None
+        self.carrier = 'none' if group.world == 1 else ('rccl' if backend in ('nccl', 'rccl') else 'host')
+        if self.carrier == 'rccl':
+            try:
+                group.init_device(ctx)
+            except Exception as e:                                     # every rank gets the same verdict (SocketGroup.init_device)
+                self.carrier, self.note = 'host', 'RCCL communicator unavailable, gathered through the host instead: %s' % e
+                if group.rank == 0:
+                    print('warning: ' + self.note, file=sys.stderr)
+
+    def describe(self):
+        return {'none': 'single rank (no collective)', 'rccl': 'ncclAllGather over xGMI (library communicator xc_comm_*, RCCL), on the compute stream',
+                'host': 'device -> host, TCP all-gather through rank 0 (xcontour_amd.distributed.SocketGroup), host result'}[self.carrier]
+
+    def run(self, send_ptr, nbytes, recv_buf):
+        """enqueue / perform the gather of `nbytes` at device `send_ptr` from every rank; returns None (rccl: result in
+        `recv_buf` on the device after ctx.sync()) or the gathered host array (world, nbytes) uint8 (host carrier)"""
+        if self.carrier == 'none':
+            return None                                                # a single rank: the block stays where it is, on the device
+        if self.carrier == 'rccl':
+            self.ctx.comm_allgather(send_ptr, recv_buf.ptr, nbytes)
+            return None
+        self.ctx.sync()
+        return self.group.allgather(self._d2h(send_ptr, nbytes))
+
+    def _d2h(self, ptr, nbytes):
+        h = np.empty(nbytes, dtype=np.uint8)
+        self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, h.ctypes.data, ptr, nbytes))
+        return h
+
+    def fetch(self, send_ptr, recv_buf, nbytes, host_result):
+        """the gathered bytes on the host, (world, nbytes) uint8, after the job (outside every timed region)"""
+        if host_result is not None:
+            return host_result
+        self.ctx.sync()
+        if self.carrier == 'none':
+            return self._d2h(send_ptr, nbytes)[None]
+        return recv_buf.download((self.group.world, nbytes), np.uint8)
+
+
 # ----------------------------------------------------------------------------- cfg4: strong scaling over the ranks
 def cfg4_launch_set(n, cus=256, blocks_per_slab=3):
     """Slabs per launch set for a rank's block of `n` cfg4 slabs.  A set that TILES the block keeps every set chained (a ragged
@@ -237,21 +333,23 @@ def cfg4_launch_set(n, cus=256, blocks_per_slab=3):
     return best if best is not None and score >= 0.96 else 256
 
 
-def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
+def cfg4_strong(ctx, nat, a, group, gather):
     """BASELINE.json configs[3]: `--cfg4-slabs` (18 944 = 512 x 37) slabs of 1440 x 721 float64, Keff per slab with per-slab
     levels; the flattened (time, level) index is cut into contiguous blocks of ceil(S/G) slabs (pipeline.shard_slabs), every
-    rank sweeps its block in chained launch sets of `--cfg4-chunk` slabs, and ONE all-gather of the nine per-slab result
-    vectors ends the job.  A job = sweep + gather; `--cfg4-reps` jobs are timed between barriers, max over ranks."""
+    rank sweeps its block in chained launch sets of `--cfg4-chunk` slabs whose results land slab-major -- [slab][9][N],
+    xc_keff_desc.out_stride -- straight in the rank's send block, and ONE all-gather of the nine per-slab result vectors ends
+    the job.  A job = sweep + gather; `--cfg4-reps` jobs are timed between barriers, max over ranks."""
     from xcontour_amd.pipeline import KeffPlan, shard_slabs, OUT_NAMES
-    from xcontour_amd.distributed import all_gather_slabs, chunks_to_slabs
     from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
     import ctypes as C
+    world, rank = group.world, group.rank
     NY4, NX4 = 721, 1440
     S, R = int(a.cfg4_slabs), max(1, int(a.cfg4_reps))
     lat = np.linspace(-90, 90, NY4)
     lon = np.arange(NX4) * 0.25
     dA = cell_area(lat, lon)
     tbl = table_from_rowsums(ctx.rowsum(None, dA, NY4, NX4), True, last_row_included(lat, 'xhistogram'))
+    per = -(-S // world)
     lo, hi = shard_slabs(S, rank, world)
     n = hi - lo
     Cn = min(int(a.cfg4_chunk) if a.cfg4_chunk > 0 else cfg4_launch_set(n), max(n, 1))
@@ -262,10 +360,7 @@ def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
         qbuf = ctx.alloc(max(n, 1) * slab_bytes)                 # this rank's block of the stack, resident in HBM
     except nat.XContourHipError as e:
         err = str(e)
-    ok = torch.tensor([0 if qbuf is None else 1], dtype=torch.int32, device=gdev)
-    if world > 1:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                # every rank skips if one could not hold its block
-    if int(ok.item()) == 0:
+    if group.allreduce_min(0 if qbuf is None else 1) < 1:        # every rank skips if one could not hold its block
         if qbuf is not None:
             qbuf.free()
         return {'skipped': 'a rank could not allocate its %d-slab block (%.1f GB): %s' % (n, n * slab_bytes / 1e9, err)}
@@ -275,10 +370,12 @@ def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
         ctx._check(ctx.lib.xc_synth_dev(ctx.handle, qbuf.ptr + c0 * slab_bytes, nat.XC_F64, m, NY4, NX4,
                                         lat_b.ptr, lon_b.ptr, SEED + lo + c0, 0))
     ctx.sync()
-    slot = KeffPlan.out_bytes(Cn, NCONT)
-    res = torch.zeros(max(nchunk, 1) * slot // 8, dtype=torch.float64, device='cuda')
+    # ONE result slot of `per` slabs, slab-major: its head is the rank's (per, 9, N) block (short blocks: zero padding)
     plan = KeffPlan(ctx, Cn, NY4, NX4, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
-                    increase=True, lt=True, nslots=max(nchunk, 1), out_ptr=res.data_ptr(), alloc_q=False, right_edge='xhistogram')
+                    increase=True, lt=True, nslots=1, out_slabs=per, alloc_q=False, right_edge='xhistogram', slab_major=True)
+    block_bytes = plan.head_bytes                                # per * 9 * N * 8
+    ctx._check(ctx.lib.xc_memset(ctx.handle, plan.out_ptr, 0, plan.slot_bytes))
+    recv = ctx.alloc(world * block_bytes) if gather.carrier == 'rccl' else None
 
     def sweep():
         for ci in range(nchunk):
@@ -287,48 +384,49 @@ def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
             plan.set_q_device(qbuf.ptr + c0 * slab_bytes)
             nxt = ((ci + 1) % nchunk) * Cn
             chain = min(Cn, n - nxt) == m                          # equal-shape launch sets chain their min/max (q_next)
-            plan._point(ci, 0, m)
+            plan._point(0, 0, m, out_s0=c0)                        # results of slab c0 + i -> block[c0 + i][:][:]
             plan.desc.q_next = (qbuf.ptr + nxt * slab_bytes) if chain else None
             ctx._check(ctx.lib.xc_keff_dev(ctx.handle, C.byref(plan.desc)))
 
     def job():
         sweep()
-        ctx.sync()                                               # the library's own stream
-        mine = chunks_to_slabs(res, slot // 8, Cn, n, NCONT)     # this rank's (n, 9, N) block in slab order
-        full = all_gather_slabs(mine if gdev == 'cuda' else mine.cpu(), S, rank, world)   # the ONE collective
-        torch.cuda.synchronize()
-        return mine, full
+        h = gather.run(plan.out_ptr, block_bytes, recv)          # the ONE collective: same stream, right behind the last launch set
+        ctx.sync()
+        return h
 
-    job()                                                        # warm-up: kernels, scratch growth, the communicator's channels
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    host = job()                                                 # warm-up: kernels, scratch growth, the communicator's channels
+    group.barrier()
+    ctx.sync()
     t0 = time.perf_counter()
     for _ in range(R):
-        mine, full = job()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=gdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    # where a job's time goes (one extra job, host clock around each stage with a sync behind it; every rank takes part)
-    stages = {}
-    ts = time.perf_counter(); sweep(); ctx.sync(); stages['sweep_ms'] = (time.perf_counter() - ts) * 1e3
-    ts = time.perf_counter(); mine = chunks_to_slabs(res, slot // 8, Cn, n, NCONT); torch.cuda.synchronize(); stages['pack_ms'] = (time.perf_counter() - ts) * 1e3
-    ts = time.perf_counter(); full = all_gather_slabs(mine if gdev == 'cuda' else mine.cpu(), S, rank, world); torch.cuda.synchronize()
-    stages['gather_ms'] = (time.perf_counter() - ts) * 1e3
+        host = job()
+    group.barrier()
+    el = group.allreduce_max(time.perf_counter() - t0)
+    # where a job's time goes: one extra job per rank, device events around the sweep and around the gather (no sync between
+    # them), host clock around the whole; every rank reports, rank 0 prints the per-rank lists and the worst of each
+    e0, e1, e2 = ctx.event(), ctx.event(), ctx.event()
+    group.barrier()
+    ts = time.perf_counter()
+    ctx.record(e0); sweep(); ctx.record(e1)
+    tg = time.perf_counter()
+    host = gather.run(plan.out_ptr, block_bytes, recv)
+    ctx.record(e2); ctx.sync()
+    t_end = time.perf_counter()
+    sweep_ms = ctx.elapsed_ms(e0, e1)
+    gather_ms = ctx.elapsed_ms(e1, e2) if gather.carrier != 'host' else (t_end - tg) * 1e3
+    st = np.array([sweep_ms, gather_ms, (t_end - ts) * 1e3])
+    stages = group.allgather(st)                                 # (world, 3)
     block = None
     if rank == 0:
-        assert tuple(full.shape) == (S, 9, NCONT)
-        fb = full.view(torch.int64).cpu().numpy()                 # bit patterns: the vectors hold NaNs
-        assert np.array_equal(fb[lo:hi], mine.view(torch.int64).cpu().numpy()), 'rank 0 block is not where it belongs'
+        full = gather.fetch(plan.out_ptr, recv, block_bytes, host).view(np.float64).reshape(world * per, 9, NCONT)[:S]
+        mine = plan.fetch(check=False)
+        mine_blk = np.stack([mine[k] for k in OUT_NAMES], axis=1)[:n]
+        fb = full.view(np.int64)                                   # bit patterns: the vectors hold NaNs
+        assert np.array_equal(fb[lo:hi], mine_blk.view(np.int64)), 'rank 0 block is not where it belongs'
         # every other rank's block sits at its place with that rank's data: recompute the FIRST slab of each block here
         checked = []
         one = KeffPlan(ctx, 1, NY4, NX4, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
                        increase=True, lt=True, right_edge='xhistogram')
-        fnp = full.cpu().numpy()
         for r in range(world):
             rlo, rhi = shard_slabs(S, r, world)
             if rhi <= rlo:
@@ -336,10 +434,10 @@ def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
             one.synth(lat, lon, SEED + rlo, 0)
             one.run()
             o = one.fetch()
-            if not np.array_equal(o['ctr'][0], fnp[rlo, OUT_NAMES.index('ctr')]):
+            if not np.array_equal(o['ctr'][0], full[rlo, OUT_NAMES.index('ctr')]):
                 raise RuntimeError('cfg4_strong: slab %d (first of rank %d) does not carry that slab\'s levels' % (rlo, r))
             for k in ('area', 'intgrdS', 'latEq'):
-                e = rel_err(fnp[rlo, OUT_NAMES.index(k)], o[k][0])
+                e = rel_err(full[rlo, OUT_NAMES.index(k)], o[k][0])
                 if not e < 1e-11:
                     raise RuntimeError('cfg4_strong: slab %d (first of rank %d): %s differs by %g' % (rlo, r, k, e))
             checked.append(rlo)
@@ -351,36 +449,42 @@ def cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev):
             ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, qbuf.ptr, min(2, n) * slab_bytes))
             for s_ in range(min(2, n)):
                 rr = O.keff_pipeline(qh[s_], dA, lat, NCONT, lon=lon, increase=True, lt=True, dtype=np.float64)
-                gpu = {k: fnp[lo:lo + 2, OUT_NAMES.index(k)] for k in OUT_NAMES}
-                gpu['counts'] = np.stack([rr['counts']] * 2)    # the nine gathered vectors carry no counts
+                gpu = {k: full[lo:lo + 2, OUT_NAMES.index(k)] for k in OUT_NAMES}
+                gpu['counts'] = mine['counts'][:2]
                 _compare_with_oracle(gpu, rr, s_)
                 oracle_checked += 1
         one.free()
-        nk = fnp[:, OUT_NAMES.index('nkeff'), :]
+        nk = full[:, OUT_NAMES.index('nkeff'), :]
         work = S * NY4 * NX4 * NCONT
         block = {
             'metric': 'lat-lon cells*contours/s, full Keff pipeline, cfg4 stack (sweep + one gather)', 'value': work * R / el,
             'unit': 'cells*contours/s', 'n_gpus': world, 'scaling': 'strong', 'jobs_timed': R, 'ms_per_job': el / R * 1e3,
-            'slabs': S, 'slab_shape': [NY4, NX4], 'slabs_per_gpu': -(-S // world), 'slabs_per_launch': Cn,
-            'us_per_slab_per_gpu': el / R / max(1, -(-S // world)) * 1e6,
-            'job_stages_rank0': stages,
-            'gathered_bytes': int(S * 9 * NCONT * 8), 'gather': ('torch.distributed all_gather_into_tensor, backend %s' % a.backend) if world > 1 else 'single rank (no collective)',
+            'slabs': S, 'slab_shape': [NY4, NX4], 'slabs_per_gpu': per, 'slabs_per_launch': Cn,
+            'us_per_slab_per_gpu': el / R / max(1, per) * 1e6,
+            'budget': {'sweep_ms_by_rank': [float(x) for x in stages[:, 0]], 'gather_ms_by_rank': [float(x) for x in stages[:, 1]],
+                       'job_ms_by_rank': [float(x) for x in stages[:, 2]], 'pack_ms': 0.0,
+                       'sweep_ms_max': float(stages[:, 0].max()), 'gather_ms_max': float(stages[:, 1].max()),
+                       'note': 'one extra job after the timed ones: HIP events around the sweep and (RCCL carrier) around the gather on the '
+                               'same stream, host clock around the job; no pack stage: the launch sets write [slab][9][N] straight into the send block'},
+            'gathered_bytes': int(world * block_bytes), 'gather': gather.describe(), 'gather_note': gather.note,
             'algorithmic_bytes': int(S * NY4 * NX4 * BYTES_PER_CELL), 'pipeline_frac': (S * NY4 * NX4 * BYTES_PER_CELL * R / el / 1e9) / HBM_PEAK_GBS / world,
             'checks': {'rank0_block_bit_identical': True, 'first_slab_of_each_rank_recomputed': checked,
                        'oracle_checked_slabs': oracle_checked, 'finite_nkeff_fraction': float(np.isfinite(nk).mean())},
             'config': 'cfg4: %d slabs of %dx%d float64 (seed + slab id), %d contours, per-slab levels, contiguous blocks of '
-                      'ceil(S/G) slabs per rank, chained launch sets of %d, ONE all-gather of (S, 9, N) f64 inside the timed job'
+                      'ceil(S/G) slabs per rank, chained launch sets of %d writing slab-major, ONE all-gather of (S, 9, N) f64 inside the timed job'
                       % (S, NX4, NY4, NCONT, Cn),
         }
+    for e in (e0, e1, e2):
+        ctx.lib.xc_event_destroy(ctx.handle, e)
     plan.free()
-    qbuf.free()
-    del res
-    torch.cuda.empty_cache()
+    qbuf.free(); lat_b.free(); lon_b.free()
+    if recv is not None:
+        recv.free()
     return block
 
 
 # ----------------------------------------------------------------------------- main
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
@@ -408,12 +512,11 @@ def main():
     ap.add_argument('--deterministic', action='store_true',
                     help='order-free fixed-point accumulation (xc_keff_desc.deterministic): bit-reproducible sums at about twice the '
                          'histogram cost')
-    ap.add_argument('--native-rccl', action='store_true',
-                    help="do the one end-of-job gather with the library's own RCCL communicator (xc_comm_*) on its "
-                         'own stream instead of torch.distributed (the id travels through the torch store)')
-    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
-                    help="process-group backend; 'nccl' IS RCCL on ROCm (default).  'gloo' stages the one gather "
-                         'through the host: only for exercising the multi-rank path on a box with fewer GPUs than ranks')
+    ap.add_argument('--native-rccl', action='store_true', help='(kept for old command lines: the library communicator is the default now)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'rccl', 'gloo', 'host'],
+                    help="carrier of the ONE end-of-job gather: 'nccl' = 'rccl' (default): ncclAllGather over xGMI through the "
+                         "library's own communicator (xc_comm_*); 'gloo' = 'host': staged through the host over the rendezvous "
+                         'sockets -- only for exercising the multi-rank path on a box with fewer GPUs than ranks')
     ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
                     help="BASELINE.json configuration: cfg2 (default, the headline metric's), or one of the secondary ones as "
                          'a bench line of the same contract (tools/bench_configs.py; single GPU; --steps / --warmup apply)')
@@ -428,34 +531,31 @@ def main():
     ap.add_argument('--cfg4-slabs', type=int, default=512 * 37)
     ap.add_argument('--cfg4-chunk', type=int, default=0, help='slabs per launch set of the cfg4 sweep (0: chosen by cfg4_launch_set: a size that tiles the rank\'s block and fills whole rounds of workgroups)')
     ap.add_argument('--cfg4-reps', type=int, default=2, help='timed cfg4 jobs (sweep + gather)')
-    a = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # the driver's plain `python3 bench.py --gpus N`: become the launcher, BEFORE anything that could touch a GPU
+        if a.config != 'cfg2':
+            raise SystemExit('--config %s is a single-GPU line; the multi-GPU cfg4 job is the `cfg4_strong` block of the default run' % a.config)
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    ndev = torch.cuda.device_count()
-    if ndev < 1:
-        raise RuntimeError('bench.py needs an MI355X (no CPU fallback)')
-    local = local if local < ndev else 0          # a launcher may expose one device per rank
-    torch.cuda.set_device(local)
-    if world > 1:
-        if a.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group('gloo')
-    if a.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
+    if a.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks (the two must agree: `value` is the '
+                         'whole-job aggregate over --gpus GPUs)' % (a.gpus, world))
 
     sys.path.insert(0, ROOT)
     from xcontour_amd import _native as nat
     if not os.path.exists(nat.LIB_PATH):
         # the in-tree library normally travels with the snapshot; if it did not, build it once per node
         # (local rank 0 compiles, the others wait for the file) -- still no fallback: without it nothing runs
-        if int(os.environ.get('LOCAL_RANK', '0')) == 0:
+        if local == 0:
             import __graft_entry__
             __graft_entry__.build()
         for _ in range(600):
@@ -463,9 +563,15 @@ def main():
                 break
             time.sleep(0.5)
     from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.distributed import SocketGroup
     from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
 
-    ctx = nat.Context(local)
+    nd = device_count(nat)
+    if nd < 1:
+        raise RuntimeError('bench.py needs an MI355X (no CPU fallback)')
+    dev = local if local < nd else local % nd     # a launcher may expose one device per rank; a rehearsal has fewer GPUs than ranks
+    ctx = nat.Context(dev)
+    group = SocketGroup(rank, world)
     if a.config != 'cfg2':
         if world > 1:
             raise SystemExit('--config %s is a single-GPU line; the multi-GPU cfg4 job is the `cfg4_strong` block of the default run' % a.config)
@@ -474,6 +580,7 @@ def main():
         print(json.dumps(bench_configs.run(a.config, ctx, a.steps, a.warmup)), flush=True)
         ctx.close()
         return
+    gather = Gather(ctx, group, a.backend)
     B, K, W = a.batch, a.steps, a.warmup
     qdt = np.dtype(np.float32 if a.dtype == 'f32' else np.float64)
     bpc = qdt.itemsize + 8                                        # algorithmic bytes per cell: tracer once + 2-D f64 dA once
@@ -489,13 +596,13 @@ def main():
     # the device; one gather at the end.
     NB = 2
     slot = KeffPlan.out_bytes(B, NCONT)
-    res = torch.empty(slot * K // 8, dtype=torch.float64, device='cuda')
-    wres = torch.empty(slot // 8, dtype=torch.float64, device='cuda')        # warm-up slot
+    res = ctx.alloc(slot * K)
+    wres = ctx.alloc(slot)                                        # warm-up slot
     plan = KeffPlan(ctx, NB * B, NY, NX, NCONT, qdt, qdt, dA=dA, lat=lat, lon=lon, tbl=tbl,
-                    tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.data_ptr(), detect_row_dA=a.row_dA,
+                    tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.ptr, detect_row_dA=a.row_dA,
                     out_slabs=B, replicate_dA=a.slab_dA, right_edge='xhistogram', deterministic=a.deterministic)
     plan.synth(lat, lon, SEED + rank * NB * B, a.variant)         # slab s of rank r: seed + r*2B + s
-    group = a.group or B
+    grp = a.group or B
     chain = bool(a.chain)
 
     def step(k, slot_idx, pl=None, ch=None):
@@ -503,62 +610,46 @@ def main():
         ch = chain if ch is None else ch
         s0 = (k % NB) * B                                         # this step's batch
         nxt = ((k + 1) % NB) * B                                  # the batch of the next step
-        for g0 in range(s0, s0 + B, group):
-            n = min(group, s0 + B - g0)
-            g1 = g0 + group if g0 + group < s0 + B else nxt       # what runs after this launch set
-            pl.run_range(slot_idx, g0, n, g1 if (ch and min(group, B) == n) else None, out_s0=g0 - s0)
+        for g0 in range(s0, s0 + B, grp):
+            n = min(grp, s0 + B - g0)
+            g1 = g0 + grp if g0 + grp < s0 + B else nxt          # what runs after this launch set
+            pl.run_range(slot_idx, g0, n, g1 if (ch and min(grp, B) == n) else None, out_s0=g0 - s0)
 
-    plan.out_ptr = wres.data_ptr()
+    plan.out_ptr = wres.ptr
     for k in range(-W, 0):                                        # ends on batch B; its pass carries batch A's min/max
         step(k, 0)
-    plan.out_ptr = res.data_ptr()
+    plan.out_ptr = res.ptr
     ctx.sync()
-    torch.cuda.synchronize()
     ev = [(ctx.event(), ctx.event()) for _ in range(K)]
-    if world > 1 and a.native_rccl:
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
-    gdev = 'cuda' if a.backend == 'nccl' else 'cpu'
-    gathered = torch.empty(res.numel() * world, dtype=torch.float64, device=gdev) if world > 1 else None
+    nres = slot * K
+    gathered = ctx.alloc(nres * world) if gather.carrier == 'rccl' else None
     if world > 1:
         # warm-up of the collective, like the W warm-up steps of the compute: the first all-gather of a communicator sets up
         # its channels / proxy connections (tens of ms), which is start-up cost and not part of a steady-state job
-        if a.native_rccl:
-            ctx.comm_allgather(res.data_ptr(), gathered.data_ptr(), res.numel() * 8)
-            ctx.sync()
-        else:
-            dist.all_gather_into_tensor(gathered, res if a.backend == 'nccl' else res.cpu())
-        torch.cuda.synchronize()
-        res.zero_(); gathered.zero_()                               # the timed region fills them again
+        gather.run(res.ptr, nres, gathered)
+        ctx.sync()
+        ctx._check(ctx.lib.xc_memset(ctx.handle, res.ptr, 0, nres))                     # the timed region fills them again
+        if gathered is not None:
+            ctx._check(ctx.lib.xc_memset(ctx.handle, gathered.ptr, 0, nres * world))
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    group.barrier()
+    ctx.sync()
     t0 = time.perf_counter()
     for k in range(K):
-        if group == B:
+        if grp == B:
             ctx.set_hist_events(ev[k][0], ev[k][1])               # events around the K3 launch only
         step(k, k)
-    if world > 1 and a.native_rccl:
-        ctx.comm_allgather(res.data_ptr(), gathered.data_ptr(), res.numel() * 8)         # the one collective, same stream
-    ctx.sync()                                                    # the library's own HIP stream
-    if world > 1 and not a.native_rccl:
-        dist.all_gather_into_tensor(gathered, res if a.backend == 'nccl' else res.cpu())   # the one collective (RCCL)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    hostg = gather.run(res.ptr, nres, gathered) if world > 1 else None    # the one collective: same stream, behind the last step
+    ctx.sync()                                                    # the library's own HIP stream (every kernel and the gather run on it)
+    group.barrier()
     t1 = time.perf_counter()
-    el = t1 - t0
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=gdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-        if rank == 0:
-            # every rank's block arrived, in rank order, and rank r's slabs differ from rank 0's (seed + r*2B + s)
-            g = gathered.view(world, -1).view(torch.int64).cpu()      # bit patterns: results hold NaNs
-            mine = res.view(torch.int64).cpu()
-            assert torch.equal(g[0], mine) and all(not torch.equal(g[r], g[0]) for r in range(1, world))
+    el = group.allreduce_max(t1 - t0)
+    if world > 1 and rank == 0:
+        # every rank's block arrived, in rank order, and rank r's slabs differ from rank 0's (seed + r*2B + s)
+        g = gather.fetch(res.ptr, gathered, nres, hostg)
+        mine = res.download((nres,), np.uint8)
+        assert np.array_equal(g[0], mine) and all(not np.array_equal(g[r], g[0]) for r in range(1, world)), 'gathered blocks are not in rank order'
+        del g, mine
 
     line = None
     if rank == 0:
@@ -572,24 +663,26 @@ def main():
             'config': {'workload': 'cfg2: synthetic %dx%d %s PV-like slabs, 2-D f64 dA, %d contours, '
                                    'full Keff (min/max + histogram with in-kernel |grad q|^2 + CDF + epilogue)'
                                    % (NX, NY, qdt.name, NCONT),
-                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': group, 'resident_batches': NB, 'variant': a.variant, 'dA': dA_kind,
+                       'slabs_per_step_per_gpu': B, 'slabs_per_launch': grp, 'resident_batches': NB, 'variant': a.variant, 'dA': dA_kind,
                        'minmax': 'folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass',
                        'sums': 'order-free fixed point (deterministic)' if a.deterministic else 'float64 LDS atomics',
-                       'parallelism': 'independent slabs per GPU, one RCCL all-gather at the end' if world > 1 else 'single GPU',
-                       'device': ctx.device_name()},
+                       'parallelism': ('independent slabs per GPU, one all-gather at the end: ' + gather.describe()) if world > 1 else 'single GPU',
+                       'launcher': ('bench.py itself (one child process per rank)' if os.environ.get('XC_BENCH_LAUNCHED') else 'external (RANK / WORLD_SIZE from the environment)') if world > 1 else 'none',
+                       'collective_note': gather.note,
+                       'host_code': 'python + ctypes, no torch', 'device': ctx.device_name()},
         }
         cells = B * NY * NX
         alg = cells * (qdt.itemsize if a.row_dA else bpc)              # tracer once + dA once per slab
 
-        def uniq_bytes(slab_dA):
+        def uniq_bytes(slab_dA, esz=qdt.itemsize):
             # bytes that MUST cross HBM once per launch: this batch's tracer + the weights that are not shared
             # (a dA plane shared by the B slabs of a launch is fetched once; per-slab dA planes B times; a per-row vector ~0)
-            return cells * qdt.itemsize + (cells * 8 if slab_dA else (NY * 8 if a.row_dA else NY * NX * 8))
+            return cells * esz + (cells * 8 if slab_dA else (NY * 8 if a.row_dA else NY * NX * 8))
 
-        def kernel_name(slab_dA, ch):
-            return ('k_hist<double,%s,%s>' if a.dtype == 'f64' else 'k_hist<float,%s,%s>') % ('DA_SLAB' if slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'), 'NEXT' if ch else 'plain')
+        def kernel_name(slab_dA, ch, f32=(a.dtype == 'f32')):
+            return ('k_hist<float,%s,%s>' if f32 else 'k_hist<double,%s,%s>') % ('DA_SLAB' if slab_dA else ('DA_ROW' if a.row_dA else 'DA_PLANE'), 'NEXT' if ch else 'plain')
 
-        if group == B:
+        if grp == B:
             ms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in ev])
             ach = alg / (ms.mean() * 1e-3) / 1e9
             uniq = uniq_bytes(a.slab_dA)
@@ -604,8 +697,8 @@ def main():
                                 'algorithmic_bytes_per_launch': alg,
                                 'hbm_unique_bytes_per_launch': uniq,
                                 'streamed_bytes_per_launch': alg + (cells * qdt.itemsize if chain else 0),
-                                'pipeline_frac': (alg * K / el / 1e9) / HBM_PEAK_GBS,
-                                'pipeline_hbm_unique_frac': (uniq * K / el / 1e9) / HBM_PEAK_GBS,
+                                'pipeline_frac': (alg * K / el / 1e9) / HBM_PEAK_GBS / world,
+                                'pipeline_hbm_unique_frac': (uniq * K / el / 1e9) / HBM_PEAK_GBS / world,
                                 'measured_stream_ceilings': stream_ceilings(),
                                 'note': 'frac = ' + str(bpc) + ' B/cell (SURVEY 8d) / launch time / 8 TB/s; its numerator counts the dA plane once per '
                                         'slab although the %d slabs of a launch share it (cache-served after the first fetch) -- '
@@ -618,12 +711,12 @@ def main():
         csum = out['counts'].sum(axis=1).astype(np.int64)
         if not ((csum == NY * NX).all() if a.dtype == 'f64' else ((csum <= NY * NX) & (csum >= NY * NX - 4)).all()) or out['status'].any():
             raise RuntimeError('bench self-check failed: counts %r status %r' % (out['counts'].sum(axis=1), out['status']))
-        extras = world == 1 and group == B and not a.no_extras
+        extras = world == 1 and grp == B and not a.no_extras
         if extras and chain:
             # transparency: the same work in the plain order (stand-alone K1 launch, then K3), a short extra run
             # AFTER the timed region (identical per-step outputs; tests/test_gpu_parity.py::test_chained_minmax_is_bit_identical)
             K2 = max(5, min(20, K))
-            plan.out_ptr = wres.data_ptr()
+            plan.out_ptr = wres.ptr
             for k in range(-3, 0):
                 step(k, 0, ch=False)
             ctx.sync()
@@ -632,7 +725,7 @@ def main():
                 step(k, 0, ch=False)
             ctx.sync()
             el2 = time.perf_counter() - t2
-            plan.out_ptr = res.data_ptr()
+            plan.out_ptr = res.ptr
             line['unchained'] = {'value': work_step * K2 / el2, 'ms_per_step': el2 / K2 * 1e3, 'steps': K2,
                                  'note': 'stand-alone min/max launch before every histogram launch (--no-chain), same slabs'}
         if extras and a.long_run_s > 0:
@@ -640,7 +733,7 @@ def main():
             # histogram launch between its own pair of HIP events: a steadier twin of the headline (results go to the warm-up slot)
             nlr = int(min(100000, max(K, np.ceil(a.long_run_s / (el / K)))))
             lev = [(ctx.event(), ctx.event()) for _ in range(nlr)]
-            plan.out_ptr = wres.data_ptr()
+            plan.out_ptr = wres.ptr
             for k in range(-2, 0):
                 step(k, 0)
             ctx.sync()
@@ -650,7 +743,7 @@ def main():
                 step(k, 0)
             ctx.sync()
             el3 = time.perf_counter() - t2
-            plan.out_ptr = res.data_ptr()
+            plan.out_ptr = res.ptr
             lms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in lev])
             line['long_run'] = {'steps': nlr, 'seconds': el3, 'ms_per_step': el3 / nlr * 1e3, 'value': work_step * nlr / el3,
                                 'launch_ms_mean': float(lms.mean()), 'launch_ms_std': float(lms.std()), 'launch_ms_min': float(lms.min()),
@@ -706,26 +799,97 @@ def main():
                     p2.free()
         if world == 1 and not a.no_cpu:
             # the oracle on slabs of the LAST timed step's batch; their vectors are compared with that step's GPU result
-            nd = max(1, min(a.cpu_slabs or 8, B))
+            nd_ = max(1, min(a.cpu_slabs or 8, B))
             s0 = ((K - 1) % NB) * B
             esz = NY * NX * qdt.itemsize
-            qh = np.empty((nd, NY, NX), dtype=qdt)
-            ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, plan._q_ptr + s0 * esz, nd * esz))
-            line['cpu_baseline'] = cpu_baseline(qh, out, nd, qdt.name)
-    # ---- cfg4 strong scaling: every rank takes part (its own timed region, after the cfg2 buffers are gone)
+            qh = np.empty((nd_, NY, NX), dtype=qdt)
+            ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, plan._q_ptr + s0 * esz, nd_ * esz))
+            line['cpu_baseline'] = cpu_baseline(qh, out, nd_, qdt.name)
     plan.free()
-    del res, wres, gathered
-    torch.cuda.empty_cache()
+    res.free(); wres.free()
+    if gathered is not None:
+        gathered.free()
+    if rank == 0 and world == 1 and a.dtype == 'f64' and grp == B and not a.no_extras and not (a.slab_dA or a.row_dA or a.deterministic):
+        # float32 tracers and contours -- the reference's default `dtype` and the dtype of the files it ships -- through the same
+        # chained schedule, so that the driver's line carries them; two slabs of its last step against the oracle
+        line.setdefault('variants', {})['f32'] = variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain)
+    # ---- cfg4 strong scaling: every rank takes part (its own timed region, after the cfg2 buffers are gone)
     if not a.no_cfg4 and a.dtype == 'f64':
-        blk = cfg4_strong(ctx, nat, a, world, rank, local, dist, torch, gdev)
+        blk = cfg4_strong(ctx, nat, a, group, gather)
         if rank == 0:
             line['cfg4_strong'] = blk
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.barrier()
     ctx.close()
+    group.close()
+
+
+def device_count(nat):
+    import ctypes as C
+    n = C.c_int(0)
+    nat.load().xc_device_count(C.byref(n))
+    return n.value
+
+
+def variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain):
+    """`variants.f32` of the default line: the headline schedule on float32 tracers with float32 contours (12 B/cell algorithmic:
+    tracer 4 + dA 8), HIP events around every histogram launch, two slabs of the last step compared with the oracle."""
+    from xcontour_amd.pipeline import KeffPlan
+    B, NB, KV = a.batch, 2, 20
+    qdt = np.dtype(np.float32)
+    p = None
+    try:
+        p = KeffPlan(ctx, NB * B, NY, NX, NCONT, qdt, qdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                     increase=True, lt=True, nslots=1, out_slabs=B, right_edge='xhistogram')
+        p.synth(lat, lon, SEED, a.variant)
+
+        def step(k):
+            s0, nxt = (k % NB) * B, ((k + 1) % NB) * B
+            p.run_range(0, s0, B, nxt if chain else None, out_s0=0)
+
+        for k in range(-4, 0):
+            step(k)
+        ctx.sync()
+        vev = [(ctx.event(), ctx.event()) for _ in range(KV)]
+        t2 = time.perf_counter()
+        for k in range(KV):
+            ctx.set_hist_events(vev[k][0], vev[k][1])
+            step(k)
+        ctx.sync()
+        el = time.perf_counter() - t2
+        vms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in vev])
+        for e0, e1 in vev:
+            ctx.lib.xc_event_destroy(ctx.handle, e0); ctx.lib.xc_event_destroy(ctx.handle, e1)
+        out = p.fetch(slot=0)
+        checked = 0
+        if not a.no_cpu:
+            sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+            import xcontour_oracle as O
+            s0 = ((KV - 1) % NB) * B
+            qh = np.empty((2, NY, NX), dtype=qdt)
+            ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, p._q_ptr + s0 * NY * NX * 4, qh.nbytes))
+            for s_ in range(2):
+                r = O.keff_pipeline(qh[s_], dA, lat, NCONT, lon=lon, increase=True, lt=True, dtype=np.float32)
+                _compare_with_oracle(out, {k: np.asarray(r[k], np.float64) for k in CHECK_NAMES + ('counts',)}, s_)
+                checked += 1
+        cells = B * NY * NX
+        alg, ub = cells * 12, cells * 4 + NY * NX * 8
+        vt, vsrc = stored_traffic('f32_chain' if chain else 'f32_nochain', B) if a.variant == 0 else (None, 'not measured')
+        work = B * NY * NX * NCONT
+        return {'steps': KV, 'ms_per_step': el / KV * 1e3, 'value': work * KV / el, 'us_per_slab': el / KV / B * 1e6,
+                'kernel': 'k_hist<float,DA_PLANE,%s>' % ('NEXT' if chain else 'plain'), 'dtype': 'f32',
+                'launch_ms': float(vms.mean()), 'launch_ms_std': float(vms.std()),
+                'frac': alg / (vms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS, 'hbm_unique_frac': ub / (vms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'algorithmic_bytes_per_launch': alg, 'hbm_unique_bytes_per_launch': ub, 'traffic': vt, 'traffic_source': vsrc,
+                'oracle_checked_slabs': checked,
+                'note': 'float32 tracer AND float32 contours (reference default dtype, core.py:21): 4 + 8 algorithmic bytes per cell; '
+                        'counts + levels bit-exact, sums 1e-11, derived 1e-6 against the oracle on the checked slabs'}
+    except nat.XContourHipError as e:
+        return {'skipped': str(e)}
+    finally:
+        if p is not None:
+            p.free()
 
 
 if __name__ == '__main__':

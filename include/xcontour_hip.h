@@ -74,6 +74,7 @@ int         xc_create(int device_id, xc_ctx** out);
 int         xc_destroy(xc_ctx* ctx);
 const char* xc_last_error(xc_ctx* ctx);          /* ctx may be NULL (creation errors) */
 const char* xc_version(void);
+int         xc_device_count(int* out_count);     /* visible HIP devices (a launcher maps local rank -> device with it) */
 int         xc_device_name(xc_ctx* ctx, char* buf, size_t buflen);
 int         xc_device_cus(xc_ctx* ctx, int* out_cus);
 int         xc_sync(xc_ctx* ctx);
@@ -319,7 +320,10 @@ typedef struct xc_keff_desc {
                                    fillna(0) selects on the dA channel (optional speed-up; 0 is always safe) */
     int32_t       q_gen;        /* generation of the tracer buffers (see q_next): any change invalidates chained min/max */
     int32_t       deterministic;/* != 0: order-free fixed-point sums (below); q_next rides in their second pass */
-    int32_t       reserved0;
+    int32_t       out_stride;   /* doubles between consecutive slabs in each of the nine vector outputs (ctr ... nkeff); 0 = N
+                                   (nine dense [nslab][N] arrays).  9 * N with ctr = base, area = base + N, ... lays the
+                                   results out slab-major, [nslab][9][N] -- the block a rank hands to the one gather
+                                   with no repacking pass.  counts / interp / status keep their dense layout. */
 } xc_keff_desc;
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
 

@@ -175,3 +175,115 @@ def test_distributed_module_does_not_import_torch():
             "assert out.shape == (4, 3); assert 'torch' not in sys.modules; print('ok')" % ROOT)
     r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
     assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr
+
+
+# ---------------------------------------------------------------- bench.py: torch-free, launches its own ranks
+def _imports_of(path):
+    import ast
+    names = set()
+    for node in ast.walk(ast.parse(open(path).read())):
+        if isinstance(node, ast.Import):
+            names.update(a.name.split('.')[0] for a in node.names)
+        elif isinstance(node, ast.ImportFrom) and node.module and node.level == 0:
+            names.add(node.module.split('.')[0])
+    return names
+
+
+def test_bench_does_not_import_torch():
+    """north_star: 'no PyTorch'.  bench.py, the secondary bench lines and every package module they use import no torch
+    (distributed.py imports it lazily on the torch-carrier path only, which bench.py never takes)"""
+    for f in ('bench.py', 'tools/bench_configs.py', 'xcontour_amd/_native.py', 'xcontour_amd/pipeline.py', 'xcontour_amd/utils.py',
+              'xcontour_amd/core.py', 'xcontour_amd/labeled.py', 'xcontour_amd/ncio.py', 'xcontour_amd/__init__.py', '__graft_entry__.py'):
+        assert 'torch' not in _imports_of(os.path.join(ROOT, f)), f
+    import subprocess
+    code = ("import sys, importlib.util; sys.argv = ['bench.py']; "
+            "spec = importlib.util.spec_from_file_location('bench_mod', %r); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); "
+            "a = m.parse_args(['--gpus', '8']); assert a.gpus == 8; import xcontour_amd.pipeline, xcontour_amd.distributed; "
+            "assert 'torch' not in sys.modules; print('ok')" % os.path.join(ROOT, 'bench.py'))
+    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr
+
+
+def test_bench_launcher_starts_the_ranks_and_reports_failure(tmp_path):
+    """`python bench.py --gpus N` without WORLD_SIZE launches N fresh rank processes with the rendezvous variables set; a rank
+    that fails makes the launcher exit non-zero instead of hanging (here: a stand-in rank program, no GPU needed)"""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    prog = tmp_path / 'rank.py'
+    prog.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from xcontour_amd.distributed import SocketGroup\n"
+        "assert 'torch' not in sys.modules\n"
+        "g = SocketGroup()\n"                                   # RANK / WORLD_SIZE / MASTER_* / XC_DIST_TOKEN from the launcher
+        "ids = g.allgather_bytes(os.environ['LOCAL_RANK'].encode())\n"
+        "assert ids == [str(r).encode() for r in range(g.world)] and len(os.environ['XC_DIST_TOKEN']) == 32\n"
+        "open(os.path.join(%r, 'rank%%d' %% g.rank), 'w').write(sys.argv[1])\n"
+        "g.barrier(); g.close()\n"
+        "sys.exit(3 if (sys.argv[1] == 'fail' and g.rank == 1) else 0)\n" % (ROOT, str(tmp_path)))
+    old = m.__file__
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'XC_DIST_TOKEN')}
+    saved = dict(os.environ)
+    try:
+        os.environ.clear(); os.environ.update(env)
+        m.__file__ = str(prog)
+        assert m.launch_ranks(3, ['ok']) == 0
+        assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith('rank') and f != 'rank.py') == ['rank0', 'rank1', 'rank2']
+        assert m.launch_ranks(2, ['fail']) == 3
+    finally:
+        m.__file__ = old
+        os.environ.clear(); os.environ.update(saved)
+    # and the real file: without a GPU every rank fails loudly and so does the launcher, in seconds
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu'],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=120)
+        assert r.returncode != 0 and 'no CPU fallback' in r.stderr and r.stdout.strip() == ''
+
+
+def test_socket_group_rejects_strangers_and_bad_ranks():
+    """rank 0 drops a peer without the job's token, a rank outside [1, world) and a duplicate, and still completes with the real
+    peer; a client facing a server without the token refuses to talk (round-3 advisor: pickle + unauthenticated accept)"""
+    import socket
+    import struct
+    import threading
+    from xcontour_amd.distributed import SocketGroup, _MAGIC
+    port = _free_port()
+    res = {}
+
+    def root():
+        g = SocketGroup(0, 2, '127.0.0.1', port, timeout=30, token='secret')
+        res['parts'] = g.allgather_bytes(b'zero')
+        g.close()
+
+    t = threading.Thread(target=root)
+    t.start()
+    import time as _t
+    for hello_rank, tok in ((1, b'wrong'), (5, b'secret')):
+        for _ in range(100):
+            try:
+                s = socket.create_connection(('127.0.0.1', port), timeout=5)
+                break
+            except OSError:
+                _t.sleep(0.05)
+        s.recv(24)
+        import hashlib
+        import hmac
+        s.sendall(_MAGIC + struct.pack('<i', hello_rank) + hmac.new(tok, b'junk', hashlib.sha256).digest())
+        s.settimeout(5)
+        try:
+            assert s.recv(32) == b''                                # dropped
+        except OSError:
+            pass
+        s.close()
+    with pytest.raises(ConnectionError):
+        SocketGroup(1, 2, '127.0.0.1', port, timeout=10, token='not the secret')
+    g1 = SocketGroup(1, 2, '127.0.0.1', port, timeout=30, token='secret')
+    assert g1.allgather_bytes(b'one') == [b'zero', b'one']
+    g1.close()
+    t.join(timeout=30)
+    assert res['parts'] == [b'zero', b'one']
+    assert 'pickle' not in _imports_of(os.path.join(ROOT, 'xcontour_amd', 'distributed.py'))

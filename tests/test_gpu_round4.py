@@ -1,0 +1,184 @@
+"""-m gpu, round 4: bench.py launching its own ranks (torch-free), the slab-major result layout, the library's RCCL gather with
+two ranks (when two devices are visible)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import xcontour_oracle as O
+from test_gpu_parity import rel, RTOL, TIGHT
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'XC_DIST_TOKEN')}
+
+
+# ---------------------------------------------------------------- bench.py --gpus 2 on the one GPU
+def test_bench_launches_two_ranks_by_itself_on_one_gpu():
+    """the driver's own command form, `python3 bench.py --gpus 2 ...` with no launcher around it: bench.py starts two rank
+    processes (both on this box's one GPU, the one gather staged through the host), the line says n_gpus 2, the gathered blocks
+    arrived in rank order (asserted inside) and the cfg4 block's checks hold -- rank 1's first slab recomputed on rank 0, two
+    slabs against the oracle; no torch in any of the three processes"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+                        '--batch', '4', '--cfg4-slabs', '64', '--cfg4-reps', '1'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=_clean_env(), timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['config']['launcher'].startswith('bench.py itself') and 'no torch' in d['config']['host_code']
+    assert d['config']['slabs_per_step_per_gpu'] == 4
+    c4 = d['cfg4_strong']
+    assert c4['n_gpus'] == 2 and c4['slabs'] == 64 and c4['slabs_per_gpu'] == 32 and c4['scaling'] == 'strong'
+    assert c4['checks']['rank0_block_bit_identical'] and c4['checks']['first_slab_of_each_rank_recomputed'] == [0, 32]
+    assert c4['checks']['oracle_checked_slabs'] == 2 and c4['checks']['finite_nkeff_fraction'] > 0.9
+    b = c4['budget']
+    assert len(b['sweep_ms_by_rank']) == 2 and len(b['gather_ms_by_rank']) == 2 and b['pack_ms'] == 0.0
+    assert all(x > 0 for x in b['sweep_ms_by_rank'])
+
+
+def test_bench_refuses_a_world_that_disagrees_with_gpus():
+    """`--gpus 8` inside a 1-rank environment used to run one rank and print n_gpus 1 (round-3 review): now an error"""
+    env = _clean_env()
+    env.update({'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0', '--no-cpu'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr and r.stdout.strip() == ''
+
+
+# ---------------------------------------------------------------- slab-major result layout (xc_keff_desc.out_stride)
+@pytest.mark.parametrize('dt,cd,inc', [(np.float64, np.float64, True), (np.float32, np.float32, False)])
+def test_slab_major_layout_is_the_dense_result_rearranged(ctx, dt, cd, inc):
+    """KeffPlan(slab_major=True): the head of the slot is ONE [slab][9][N] block -- bit for bit the nine dense vectors, launch
+    sets landing at their slab offset (the cfg4 sweep), counts / status / interp unchanged; and against the oracle"""
+    from xcontour_amd.pipeline import KeffPlan, OUT_NAMES
+    from xcontour_amd.utils import cell_area, table_from_rowsums
+    ny, nx, N, S = 181, 360, 41, 7
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 1.0
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(dA.sum(1), True)
+    pre = np.linspace(-80, 80, 33)
+    kw = dict(dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=inc, lt=True, preY=pre, deterministic=True)
+    dense = KeffPlan(ctx, S, ny, nx, N, dt, cd, **kw)
+    dense.synth(lat, lon, 5, 0)
+    dense.run(0)
+    ref = dense.fetch()
+    sm = KeffPlan(ctx, 3, ny, nx, N, dt, cd, alloc_q=False, out_slabs=S, slab_major=True, **kw)
+    esz = ny * nx * np.dtype(dt).itemsize
+    ctx._check(ctx.lib.xc_memset(ctx.handle, sm.out_ptr, 0, sm.slot_bytes))
+    for c0 in range(0, S, 3):                                        # ragged launch sets 3 + 3 + 1 into one block
+        m = min(3, S - c0)
+        sm.set_q_device(dense._q_ptr + c0 * esz)
+        sm._point(0, 0, m, out_s0=c0)
+        sm.desc.q_next = None
+        ctx._check(ctx.lib.xc_keff_dev(ctx.handle, __import__('ctypes').byref(sm.desc)))
+    got = sm.fetch()
+    assert sm.head_bytes == S * 9 * N * 8
+    raw = np.empty(sm.head_bytes, dtype=np.uint8)
+    ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, raw.ctypes.data, sm.out_ptr, sm.head_bytes))
+    blk = raw.view(np.float64).reshape(S, 9, N)
+    for i, k in enumerate(OUT_NAMES):
+        assert np.array_equal(bits(got[k]), bits(ref[k])), k
+        assert np.array_equal(bits(blk[:, i, :]), bits(ref[k])), k
+    assert np.array_equal(got['counts'], ref['counts']) and np.array_equal(got['status'], ref['status'])
+    for k in ref:
+        if k.endswith('_eq'):
+            assert np.array_equal(bits(got[k]), bits(ref[k])), k
+    q = dense.download_q()
+    r = O.keff_pipeline(q[4], dA, lat, N, lon=lon, increase=inc, lt=True, dtype=cd)
+    assert np.array_equal(blk[4, 0], r['ctr'].astype(np.float64)) and np.array_equal(got['counts'][4].astype(np.int64), r['counts'])
+    assert rel(blk[4, 1], r['area']) < TIGHT and rel(blk[4, 3], r['latEq']) < RTOL
+    dense.free(); sm.free()
+
+
+def test_out_stride_is_validated(ctx):
+    from xcontour_amd import _native as nat
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums
+    ny, nx, N = 19, 36, 11
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 10.0
+    dA = cell_area(lat, lon)
+    p = KeffPlan(ctx, 1, ny, nx, N, dA=dA, lat=lat, lon=lon, tbl=table_from_rowsums(dA.sum(1), True), tbl_coord=lat)
+    p.synth(lat, lon, 1, 0)
+    p.desc.out_stride = N - 1
+    with pytest.raises(nat.XContourHipError):
+        p.run()
+    p.free()
+
+
+# ---------------------------------------------------------------- the library's own RCCL gather with two ranks
+_RCCL_RANK = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from xcontour_amd import _native as nat
+from xcontour_amd.distributed import SocketGroup
+assert 'torch' not in sys.modules
+g = SocketGroup()
+ctx = nat.Context(g.rank)                          # one GPU per rank
+g.init_device(ctx)
+n = 1 << 20
+send = ctx.to_device(np.full(n, g.rank + 1, dtype=np.float64))
+recv = ctx.alloc(g.world * n * 8)
+for _ in range(2):
+    g.allgather_device(send.ptr, recv.ptr, n * 8)
+ctx.sync()
+out = recv.download((g.world, n), np.float64)
+assert all((out[r] == r + 1).all() for r in range(g.world)), out[:, :4]
+g.barrier(); ctx.comm_finalize(); ctx.close(); g.close()
+print('rank %%d ok' %% g.rank)
+'''
+
+
+def test_native_rccl_allgather_two_ranks_two_gpus(tmp_path):
+    """xc_comm_* with world 2: ncclGetUniqueId on rank 0, the id through the sockets, ncclCommInitRank, ncclAllGather on each
+    context's stream.  Needs two visible devices (RCCL refuses two ranks on one GPU): skipped on the one-GPU test box."""
+    import ctypes as C
+    import importlib.util
+    from xcontour_amd import _native as nat
+    n = C.c_int(0)
+    nat.load().xc_device_count(C.byref(n))
+    if n.value < 2:
+        pytest.skip('one visible device: RCCL needs one GPU per rank')
+    prog = tmp_path / 'rccl_rank.py'
+    prog.write_text(_RCCL_RANK % {'root': ROOT})
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    saved = dict(os.environ)
+    try:
+        os.environ.clear(); os.environ.update(_clean_env())
+        m.__file__ = str(prog)
+        assert m.launch_ranks(2, []) == 0
+    finally:
+        os.environ.clear(); os.environ.update(saved)
+
+
+def test_rccl_unavailable_falls_back_to_the_host_carrier_loudly():
+    """two ranks on ONE GPU with the default backend: ncclCommInitRank fails on every rank ('duplicate GPU'), every rank
+    learns it (SocketGroup.init_device), the job gathers through the host and the line says so"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
+                        '--no-cpu', '--no-cfg4'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=_clean_env(), timeout=600, cwd=ROOT)
+    import ctypes as C
+    from xcontour_amd import _native as nat
+    n = C.c_int(0)
+    nat.load().xc_device_count(C.byref(n))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 2
+    if n.value < 2:
+        assert 'RCCL communicator unavailable' in d['config']['collective_note'] and 'host' in d['config']['parallelism']
+    else:
+        assert d['config']['collective_note'] is None and 'ncclAllGather' in d['config']['parallelism']

@@ -10,7 +10,7 @@ done
 echo "== secondary configs"
 for c in cfg3 cfg4 cfg5; do timeout -k 10 300 python3 bench.py --config $c --steps 50 --warmup 5 2>/dev/null | grep '^{' > $O/${RD}_bench_$c.json || exit 1; done
 echo "== 2 ranks on this one GPU, gloo (the N > 1 path of bench.py incl. cfg4_strong; correctness evidence, not a speed)"
-timeout -k 10 500 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --backend gloo --steps 20 --warmup 3 2>/dev/null | grep '^{' > $O/${RD}_bench_2ranks_gloo_1gpu.json || exit 1
+timeout -k 10 500 python3 bench.py --gpus 2 --backend gloo --steps 20 --warmup 3 2>/dev/null | grep '^{' > $O/${RD}_bench_2ranks_gloo_1gpu.json || exit 1
 echo "== kernel timings"
 timeout -k 10 500 python3 tools/kernel_times.py sort lwa cross pipe land single > $O/${RD}_kernel_times.jsonl 2>&1 || exit 1
 XC_FACADE_STACK=128 XC_FACADE_SMALL=1 timeout -k 10 300 python3 tools/facade_time.py 2>/dev/null | grep '^{' > $O/${RD}_facade_time.jsonl || exit 1

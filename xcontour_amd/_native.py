@@ -61,7 +61,7 @@ class KeffDesc(C.Structure):
         ('dqdA', _vp), ('dintSdA', _vp), ('Leq2', _vp), ('Lmin', _vp), ('nkeff', _vp),
         ('counts', _vp), ('interp', _vp), ('status', _vp), ('q_next', _vp),
         ('dA_pos_finite', _i32), ('q_gen', _i32),
-        ('deterministic', _i32), ('reserved0', _i32),
+        ('deterministic', _i32), ('out_stride', _i32),
     ]
 
 
@@ -71,6 +71,7 @@ PROTOTYPES = {
     'xc_destroy': (C.c_int, [_vp]),
     'xc_last_error': (C.c_char_p, [_vp]),
     'xc_version': (C.c_char_p, []),
+    'xc_device_count': (C.c_int, [C.POINTER(C.c_int)]),
     'xc_device_name': (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     'xc_device_cus': (C.c_int, [_vp, C.POINTER(C.c_int)]),
     'xc_sync': (C.c_int, [_vp]),

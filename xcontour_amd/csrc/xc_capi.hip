@@ -143,6 +143,15 @@ extern "C" {
 
 const char* xc_version(void) { return "xcontour_hip 0.1.0 (gfx950)"; }
 
+int xc_device_count(int* out_count)
+{
+    if (!out_count) return fail(nullptr, XC_EBADARG, "xc_device_count: out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *out_count = n;
+    return XC_OK;
+}
+
 const char* xc_last_error(xc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
 int xc_create(int device_id, xc_ctx** out)
@@ -251,21 +260,31 @@ int xc_keep_resident(xc_ctx* ctx, const void* host_ptr, size_t bytes)
     if (!host_ptr || bytes == 0) return fail(ctx, XC_EBADARG, "xc_keep_resident: bad arguments");
     XC_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (auto& e : ctx->resident)
-        if (e.host == (const char*)host_ptr) {                      // registered before: refresh (the caller changed the array)
+    for (size_t i = 0; i < ctx->resident.size(); ++i)
+        if (ctx->resident[i].host == (const char*)host_ptr) {       // registered before: refresh (the caller changed the array)
+            auto& e = ctx->resident[i];
+            hipError_t he = hipSuccess;
             if (bytes > e.bytes) {
-                XC_HIP(ctx, hipFree(e.dev)); e.dev = nullptr; e.bytes = 0;
-                XC_HIP(ctx, hipMalloc(&e.dev, bytes));
+                (void)hipFree(e.dev); e.dev = nullptr; e.bytes = 0;
+                he = hipMalloc(&e.dev, bytes);
+            }
+            if (he == hipSuccess) he = hipMemcpy(e.dev, host_ptr, bytes, hipMemcpyHostToDevice);
+            if (he != hipSuccess) {                                 // never leave a dead or half-refreshed mirror registered
+                if (e.dev) (void)hipFree(e.dev);
+                ctx->resident.erase(ctx->resident.begin() + (long)i);
+                return hipfail(ctx, he, "xc_keep_resident: refresh");
             }
             e.bytes = bytes;                                        // (a shorter array now: the tail of the old mirror is no longer valid)
-            XC_HIP(ctx, hipMemcpy(e.dev, host_ptr, bytes, hipMemcpyHostToDevice));
+            // most recently refreshed first: an overlapping registration (an array and a sub-slab of it at another base
+            // pointer) resolves to the mirror that was uploaded last
+            if (i != 0) { auto me = e; ctx->resident.erase(ctx->resident.begin() + (long)i); ctx->resident.insert(ctx->resident.begin(), me); }
             return XC_OK;
         }
     void* dev = nullptr;
     XC_HIP(ctx, hipMalloc(&dev, bytes));
     hipError_t e = hipMemcpy(dev, host_ptr, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(dev); return hipfail(ctx, e, "xc_keep_resident: upload"); }
-    ctx->resident.push_back({(const char*)host_ptr, bytes, dev});
+    ctx->resident.insert(ctx->resident.begin(), {(const char*)host_ptr, bytes, dev});       // newest first (see the refresh path)
     return XC_OK;
 }
 
@@ -914,6 +933,8 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     if (d->dA_rank < XC_DA_NONE || d->dA_rank > XC_DA_SLAB || (d->dA_rank != XC_DA_NONE && !d->dA)) return fail(ctx, XC_EBADARG, "xc_keff: bad dA");
     if (d->grad ? (!d->rdx || !d->rdy) : !d->grdS) return fail(ctx, XC_EBADARG, "xc_keff: need rdx/rdy (grad=1) or grdS (grad=0)");
     if (d->npre < 0 || (d->npre > 0 && d->interp && !d->preY)) return fail(ctx, XC_EBADARG, "xc_keff: preY is NULL");
+    if (d->out_stride != 0 && d->out_stride < d->N) return fail(ctx, XC_EBADARG, "xc_keff: out_stride must be 0 (dense) or >= N");
+    const int vstride = d->out_stride ? d->out_stride : d->N;
     const int N = d->N, nch = 2;
     const int det = d->deterministic ? 1 : 0;
     const void* q_next = d->q_next;                          // (deterministic sums: carried by the fixed-point pass)
@@ -968,7 +989,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     a.prod_f32 = d->prod_f32;
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
-    a.part_h = part_h; a.part_c = part_c; a.ctr_out = d->ctr; a.status = d->status;
+    a.part_h = part_h; a.part_c = part_c; a.ctr_out = d->ctr; a.ctr_stride = vstride; a.status = d->status;
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = part_h; f.part_c = part_c; f.bps = g.bps; f.nch = nch; f.nbin = N;
     f.red_h = (double*)((char*)ctx->scratch + mb + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + mb + ph + pc + rh);
@@ -988,7 +1009,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
 
     f.lt = d->lt; f.reverse = !d->increase;       // decreasing levels -> flip to level order (core.py:454-455)
     f.counts = d->counts;
-    f.keff = 1; f.ctr_f32 = a.ctr_f32; f.ctr = d->ctr;
+    f.keff = 1; f.ctr_f32 = a.ctr_f32; f.ctr = d->ctr; f.vstride = vstride;
     f.tbl = d->tbl; f.tbl_coord = d->tbl_coord; f.ntbl = (int)d->ny;
     f.preY = d->preY; f.npre = d->interp ? d->npre : 0;
     f.nkeff_mask = d->nkeff_mask; f.lmin_scale = d->lmin_scale;

@@ -230,7 +230,7 @@ void k_hist(const HistArgs a)
         for (int k = tid; k < N; k += blockDim.x) {
             const double c = level_value(mn, mx, k, a.increase, a.q_f32, a.ctr_f32, a.inv_nm1);
             s_edges[a.increase ? k + 1 : N - k] = c;
-            if (bx == 0 && a.ctr_out) a.ctr_out[(size_t)slab * N + k] = c;
+            if (bx == 0 && a.ctr_out) a.ctr_out[(size_t)slab * a.ctr_stride + k] = c;
         }
         __syncthreads();
         if (tid == 0) {

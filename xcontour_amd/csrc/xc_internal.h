@@ -121,7 +121,8 @@ struct HistArgs {
     int           nchunk;       // > 0: wave -> (row chunk, strip) with the strip fastest (see k_hist); 0: even split of the strip-major pairs
     double*       part_h;       // [nslab][bps][nch][nbin]
     unsigned*     part_c;       // [nslab][bps][nbin]
-    double*       ctr_out;      // [nslab][nbin]   (levels mode, may be null)
+    double*       ctr_out;      // levels of slab s at ctr_out + s * ctr_stride (levels mode, may be null)
+    int           ctr_stride;   // doubles between consecutive slabs in ctr_out (nbin: dense)
     double*       edges_out;    // [nslab][nbin+1] (levels mode, may be null)
     int32_t*      status;       // [nslab]         (levels mode, may be null)
     const int*    det_scale;    // [nslab][nch][nbin] binary exponents of the fixed-point pass (DET == 2), else null
@@ -142,7 +143,8 @@ struct FinalArgs {
     // Keff epilogue (enabled when keff != 0); channel 0 = area, channel 1 = intgrdS
     int             keff;
     int             ctr_f32;
-    const double*   ctr;      // [nslab][nbin] level order
+    const double*   ctr;      // level order, slab s at ctr + s * vstride
+    int             vstride;  // doubles between consecutive slabs in ctr and in the o_* vector outputs (0: nbin)
     const double*   tbl;      const double* tbl_coord;   int ntbl;   int tbl_in_lds;
     double*         big;      size_t big_stride;         // work arrays in global memory instead of LDS (doubles per slab), or null
     const double*   preY;     int npre;

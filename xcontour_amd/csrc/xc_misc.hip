@@ -371,7 +371,7 @@ void k_finalize(const FinalArgs a)
     }
     const int tinc = tblp[a.ntbl - 1] > tblp[0];            // Table.__init__, core.py:1122-1128
     for (int k = tid; k < N; k += nthr) {
-        s_ctr[k] = a.ctr[(size_t)slab * N + k];
+        s_ctr[k] = a.ctr[(size_t)slab * a.vstride + k];
         const int jt = interp_locate(area[k], tblp, a.ntbl, !tinc);
         const double le = interp_eval(area[k], jt, tblp, crdp, a.ntbl, !tinc);       // core.py:1136-1174
         s_lat[k] = le;
@@ -386,7 +386,7 @@ void k_finalize(const FinalArgs a)
         double nk = __ddiv_rn(__ddiv_rn(leq, s_lmin[k]), s_lmin[k]);              // core.py:963
         if (!(nk < a.nkeff_mask)) nk = dnan();                                    // core.py:964
         s_dS[k] = dS; s_dq[k] = dq; s_leq[k] = leq; s_nk[k] = nk;
-        const size_t o = (size_t)slab * N + k;
+        const size_t o = (size_t)slab * a.vstride + k;
         if (a.o_area)  a.o_area[o]  = area[k];
         if (a.o_intS)  a.o_intS[o]  = intS[k];
         if (a.o_latEq) a.o_latEq[o] = s_lat[k];
@@ -550,6 +550,7 @@ int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab,
 int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
 {
     FinalArgs a = a_in;
+    if (a.vstride <= 0) a.vstride = a.nbin;
     hipStream_t st = ctx->stream;
     size_t lds = ((size_t)2 * a.nch * a.nbin + (a.keff ? 7 * (size_t)a.nbin : 0)) * sizeof(double);
     a.big = nullptr; a.big_stride = 0;

@@ -16,8 +16,9 @@ Two carriers for that one collective:
 * a `torch.distributed` process group (gloo / nccl) if the caller already lives in one --
   torch is imported lazily and only then; nothing else in the package touches it.
 """
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import time
@@ -28,12 +29,20 @@ from .pipeline import shard_slabs
 
 
 # ----------------------------------------------------------------------------- torch-free process group
+_MAGIC = b'XCDG1\0\0\0'
+MAX_FRAME_BYTES = 8 << 30          # a frame length read off the wire is checked against this before anything is allocated
+
+
 def _send(sock, payload):
-    sock.sendall(struct.pack('<Q', len(payload)) + payload)
+    sock.sendall(struct.pack('<Q', len(payload)))
+    if len(payload):
+        sock.sendall(payload)
 
 
-def _recv(sock):
+def _recv(sock, limit=MAX_FRAME_BYTES):
     n = struct.unpack('<Q', _recv_exact(sock, 8))[0]
+    if n > limit:
+        raise ConnectionError('xcontour_amd.distributed: frame of %d bytes exceeds the limit of %d' % (n, limit))
     return _recv_exact(sock, n)
 
 
@@ -48,18 +57,51 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-class SocketGroup(object):
-    """One process per rank, a star over TCP through rank 0.  Built for ONE small collective at the end of a job
-    (a few hundred MB at most), not for bandwidth: the device path is `allgather_device` (RCCL)."""
+def _pack_parts(parts):
+    """a list of byte strings as ONE frame: count, then (length, bytes) per part -- no pickle: nothing received is executed"""
+    return b''.join([struct.pack('<I', len(parts))] + [struct.pack('<Q', len(p)) + p for p in parts])
 
-    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0):
+
+def _unpack_parts(blob, world):
+    n = struct.unpack_from('<I', blob, 0)[0]
+    if n != world:
+        raise ConnectionError('xcontour_amd.distributed: gathered frame holds %d parts, expected %d' % (n, world))
+    off, parts = 4, []
+    for _ in range(n):
+        k = struct.unpack_from('<Q', blob, off)[0]
+        off += 8
+        if off + k > len(blob):
+            raise ConnectionError('xcontour_amd.distributed: malformed gathered frame')
+        parts.append(blob[off:off + k])
+        off += k
+    return parts
+
+
+class SocketGroup(object):
+    """One process per rank, a star over TCP through rank 0.  Built for the rendezvous and ONE small collective at the end of
+    a job (a few hundred MB at most), not for bandwidth: the device path is `allgather_device` (RCCL).
+
+    Trust: a peer must present the job's token -- `token` or the environment's XC_DIST_TOKEN (the launcher of bench.py draws a
+    random one per job); rank 0 answers with a proof of the same token, so neither side talks to a stranger that merely got to
+    the port first.  Frames are length-prefixed byte strings (no pickle); ranks are checked for range and uniqueness and frame
+    lengths against `MAX_FRAME_BYTES` before anything is allocated."""
+
+    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0, token=None):
         self.rank = int(os.environ.get('RANK', 0) if rank is None else rank)
         self.world = int(os.environ.get('WORLD_SIZE', 1) if world is None else world)
         addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
         port = int(port if port is not None else int(os.environ.get('MASTER_PORT', 29500)) + 1)     # + 1: the launcher's own store owns MASTER_PORT
-        self._peers, self._up = [], None
+        tok = token if token is not None else os.environ.get('XC_DIST_TOKEN', '')
+        tok = tok.encode() if isinstance(tok, str) else bytes(tok)
+        self._peers, self._up, self._ctx = [], None, None
+        if not (0 <= self.rank < self.world):
+            raise Exception('SocketGroup: rank %d outside [0, %d)' % (self.rank, self.world))
         if self.world == 1:
             return
+
+        def proof(side, nonce, r):
+            return hmac.new(tok, side + nonce + struct.pack('<i', r), hashlib.sha256).digest()
+
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -67,11 +109,27 @@ class SocketGroup(object):
             srv.listen(self.world)
             srv.settimeout(timeout)
             peers = {}
+            t_end = time.time() + timeout
             while len(peers) < self.world - 1:
+                if time.time() > t_end:
+                    raise ConnectionError('SocketGroup: %d of %d peers arrived within %.0f s' % (len(peers), self.world - 1, timeout))
                 c, _ = srv.accept()
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.settimeout(timeout)
-                peers[struct.unpack('<i', _recv_exact(c, 4))[0]] = c
+                try:
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    c.settimeout(min(timeout, 10.0))
+                    nonce = os.urandom(16)
+                    c.sendall(_MAGIC + nonce)
+                    hello = _recv_exact(c, 8 + 4 + 32)
+                    r = struct.unpack('<i', hello[8:12])[0]
+                    if hello[:8] != _MAGIC or not (1 <= r < self.world) or r in peers or \
+                            not hmac.compare_digest(hello[12:], proof(b'C', nonce, r)):
+                        c.close()                                  # a stranger, a bad rank or a duplicate: dropped, the job's peers may still come
+                        continue
+                    c.sendall(proof(b'S', nonce, r))
+                    c.settimeout(timeout)
+                    peers[r] = c
+                except (OSError, struct.error):
+                    c.close()
             srv.close()
             self._peers = [peers[r] for r in range(1, self.world)]
         else:
@@ -86,7 +144,15 @@ class SocketGroup(object):
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
-            s.sendall(struct.pack('<i', self.rank))
+            hello = _recv_exact(s, 8 + 16)
+            if hello[:8] != _MAGIC:
+                s.close()
+                raise ConnectionError('SocketGroup: %s:%d does not speak this protocol' % (addr, port))
+            nonce = hello[8:]
+            s.sendall(_MAGIC + struct.pack('<i', self.rank) + proof(b'C', nonce, self.rank))
+            if not hmac.compare_digest(_recv_exact(s, 32), proof(b'S', nonce, self.rank)):
+                s.close()
+                raise ConnectionError('SocketGroup: rank 0 at %s:%d does not hold this job\'s token' % (addr, port))
             self._up = s
 
     # -- primitives
@@ -96,12 +162,25 @@ class SocketGroup(object):
             return [payload]
         if self.rank == 0:
             parts = [payload] + [_recv(c) for c in self._peers]
-            blob = pickle.dumps(parts, protocol=pickle.HIGHEST_PROTOCOL)
+            blob = _pack_parts(parts)
             for c in self._peers:
                 _send(c, blob)
             return parts
         _send(self._up, payload)
-        return pickle.loads(_recv(self._up))
+        return _unpack_parts(_recv(self._up), self.world)
+
+    def gather_bytes(self, payload):
+        """contributions of all ranks in rank order on rank 0, None elsewhere (a gather to the root moves 1/world of an all-gather)"""
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv(c) for c in self._peers]
+            for c in self._peers:
+                _send(c, b'')                                      # the release: nobody runs ahead of the root
+            return parts
+        _send(self._up, payload)
+        _recv(self._up, 0)
+        return None
 
     def broadcast_bytes(self, payload, src=0):
         return self.allgather_bytes(payload if self.rank == src else b'')[src]
@@ -112,17 +191,40 @@ class SocketGroup(object):
     def allreduce_max(self, x):
         return max(struct.unpack('<d', p)[0] for p in self.allgather_bytes(struct.pack('<d', float(x))))
 
+    def allreduce_min(self, x):
+        return min(struct.unpack('<d', p)[0] for p in self.allgather_bytes(struct.pack('<d', float(x))))
+
     def allgather(self, arr):
         """equal-shape host arrays -> (world,) + shape, on every rank"""
         arr = np.ascontiguousarray(arr)
         parts = self.allgather_bytes(arr.tobytes())
+        if any(len(p) != arr.nbytes for p in parts):
+            raise ConnectionError('SocketGroup.allgather: ranks contributed blocks of different sizes')
         return np.stack([np.frombuffer(p, dtype=arr.dtype).reshape(arr.shape) for p in parts])
 
     # -- the device path: the library's RCCL communicator over xGMI
     def init_device(self, ctx):
-        """create the RCCL communicator of `ctx` (one context = one GPU per rank); the unique id travels through the sockets"""
-        uid = self.broadcast_bytes(ctx.comm_unique_id() if self.rank == 0 else b'')
-        ctx.comm_init(self.world, self.rank, uid)
+        """create the RCCL communicator of `ctx` (one context = one GPU per rank); the unique id travels through the sockets.
+        Every rank learns whether EVERY rank succeeded (an exception on all of them otherwise: nobody is left waiting)."""
+        err = ''
+        try:
+            uid = self.broadcast_bytes(ctx.comm_unique_id() if self.rank == 0 else b'')
+        except Exception as e:                                     # rank 0 could not create the id (librccl missing ...)
+            uid, err = self.broadcast_bytes(b''), str(e)
+        if len(uid) == 128 and not err:
+            try:
+                ctx.comm_init(self.world, self.rank, uid)
+            except Exception as e:
+                err = str(e)
+        elif not err:
+            err = 'rank 0 could not create the RCCL unique id'
+        errs = [p.decode('utf-8', 'replace') for p in self.allgather_bytes(err.encode())]
+        if any(errs):
+            try:
+                ctx.comm_finalize()
+            except Exception:
+                pass
+            raise Exception('RCCL communicator not created: ' + '; '.join('rank %d: %s' % (r, e) for r, e in enumerate(errs) if e))
         self._ctx = ctx
 
     def allgather_device(self, send_ptr, recv_ptr, bytes_per_rank):
@@ -201,13 +303,17 @@ def chunks_to_slabs(res, slot_elems, chunk, nlocal, N, nvec=9):
     return np.ascontiguousarray(np.concatenate(parts, axis=0))
 
 
-def run_sharded(process, nslab, rank, world, device=None, group=None):
+def run_sharded(process, nslab, rank, world, device=None, group=None, as_numpy=None):
     """Process slabs [lo, hi) on this rank with `process(lo, hi) -> ndarray (hi-lo, ...)`
-    (e.g. a KeffPlan over the rank's block) and gather every rank's result: through `group` (a SocketGroup: numpy in,
-    numpy out, no torch) or, without one, through the torch.distributed process group the caller initialised."""
+    (e.g. a KeffPlan over the rank's block) and gather every rank's result.  The CARRIER decides the return type, not the
+    world size: with `group` (a SocketGroup) numpy in, numpy out, no torch; without one the torch.distributed process group
+    the caller initialised, a torch tensor on `device` out -- also at world == 1.  `as_numpy=True` asks for the numpy path
+    explicitly (world == 1 needs no group then)."""
     lo, hi = shard_slabs(nslab, rank, world)
     out = np.ascontiguousarray(np.asarray(process(lo, hi)))
-    if group is not None or world == 1:
+    if as_numpy is None:
+        as_numpy = group is not None
+    if as_numpy:
         return all_gather_slabs(out, nslab, rank, world, group)
     import torch
     t = torch.from_numpy(out)

@@ -38,7 +38,7 @@ class KeffPlan(object):
                  tbl=None, tbl_coord=None, preY=None, increase=True, lt=True,
                  right_edge='xhistogram', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
                  prod_f32=False, alloc_q=True, nslots=1, out_ptr=None, detect_row_dA=False,
-                 out_slabs=None, replicate_dA=False, deterministic=False):
+                 out_slabs=None, replicate_dA=False, deterministic=False, slab_major=False):
         """dA: None | (ny,) | (ny,nx) | (nslab,ny,nx) f64 (the last: weights that change with the leading
         (time, level) index, which the reference allows -- core.py:1271-1274).  Gradient metrics either `rdx, rdy`
         (per-row reciprocals) or derived from `lat, lon` (sphere).  If
@@ -51,6 +51,9 @@ class KeffPlan(object):
         to the kernels as its first column (identical results, 8 B/cell less traffic).
         `replicate_dA`: store a (ny,nx) dA once PER SLAB on the device and run the per-slab-weights path
         (XC_DA_SLAB) on it -- what a time-varying metric costs, without a (nslab,ny,nx) host array.
+        `slab_major`: lay the nine result vectors of a slot out as ONE [out_slabs][9][N] block (pipeline.OUT_NAMES order,
+        xc_keff_desc.out_stride = 9 N) instead of nine [out_slabs][N] arrays: the head of the slot IS the block a rank hands to
+        the one gather at the end of a job, no repacking pass; `head_bytes` is its size.
         `deterministic`: order-free fixed-point sums (xc_keff_desc.deterministic): area / intgrdS and everything derived
         from them are bit-identical between runs, launch-set sizes and ranks, chained (q_next) or not."""
         self.ctx = ctx
@@ -132,12 +135,16 @@ class KeffPlan(object):
         # outputs: one allocation, [9][out_slabs][N] f64 | counts | interp | status
         # (out_slabs < nslab: the tracer buffer holds several batches, a slot one batch)
         self.out_slabs = self.nslab if out_slabs is None else int(out_slabs)
+        self.slab_major = bool(slab_major)
         nN = self.out_slabs * self.N
         self._off = {}
         off = 0
-        for name in OUT_NAMES:
-            self._off[name] = off
+        for i, name in enumerate(OUT_NAMES):
+            self._off[name] = i * self.N * 8 if self.slab_major else off
             off += nN * 8
+        self.head_bytes = off                                       # the nine vectors of every slab of the slot
+        self._vstep = (9 if self.slab_major else 1) * self.N * 8    # bytes from one slab to the next inside a vector output
+        d.out_stride = 9 * self.N if self.slab_major else 0
         self._off['counts'] = off
         off += nN * 8
         self._off['interp'] = off
@@ -156,7 +163,7 @@ class KeffPlan(object):
 
     @staticmethod
     def out_bytes(nslab, N, npre=0):
-        """bytes of one result slot (so that a caller can own the allocation)"""
+        """bytes of one result slot (so that a caller can own the allocation); the same for both layouts"""
         off = 9 * nslab * N * 8 + nslab * N * 8 + nslab * 9 * npre * 8 + nslab * 4
         return (off + 255) & ~255
 
@@ -167,7 +174,7 @@ class KeffPlan(object):
         o0 = s0 if out_s0 is None else out_s0
         base = self.out_ptr + slot * self.slot_bytes
         for name in OUT_NAMES:
-            setattr(d, name, base + self._off[name] + o0 * self.N * 8)
+            setattr(d, name, base + self._off[name] + o0 * self._vstep)
         d.counts = base + self._off['counts'] + o0 * self.N * 8
         d.interp = (base + self._off['interp'] + o0 * 9 * self.npre * 8) if self.npre else None
         d.status = base + self._off['status'] + o0 * 4
@@ -249,8 +256,13 @@ class KeffPlan(object):
         """one result slot (bytes as a uint8 ndarray) -> dict of arrays"""
         S, N = self.out_slabs, self.N
         out = {}
-        for name in OUT_NAMES:
-            out[name] = raw[self._off[name]:self._off[name] + S * N * 8].view(np.float64).reshape(S, N)
+        if self.slab_major:
+            blk = raw[:S * 9 * N * 8].view(np.float64).reshape(S, 9, N)
+            for i, name in enumerate(OUT_NAMES):
+                out[name] = blk[:, i, :]
+        else:
+            for name in OUT_NAMES:
+                out[name] = raw[self._off[name]:self._off[name] + S * N * 8].view(np.float64).reshape(S, N)
         out['counts'] = raw[self._off['counts']:self._off['counts'] + S * N * 8].view(np.uint64).reshape(S, N)
         if self.npre:
             it = raw[self._off['interp']:self._off['interp'] + S * 9 * self.npre * 8].view(np.float64).reshape(S, 9, self.npre)
