@@ -20,6 +20,9 @@ template <> struct RowLoad<double, 4> {        // two 16-byte loads per lane: 2 
 template <> struct RowLoad<float, 4> {
     static __device__ __forceinline__ void ld(const float* p, double (&v)[4]) {
         const float4 t = *reinterpret_cast<const float4*>(p); v[0] = (double)t.x; v[1] = (double)t.y; v[2] = (double)t.z; v[3] = (double)t.w; }
+    // raw float32 (the E32 variant of K3 keeps rows unconverted while they wait in their buffers)
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
 };
 template <> struct RowLoad<double, 1> {
     static __device__ __forceinline__ void ld(const double* p, double (&v)[1]) { v[0] = *p; }
@@ -52,6 +55,9 @@ template <> struct RowLoadNT<float, 4> {
     static __device__ __forceinline__ void ld(const float* p, double (&v)[4]) {
         const xc_f4v t = __builtin_nontemporal_load(reinterpret_cast<const xc_f4v*>(p));
         v[0] = (double)t.x; v[1] = (double)t.y; v[2] = (double)t.z; v[3] = (double)t.w; }
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const xc_f4v t = __builtin_nontemporal_load(reinterpret_cast<const xc_f4v*>(p));
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
 };
 template <> struct RowLoadNT<double, 1> {
     static __device__ __forceinline__ void ld(const double* p, double (&v)[1]) { v[0] = __builtin_nontemporal_load(p); }

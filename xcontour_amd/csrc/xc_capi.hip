@@ -181,7 +181,7 @@ int xc_create(int device_id, xc_ctx** out)
         // the only place the library reads the environment: K3 geometry knobs for experiments (xc_internal.h, HistKnobs)
         auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         HistKnobs& k = ctx->knobs;
-        k.xcd_map = env_int("XC_HIST_XCDMAP", 1); k.tile_map = env_int("XC_HIST_TILEMAP", 1); k.vec4 = env_int("XC_HIST_VEC4", -1);
+        k.xcd_map = env_int("XC_HIST_XCDMAP", 1); k.tile_map = env_int("XC_HIST_TILEMAP", 1); k.vec4 = env_int("XC_HIST_VEC4", -1); k.e32 = env_int("XC_HIST_E32", 1);
         k.threads = env_int("XC_HIST_THREADS", 0); k.ncopy = env_int("XC_HIST_NCOPY", 0); k.rows = env_int("XC_HIST_ROWS", 0);
         k.bps = env_int("XC_HIST_BPS", 0);
         k.cross_ncopy = env_int("XC_CROSS_NCOPY", 0); k.cross_blocks = env_int("XC_CROSS_BLOCKS", 0);

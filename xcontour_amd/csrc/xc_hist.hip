@@ -117,7 +117,9 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     // largest power-of-two copy count that fits the LDS budget
     int ncopy = (env_ncopy >= 1 && env_ncopy <= kMaxCopies && (env_ncopy & (env_ncopy - 1)) == 0) ? env_ncopy : kMaxCopies;
     // (the fixed-point pass keeps its (nbin + 1) x nch binary exponents behind the cells)
-    const size_t fixed = (64 + ((nbin + 2) & ~1) + (det ? ((size_t)(nbin + 1) * nch + 1) / 2 : 0)) * sizeof(double);
+    // (and the float32 Keff layout a float32 copy of its nbin + 1 edges, same place)
+    const size_t behind = det ? ((size_t)(nbin + 1) * nch + 1) / 2 : ((keff_fast_layout == 1 && q_dtype == XC_F32 && nbin <= kE32MaxBins) ? ((size_t)nbin + 2) / 2 : 0);
+    const size_t fixed = (64 + ((nbin + 2) & ~1) + behind) * sizeof(double);
     const size_t cell = (size_t)(nch + 1) * 8;             // nch sums + the count, side by side; nbin + 1 bins (the last is the trash bin)
     while (ncopy > 1 && fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget) ncopy >>= 1;
     if (fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget)
@@ -163,6 +165,10 @@ int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g,
         if (q_dtype == XC_F64)
             return a.q_next ? launch_three<double, 4, 0, true, true, true, true>(ctx, g, nslab, a)
                             : launch_three<double, 4, 0, true, true, false, true>(ctx, g, nslab, a);
+        // float32 tracer AND float32 contour levels (the reference's default dtype): the E32 variant, unless XC_HIST_E32=0
+        if (a.levels_mode && a.ctr_f32 && a.nbin <= kE32MaxBins && ctx->knobs.e32)
+            return a.q_next ? launch_three<float, 4, 0, true, true, true, true, 0, true>(ctx, g, nslab, a)
+                            : launch_three<float, 4, 0, true, true, false, true, 0, true>(ctx, g, nslab, a);
         return a.q_next ? launch_three<float, 4, 0, true, true, true, true>(ctx, g, nslab, a)
                         : launch_three<float, 4, 0, true, true, false, true>(ctx, g, nslab, a);
     }

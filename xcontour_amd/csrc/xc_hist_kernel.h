@@ -9,6 +9,9 @@
 // Measured on MI355X (bench.py, 64 slabs per launch): the non-temporal hint on the NEXT stream -- read once, used for
 // two compares, never needed again by this launch -- keeps the shared dA plane in the XCD L2s: 1.367 -> 1.285 ms per
 // launch; the same hint on the binned stream costs 9 % (its halo / neighbour re-reads want the line), on both 7 %.
+#ifndef XC_E32_NBUF
+#define XC_E32_NBUF 2
+#endif
 #ifndef XC_HIST_QNT
 #define XC_HIST_QNT 2
 #endif
@@ -24,13 +27,15 @@ template <int VEC> struct RowsPerBatch { static constexpr int value = VEC >= 4 ?
 
 #include "xc_binning.h"
 
-template <int VEC, int NINT>
+// TB: the type the tracer values are KEPT in while a row waits in its buffer: double (converted by the load), or float for
+// the E32 variant (raw float32: half the registers per buffered row, converted when the row is consumed)
+template <int VEC, int NINT, typename TB = double>
 struct RowBuf {
-    double q[VEC];          // GRAD: row (centre+1); else: the centre row itself
-    double h;               // GRAD: lane 0 = left halo of that row, lane 63 = right halo
+    TB     q[VEC];          // GRAD: row (centre+1); else: the centre row itself
+    TB     h;               // GRAD: lane 0 = left halo of that row, lane 63 = right halo
     double dA[VEC];
     double in[NINT > 0 ? NINT : 1][VEC];
-    double qn[VEC];         // NEXT: the same cells of the next batch (min/max by-product)
+    TB     qn[VEC];         // NEXT: the same cells of the next batch (min/max by-product)
 };
 
 // DA2D: dA is a [ny][nx] plane (vector loads); otherwise one value per row (scalar).
@@ -43,13 +48,23 @@ struct RowBuf {
 // pass 1's maximum and count so that the bin's sum stays below 2^62, and the integers are added with ds_add_u64 -- integer
 // addition is associative, so the per-bin sums do not depend on the order of arrival, the block geometry or the number of
 // slabs per launch.
-template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT, bool FAST = false, int DET = 0>
+// E32 (float32 tracer AND float32 contour levels, the Keff FAST layout; round 4): everything that is exact in float32 stays in
+// float32 -- the bin search (float32 values against float32 edges: the comparison np.digitize makes, so the counts are the same
+// bits; the nearest-edge guess in float32 is good to ~1e-4 of a bin, the decision is the exact compare), the min / max of the
+// NEXT stream, the rows waiting in their buffers.  The squared gradient and the weights stay float64 (oracle.grad2_sphere
+// fixes that arithmetic).  Measured (bench.py --dtype f32, 64 slabs per launch): chained 0.809 -> 0.760 ms, unchained K3 0.699 ->
+// 0.682.  A THIRD row of loads in flight with the freed registers (XC_E32_NBUF = 3) does not pay: unchained 0.684 (the kernel
+// is not short of bytes in flight), chained 1.185 (45 spilled registers).
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT, bool FAST = false, int DET = 0, bool E32 = false>
 __global__ __launch_bounds__(kHistThreads)
 void k_hist(const HistArgs a)
 {
     constexpr int NCH = 1 + NINT + (GRAD ? 1 : 0);
     constexpr int W = 64 * VEC;
     constexpr int U = RowsPerBatch<VEC>::value;
+    constexpr int NBUF = E32 ? XC_E32_NBUF : 2;                            // ring of row batches: NBUF - 1 of them in flight while one is processed
+    using TB = typename std::conditional<E32, float, double>::type;
+    static_assert(!E32 || (std::is_same<TQ, float>::value && GRAD && NINT == 0 && FAST && DET == 0), "E32: float32 Keff layout only");
     extern __shared__ __align__(16) double smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,7 +113,7 @@ void k_hist(const HistArgs a)
     const size_t rowq = (size_t)nx * sizeof(TQ), rowd = (size_t)nx * sizeof(double);
     const TQ* __restrict__ qs = reinterpret_cast<const TQ*>(a.q) + slab_off;
     const TQ* __restrict__ qnx = NEXT ? reinterpret_cast<const TQ*>(a.q_next) + slab_off : nullptr;
-    double nmn = dinf(), nmx = -dinf();
+    TB nmn = (TB)dinf(), nmx = (TB)-dinf();
     const double* __restrict__ dAp = (DA2D && a.dA_rank == XC_DA_SLAB) ? a.dA + slab_off : a.dA;
     const double* __restrict__ rdxp = a.rdx;
     const double* __restrict__ rdyp = a.rdy;
@@ -155,7 +170,7 @@ void k_hist(const HistArgs a)
     const char* qbase = reinterpret_cast<const char*>(qs);
     const char* nbase = reinterpret_cast<const char*>(qnx);
     const char* dbase = reinterpret_cast<const char*>(dAp);
-    auto load_row = [&](RowBuf<VEC, NINT>& r, int yq, int yw) {
+    auto load_row = [&](RowBuf<VEC, NINT, TB>& r, int yq, int yw) {
         yq = yq < ny - 1 ? yq : ny - 1;
         yw = yw < ny - 1 ? yw : ny - 1;
         const char* qrow = qbase + (size_t)yq * rowq;                          // wave-uniform
@@ -164,7 +179,7 @@ void k_hist(const HistArgs a)
 #else
         RowLoad<TQ, VEC>::ld(reinterpret_cast<const TQ*>(qrow + xo_q), r.q);
 #endif
-        if (GRAD) r.h = (double)*reinterpret_cast<const TQ*>(qrow + xo_h);
+        if (GRAD) r.h = (TB)*reinterpret_cast<const TQ*>(qrow + xo_h);
 #if (XC_HIST_QNT & 2)
         if (NEXT) RowLoadNT<TQ, VEC>::ld(reinterpret_cast<const TQ*>(nbase + (size_t)yw * rowq + xo_q), r.qn);
 #else
@@ -187,31 +202,36 @@ void k_hist(const HistArgs a)
                                          (slab_off + (size_t)yw * nx) * 8 + xo_d), r.in[i]);
         }
     };
-    auto load_batch = [&](RowBuf<VEC, NINT> (&L)[U], int yb) {
+    auto load_batch = [&](RowBuf<VEC, NINT, TB> (&L)[U], int yb) {
 #pragma unroll
         for (int i = 0; i < U; ++i) load_row(L[i], GRAD ? yb + i + 1 : yb + i, yb + i);
     };
 
     // issue the first loads of this wave BEFORE the edge prologue so that their HBM latency
     // overlaps the min/max reduction and the barriers below
-    RowBuf<VEC, NINT> A[U], B[U];
-    double qm[VEC], qcur[VEC], hcur = 0.0;
-    bool have = g0 < g1;
-    if (have) {
+    RowBuf<VEC, NINT, TB> R[NBUF][U];
+    double qm[VEC], qcur[VEC];
+    TB hcur = (TB)0, qc32[E32 ? VEC : 1];                        // E32: the centre row once more, raw, for the bin search
+    // first rows of a segment: the two rows above the sweep (gradient window) and NBUF - 1 batches in flight
+    auto prime = [&]() {
         begin_segment();
         if (GRAD) {
             load_metrics(y0);
-            RowBuf<VEC, NINT> t;
+            RowBuf<VEC, NINT, TB> t;
             load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) qm[c] = t.q[c];
+            for (int c = 0; c < VEC; ++c) qm[c] = (double)t.q[c];
             load_row(t, y0, y0);
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) qcur[c] = t.q[c];
+            for (int c = 0; c < VEC; ++c) { qcur[c] = (double)t.q[c]; if (E32) qc32[c] = t.q[c]; }
             hcur = t.h;
         }
-        load_batch(A, y0);
-    }
+#pragma unroll
+        for (int b = 0; b < NBUF - 1; ++b)
+            if (y0 + b * U < y1) load_batch(R[b], y0 + b * U);
+    };
+    bool have = g0 < g1;
+    if (have) prime();
 
     for (int i = tid; i < CW * hsz; i += blockDim.x) s_cell[i] = 0.0;
 
@@ -255,6 +275,10 @@ void k_hist(const HistArgs a)
     }
     const double e0 = s_edges[0], eN = s_edges[N];
     const double inv = (double)N / (eN - e0);
+    // E32: a float32 copy of the edges (they ARE float32 values: ctr_f32) behind the cells, for 4-byte reads
+    float* s_e32 = reinterpret_cast<float*>(s_cell + (size_t)CW * hsz);
+    const float e0f = (float)e0, invf = (float)inv;
+    if (E32) { for (int k = tid; k <= N; k += blockDim.x) s_e32[k] = (float)s_edges[k]; }
     const int last_closed = FAST ? 0 : a.last_closed;           // FAST: the half-open (xhistogram) rule is a compile-time fact
     // Are the edges equally spaced to a quarter of a bin?  Then the NEAREST edge j = floor((v - e0) / h + 1/2) brackets v
     // between e[j-1] and e[j+1], and ONE exact comparison against e[j] gives np.digitize's answer (one 8-byte LDS read
@@ -299,13 +323,25 @@ void k_hist(const HistArgs a)
     // one centre row: bins, weights, accumulate
     auto do_row = [&](const double (&qc)[VEC], const double (&qS)[VEC], const double (&qN)[VEC],
                       double hc, const double (&dAv)[VEC], const double (&inv_)[NINT > 0 ? NINT : 1][VEC],
-                      double rdx, double rdy) {
+                      double rdx, double rdy, const TB (&qraw)[E32 ? VEC : 1]) {
         unsigned k[VEC];                 // bin, or N (the trash bin) for a dropped cell
         double w[NCH][VEC];
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
             const double vb = (!GRAD && negate) ? -qc[c] : qc[c];
             int kb;
+            if (E32) {
+                // float32 value against float32 edges (only launched when the edges are equally spaced: xc_keff_dev checks
+                // nothing -- `uni` is checked below and the non-uniform case takes the float64 search)
+                const float vf = (float)qraw[E32 ? c : 0];
+                if (uni) {
+                    int j = (int)__builtin_fmaf(vf - e0f, invf, 0.5f);                  // NaN -> 0
+                    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(j) : "v"(j), "s"(N));
+                    kb = (vf >= s_e32[j]) ? j : j - 1;
+                } else {
+                    kb = find_bin(vb, s_edges, N, e0, eN, inv, last_closed);
+                }
+            } else
             if (uni) {
                 int j = (int)__builtin_fma(vb - e0, inv, 0.5);                      // NaN -> 0
                 asm("v_med3_i32 %0, %1, 0, %2" : "=v"(j) : "v"(j), "s"(N));         // clamp to [0, N]
@@ -402,66 +438,61 @@ void k_hist(const HistArgs a)
     };
 
     // batch of U centre rows starting at yb; L holds (GRAD) q rows yb+1.. and weights rows yb..
-    auto process_batch = [&](RowBuf<VEC, NINT> (&L)[U], int yb) {
+    auto process_batch = [&](RowBuf<VEC, NINT, TB> (&L)[U], int yb) {
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             if (yb + i < y1) {
                 if (NEXT && active) {
 #pragma unroll
                     for (int c = 0; c < VEC; ++c) {              // NaN never wins a compare: NaN-skipping
-                        const double v = L[i].qn[c];
-                        nmn = fmin(nmn, v); nmx = fmax(nmx, v);                  // fmin / fmax skip NaN
+                        const TB v = L[i].qn[c];
+                        if (E32) { nmn = fminf(nmn, v); nmx = fmaxf(nmx, v); }   // exact in float32
+                        else { nmn = fmin(nmn, v); nmx = fmax(nmx, v); }         // fmin / fmax skip NaN
                     }
                 }
                 if (GRAD) {
                     if (yb + i - ymet0 >= 64) load_metrics(yb + i);               // wave-uniform, once per 64 rows
-                    do_row(qcur, qm, L[i].q, hcur, L[i].dA, L[i].in,
-                           lane_get(rdxv, yb + i - ymet0), lane_get(rdyv, yb + i - ymet0));
+                    double qn64[VEC];
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) { qm[c] = qcur[c]; qcur[c] = L[i].q[c]; }
+                    for (int c = 0; c < VEC; ++c) qn64[c] = (double)L[i].q[c];
+                    do_row(qcur, qm, qn64, (double)hcur, L[i].dA, L[i].in,
+                           lane_get(rdxv, yb + i - ymet0), lane_get(rdyv, yb + i - ymet0), qc32);
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) { qm[c] = qcur[c]; qcur[c] = qn64[c]; if (E32) qc32[c] = L[i].q[c]; }
                     hcur = L[i].h;
                 } else {
-                    do_row(L[i].q, L[i].q, L[i].q, 0.0, L[i].dA, L[i].in, 0.0, 0.0);
+                    if constexpr (!E32) do_row(L[i].q, L[i].q, L[i].q, 0.0, L[i].dA, L[i].in, 0.0, 0.0, qc32);
                 }
             }
         }
     };
 
     while (have) {
-        for (int yb = y0; yb < y1; yb += 2 * U) {
-            if (yb + U < y1) load_batch(B, yb + U);
-            process_batch(A, yb);
-            if (yb + U >= y1) break;
-            if (yb + 2 * U < y1) load_batch(A, yb + 2 * U);
-            process_batch(B, yb + U);
+        for (int yb = y0; yb < y1; yb += NBUF * U) {
+#pragma unroll
+            for (int b = 0; b < NBUF; ++b) {
+                const int yy = yb + b * U;
+                if (yy >= y1) break;                              // wave-uniform
+                const int yl = yy + (NBUF - 1) * U;
+                if (yl < y1) load_batch(R[(b + NBUF - 1) % NBUF], yl);
+                process_batch(R[b], yy);
+            }
         }
         have = g0 < g1;
-        if (have) {                                   // next segment (the range crossed a strip boundary)
-            begin_segment();
-            if (GRAD) {
-                load_metrics(y0);
-                RowBuf<VEC, NINT> t;
-                load_row(t, y0 > 0 ? y0 - 1 : 0, y0);
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) qm[c] = t.q[c];
-                load_row(t, y0, y0);
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) qcur[c] = t.q[c];
-                hcur = t.h;
-            }
-            load_batch(A, y0);
-        }
+        if (have) prime();                            // next segment (the range crossed a strip boundary)
     }
     flush();
     if (NEXT) {
-        for (int o = 32; o > 0; o >>= 1) { nmn = fmin(nmn, __shfl_xor(nmn, o)); nmx = fmax(nmx, __shfl_xor(nmx, o)); }
-        if (lane == 0) { s_red[2 * wave] = nmn; s_red[2 * wave + 1] = nmx; }
+        double dmn = (double)nmn, dmx = (double)nmx;
+        for (int o = 32; o > 0; o >>= 1) { dmn = fmin(dmn, __shfl_xor(dmn, o)); dmx = fmax(dmx, __shfl_xor(dmx, o)); }
+        if (lane == 0) { s_red[2 * wave] = dmn; s_red[2 * wave + 1] = dmx; }
     }
     __syncthreads();
     if (NEXT && tid == 0) {
-        for (int w = 1; w < nwave; ++w) { nmn = fmin(nmn, s_red[2 * w]); nmx = fmax(nmx, s_red[2 * w + 1]); }
+        double dmn = s_red[0], dmx = s_red[1];
+        for (int w = 1; w < nwave; ++w) { dmn = fmin(dmn, s_red[2 * w]); dmx = fmax(dmx, s_red[2 * w + 1]); }
         double* o = a.mm_next + ((size_t)slab * nbx + bx) * 2;
-        o[0] = nmn; o[1] = nmx;
+        o[0] = dmn; o[1] = dmx;
     }
 
     // ------------------------------------------------------------------ per-block partials (plain stores)
@@ -496,10 +527,10 @@ void k_hist(const HistArgs a)
 }
 
 
-template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT, bool FAST = false, int DET = 0>
+template <typename TQ, int VEC, int NINT, bool GRAD, bool DA2D, bool NEXT, bool FAST = false, int DET = 0, bool E32 = false>
 int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& a)
 {
-    auto kern = k_hist<TQ, VEC, NINT, GRAD, DA2D, NEXT, FAST, DET>;
+    auto kern = k_hist<TQ, VEC, NINT, GRAD, DA2D, NEXT, FAST, DET, E32>;
     { const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(kern), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; }
     HistArgs b = a;
     // the XCD-aware order needs whole groups of 8 row groups, otherwise it would leave XCDs idle (bps = 1 with many

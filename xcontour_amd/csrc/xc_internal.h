@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "../../include/xcontour_hip.h"
 
@@ -14,6 +15,7 @@ struct HistKnobs {
     int xcd_map = 1;     // XC_HIST_XCDMAP   XCD-aware block order when blocks per slab is a multiple of 8
     int tile_map = 1;    // XC_HIST_TILEMAP  strip-fastest wave order
     int vec4 = -1;       // XC_HIST_VEC4     four cells per lane: -1 float32 tracers only, 0 never, 1 always
+    int e32 = 1;         // XC_HIST_E32      float32 tracer + float32 levels: raw float32 rows, float32 bin search, three rows in flight
     int threads = 0;     // XC_HIST_THREADS  threads per block
     int ncopy = 0;       // XC_HIST_NCOPY    LDS histogram copies
     int rows = 0;        // XC_HIST_ROWS     (strip, row) pairs per wave
@@ -80,6 +82,7 @@ inline int minmax_blocks(int64_t ncell) { const int64_t p = (ncell + 8191) / 819
 constexpr int kHistThreads  = 1024;   // 16 waves: one block per CU (LDS-bound)
 constexpr int kMaxCopies    = 16;     // lane-privatised LDS histogram copies
 constexpr size_t kLdsBudget = 150 * 1024;
+constexpr int kE32MaxBins  = 2048;   // the float32-edges variant of K3 (E32) keeps a float32 copy of the edges in LDS: ordinary contour counts only
 
 struct HistGeom {
     int threads;    // threads per block (multiple of 64, <= kHistThreads)
