@@ -224,3 +224,42 @@ def test_e32_bin_search_ties_infinities_and_collapsed_levels(ctx):
                 _, cnt = O.cal_integral_within_contours_hist(qs, ctr, dA, None, True, return_counts=True)
                 assert np.array_equal(b['counts'][s].astype(np.int64), cnt), (s, inc)
         plan.free()
+
+
+# ---------------------------------------------------------------- resident mirrors keyed on the source's identity
+def test_resident_memo_follows_reassignment_and_is_private(ctx, baro):
+    """Contour2D(resident=True): `c.tracer = other` / `c.dA = other` must not be served the OLD mirror (round-3 advisor), and
+    what is registered is a private copy: a second, non-resident object that hands the SAME ndarray to the library after an
+    in-place change gets the new values, not the first object's mirror"""
+    import xcontour_amd as xa
+    q0, lat, lon = baro
+    c2 = {'latitude': lat, 'longitude': lon}
+    q = np.ascontiguousarray(q0.astype(np.float64))
+    tr = xa.DataArray(q, ('latitude', 'longitude'), c2, 'absolute_vorticity')
+    dAv = O.cell_area(lat, lon)
+    dA = xa.DataArray(dAv, ('latitude', 'longitude'), c2, 'rA')
+    kw = dict(dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True, deterministic=True)
+
+    def area(cm):
+        return cm.cal_integral_within_contours_hist(cm.cal_contours(41)).values
+
+    res = xa.Contour2D(tr, dA, resident=True, **kw)
+    a0 = area(res)
+    # 1. reassign the tracer and the weights
+    q2 = np.ascontiguousarray(np.roll(q, 17, axis=0) * 1.5)
+    res.tracer = xa.DataArray(q2, ('latitude', 'longitude'), c2, 'absolute_vorticity')
+    a1 = area(res)
+    ref1 = area(xa.Contour2D(res.tracer, dA, **kw))
+    assert np.array_equal(bits(a1), bits(ref1)) and not np.array_equal(bits(a1), bits(a0))
+    res.dA = xa.DataArray(dAv * 2.0, ('latitude', 'longitude'), c2, 'rA')
+    a2 = area(res)
+    assert np.array_equal(bits(a2), bits(area(xa.Contour2D(res.tracer, res.dA, **kw))))
+    assert np.array_equal(bits(a2), bits(2.0 * a1))
+    # 2. the registered host memory is not the caller's array
+    assert all(not np.shares_memory(arr, q2) for arr in res.ctx._resident.values())
+    q2[:] = np.roll(q2, 5, axis=0)                                   # in place, no touch(): res keeps its (documented) old mirror ...
+    other = xa.Contour2D(res.tracer, res.dA, **kw)                  # ... but a non-resident object must see the new values
+    b = area(other)
+    res.touch()
+    assert np.array_equal(bits(b), bits(area(res))) and not np.array_equal(bits(b), bits(a2))
+    res.close(); other.close()

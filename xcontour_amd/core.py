@@ -83,20 +83,37 @@ class Contour2D(object):
     # ------------------------------------------------------------------ plumbing
     def touch(self):
         """resident=True: the tracer / weights were modified in place -- forget the device mirrors (the next call uploads again)"""
-        for v in self.__dict__.get('_memo', {}).values():
+        for _, v in self.__dict__.get('_memo', {}).values():
             try:
                 self.ctx.release_resident(v[0])
             except Exception:
                 pass
         self._memo = {}
 
-    def _keep(self, key, make):
-        """memoised (array, ...) tuple whose first element stays registered as a resident input of the context"""
-        if key not in self._memo:
-            t = make()
-            self.ctx.keep_resident(t[0])
-            self._memo[key] = t
-        return self._memo[key]
+    def _keep(self, key, src, make):
+        """memoised (array, ...) tuple whose first element stays registered as a resident input of the context.  The memo is
+        keyed on the IDENTITY of the object it was made from: `c.tracer = other_field` (or `c.dA = ...`) drops the old mirror
+        and registers the new field on the next call (round-3 advisor: the old key survived a reassignment).  What is
+        registered is always a PRIVATE host copy, never the caller's own array: the context finds mirrors by host address,
+        and another (non-resident) object handing the same ndarray to the library must not be served this object's mirror."""
+        ent = self._memo.get(key)
+        if ent is not None and ent[0] is src:
+            return ent[1]
+        if ent is not None:
+            try:
+                self.ctx.release_resident(ent[1][0])
+            except Exception:
+                pass
+            del self._memo[key]
+        t = make()
+        a = t[0]
+        raw = lb.unwrap(src)[0] if lb.is_labeled(src) else src
+        if isinstance(raw, np.ndarray) and np.shares_memory(a, raw):
+            a = a.copy()
+            t = (a,) + tuple(t[1:])
+        self.ctx.keep_resident(a)
+        self._memo[key] = (src, t)
+        return t
 
     def close(self):
         """Release the device buffers kept between keff() calls (also done when the object is collected)."""
@@ -121,7 +138,7 @@ class Contour2D(object):
             def make():
                 v, lead, lshape, coords = self._plane_of(arr)
                 return np.ascontiguousarray(self._float(v)), lead, lshape, coords
-            return self._keep('tracer', make)
+            return self._keep('tracer', arr, make)
         return self._plane_of(arr)
 
     def _plane_of(self, arr):
@@ -142,7 +159,7 @@ class Contour2D(object):
     def _dA_array(self, ny, nx, nslab):
         """self.dA -> (float64 ndarray of shape (ny,), (ny,nx) or (nslab,ny,nx), was_f32)"""
         if self.resident:
-            return self._keep(('dA', ny, nx, nslab), lambda: self._dA_array_of(ny, nx, nslab))
+            return self._keep(('dA', ny, nx, nslab), self.dA, lambda: self._dA_array_of(ny, nx, nslab))
         return self._dA_array_of(ny, nx, nslab)
 
     def _dA_array_of(self, ny, nx, nslab):

@@ -452,7 +452,7 @@ int xc_minmax_dev(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_
     XC_TRY(ensure_scratch(ctx, al((size_t)nslab * kMinmaxBlocks * 2 * sizeof(double))));
     double* part = (double*)ctx->scratch;
     XC_TRY(launch_minmax_partial(ctx, q, q_dtype, nslab, ncell, part));
-    return launch_minmax_final(ctx, part, nslab, minmax_blocks(ncell), out_minmax);
+    return launch_minmax_final(ctx, part, nslab, minmax_blocks(ncell, nslab), out_minmax);
 }
 
 int xc_minmax(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* out_minmax)
@@ -959,7 +959,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     double* mmpart = (double*)ctx->scratch;
     double* part_h = (double*)((char*)ctx->scratch + mb);
     unsigned* part_c = (unsigned*)((char*)ctx->scratch + mb + ph);
-    int mmP = minmax_blocks(d->ny * d->nx);
+    int mmP = minmax_blocks(d->ny * d->nx, d->nslab);
 
     // min/max partials: either produced by the previous call's histogram pass (q_next) or by K1 now
     if (ctx->mm_valid && ctx->mm_q == d->q && ctx->mm_nslab == d->nslab && ctx->mm_ny == d->ny &&

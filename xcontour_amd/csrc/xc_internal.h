@@ -75,10 +75,23 @@ int ensure_ones(xc_ctx* ctx, size_t n);
 int ensure_big(xc_ctx* ctx, size_t bytes);
 
 // ---------------------------------------------------------------- launch geometry
-constexpr int kMinmaxBlocks = 1024;   // partial min/max pairs per slab (upper bound, see minmax_blocks)
+constexpr int kMinmaxBlocks = 2048;   // partial min/max pairs per slab (upper bound, see minmax_blocks)
 // blocks per slab of the K1 pass: at least ~8192 cells per block, so that a stack of many small slabs is not
-// shredded into half a million 16-cell blocks (512 slabs of 90x180: 70 -> ~2 ps per cell)
-inline int minmax_blocks(int64_t ncell) { const int64_t p = (ncell + 8191) / 8192; return (int)(p < 1 ? 1 : (p > kMinmaxBlocks ? kMinmaxBlocks : p)); }
+// shredded into half a million 16-cell blocks (512 slabs of 90x180: 70 -> ~2 ps per cell).  A launch of FEW large slabs
+// (one cfg2 slab = 52 MB) instead wants every byte requested at once: up to 8 blocks per CU on 256 CUs, one batch of eight
+// 16-byte loads per thread (4096 float64 cells per block) -- one slab: 792 blocks, two dependent rounds -> 1583, one round
+inline int minmax_blocks(int64_t ncell, int64_t nslab)
+{
+    int64_t p = (ncell + 8191) / 8192;
+    if (p > 1024) p = 1024;
+    if (nslab < 1) nslab = 1;
+    if (p * nslab < 2048) {
+        int64_t f = (ncell + 4095) / 4096;
+        if (f * nslab > 2048) f = 2048 / nslab;
+        if (f > p) p = f;
+    }
+    return (int)(p < 1 ? 1 : (p > kMinmaxBlocks ? kMinmaxBlocks : p));
+}
 constexpr int kHistThreads  = 1024;   // 16 waves: one block per CU (LDS-bound)
 constexpr int kMaxCopies    = 16;     // lane-privatised LDS histogram copies
 constexpr size_t kLdsBudget = 150 * 1024;

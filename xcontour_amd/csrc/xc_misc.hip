@@ -518,7 +518,7 @@ int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab
 {
     if (!q || !part || nslab < 1 || ncell < 1) return fail(ctx, XC_EBADARG, "xc_minmax: bad arguments");
     if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_minmax: at most 65535 slabs per launch");
-    dim3 grid((unsigned)minmax_blocks(ncell), (unsigned)nslab);      // partials: [nslab][minmax_blocks(ncell)][2]
+    dim3 grid((unsigned)minmax_blocks(ncell, nslab), (unsigned)nslab);      // partials: [nslab][minmax_blocks(ncell, nslab)][2]
     if (q_dtype == XC_F64)
         hipLaunchKernelGGL(k_minmax_partial<double>, grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part);
     else if (q_dtype == XC_F32)

@@ -883,7 +883,7 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
             // ---- three passes over the 24-bit range key, then the short runs (see the head of this file)
             XC_TRY_(launch_minmax_partial(ctx, q, q_dtype, nslab, n, mmpart));
             XC_HIP(ctx, hipMemsetAsync(flag, 0, 256 + S * RANGE_NB * 4, ctx->stream));      // the flag and the coarse histogram behind it
-            XC_TRY_(launch_minmax_final(ctx, mmpart, nslab, minmax_blocks(n), mm));
+            XC_TRY_(launch_minmax_final(ctx, mmpart, nslab, minmax_blocks(n, nslab), mm));
             {
                 const int64_t samp = n > (int64_t)256 * RANGE_SAMPLE * 64 ? RANGE_SAMPLE : 1;
                 int64_t hb = ((n + 256 * samp - 1) / (256 * samp) + 7) / 8;                  // eight 256-cell segments per block and round
