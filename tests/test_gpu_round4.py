@@ -263,3 +263,95 @@ def test_resident_memo_follows_reassignment_and_is_private(ctx, baro):
     res.touch()
     assert np.array_equal(bits(b), bits(area(res))) and not np.array_equal(bits(b), bits(a2))
     res.close(); other.close()
+
+
+# ---------------------------------------------------------------- xarray in, xarray out (a test double of xarray)
+def test_facade_call_sequences_through_the_xarray_branch():
+    """the Keff (tests/test_hist.py), contour-mean and LWA (tests/test_LWA.py) call sequences of the reference with xarray
+    objects in: every result is an xarray object with the reference's dims and names ('AeqCTbl', 'd...dA', 'Leq2', 'nkeff',
+    'LWA', 'LAPE', 'cm...'), values bit-identical to the same calls on the in-house DataArray, the fused pipeline against
+    the oracle (subprocess: the double must be importable BEFORE the package is)"""
+    env = dict(_clean_env(), PYTHONPATH=os.path.join(ROOT, 'tests', 'fake_xarray'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'xarray_branch_script.py'), 'gpu'], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok gpu'), r.stderr[-3000:]
+
+
+# ---------------------------------------------------------------- lazy stacks stay lazy
+class _Budget(object):
+    """a lazy (time, level, lat, lon) source that refuses to hand out more than `limit` bytes at once"""
+
+    def __init__(self, a, limit):
+        self.a, self.shape, self.dtype, self.limit, self.peak, self.reads = a, a.shape, a.dtype, limit, 0, 0
+
+    def __getitem__(self, k):
+        r = self.a[k]
+        self.peak = max(self.peak, r.nbytes)
+        self.reads += 1
+        if r.nbytes > self.limit:
+            raise MemoryError('asked for %d bytes at once, budget %d' % (r.nbytes, self.limit))
+        return r
+
+
+def test_lazy_stack_goes_through_in_batches(baro, tmp_path):
+    """the reference's histogram API is lazy (dask='allowed', core.py:242, 258): a lazy tracer stack -- here a source that
+    RAISES when more than two slabs are requested at once, and a multi-record .nc opened with lazy=True -- is pulled through
+    cal_contours / the histogram integrals / contour means / keff / LWA / crossing batch by batch under max_batch_bytes; results equal the eager run bit for bit"""
+    import xcontour_amd as xa
+    from xcontour_amd import ncio
+    q0, lat, lon = baro
+    T, Z = 3, 2
+    rng = np.random.default_rng(8)
+    q = np.stack([q0 * (1 + 0.05 * k) for k in range(T * Z)]).reshape(T, Z, *q0.shape).astype(np.float32)
+    g = rng.random(q.shape).astype(np.float32)
+    c4 = {'time': np.arange(T), 'level': np.arange(Z), 'latitude': lat, 'longitude': lon}
+    c2 = {'latitude': lat, 'longitude': lon}
+    d4 = ('time', 'level', 'latitude', 'longitude')
+    dA = xa.DataArray(O.cell_area(lat, lon), ('latitude', 'longitude'), c2, 'rA')
+    mask = xa.DataArray(np.ones_like(q0), ('latitude', 'longitude'), c2, 'mask')
+    kw = dict(dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True, deterministic=True)
+    L = np.load(os.path.join(ROOT, 'tests', 'golden', 'baro_lwa_N121.npz'))
+
+    def run(tr, grd):
+        cm = xa.Contour2D(tr, dA, **kw)
+        table = cm.cal_area_eqCoord_table_hist(mask)
+        ctr = cm.cal_contours(41)
+        area = cm.cal_integral_within_contours_hist(ctr)
+        intS = cm.cal_integral_within_contours_hist(ctr, integrand=grd)
+        strict = cm.cal_integral_within_contours(ctr)
+        mean = cm.cal_contour_mean_hist(ctr, grd, grd)
+        ds = cm.keff(41, table, lat=lat, lon=lon, max_batch_bytes=2 * q0.nbytes + 64)
+        Q = xa.DataArray(L['Q'], ('latitude',), {'latitude': lat}, 'Q')
+        lwa = cm.cal_local_wave_activity(tr, Q, metric=L['dy'])
+        cross = cm.cal_contour_crossing(ctr, stride=2)
+        cm.close()
+        return [ctr.values, area.values, intS.values, strict.values, mean.values, ds['nkeff'].values, ds['area'].values, lwa.values, cross.values]
+
+    eager = run(xa.DataArray(q, d4, c4, 'pv'), xa.DataArray(g, d4, c4, 'grdS'))
+    from xcontour_amd import _native as nat
+    ctx = nat.default_context(0)                                     # the facade's own context
+    old = ctx.max_batch_bytes
+    try:
+        ctx.max_batch_bytes = 2 * q0.nbytes + 64                     # at most two slabs per batch, one when an integrand rides along
+        src, gsrc = _Budget(q, 2 * q0.nbytes), _Budget(g, 2 * q0.nbytes)
+        lazy = run(xa.DataArray(src, d4, c4, 'pv'), xa.DataArray(gsrc, d4, c4, 'grdS'))
+        assert 0 < src.peak <= 2 * q0.nbytes and src.reads >= 3 * 6 and gsrc.peak <= 2 * q0.nbytes
+        for a, b in zip(lazy, eager):
+            assert np.array_equal(bits(a), bits(b))
+        # the same from a file: a classic NetCDF stack opened lazily
+        from scipy.io import netcdf_file
+        path = str(tmp_path / 'stack.nc')
+        with netcdf_file(path, 'w', version=2) as f:
+            f.createDimension('time', None); f.createDimension('level', Z); f.createDimension('latitude', len(lat)); f.createDimension('longitude', len(lon))
+            for n_, v_ in (('latitude', lat), ('longitude', lon)):
+                w = f.createVariable(n_, 'f4', (n_,)); w[:] = v_
+            w = f.createVariable('pv', 'f4', d4); w[:] = q
+            w = f.createVariable('grdS', 'f4', d4); w[:] = g
+        ds = ncio.open_dataset(path, lazy=True)
+        assert isinstance(ds.pv.data, ncio.LazyVariable) and ds.pv.dims == d4
+        filed = run(ds.pv, ds.grdS)
+        for a, b in zip(filed, eager):
+            assert np.array_equal(bits(a), bits(b))
+        assert ds.pv.data.rows_read >= T and isinstance(ds.pv.data, ncio.LazyVariable)      # still lazy afterwards
+    finally:
+        ctx.max_batch_bytes = old

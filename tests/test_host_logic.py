@@ -175,3 +175,15 @@ def test_cfg4_launch_sets_tile_the_blocks_of_every_rank_count():
         rounds = 3 * d / 256.0
         assert rounds / np.ceil(rounds) > 0.98
     assert m.cfg4_launch_set(11) == 256 and m.cfg4_launch_set(3157) == 256       # no divisor that fills the rounds: ragged sets of 256
+
+
+def test_xarray_branch_of_labeled_runs_with_a_test_double():
+    """xarray is the reference's in/out type (core.py:8-13) and is absent from both boxes: tests/fake_xarray/xarray.py is a
+    60-line double that makes `labeled.is_xarray` true, so unwrap (coords filter included) / wrap / merge run for real
+    (CPU part here; the facade's call sequences through it: tests/test_gpu_round4.py)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'tests', 'fake_xarray'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'xarray_branch_script.py'), 'cpu'], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip() == 'ok cpu', r.stderr[-2000:]

@@ -181,6 +181,20 @@ def _ptr(a):
     return a.ctypes.data_as(_vp)
 
 
+def _is_lazy(q):
+    """a labeled.LazyStack (or anything with its protocol): (S, ny, nx) shape / dtype known, slabs read on `q[s0:s1]`"""
+    return bool(getattr(q, '_xc_lazy_stack', False))
+
+
+def _stack_in(q):
+    return q if _is_lazy(q) else np.ascontiguousarray(q)
+
+
+def _stack_now(q):
+    """the batch is about to be staged on the device: a lazy stack is read now (this one batch, nothing more)"""
+    return np.ascontiguousarray(q[:]) if _is_lazy(q) else q
+
+
 class DeviceBuffer(object):
     """A device allocation owned by a Context (freed with the context or explicitly)."""
 
@@ -201,6 +215,10 @@ class DeviceBuffer(object):
         """copy on the context's copy stream (overlaps kernels already enqueued); pair with Context.stream_wait_copies()"""
         arr = np.ascontiguousarray(arr)
         assert offset_bytes + arr.nbytes <= self.nbytes
+        # lifetime rule: the source must stay alive until the copy has run.  Pageable sources make hipMemcpyAsync return
+        # after the copy today, but that is how the runtime behaves, not a promise (and a pinned source returns at once):
+        # the context holds a reference until its next sync()
+        self.ctx._staged.append(arr)
         self.ctx._check(self.ctx.lib.xc_memcpy_h2d_async(self.ctx.handle, self.ptr + offset_bytes, _ptr(arr), arr.nbytes))
         return self
 
@@ -231,6 +249,7 @@ class Context(object):
         self.device = int(device)
         self._buffers = []
         self._resident = {}          # data pointer -> ndarray registered with xc_keep_resident (kept alive here)
+        self._staged = []            # host arrays of asynchronous uploads in flight (DeviceBuffer.upload_async), dropped by sync()
         # host-pointer entry points stage at most this many bytes of per-slab data (tracer, integrands, per-slab weights,
         # per-slab outputs) on the device at once: larger stacks go through in batches of whole slabs (the reference's
         # histogram path is lazy / dask-friendly, core.py:158-160, 241-246)
@@ -256,6 +275,10 @@ class Context(object):
 
     def sync(self):
         self._check(self.lib.xc_sync(self.handle))
+        if self._staged:
+            self.stream_wait_copies()
+            self._check(self.lib.xc_sync(self.handle))            # the compute stream now also stands behind every copy issued
+            del self._staged[:]
 
     def stream_wait_copies(self):
         self._check(self.lib.xc_stream_wait_copies(self.handle))
@@ -355,11 +378,12 @@ class Context(object):
 
     def minmax(self, q):
         """q: (nslab, ny, nx) or (nslab, ncell) f32/f64 -> (nslab, 2) f64"""
-        q = np.ascontiguousarray(q)
+        q = _stack_in(q)
         nslab = q.shape[0]
         bt = self._batches(nslab, q.nbytes // max(1, nslab))
         if len(bt) > 1:
             return np.concatenate([self.minmax(q[s0:s1]) for s0, s1 in bt])
+        q = _stack_now(q)
         out = np.empty((nslab, 2), dtype=np.float64)
         self._check(self.lib.xc_minmax(self.handle, _ptr(q), dtype_code(q.dtype), nslab,
                                        int(q.size // nslab), _ptr(out)))
@@ -382,10 +406,10 @@ class Context(object):
         dA: None | (ny,) | (ny,nx) | (nslab,ny,nx) (converted to f64).
         grad: None or (rdx, rdy, periodic_x).  deterministic: order-free fixed-point sums (bit-reproducible).
         Returns dict of requested outputs."""
-        q = np.ascontiguousarray(q)
+        q = _stack_in(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
-        per = ny * nx * (q.dtype.itemsize + sum(np.asarray(v).dtype.itemsize for v in integrands) + (8 if dA is not None and np.ndim(dA) == 3 else 0))
+        per = ny * nx * (q.dtype.itemsize + sum(np.dtype(v.dtype).itemsize for v in integrands) + (8 if dA is not None and np.ndim(dA) == 3 else 0))
         bt = self._batches(nslab, per)
         if len(bt) > 1:                                      # more than one launch / one arena takes: batches of whole slabs
             parts = []
@@ -394,9 +418,11 @@ class Context(object):
                 e = np.asarray(edges)
                 d3 = dA is not None and np.ndim(dA) == 3
                 parts.append(self.hist(q[sl], e[sl] if e.ndim == 2 else e, dA[sl] if d3 else dA,
-                                       [np.asarray(v)[sl] for v in integrands], grad, last_closed, lt, reverse,
+                                       [v[sl] for v in integrands], grad, last_closed, lt, reverse,
                                        prod_f32, negate, want, deterministic))
             return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+        q = _stack_now(q)
+        integrands = [_stack_now(v) for v in integrands]
         edges = np.ascontiguousarray(edges, dtype=np.float64)
         d = HistDesc()
         keep = [q, edges]
@@ -491,12 +517,13 @@ class Context(object):
         return out
 
     def grad2(self, q, rdx, rdy, periodic_x=True):
-        q = np.ascontiguousarray(q)
+        q = _stack_in(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
         bt = self._batches(nslab, ny * nx * (q.dtype.itemsize + 8))
         if len(bt) > 1:
             return np.concatenate([self.grad2(q[s0:s1], rdx, rdy, periodic_x) for s0, s1 in bt])
+        q = _stack_now(q)
         rdx = np.ascontiguousarray(rdx, dtype=np.float64)
         rdy = np.ascontiguousarray(rdy, dtype=np.float64)
         out = np.empty(q.shape, dtype=np.float64)
@@ -508,7 +535,7 @@ class Context(object):
         """Box-counting contour crossing (xc_crossing).  q (nslab, ny, nx) f32/f64; contours (N,) or
         (nslab, N) ASCENDING f64; area (ny, nx) or (nslab, ny, nx) f32/f64.
         Returns (lengths f64 (nslab, N), box counts uint64 (nslab, N))."""
-        q = np.ascontiguousarray(q)
+        q = _stack_in(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
         contours = np.ascontiguousarray(contours, dtype=np.float64)
@@ -530,6 +557,7 @@ class Context(object):
             if np.ndim(stride) > 0:
                 return [(np.concatenate([p[i][0] for p in parts]), np.concatenate([p[i][1] for p in parts])) for i in range(len(parts[0]))]
             return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        q = _stack_now(q)
         if np.ndim(stride) > 0:
             # several strides on the same padded slab: one upload, one device call per stride
             # (`stride` may be a list; returns lists of results in the same order)
@@ -563,7 +591,7 @@ class Context(object):
         return lens, cnts
 
     def lwa(self, q, Q, coord, dA, dA_max, M=None, increase=True, part=0, mask_idx=None, variant=0):
-        q = np.ascontiguousarray(q)
+        q = _stack_in(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
         Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(nslab, ny)
@@ -572,6 +600,7 @@ class Context(object):
             parts = [self.lwa(q[s0:s1], Q[s0:s1], coord, dA, dA_max, M, increase, part, mask_idx, variant) for s0, s1 in bt]
             return (np.concatenate([p[0] for p in parts]),
                     None if parts[0][1] is None else np.concatenate([p[1] for p in parts]))
+        q = _stack_now(q)
         coord = np.ascontiguousarray(coord, dtype=np.float64)
         dA = np.ascontiguousarray(dA, dtype=np.float64)
         dr = XC_DA_ROW if dA.shape == (ny,) else XC_DA_PLANE
@@ -598,7 +627,7 @@ class Context(object):
         as before; q (nslab, ny, nx): a stack sorted by ONE set of launches -> leading slab dim on every
         output ('nvalid' (nslab,), 'Q' (nslab, J), 'q_sorted' / 'acum' (nslab, ny*nx), 'bpe' (nslab,)).
         dA: None | (ny,) | (ny, nx) | (nslab, ny, nx); mask: (ny, nx) or (nslab, ny, nx)."""
-        q = np.ascontiguousarray(q)
+        q = _stack_in(q)
         single = q.ndim == 2
         if single:
             q = q[None]
@@ -613,6 +642,7 @@ class Context(object):
                                        mask[s0:s1] if mask is not None and np.ndim(mask) == 3 else mask,
                                        targets, tbl, coord, want_sorted, want_acum, negate) for s0, s1 in bt]
             return {k: np.concatenate([np.atleast_1d(p[k]) for p in parts]) for k in parts[0]}
+        q = _stack_now(q)
         rank = XC_DA_NONE
         if dA is not None:
             dA = np.ascontiguousarray(dA, dtype=np.float64)

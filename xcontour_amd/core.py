@@ -133,8 +133,9 @@ class Contour2D(object):
         return nat.default_context(self.device)
 
     def _plane(self, arr):
-        """labelled array -> (values (S, ny, nx) C-contiguous, lead dims, lead shape, coords)"""
-        if self.resident and arr is self.tracer:
+        """labelled array -> (values (S, ny, nx) C-contiguous -- or a LazyStack of that shape for a lazy source --, lead dims,
+        lead shape, coords)"""
+        if self.resident and arr is self.tracer and not lb.is_lazy_data(lb.unwrap(arr, lazy=True)[0]):
             def make():
                 v, lead, lshape, coords = self._plane_of(arr)
                 return np.ascontiguousarray(self._float(v)), lead, lshape, coords
@@ -142,16 +143,23 @@ class Contour2D(object):
         return self._plane_of(arr)
 
     def _plane_of(self, arr):
-        v, dims, coords, _ = lb.unwrap(arr)
+        v, dims, coords, _ = lb.unwrap(arr, lazy=True)
         if self.dimEqV not in dims or self._xdim not in dims:
             raise Exception('array should have the dims %s' % self.dimVs)
         lead = tuple(d for d in dims if d not in (self.dimEqV, self._xdim))
+        if lb.is_lazy_data(v):
+            # a lazy stack stays lazy (the reference: dask='allowed', core.py:242, 258): the native entry points read it
+            # in batches of whole slabs below Context.max_batch_bytes
+            st = lb.LazyStack(v, [dims.index(d) for d in lead], dims.index(self.dimEqV), dims.index(self._xdim))
+            return st, lead, st.lshape, coords
         order = [dims.index(d) for d in lead] + [dims.index(self.dimEqV), dims.index(self._xdim)]
         v = np.ascontiguousarray(np.transpose(v, order))
         lshape = v.shape[:-2]
         return v.reshape((-1,) + v.shape[-2:]), lead, lshape, coords
 
     def _float(self, v):
+        if getattr(v, '_xc_lazy_stack', False):
+            return v                                                    # converts as it reads
         if v.dtype not in (np.float32, np.float64):
             v = v.astype(np.float64)
         return v
@@ -346,7 +354,7 @@ class Contour2D(object):
             g, _, _, _ = self._plane(integrand)
             g = self._float(g)
             if g.shape != q.shape:
-                g = np.ascontiguousarray(np.broadcast_to(g, q.shape))
+                g = np.ascontiguousarray(np.broadcast_to(np.asarray(g), q.shape))
             integ = [g]
             prod_f32 = bool(g.dtype == np.float32 and dA_f32)         # f32*f32 stays f32 (core.py:444)
         return tracer, q, lead, lshape, coords, dA, integ, prod_f32
@@ -483,7 +491,7 @@ class Contour2D(object):
         for it in integrands:
             g = self._float(self._plane(it)[0])
             if g.shape != q.shape:
-                g = np.ascontiguousarray(np.broadcast_to(g, q.shape))
+                g = np.ascontiguousarray(np.broadcast_to(np.asarray(g), q.shape))
             gs.append(g)
             flags.append(bool(g.dtype == np.float32 and dA_f32))           # f32*f32 stays f32 (core.py:444)
         if len(gs) > nat.XC_MAX_INTEGRANDS or len(set(flags)) > 1:

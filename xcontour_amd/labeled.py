@@ -19,22 +19,103 @@ except Exception:                       # pragma: no cover - not installed here
     _xr = None
 
 
+def is_lazy_data(x):
+    """not an ndarray (nor a list / scalar) but array-like enough to be read piecewise: shape, dtype, __getitem__"""
+    return (not isinstance(x, (np.ndarray, np.generic, list, tuple, int, float)) and hasattr(x, 'shape') and hasattr(x, 'dtype')
+            and hasattr(x, '__getitem__') and not isinstance(x, DataArray) and len(getattr(x, 'shape', ())) > 0)
+
+
+class LazyStack(object):
+    """The (S, ny, nx) face of a LAZY (..., eq, x) stack: shape and dtype are known, the slabs are read when a batch of
+    them is asked for (`stack[s0:s1]`, `stack[[3, 7]]` -> C-contiguous ndarray in (slab, eq, x) order, float32 / float64).
+    The reference's histogram API is lazy too (`dask='allowed'`, core.py:242, 258; docstring 158-160 'memory-friendly');
+    the native entry points cut such a stack into batches below `Context.max_batch_bytes` and read one batch at a time."""
+    _xc_lazy_stack = True
+
+    def __init__(self, data, lead_axes, eq_axis, x_axis):
+        self.src = data
+        self.lead_axes, self.eq_axis, self.x_axis = tuple(lead_axes), int(eq_axis), int(x_axis)
+        shp = tuple(int(n) for n in data.shape)
+        self.lshape = tuple(shp[a] for a in self.lead_axes)
+        self.shape = (int(np.prod(self.lshape, dtype=np.int64)), shp[self.eq_axis], shp[self.x_axis])
+        dt = np.dtype(data.dtype)
+        self.dtype = dt if dt in (np.dtype(np.float32), np.dtype(np.float64)) else np.dtype(np.float64)
+        self.ndim = 3
+        self.largest_request_bytes = 0
+        # consecutive slabs are consecutive along the LAST leading axis when the leading axes come first and in order:
+        # a run of them is then ONE read of the source
+        self._runs = self.lead_axes == tuple(range(len(self.lead_axes))) and len(self.lead_axes) > 0
+
+    @property
+    def size(self):
+        return self.shape[0] * self.shape[1] * self.shape[2]
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    def __len__(self):
+        return self.shape[0]
+
+    def _read(self, key, nslab):
+        a = np.asarray(self.src[tuple(key)])
+        self.largest_request_bytes = max(self.largest_request_bytes, a.nbytes)
+        if self.eq_axis > self.x_axis:
+            a = np.swapaxes(a, -1, -2)
+        return a.reshape((nslab,) + self.shape[1:])
+
+    def take(self, idx):
+        """slabs `idx` (flat indices over the leading dims) -> (len(idx), ny, nx) C-contiguous in the stack's float dtype"""
+        idx = [int(i) for i in idx]
+        out = np.empty((len(idx),) + self.shape[1:], dtype=self.dtype)
+        nd = len(self.src.shape)
+        i = 0
+        while i < len(idx):
+            lead = np.unravel_index(idx[i], self.lshape) if self.lshape else ()
+            run = 1
+            if self._runs:                                           # extend over consecutive slabs inside the last leading axis
+                last = self.lshape[-1]
+                while i + run < len(idx) and idx[i + run] == idx[i] + run and lead[-1] + run < last:
+                    run += 1
+            key = [slice(None)] * nd
+            for a, l in zip(self.lead_axes, lead):
+                key[a] = int(l)
+            if run > 1 or (self._runs and len(self.lead_axes) >= 1):
+                key[self.lead_axes[-1]] = slice(int(lead[-1]), int(lead[-1]) + run)
+            out[i:i + run] = self._read(key, run)
+            i += run
+        return out
+
+    def __getitem__(self, key):
+        if isinstance(key, (int, np.integer)):
+            return self.take([key + self.shape[0] if key < 0 else key])[0]
+        if isinstance(key, slice):
+            return self.take(range(*key.indices(self.shape[0])))
+        return self.take(list(np.asarray(key).reshape(-1)))
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self[:], dtype=dtype)
+
+
 class DataArray(object):
     """values + dims + 1-D coords + name.  Only what the hot path needs."""
 
     def __init__(self, data, dims=None, coords=None, name=None):
-        self.values = np.asarray(data)
+        # `data` may be LAZY: anything that is not an ndarray but has shape, dtype and __getitem__ (a dask array, an
+        # `ncio` variable opened with lazy=True, an h5py / zarr dataset).  It is kept as it is -- `values` materialises it,
+        # `data` hands it out untouched -- and the hot path pulls it slab batch by slab batch (core._plane_of, LazyStack).
+        self._data = data if is_lazy_data(data) else np.asarray(data)
         if dims is None:
-            dims = tuple('dim_%d' % i for i in range(self.values.ndim))
+            dims = tuple('dim_%d' % i for i in range(self.ndim))
         if isinstance(dims, str):
             dims = (dims,)
         self.dims = tuple(dims)
-        if len(self.dims) != self.values.ndim:
-            raise ValueError('dims %r do not match data of shape %r' % (self.dims, self.values.shape))
+        if len(self.dims) != self.ndim:
+            raise ValueError('dims %r do not match data of shape %r' % (self.dims, self.shape))
         self.coords = {}
         for k, v in (coords or {}).items():
             v = np.asarray(v.values if isinstance(v, DataArray) else v)
-            if k in self.dims and v.shape != (self.values.shape[self.dims.index(k)],):
+            if k in self.dims and v.shape != (self.shape[self.dims.index(k)],):
                 raise ValueError('coordinate %r has wrong length' % k)
             self.coords[k] = v
         self.name = name
@@ -42,30 +123,45 @@ class DataArray(object):
 
     # -- numpy-ish
     @property
+    def values(self):
+        """the data as an ndarray (a lazy source is read in full: use `data` / slices to stay lazy)"""
+        return self._data if isinstance(self._data, np.ndarray) else np.asarray(self._data[(slice(None),) * len(self._data.shape)])
+
+    @values.setter
+    def values(self, v):
+        self._data = np.asarray(v)
+
+    @property
+    def data(self):
+        """the underlying array, lazy or not (xarray's name for it)"""
+        return self._data
+
+    @property
     def shape(self):
-        return self.values.shape
+        return tuple(self._data.shape)
 
     @property
     def dtype(self):
-        return self.values.dtype
+        return np.dtype(self._data.dtype)
 
     @property
     def ndim(self):
-        return self.values.ndim
+        return len(self._data.shape)
 
     @property
     def size(self):
-        return self.values.size
+        return int(np.prod(self._data.shape, dtype=np.int64))
 
     def __len__(self):
-        return len(self.values)
+        return int(self._data.shape[0])
 
     def __array__(self, dtype=None, copy=None):
         return np.asarray(self.values, dtype=dtype)
 
     def __repr__(self):
         return '<xcontour_amd.DataArray %r %s %s>\n%r' % (
-            self.name, dict(zip(self.dims, self.shape)), self.dtype, self.values)
+            self.name, dict(zip(self.dims, self.shape)), self.dtype,
+            self._data if isinstance(self._data, np.ndarray) else '(lazy %s)' % type(self._data).__name__)
 
     # -- xarray-ish
     def copy(self, data=None):
@@ -73,6 +169,8 @@ class DataArray(object):
                          dict(self.coords), self.name)
 
     def load(self):
+        """read a lazy source into memory (in place, like xarray)"""
+        self._data = self.values
         return self
 
     def astype(self, dtype):
@@ -82,8 +180,8 @@ class DataArray(object):
         if isinstance(new, dict):
             dims = tuple(new.get(d, d) for d in self.dims)
             coords = {new.get(k, k): v for k, v in self.coords.items()}
-            return DataArray(self.values, dims, coords, self.name)
-        return DataArray(self.values, self.dims, dict(self.coords), new)
+            return DataArray(self._data, dims, coords, self.name)
+        return DataArray(self._data, self.dims, dict(self.coords), new)
 
     def squeeze(self):
         keep = [i for i, n in enumerate(self.shape) if n != 1]
@@ -118,7 +216,7 @@ class DataArray(object):
     def assign_coords(self, coords):
         c = dict(self.coords)
         c.update({k: np.asarray(v) for k, v in coords.items()})
-        return DataArray(self.values, self.dims, c, self.name)
+        return DataArray(self._data, self.dims, c, self.name)
 
 
 class Dataset(dict):
@@ -163,12 +261,16 @@ def is_labeled(x):
     return isinstance(x, DataArray) or is_xarray(x)
 
 
-def unwrap(x):
-    """-> (values ndarray, dims tuple, coords dict of ndarrays, name)"""
+def unwrap(x, lazy=False):
+    """-> (values ndarray, dims tuple, coords dict of ndarrays, name).  `lazy=True`: a lazy source (dask array behind an
+    xarray.DataArray, a lazy `ncio` variable, ...) is handed out as it is instead of being read in full."""
     if isinstance(x, DataArray):
-        return x.values, x.dims, dict(x.coords), x.name
+        return (x.data if lazy else x.values), x.dims, dict(x.coords), x.name
     if is_xarray(x):
         coords = {k: np.asarray(v.values) for k, v in x.coords.items() if v.ndim == 1 and k in x.dims}
+        raw = getattr(x, 'data', None)
+        if lazy and raw is not None and is_lazy_data(raw):
+            return raw, tuple(x.dims), coords, x.name
         return np.asarray(x.values), tuple(x.dims), coords, x.name
     raise TypeError('expected a DataArray (xcontour_amd.DataArray or xarray.DataArray), got %r' % type(x))
 

@@ -39,24 +39,97 @@ class NetCDFError(Exception):
     pass
 
 
-def open_dataset(path, mask_and_scale=True, decode_times=True):
+class LazyVariable(object):
+    """A variable that stays in the file until a piece of it is asked for (`open_dataset(..., lazy=True)`): shape, dtype,
+    ndim are known; `v[i0:i1]` (any numpy index whose FIRST axis is an int or a slice) reads and decodes only the leading
+    rows it needs -- the records of a NetCDF-3 record variable, the chunks of an HDF5 chunked dataset that overlap the range,
+    the pages of a contiguous one (the file is memory-mapped).  `np.asarray(v)` reads everything.  This is what the hot
+    path's lazy stacks are made of (labeled.LazyStack pulls whole (time, level) slabs batch by batch)."""
+
+    def __init__(self, shape, dtype, fetch):
+        self.shape, self.dtype, self._fetch = tuple(int(n) for n in shape), np.dtype(dtype), fetch
+        self.ndim = len(self.shape)
+        self.rows_read = 0                                          # leading rows fetched so far (tests, diagnostics)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def map(self, fn):
+        """the same variable seen through `fn` (CF decoding ...): applied to every piece as it is read"""
+        probe = fn(np.zeros((0,) + self.shape[1:], dtype=self.dtype))
+        if probe.dtype == self.dtype:
+            # (fn may still change values -- masks, scales: keep it)
+            pass
+        return LazyVariable(self.shape, probe.dtype, lambda i0, i1: fn(self._fetch(i0, i1)))
+
+    def __getitem__(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        if any(k is Ellipsis for k in key):
+            i = [j for j, k in enumerate(key) if k is Ellipsis][0]
+            key = key[:i] + (slice(None),) * (self.ndim - (len(key) - 1)) + key[i + 1:]
+        k0, rest = (key[0] if key else slice(None)), tuple(key[1:])
+        n = self.shape[0]
+        if isinstance(k0, (int, np.integer)):
+            i = int(k0) + n if k0 < 0 else int(k0)
+            if not 0 <= i < n:
+                raise IndexError('index %d out of range' % k0)
+            self.rows_read += 1
+            return self._fetch(i, i + 1)[(0,) + rest]
+        if isinstance(k0, slice):
+            i0, i1, st = k0.indices(n)
+            if st == 1:
+                i1 = max(i0, i1)
+                self.rows_read += i1 - i0
+                return self._fetch(i0, i1)[(slice(None),) + rest]
+        idx = np.arange(n)[k0]                                         # a strided slice or an index array: row by row
+        self.rows_read += len(idx)
+        blk = np.stack([self._fetch(int(i), int(i) + 1)[0] for i in idx]) if len(idx) else self._fetch(0, 0)
+        return blk[(slice(None),) + rest]
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self[:], dtype=dtype)
+
+
+_LAZY_MIN_BYTES = 1 << 20       # lazy=True: variables of three or more dims and at least this size stay in the file
+
+
+def open_dataset(path, mask_and_scale=True, decode_times=True, lazy=False):
     """Read every root-group variable of a NetCDF-3 / NetCDF-4 file -> `Dataset` of `DataArray`s
-    (dims, 1-D coordinate values, `attrs`); `ds.attrs` holds the global attributes."""
+    (dims, 1-D coordinate values, `attrs`); `ds.attrs` holds the global attributes.
+    `lazy=True`: the file is memory-mapped and every variable with three or more dims (a stack of planes) of at least 1 MiB
+    becomes a `LazyVariable` behind its DataArray (`.data`; `.values` reads it in full): the Contour2D methods then pull it
+    through the device batch by batch (the reference: xr.open_dataset + dask, core.py:158-160, 241-246)."""
+    lazy = 0 if not lazy else (_LAZY_MIN_BYTES if lazy is True else max(1, int(lazy)))     # an int: the size from which a stack stays lazy
     with open(path, 'rb') as f:
-        buf = f.read()
+        if lazy:
+            import mmap
+            buf = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)       # stays mapped while a variable refers to it
+        else:
+            buf = f.read()
     if buf[:3] == b'CDF':
-        raw, gattrs = _read_classic(buf)
+        raw, gattrs = _read_classic(buf, lazy)
     else:
-        raw, gattrs = _H5File(buf).variables()
+        raw, gattrs = _H5File(buf, lazy).variables()
     coords = {n: v for n, (v, dims, a) in raw.items() if isinstance(v, np.ndarray) and dims == (n,)}
     ds = Dataset()
     for name, (values, dims, attrs) in raw.items():
         if isinstance(values, Exception):
             continue
-        if mask_and_scale:
-            values = _cf_decode(values, attrs)
-        if decode_times:
-            values = _cf_time(values, attrs)
+        if isinstance(values, LazyVariable):
+            if mask_and_scale:
+                values = values.map(lambda a, attrs=attrs: _cf_decode(a, attrs))
+            if decode_times:
+                values = values.map(lambda a, attrs=attrs: _cf_time(a, attrs))
+        else:
+            if mask_and_scale:
+                values = _cf_decode(values, attrs)
+            if decode_times:
+                values = _cf_time(values, attrs)
         c = {}
         for d in dims:
             if d in coords:
@@ -137,7 +210,7 @@ def _cf_time(values, attrs):
 _NC3_TYPES = {1: 'i1', 2: 'S1', 3: '>i2', 4: '>i4', 5: '>f4', 6: '>f8', 7: 'u1', 8: '>u2', 9: '>u4', 10: '>i8', 11: '>u8'}
 
 
-def _read_classic(buf):
+def _read_classic(buf, lazy=False):
     ver = buf[3]
     if ver not in (1, 2, 5):
         raise NetCDFError('unknown classic NetCDF version byte %d' % ver)
@@ -214,11 +287,26 @@ def _read_classic(buf):
         dt = np.dtype(_NC3_TYPES[t])
         dnames = tuple(dims[i][0] for i in dimids)
         shape = [dims[i][1] for i in dimids]
+        if rec:
+            shape[0] = numrecs
+        native = dt.newbyteorder('=')
+        if lazy and t != 2 and len(shape) >= 3 and int(np.prod(shape, dtype=np.int64)) * dt.itemsize >= int(lazy):
+            inner = int(np.prod(shape[1:], dtype=np.int64))
+            if not rec:
+                whole = np.frombuffer(buf, dtype=dt, count=shape[0] * inner, offset=begin).reshape(shape)     # a view of the mapping
+                fetch = lambda i0, i1, whole=whole, native=native: whole[i0:i1].astype(native)
+            else:
+                def fetch(i0, i1, dt=dt, inner=inner, begin=begin, tail=tuple(shape[1:]), native=native):
+                    a = np.empty((i1 - i0, inner), dtype=native)
+                    for r in range(i0, i1):
+                        a[r - i0] = np.frombuffer(buf, dtype=dt, count=inner, offset=begin + r * recsize)
+                    return a.reshape((i1 - i0,) + tail)
+            out[vn] = (LazyVariable(shape, native, fetch), dnames, va)
+            continue
         if not rec:
             cnt = int(np.prod(shape, dtype=np.int64))
             a = np.frombuffer(buf, dtype=dt, count=cnt, offset=begin).reshape(shape)
         else:
-            shape[0] = numrecs
             inner = int(np.prod(shape[1:], dtype=np.int64))
             a = np.empty([numrecs, inner], dtype=dt)
             for r in range(numrecs):
@@ -235,7 +323,8 @@ def _read_classic(buf):
 # HDF5
 # =============================================================================================
 class _H5File(object):
-    def __init__(self, buf):
+    def __init__(self, buf, lazy=False):
+        self.lazy = int(lazy)                        # 0: read everything; else the size in bytes from which a stack stays in the file
         self.buf = buf
         off = 0
         while buf[off:off + 8] != _HDF5_SIG:
@@ -360,7 +449,7 @@ class _H5File(object):
         hdata = self.addr(heap + 8 + 2 * self.L)
 
         def name_at(o):
-            e = buf.index(b'\x00', hdata + o)
+            e = buf.find(b'\x00', hdata + o)
             return buf[hdata + o:e].decode('utf-8')
 
         def node(a):
@@ -602,12 +691,32 @@ class _H5File(object):
         if shape is None:
             raise NotImplementedError('null dataspace')
         n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        native = dt.newbyteorder('=') if dt.kind != 'S' else dt
+        want_lazy = bool(self.lazy) and dt.kind != 'S' and len(shape) >= 3 and n * dt.itemsize >= self.lazy
 
-        def filled():
-            a = np.zeros(n, dtype=dt)
+        def filled(shp=None):
+            a = np.zeros(n if shp is None else shp, dtype=dt)
             if fill is not None and len(fill) == dt.itemsize:
-                a[:] = np.frombuffer(fill, dtype=dt)[0]
+                a[...] = np.frombuffer(fill, dtype=dt)[0]
             return a
+
+        def contiguous(offset):
+            """a dataset stored in one piece at `offset` (None: never written -> the fill value)"""
+            if offset is None:
+                if want_lazy:
+                    return LazyVariable(shape, native, lambda i0, i1: filled((i1 - i0,) + tuple(shape[1:])).astype(native))
+                return filled()
+            flat = np.frombuffer(buf, dtype=dt, count=n, offset=offset)          # a view (of the mapping when lazy)
+            if want_lazy:
+                whole = flat.reshape(shape)
+                return LazyVariable(shape, native, lambda i0, i1: whole[i0:i1].astype(native))
+            return flat
+
+        def chunked(bt, cdims):
+            if want_lazy:
+                index = self._chunk_index(bt, len(shape))
+                return LazyVariable(shape, native, lambda i0, i1: self._chunk_read(index, cdims, shape, dt, filters, filled, i0, i1).astype(native))
+            return self._chunked(bt, cdims, shape, dt, filters, filled).reshape(-1)
 
         p = layout
         ver = buf[p]
@@ -617,13 +726,12 @@ class _H5File(object):
                 sz = self.uint(p + 2, 2)
                 flat = np.frombuffer(buf, dtype=dt, count=n, offset=p + 4) if sz else filled()
             elif cls == 1:
-                a = self.addr(p + 2)
-                flat = np.frombuffer(buf, dtype=dt, count=n, offset=a) if a is not None else filled()
+                flat = contiguous(self.addr(p + 2))
             elif cls == 2 and ver == 3:
                 nd = buf[p + 2]
                 bt = self.addr(p + 3)
                 cdims = [self.uint(p + 3 + self.O + 4 * i, 4) for i in range(nd)]
-                flat = self._chunked(bt, cdims[:-1], shape, dt, filters, filled).reshape(-1)
+                flat = chunked(bt, cdims[:-1])
             else:
                 raise NotImplementedError('HDF5 data layout class %d, version %d' % (cls, ver))
         elif ver in (1, 2):
@@ -635,13 +743,15 @@ class _H5File(object):
             dims_ = [self.uint(q + 4 * i, 4) for i in range(nd)]
             q += 4 * nd
             if cls == 1:
-                flat = np.frombuffer(buf, dtype=dt, count=n, offset=a) if a is not None else filled()
+                flat = contiguous(a)
             elif cls == 2:
-                flat = self._chunked(a, dims_[:-1], shape, dt, filters, filled).reshape(-1)
+                flat = chunked(a, dims_[:-1])
             else:
                 flat = np.frombuffer(buf, dtype=dt, count=n, offset=q + 4)
         else:
             raise NotImplementedError('HDF5 data layout version %d' % ver)
+        if isinstance(flat, LazyVariable):
+            return flat
         out = flat.reshape(shape)
         return out.astype(dt.newbyteorder('=')) if dt.kind != 'S' else out
 
@@ -666,13 +776,39 @@ class _H5File(object):
         return out
 
     def _chunked(self, bt, cdims, shape, dt, filters, filled):
+        """the whole chunked dataset"""
+        if bt is None:
+            return filled().reshape(shape)
+        return self._chunk_read(self._chunk_index(bt, len(shape)), cdims, shape, dt, filters, filled, 0, shape[0])
+
+    def _chunk_index(self, bt, nd):
+        """leaves of the version-1 chunk B-tree: [(offsets, address, stored bytes, filter mask)]"""
         buf, O = self.buf, self.O
-        nd = len(shape)
-        out = filled().reshape(shape)
+        keysz = 8 + 8 * (nd + 1)
+        out = []
         if bt is None:
             return out
+
+        def node(a):
+            if buf[a:a + 4] != b'TREE' or buf[a + 4] != 1:
+                raise NetCDFError('bad chunk B-tree node')
+            level, n = buf[a + 5], self.uint(a + 6, 2)
+            p = a + 8 + 2 * O
+            for i in range(n):
+                k = p + i * (keysz + O)
+                child = self.addr(k + keysz)
+                if level > 0:
+                    node(child)
+                    continue
+                out.append(([self.uint(k + 8 + 8 * d, 8) for d in range(nd)], child, self.uint(k, 4), self.uint(k + 4, 4)))
+        node(bt)
+        return out
+
+    def _chunk_read(self, index, cdims, shape, dt, filters, filled, i0, i1):
+        """rows [i0, i1) of the leading axis: only the chunks that overlap them are decompressed"""
+        buf = self.buf
+        out = filled((max(0, i1 - i0),) + tuple(shape[1:]))
         csize = int(np.prod(cdims, dtype=np.int64)) * dt.itemsize
-        keysz = 8 + 8 * (nd + 1)
 
         def decode(raw, mask):
             for i in range(len(filters) - 1, -1, -1):
@@ -691,24 +827,15 @@ class _H5File(object):
                     raise NotImplementedError('HDF5 filter id %d' % fid)
             return raw
 
-        def node(a):
-            if buf[a:a + 4] != b'TREE' or buf[a + 4] != 1:
-                raise NetCDFError('bad chunk B-tree node')
-            level, n = buf[a + 5], self.uint(a + 6, 2)
-            p = a + 8 + 2 * O
-            for i in range(n):
-                k = p + i * (keysz + O)
-                child = self.addr(k + keysz)
-                if level > 0:
-                    node(child)
-                    continue
-                nbytes, mask = self.uint(k, 4), self.uint(k + 4, 4)
-                offs = [self.uint(k + 8 + 8 * d, 8) for d in range(nd)]
-                raw = decode(buf[child:child + nbytes], mask)
-                chunk = np.frombuffer(raw, dtype=dt, count=csize // dt.itemsize).reshape(cdims)
-                sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, shape))
-                out[sl] = chunk[tuple(slice(0, s.stop - s.start) for s in sl)]
-        node(bt)
+        for offs, child, nbytes, mask in index:
+            if offs[0] >= i1 or offs[0] + cdims[0] <= i0:
+                continue
+            raw = decode(bytes(buf[child:child + nbytes]), mask)
+            chunk = np.frombuffer(raw, dtype=dt, count=csize // dt.itemsize).reshape(cdims)
+            sl = [slice(o, min(o + c, s_)) for o, c, s_ in zip(offs, cdims, shape)]
+            lo, hi = max(sl[0].start, i0), min(sl[0].stop, i1)
+            src = (slice(lo - offs[0], hi - offs[0]),) + tuple(slice(0, t.stop - t.start) for t in sl[1:])
+            out[(slice(lo - i0, hi - i0),) + tuple(sl[1:])] = chunk[src]
         return out
 
     # ---------------------------------------------------------------- the NetCDF-4 view
