@@ -77,7 +77,7 @@ def keff_sequence(cls, mk):
 
 
 X, M = both(lambda cls, mk: keff_sequence(cls, mk))
-names = {'table': 'AeqCTbl', 'dintSdA': 'dgrdSdA', 'Leq2': 'Leq2', 'nkeff': 'nkeff', 'mean': 'cmgrdS'}
+names = {'table': 'AeqCTbl', 'dintSdA': 'dhistogram_absolute_vorticitydA', 'Leq2': 'Leq2', 'nkeff': 'nkeff', 'mean': 'cmgrdS'}   # 'd' + name + 'dA', core.py:485-488
 for k in ('table', 'ctr', 'area', 'intS', 'latEq', 'dintSdA', 'dqdA', 'Leq2', 'Lmin', 'nkeff', 'mean'):
     a, b = X[k], M[k]
     assert isinstance(a, xr.DataArray) and isinstance(b, xa.DataArray), k

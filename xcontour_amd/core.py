@@ -198,7 +198,7 @@ class Contour2D(object):
         return v, was_f32
 
     def _eq_coord(self, arr):
-        _, _, coords, _ = lb.unwrap(arr)
+        _, _, coords, _ = lb.unwrap(arr, lazy=True)
         if self.dimEqV not in coords:
             raise Exception('no coordinate values for %s' % self.dimEqV)
         return np.asarray(coords[self.dimEqV])
@@ -290,7 +290,7 @@ class Contour2D(object):
             mmin = mm[:, 0].astype(q.dtype)
             ctr = ((mmin - mmin)[:, None] + levs[None, :]).astype(self.dtype)   # core.py:254
             ccoord = levs
-        return self._wrap_contour(ctr, lead, lshape, coords, lb.unwrap(self.tracer)[3], self.tracer, ccoord)
+        return self._wrap_contour(ctr, lead, lshape, coords, lb.unwrap(self.tracer, lazy=True)[3], self.tracer, ccoord)
 
     def _contour_values(self, contour, nslab, lead, lshape):
         """-> ndarray (nslab, N) of levels (per slab or broadcast) in their own dtype"""
@@ -334,9 +334,9 @@ class Contour2D(object):
         ctr = self.cal_contours(N)
         area = self.cal_integral_within_contours_hist(ctr) if hist else self.cal_integral_within_contours(ctr)
         dimEq = table.lookup_coordinates(area).rename('Z')
-        pd = lb.unwrap(predef)[1][0]
+        pd = lb.unwrap(predef, lazy=True)[1][0]
         qIntp = self.interp_to_coords(predef.squeeze(), dimEq, ctr.squeeze()) \
-            .rename({pd: 'contour'}).rename(lb.unwrap(ctr)[3])
+            .rename({pd: 'contour'}).rename(lb.unwrap(ctr, lazy=True)[3])
         v, dims, coords, name = lb.unwrap(qIntp)
         coords['contour'] = np.linspace(0, N - 1, N, dtype=self.dtype)
         return lb.wrap(v, dims, coords, name, qIntp)
@@ -375,7 +375,7 @@ class Contour2D(object):
         cdf = out['cdf'][:, 1 if integ else 0, :]
         N = b.shape[1]
         binNum = np.arange(N).astype(np.float32)                      # core.py:1255-1257
-        name = lb.unwrap(tracer)[3]
+        name = lb.unwrap(tracer, lazy=True)[3]
         CDF = self._wrap_contour(cdf, lead, lshape, coords, 'histogram_%s' % name, tracer, binNum)
         if self.check_mono:
             _check_monotonicity(CDF, 'contour')
@@ -411,8 +411,8 @@ class Contour2D(object):
             cdf = res['cdf'][:, 1 if integ else 0, :]
             for i, s in enumerate(grp):
                 out[s] = cdf[i][np.searchsorted(uniq[s], sgn * b[s])]
-        name = 'intVar' if integrand is None else lb.unwrap(integrand)[3]
-        ccoord = lb.unwrap(contour)[2].get('contour', np.arange(N))
+        name = 'intVar' if integrand is None else lb.unwrap(integrand, lazy=True)[3]
+        ccoord = lb.unwrap(contour, lazy=True)[2].get('contour', np.arange(N))
         intVar = self._wrap_contour(out, lead, lshape, coords, name, tracer, ccoord)
         if self.check_mono:
             _check_monotonicity(intVar, 'contour')
@@ -425,7 +425,7 @@ class Contour2D(object):
         a, adims, _, _ = lb.unwrap(area)
         ax = dims.index('contour')
         k = np.asarray(coords.get('contour', np.arange(v.shape[ax])))
-        ka = np.asarray(lb.unwrap(area)[2].get('contour', np.arange(a.shape[adims.index('contour')])))
+        ka = np.asarray(lb.unwrap(area, lazy=True)[2].get('contour', np.arange(a.shape[adims.index('contour')])))
         with np.errstate(divide='ignore', invalid='ignore'):
             dfVar = np.gradient(v, k, axis=ax, edge_order=1)
             dfArea = np.gradient(a, ka, axis=adims.index('contour'), edge_order=1)
@@ -438,7 +438,7 @@ class Contour2D(object):
         if area is None:
             area = self.cal_integral_within_contours(contour)
         lmA = self.cal_gradient_wrt_area(intA, area)
-        iname = lb.unwrap(integrand)[3]
+        iname = lb.unwrap(integrand, lazy=True)[3]
         return lmA.rename('lwm' if iname is None else 'lwm' + iname)
 
     def cal_contour_weigh_mean_hist(self, contour, integrand, area=None):
@@ -447,7 +447,7 @@ class Contour2D(object):
         if area is None:
             area = self.cal_integral_within_contours_hist(contour)
         lmA = self.cal_gradient_wrt_area(intA, area)
-        iname = lb.unwrap(integrand)[3]
+        iname = lb.unwrap(integrand, lazy=True)[3]
         return lmA.rename('lwm' if iname is None else 'lwm' + iname)
 
     def cal_contour_mean(self, contour, integrand, grdm, area=None):
@@ -459,9 +459,12 @@ class Contour2D(object):
         return self._contour_mean(contour, integrand, grdm, area, self.cal_contour_weigh_mean_hist)
 
     def _contour_mean(self, contour, integrand, grdm, area, fn):
-        iv, idims, icoords, iname = lb.unwrap(integrand)
-        gv, gdims, _, _ = lb.unwrap(grdm)
-        prod = lb.wrap(iv * _align(gv, gdims, idims), idims, icoords, None, integrand)
+        iv, idims, icoords, iname = lb.unwrap(integrand, lazy=True)
+        gv, gdims, _, _ = lb.unwrap(grdm, lazy=True)
+        if (lb.is_lazy_data(iv) or lb.is_lazy_data(gv)) and tuple(gdims) == tuple(idims) and tuple(gv.shape) == tuple(iv.shape):
+            prod = lb.wrap(lb.LazyProduct(iv, gv), idims, icoords, None, integrand)      # stays lazy: multiplied batch by batch
+        else:
+            prod = lb.wrap(np.asarray(iv) * _align(np.asarray(gv), gdims, idims), idims, icoords, None, integrand)
         fused = self._integrals_hist(contour, [prod, grdm]) if fn == self.cal_contour_weigh_mean_hist else None
         if fused is not None:
             # area, int(integrand*grdm) and int(grdm) as three weight channels of ONE histogram
@@ -501,7 +504,7 @@ class Contour2D(object):
         out = self.ctx.hist(q, edges, dA=dA, integrands=gs, last_closed=last_closed, lt=self.lt,
                             reverse=not binc, prod_f32=flags[0], want=('cdf',), deterministic=self.deterministic)
         binNum = np.arange(b.shape[1]).astype(np.float32)                  # core.py:1255-1257
-        name = 'histogram_%s' % lb.unwrap(self.tracer)[3]
+        name = 'histogram_%s' % lb.unwrap(self.tracer, lazy=True)[3]
         res = [self._wrap_contour(np.ascontiguousarray(out['cdf'][:, c, :]), lead, lshape, coords, name, self.tracer, binNum)
                for c in range(1 + len(gs))]
         if self.check_mono:
@@ -536,7 +539,7 @@ class Contour2D(object):
                 re.append(self.interp_to_coords(predef, dimEq, vs[var]).rename(var))
         else:
             for var in vs:
-                re.append(self.interp_to_coords(predef, dimEq, var).rename(lb.unwrap(var)[3]))
+                re.append(self.interp_to_coords(predef, dimEq, var).rename(lb.unwrap(var, lazy=True)[3]))
         return lb.merge(re, re[0])
 
     def interp_to_coords(self, predef, eqCoords, var, interpDim='contour'):
@@ -546,7 +549,7 @@ class Contour2D(object):
         if isinstance(predef, (np.ndarray, list)):
             predef = _as_labeled_1d(np.asarray(predef), dimTmp)
         else:
-            dimTmp = lb.unwrap(predef)[1][0]
+            dimTmp = lb.unwrap(predef, lazy=True)[1][0]
         pv = np.asarray(lb.unwrap(predef)[0])
         ev, edims, _, _ = lb.unwrap(eqCoords)
         vv, vdims, vcoords, vname = lb.unwrap(var)
@@ -592,7 +595,7 @@ class Contour2D(object):
             raise Exception('stride should be a positive integer')
         if mode not in nat.PAD_MODES:
             raise Exception('unsupported pad mode %r (one of %s)' % (mode, sorted(nat.PAD_MODES)))
-        dims = lb.unwrap(self.tracer)[1]
+        dims = lb.unwrap(self.tracer, lazy=True)[1]
         if [d for d in dims if d in self.dimVs] != [self.dimEqV, self._xdim]:
             raise Exception('cal_contour_crossing expects the tracer stored as (..., %s, %s)' % (self.dimEqV, self._xdim))
         has_x = 'X' in self.dims                                               # core.py:673-679
@@ -610,7 +613,7 @@ class Contour2D(object):
         b[np.isnan(b)] = np.inf                        # a NaN level is never crossed; neither is +inf
         order = np.argsort(b, axis=1, kind='stable')
         bs = np.take_along_axis(b, order, axis=1)
-        ccoord = lb.unwrap(ctr)[2].get('contour') if lb.is_labeled(ctr) else None
+        ccoord = lb.unwrap(ctr, lazy=True)[2].get('contour') if lb.is_labeled(ctr) else None
         if ccoord is None:
             ccoord = np.arange(b.shape[1]).astype(self.dtype)
         re = []
@@ -673,7 +676,7 @@ class Contour2D(object):
         pcode = {'all': 0, 'upper': 1, 'lower': 2}[part]
         lwa, masks = self.ctx.lwa(qv, Qv, eq.astype(np.float64), dA, dmax, M=M, increase=self.increase,
                                   part=pcode, mask_idx=mask_idx, variant=variant)
-        qdims = lb.unwrap(q)[1]
+        qdims = lb.unwrap(q, lazy=True)[1]
         full = tuple(lead) + (self.dimEqV, self._xdim)
         out = lwa.reshape(tuple(lshape) + (ny, nx))
         out = np.transpose(out, [full.index(d) for d in qdims])                # .transpose(*q.dims), core.py:793
@@ -685,7 +688,7 @@ class Contour2D(object):
         contours, mlist = [], []
         Ql_coords = {d: coords[d] for d in lead if d in coords}
         for i, j in enumerate(mask_idx):
-            contours.append(lb.wrap(Qv[:, j].reshape(lshape) if lshape else Qv[0, j], tuple(lead), Ql_coords, lb.unwrap(Q)[3], q))
+            contours.append(lb.wrap(Qv[:, j].reshape(lshape) if lshape else Qv[0, j], tuple(lead), Ql_coords, lb.unwrap(Q, lazy=True)[3], q))
             m = masks[:, i].reshape(tuple(lshape) + (ny, nx)).astype(np.int64)
             mlist.append(lb.wrap(np.transpose(m, [full.index(d) for d in qdims]), qdims, c, None, q))
         return LWA, contours, mlist
@@ -703,9 +706,9 @@ class Contour2D(object):
                                     lon if lon is not None else coords[self._xdim])
         g = self.ctx.grad2(q, rdx, rdy, periodic_x)
         full = tuple(lead) + (self.dimEqV, self._xdim)
-        tdims = lb.unwrap(tracer)[1]
+        tdims = lb.unwrap(tracer, lazy=True)[1]
         g = np.transpose(g.reshape(tuple(lshape) + q.shape[1:]), [full.index(d) for d in tdims])
-        name = lb.unwrap(tracer)[3]
+        name = lb.unwrap(tracer, lazy=True)[3]
         return lb.wrap(g, tdims, coords, 'grdS' + (name or ''), tracer)
 
     def cal_sorted_profile(self, table, tracer=None, mask=None, return_sorted=False):
@@ -756,7 +759,7 @@ class Contour2D(object):
         c = {d: coords[d] for d in lead if d in coords}
         c[self.dimEqV] = cs
         Q = lb.wrap(Qs[0].reshape(tuple(lshape) + (len(cs),)), tuple(lead) + (self.dimEqV,), c,
-                    lb.unwrap(tracer)[3], tracer)
+                    lb.unwrap(tracer, lazy=True)[3], tracer)
         if return_sorted:
             return Q, (sorted_[0] if nslab == 1 and not lead else sorted_)
         return Q

@@ -97,6 +97,20 @@ class LazyStack(object):
         return np.asarray(self[:], dtype=dtype)
 
 
+class LazyProduct(object):
+    """a * b of two equally shaped sources, at least one of them lazy, evaluated piece by piece (the `integrand * grdm` of
+    cal_contour_mean, reference core.py:568-570 / 599-601, which xarray + dask also leave lazy)"""
+
+    def __init__(self, a, b):
+        if tuple(a.shape) != tuple(b.shape):
+            raise ValueError('LazyProduct needs equal shapes')
+        self.a, self.b, self.shape = a, b, tuple(int(n) for n in a.shape)
+        self.dtype = np.result_type(np.dtype(a.dtype), np.dtype(b.dtype))
+
+    def __getitem__(self, key):
+        return np.asarray(self.a[key]) * np.asarray(self.b[key])
+
+
 class DataArray(object):
     """values + dims + 1-D coords + name.  Only what the hot path needs."""
 
