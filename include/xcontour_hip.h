@@ -217,6 +217,17 @@ int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const doubl
            int64_t nslab, int64_t ny, int64_t nx, int increase, int part, int variant,
            const int32_t* mask_idx, int nmask, double* out_lwa, int8_t* out_masks);
 
+/* Planes of more than 512 rows take an O(ny log ny)-per-column path (variant 0): because the sorted reference state Q is
+ * monotone, the targets j a cell contributes to form one interval, so one binary search in Q and four adds into a
+ * difference array replace the walk over every (target, row) pair; per-column prefix sums finish.  The premises -- no NaN in
+ * Q, s*Q non-decreasing (s = +1 if increase else -1), the coordinate strictly monotone -- are checked on the device first and
+ * read back (the ONE host round trip of these calls, also the _dev form); if they fail the band walk runs.  Same sums in
+ * another order: agreement with the band walk ~1e-13 of the column's largest value (tests 1e-9), not bit for bit.
+ * xc_set_lwa_exact(ctx, 1) keeps the bit-exact band walk for every plane.  xc_last_lwa_path: 0 band walk, 1 interval
+ * kernel, 2 its premises failed the check. */
+int xc_set_lwa_exact(xc_ctx* ctx, int exact);
+int xc_last_lwa_path(xc_ctx* ctx, int* out_path);
+
 /* ------------------------------------------------------------------ K8  exact adiabatic rearrangement (radix sort)
  * No reference call site (the reference "sorts" by histogram CDF + table lookup);
  * SURVEY 8-a9, pinned by oracle.sorted_profile.  One slab: drop NaN / mask != 1 cells, stable

@@ -355,3 +355,72 @@ def test_lazy_stack_goes_through_in_batches(baro, tmp_path):
         assert ds.pv.data.rows_read >= T and isinstance(ds.pv.data, ncio.LazyVariable)      # still lazy afterwards
     finally:
         ctx.max_batch_bytes = old
+
+
+# ---------------------------------------------------------------- K7F: the O(ny log ny) interval kernel of large planes
+def _lwa_case(rng, ny, nx, dt, increase, coord_up, with_nan):
+    lat = np.linspace(-80, 80, ny) if coord_up else np.linspace(80, -80, ny)
+    prof = np.sin(np.deg2rad(np.linspace(-80, 80, ny)))
+    if not increase:
+        prof = -prof
+    q = (prof[:, None] + 0.3 * np.sin(np.linspace(0, 12, nx))[None, :] * np.cos(np.deg2rad(lat))[:, None]
+         + 0.05 * rng.standard_normal((ny, nx))).astype(dt)
+    Q = np.sort(q.astype(np.float64).mean(axis=1))
+    if not increase:
+        Q = Q[::-1].copy()
+    # ties: some cells exactly ON reference levels
+    idx = rng.integers(0, ny * nx, 500)
+    q.ravel()[idx] = Q[rng.integers(0, ny, 500)].astype(dt)
+    if with_nan:
+        q[rng.integers(0, ny, 40), rng.integers(0, nx, 40)] = np.nan
+        q[5:9, 10:30] = np.nan
+    dA = np.abs(np.cos(np.deg2rad(lat)))[:, None] * np.ones((1, nx)) * 1e9 + 1e7 * rng.random((ny, nx))
+    return lat, q, Q, dA
+
+
+@pytest.mark.parametrize('dt,increase,coord_up,part,mkind', [
+    (np.float64, True, True, 'all', 'row'), (np.float32, True, False, 'upper', 'plane'), (np.float64, False, True, 'lower', None),
+    (np.float32, False, False, 'all', 'row'), (np.float64, True, True, 'upper', None), (np.float64, False, False, 'upper', 'plane')])
+def test_lwa_interval_kernel_matches_the_oracle(ctx, dt, increase, coord_up, part, mkind):
+    """planes of more than 512 rows: one binary search in the (monotone) reference state per cell + difference arrays + prefix
+    sums instead of the band walk -- against the oracle's literal python loop (core.py:752-791) for both directions of the
+    tracer and of the coordinate, every `part`, the three metric forms, float32 / float64 tracers, NaN cells, ties with
+    levels: <= 1e-11 of the plane's largest value (summation order; the bit-exact band walk is `exact=True`)"""
+    rng = np.random.default_rng(int(increase) * 4 + int(coord_up) * 2 + (mkind is not None))
+    ny, nx = 600, 334                                       # 334: a ragged last column group
+    lat, q, Q, dA = _lwa_case(rng, ny, nx, dt, increase, coord_up, True)
+    M = None if mkind is None else (np.abs(np.gradient(np.deg2rad(lat))) * 6.371e6 if mkind == 'row' else 1.0 + rng.random((ny, nx)))
+    pcode = {'all': 0, 'upper': 1, 'lower': 2}[part]
+    got, _ = ctx.lwa(q[None], Q[None], lat, dA, float(dA.max()), M=M, increase=increase, part=pcode)
+    assert ctx.last_lwa_path() == 1
+    ref = O.cal_local_wave_activity(q, Q, lat, dA, increase, part, metric=M)
+    scale = np.abs(ref).max()
+    assert scale > 0 and np.abs(got[0] - ref).max() <= 1e-11 * scale
+    ex, _ = ctx.lwa(q[None], Q[None], lat, dA, float(dA.max()), M=M, increase=increase, part=pcode, exact=True)
+    assert ctx.last_lwa_path() == 0 and np.array_equal(ex[0], ref)              # the band walk: numpy's own summation order
+
+
+def test_lwa_interval_kernel_premises_and_stacks(ctx):
+    """a reference state that is NOT monotone (or holds a NaN), or a coordinate with a repeated value, sends the call to the
+    bit-exact band walk (path 2); a stack of slabs with per-slab Q; masks for mask_idx stay exact on the fast path; planes of
+    up to 512 rows never take it"""
+    rng = np.random.default_rng(9)
+    ny, nx = 520, 128
+    lat, q, Q, dA = _lwa_case(rng, ny, nx, np.float64, True, True, False)
+    Qbad = Q.copy(); Qbad[100], Qbad[101] = Q[101], Q[100]
+    for Qx, c in ((Qbad, lat), (np.where(np.arange(ny) == 7, np.nan, Q), lat), (Q, np.where(np.arange(ny) == 300, lat[299], lat))):
+        got, _ = ctx.lwa(q[None], Qx[None], c, dA, float(dA.max()))
+        assert ctx.last_lwa_path() == 2
+        assert np.array_equal(got[0], O.cal_local_wave_activity(q, Qx, c, dA, True, 'all'), equal_nan=True)
+    S = 3
+    qs = np.stack([q * (1 + 0.1 * s) for s in range(S)])
+    Qs = np.stack([Q * (1 + 0.1 * s) for s in range(S)])
+    got, masks = ctx.lwa(qs, Qs, lat, dA, float(dA.max()), mask_idx=[3, 400])
+    assert ctx.last_lwa_path() == 1
+    for s in range(S):
+        ref, _, mref = O.cal_local_wave_activity(qs[s], Qs[s], lat, dA, True, 'all', mask_idx=[3, 400])
+        assert np.abs(got[s] - ref).max() <= 1e-11 * np.abs(ref).max()
+        assert np.array_equal(masks[s, 0], mref[0]) and np.array_equal(masks[s, 1], mref[1])
+    small = _lwa_case(rng, 256, 128, np.float64, True, True, False)
+    g2, _ = ctx.lwa(small[1][None], small[2][None], small[0], small[3], float(small[3].max()))
+    assert ctx.last_lwa_path() == 0 and np.array_equal(g2[0], O.cal_local_wave_activity(small[1], small[2], small[0], small[3], True, 'all'))

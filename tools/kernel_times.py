@@ -131,16 +131,24 @@ def cmd_lwa(ctx, T):
     out = ctx.alloc(NY * NX * 8)
     fn = lambda: ctx._check(ctx.lib.xc_lwa_dev(ctx.handle, qb.ptr, nat.XC_F64, dQ.ptr, dc.ptr, dd.ptr, nat.XC_DA_PLANE, float(dA.max()),
                                               dM.ptr, nat.XC_DA_ROW, 1, NY, NX, 1, 0, 0, None, 0, out.ptr, None))
-    ms = T.ms(fn, reps=3, warm=1)
-    got = out.download((NY, NX), np.float64)
     wei = dA / dA.max()
-    ok = True
+    rows = {}
     for j in (0, 300, 900, 901, 1500, 1800):
         qe = q - Q[j]
         m = (lat >= lat[j])[:, None]
         mask3 = np.where(np.logical_and(qe < 0, m), 1, np.where(m, 0, np.where(qe > 0, -1, 0))).astype(np.float64)
-        ok &= bool(np.array_equal(got[j], -np.nansum(qe * mask3 * wei * dy[:, None], axis=0)))
-    emit(kernel='K7 lwa', config='one cfg2-sized f64 slab, J = 1801', ms=ms, cell_rows_per_s=NY * NY * NX / ms * 1e3, six_rows_bit_identical=ok)
+        rows[j] = -np.nansum(qe * mask3 * wei * dy[:, None], axis=0)
+    for exact in (0, 1):                                           # the O(ny log ny) interval kernel (default for ny > 512), then the band walk
+        ctx._check(ctx.lib.xc_set_lwa_exact(ctx.handle, exact))
+        ms = T.ms(fn, reps=3, warm=1)
+        got = out.download((NY, NX), np.float64)
+        path = ctx.last_lwa_path()
+        scale = max(float(np.abs(r).max()) for r in rows.values())
+        err = max(float(np.abs(got[j] - r).max()) for j, r in rows.items()) / scale
+        emit(kernel='K7 lwa', config='one cfg2-sized f64 slab, J = 1801', path={0: 'band walk (bit-exact)', 1: 'interval kernel', 2: 'check failed -> band walk'}[path],
+             ms=ms, cell_rows_per_s=NY * NY * NX / ms * 1e3, six_rows_bit_identical=bool(all(np.array_equal(got[j], r) for j, r in rows.items())),
+             six_rows_max_err_over_max_value=err)
+    ctx._check(ctx.lib.xc_set_lwa_exact(ctx.handle, 0))
 
 
 # ----------------------------------------------------------------------------------------------------------------- K9

@@ -117,6 +117,8 @@ PROTOTYPES = {
     'xc_sort_profile_batch': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i64, _i64, _i64, C.c_int,
                                         _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'xc_last_sort_path': (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    'xc_set_lwa_exact': (C.c_int, [_vp, C.c_int]),
+    'xc_last_lwa_path': (C.c_int, [_vp, C.POINTER(C.c_int)]),
     'xc_keff_dev': (C.c_int, [_vp, C.POINTER(KeffDesc)]),
     'xc_keff_epilogue_dev': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int,
                                        C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -340,6 +342,12 @@ class Context(object):
         """K8, last call: 0 key passes only, 1 the three range-key passes sufficed, 2 they failed the check (re-sorted)"""
         p = C.c_int()
         self._check(self.lib.xc_last_sort_path(self.handle, C.byref(p)))
+        return p.value
+
+    def last_lwa_path(self):
+        """K7, last call: 0 band walk (bit-exact), 1 the O(ny log ny) interval kernel, 2 its premises failed the check"""
+        p = C.c_int()
+        self._check(self.lib.xc_last_lwa_path(self.handle, C.byref(p)))
         return p.value
 
     def set_kernel_timing(self, on):
@@ -590,14 +598,15 @@ class Context(object):
                                          int(stride), 1 if full_width else 0, _ptr(lens), _ptr(cnts)))
         return lens, cnts
 
-    def lwa(self, q, Q, coord, dA, dA_max, M=None, increase=True, part=0, mask_idx=None, variant=0):
+    def lwa(self, q, Q, coord, dA, dA_max, M=None, increase=True, part=0, mask_idx=None, variant=0, exact=False):
+        """`exact=True`: the bit-exact band walk also for planes of more than 512 rows (xc_set_lwa_exact)"""
         q = _stack_in(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
         Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(nslab, ny)
         bt = self._batches(nslab, ny * nx * (q.dtype.itemsize + 8 + (0 if mask_idx is None else len(mask_idx))))
         if len(bt) > 1:
-            parts = [self.lwa(q[s0:s1], Q[s0:s1], coord, dA, dA_max, M, increase, part, mask_idx, variant) for s0, s1 in bt]
+            parts = [self.lwa(q[s0:s1], Q[s0:s1], coord, dA, dA_max, M, increase, part, mask_idx, variant, exact) for s0, s1 in bt]
             return (np.concatenate([p[0] for p in parts]),
                     None if parts[0][1] is None else np.concatenate([p[1] for p in parts]))
         q = _stack_now(q)
@@ -614,9 +623,13 @@ class Context(object):
         nmask = 0 if mask_idx is None else len(mask_idx)
         mi = np.ascontiguousarray(mask_idx, dtype=np.int32) if nmask else None
         mo = np.empty((nslab, nmask, ny, nx), dtype=np.int8) if nmask else None
-        self._check(self.lib.xc_lwa(self.handle, _ptr(q), dtype_code(q.dtype), _ptr(Q), _ptr(coord),
-                                    _ptr(dA), dr, float(dA_max), _ptr(M), mr, nslab, ny, nx,
-                                    1 if increase else 0, int(part), int(variant), _ptr(mi), nmask, _ptr(out), _ptr(mo)))
+        self._check(self.lib.xc_set_lwa_exact(self.handle, 1 if exact else 0))
+        try:
+            self._check(self.lib.xc_lwa(self.handle, _ptr(q), dtype_code(q.dtype), _ptr(Q), _ptr(coord),
+                                        _ptr(dA), dr, float(dA_max), _ptr(M), mr, nslab, ny, nx,
+                                        1 if increase else 0, int(part), int(variant), _ptr(mi), nmask, _ptr(out), _ptr(mo)))
+        finally:
+            self.lib.xc_set_lwa_exact(self.handle, 0)
         return out, mo
 
 

@@ -626,25 +626,28 @@ class Contour2D(object):
         return re if isiterable else re[0]
 
     # ------------------------------------------------------------------ local wave activity
-    def cal_local_wave_activity(self, q, Q, mask_idx=None, part='all', metric=None):
+    def cal_local_wave_activity(self, q, Q, mask_idx=None, part='all', metric=None, exact=False):
         """
         Local finite-amplitude wave activity density (reference core.py:696-799;
         Huang and Nakamura 2016).  The J-iteration python loop of the reference is one
         GPU kernel.  `metric=None` follows the snapshot (M = dA, core.py:789); pass the
         1-D length metric (e.g. dy) for the legacy grid.get_metric form (core.py:787-788).
+        Planes of up to 512 rows are summed in numpy's own order (bit-identical to the reference's nansum); larger ones take
+        an O(ny log ny)-per-column path that needs a monotone Q (checked; else the exact walk runs) and agrees to ~1e-13;
+        `exact=True` keeps the bit-exact walk everywhere.
         """
-        return self._lwa(q, Q, mask_idx, part, metric, 'LWA')
+        return self._lwa(q, Q, mask_idx, part, metric, 'LWA', exact=exact)
 
     def cal_local_wave_activity2(self, q, Q, mask_idx=None, part='all', metric=None):
         """The impulse-Casimir flavoured variant (reference core.py:802-905): qe = q[row j] - Q
         with the opposite sign convention; same GPU kernel family."""
         return self._lwa(q, Q, mask_idx, part, metric, 'LWA', variant=1)
 
-    def cal_local_APE(self, q, Q, mask_idx=None, part='all', metric=None):
+    def cal_local_APE(self, q, Q, mask_idx=None, part='all', metric=None, exact=False):
         """Local available potential energy density (reference core.py:908-942)."""
-        return self._lwa(q, Q, mask_idx, part, metric, 'LAPE')
+        return self._lwa(q, Q, mask_idx, part, metric, 'LAPE', exact=exact)
 
-    def _lwa(self, q, Q, mask_idx, part, metric, name, variant=0):
+    def _lwa(self, q, Q, mask_idx, part, metric, name, variant=0, exact=False):
         part = part.lower()
         if part not in ['all', 'upper', 'lower']:
             raise Exception('invalid part, should be in [\'all\', \'upper\', \'lower\']')
@@ -675,7 +678,7 @@ class Contour2D(object):
             M = np.asarray(lb.unwrap(metric)[0] if lb.is_labeled(metric) else metric, dtype=np.float64).squeeze()
         pcode = {'all': 0, 'upper': 1, 'lower': 2}[part]
         lwa, masks = self.ctx.lwa(qv, Qv, eq.astype(np.float64), dA, dmax, M=M, increase=self.increase,
-                                  part=pcode, mask_idx=mask_idx, variant=variant)
+                                  part=pcode, mask_idx=mask_idx, variant=variant, exact=exact)
         qdims = lb.unwrap(q, lazy=True)[1]
         full = tuple(lead) + (self.dimEqV, self._xdim)
         out = lwa.reshape(tuple(lshape) + (ny, nx))

@@ -185,7 +185,7 @@ int xc_create(int device_id, xc_ctx** out)
         k.threads = env_int("XC_HIST_THREADS", 0); k.ncopy = env_int("XC_HIST_NCOPY", 0); k.rows = env_int("XC_HIST_ROWS", 0);
         k.bps = env_int("XC_HIST_BPS", 0);
         k.cross_ncopy = env_int("XC_CROSS_NCOPY", 0); k.cross_blocks = env_int("XC_CROSS_BLOCKS", 0);
-        k.sort_range = env_int("XC_SORT_RANGE", 1); k.lwa_strip = env_int("XC_LWA_STRIP", 1);
+        k.sort_range = env_int("XC_SORT_RANGE", 1); k.lwa_fast = env_int("XC_LWA_FAST", 1); k.lwa_strip = env_int("XC_LWA_STRIP", 1);
     }
     ctx->cus = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -851,6 +851,20 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
     if (dA_rank == XC_DA_SLAB) return fail(ctx, XC_EBADARG, "xc_sort_profile: dA_rank must be NONE, ROW or PLANE");
     return xc_sort_profile_batch(ctx, q, q_dtype, mask, mask_dtype, 0, dA, dA_rank, 1, ny, nx, negate, targets, J, tbl, coord, ntbl,
                                  out_Q, out_qsorted, out_acum, out_nvalid, out_bpe);
+}
+
+int xc_set_lwa_exact(xc_ctx* ctx, int exact)
+{
+    if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
+    ctx->lwa_exact = exact ? 1 : 0;
+    return XC_OK;
+}
+
+int xc_last_lwa_path(xc_ctx* ctx, int* out_path)
+{
+    if (!ctx || !out_path) return fail(ctx, XC_EBADARG, "xc_last_lwa_path: bad arguments");
+    *out_path = ctx->last_lwa_path;
+    return XC_OK;
 }
 
 int xc_last_sort_path(xc_ctx* ctx, int* out_path)

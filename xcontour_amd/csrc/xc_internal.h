@@ -21,6 +21,7 @@ struct HistKnobs {
     int rows = 0;        // XC_HIST_ROWS     (strip, row) pairs per wave
     int bps = 0;         // XC_HIST_BPS      blocks per slab
     int cross_ncopy = 0, cross_blocks = 0;   // XC_CROSS_NCOPY, XC_CROSS_BLOCKS (K9)
+    int lwa_fast = 1;    // XC_LWA_FAST      K7: the O(ny log ny) interval kernel for planes of more than 512 rows (0: never, 2: for every plane)
     int lwa_strip = 1;   // XC_LWA_STRIP     K7: the one-launch kernel with the strip in LDS where it fits (0: always prep + streaming kernel)
     int sort_range = 1;  // XC_SORT_RANGE    K8: three range-key passes + short-run repair for float64 tracers (0: always eight passes)
 };
@@ -52,6 +53,8 @@ struct xc_ctx {
     double* mmnext[2] = {nullptr, nullptr};  size_t mmnext_bytes[2] = {0, 0};
     int mm_cur = 0, mm_valid = 0, mm_P = 0, mm_dtype = 0;
     const void* mm_q = nullptr;  int64_t mm_nslab = 0, mm_ny = 0, mm_nx = 0;  int mm_gen = 0;
+    int lwa_exact = 0;          // xc_set_lwa_exact: keep the bit-exact band walk for every plane
+    int last_lwa_path = 0;      // K7, last call: 0 band walk, 1 interval kernel, 2 its premises failed the check (band walk)
     int last_sort_path = 0;     // K8, last call: 0 eight / four key passes, 1 three range-key passes sufficed, 2 they did not (re-sorted)
 };
 

@@ -372,6 +372,137 @@ void k_lwa_strip(const T* __restrict__ q, const double* __restrict__ Q, const do
     }
 }
 
+
+// =====================================================================================
+// K7F  large planes: O(ny log ny) per column instead of O(J * band)            (round 4)
+// =====================================================================================
+// With q' = s q, Q' = s Q (s = +1 if increase else -1; Q' non-decreasing in j -- it is the sorted reference state) the
+// sum of core.py:789 is, per column x and target row j,
+//     lwa[j, x] = s * (  sum_{y >= j, q'_y < Q'_j} (Q'_j - q'_y) W_y   [near side, mask3 = +1]
+//                      + sum_{y <  j, q'_y > Q'_j} (q'_y - Q'_j) W_y ) [far side,  mask3 = -1],   W = (dA / max dA) * M.
+// Because Q' is monotone, the targets a cell (y, x) contributes to form ONE interval of j: with b = #{j: Q'_j < q'_y} and
+// a = #{j: Q'_j <= q'_y} (two bounds of one binary search) the cell is a near-side term of j in [a, y] (if a <= y) or a
+// far-side term of j in [y + 1, b - 1] (if b >= y + 2), never both.  Either way it adds +W at index p (= a or b) and -W at
+// index y + 1 of a difference array D0, and the same with (q'_y - c) W in D1 (c: a reference level that keeps the two big
+// terms of the final difference small).  Prefix sums S0, S1 over j then give lwa = s ((Q'_j - c) S0_j - S1_j).
+// One binary search and four LDS adds per cell; the band walk costs O(band) per (cell, target group).  The sums are formed
+// in another order and through a difference of two products: agreement with the bit-exact kernels is ~1e-13 relative to
+// the column's largest value (tests: 1e-9), not bit for bit -- so this path serves planes of more than kLwaFastMinRows rows
+// (where the band walk takes milliseconds) and only after k_lwa_check has PROVED its premises (no NaN in Q, Q' monotone,
+// the coordinate strictly monotone); xc_set_lwa_exact(ctx, 1) keeps the band walk everywhere.
+constexpr int kLwaFastMinRows = 512;
+
+__global__ __launch_bounds__(256)
+void k_lwa_check(const double* __restrict__ Q, const double* __restrict__ coord, int ny, int increase, unsigned* __restrict__ flag)
+{
+    const double* Qs = Q + (size_t)blockIdx.x * ny;
+    const double s = increase ? 1.0 : -1.0;
+    const bool cinc = !(coord[ny - 1] < coord[0]);
+    int bad = 0;
+    for (int j = threadIdx.x; j < ny; j += 256) {
+        const double v = Qs[j];
+        bad |= (v != v);
+        if (j + 1 < ny) {
+            bad |= !(s * Qs[j + 1] >= s * v);                          // (a NaN neighbour fails too)
+            bad |= cinc ? !(coord[j + 1] > coord[j]) : !(coord[j + 1] < coord[j]);
+        }
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(flag, 1u);
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024)
+void k_lwa_fast(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ dA, int dA_rank, double dA_max,
+                const double* __restrict__ M, int M_rank, int ny, int64_t nx, int increase, int side, int CG,
+                double* __restrict__ out)
+{
+    extern __shared__ __align__(16) double sm[];
+    const int tid = threadIdx.x, nthr = blockDim.x, slab = blockIdx.y;
+    const int64_t x0 = (int64_t)blockIdx.x * CG;
+    const int ncol = (int)((nx - x0 < CG) ? nx - x0 : CG);
+    const int L = ny + 1;
+    double* Qs = sm;                         // [ny]  Q' = s Q
+    double* D0 = sm + L;                     // [CG][ny + 1]
+    double* D1 = D0 + (size_t)CG * L;        // [CG][ny + 1]
+    const double s = increase ? 1.0 : -1.0;
+    const double* Qg = Q + (size_t)slab * ny;
+    for (int j = tid; j < ny; j += nthr) Qs[j] = s * Qg[j];
+    for (int i = tid; i < 2 * CG * L; i += nthr) D0[i] = 0.0;
+    __syncthreads();
+    const double cref = Qs[ny / 2];
+    const T* qs = q + (size_t)slab * ny * nx;
+    // cells: row-major over (y, column of the group); two cells per thread and round so that two searches overlap
+    const int ncell = ny * ncol;
+    for (int i0 = tid; i0 < ncell; i0 += 2 * nthr) {
+        int yy[2], cc[2], bb[2], aa[2];
+        double qv[2], wv[2];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + u * nthr;
+            ok[u] = i < ncell;
+            const int ii = ok[u] ? i : 0;
+            yy[u] = ii / ncol; cc[u] = ii - yy[u] * ncol;
+            const size_t cell = (size_t)yy[u] * nx + x0 + cc[u];
+            qv[u] = s * (double)qs[cell];
+            const double da = dA_rank == XC_DA_ROW ? dA[yy[u]] : dA[cell];
+            const double m = M_rank == XC_DA_NONE ? da : (M_rank == XC_DA_ROW ? M[yy[u]] : M[cell]);
+            wv[u] = (da / dA_max) * m;                                    // (u * wei) * M of core.py:789, weights first
+            ok[u] = ok[u] && (qv[u] == qv[u]) && (wv[u] == wv[u]);        // NaN tracer / weight: the term is NaN and nansum skips it
+        }
+        int lo[2] = {0, 0}, hi[2] = {ny, ny};                             // lower bound: first j with Q'_j >= q'
+        while (lo[0] < hi[0] || lo[1] < hi[1]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (lo[u] < hi[u]) { const int mid = (lo[u] + hi[u]) >> 1; if (Qs[mid] < qv[u]) lo[u] = mid + 1; else hi[u] = mid; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bb[u] = lo[u];
+            int a = lo[u];
+            while (a < ny && Qs[a] == qv[u]) ++a;                          // upper bound: ties with a level are rare
+            aa[u] = a;
+            int p = -1;
+            if (aa[u] <= yy[u]) { if (side != 2) p = aa[u]; }              // near-side term of targets [a, y]
+            else if (bb[u] >= yy[u] + 2) { if (side != 1) p = bb[u]; }     // far-side term of targets [y + 1, b - 1]
+            if (ok[u] && p >= 0) {
+                double* d0 = D0 + (size_t)cc[u] * L;
+                double* d1 = D1 + (size_t)cc[u] * L;
+                const double w = wv[u], qw = (qv[u] - cref) * w;
+                atomicAdd(d0 + p, w);  atomicAdd(d0 + yy[u] + 1, -w);
+                atomicAdd(d1 + p, qw); atomicAdd(d1 + yy[u] + 1, -qw);
+            }
+        }
+    }
+    __syncthreads();
+    // prefix sums over j, one wave per (column, array); the result overwrites D0: lwa[j] = s ((Q'_j - c) S0_j - S1_j)
+    {
+        const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+        for (int c = wave; c < ncol; c += nw) {
+            double* d0 = D0 + (size_t)c * L;
+            double* d1 = D1 + (size_t)c * L;
+            double c0 = 0.0, c1 = 0.0;
+            for (int j0 = 0; j0 < ny; j0 += 64) {
+                const int j = j0 + lane;
+                double v0 = j < ny ? d0[j] : 0.0, v1 = j < ny ? d1[j] : 0.0;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double t0 = __shfl_up(v0, o), t1 = __shfl_up(v1, o);
+                    if (lane >= o) { v0 += t0; v1 += t1; }
+                }
+                v0 += c0; v1 += c1;
+                if (j < ny) d0[j] = s * ((Qs[j] - cref) * v0 - v1);
+                c0 = __shfl(v0, 63); c1 = __shfl(v1, 63);
+            }
+        }
+    }
+    __syncthreads();
+    double* os = out + (size_t)slab * ny * nx;
+    for (int i = tid; i < ncell; i += nthr) {
+        const int y = i / ncol, c = i - y * ncol;
+        os[(size_t)y * nx + x0 + c] = D0[(size_t)c * L + y];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_lwa_masks(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
@@ -407,6 +538,39 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     if (ny > 65535 || nslab * (nmask > 0 ? nmask : 1) > 65535) return fail(ctx, XC_EBADARG, "xc_lwa: ny / nslab too large");
     if (variant != 0 && variant != 1) return fail(ctx, XC_EBADARG, "xc_lwa: variant must be 0 or 1");
     if (q_dtype != XC_F32 && q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
+    if (variant == 0 && !ctx->lwa_exact && ctx->knobs.lwa_fast && (ny > kLwaFastMinRows || ctx->knobs.lwa_fast > 1) && nx <= 0x7fffffff) {
+        // ---- large planes: the O(ny log ny) interval kernel, once its premises are proved (one host round trip: the flag)
+        int CG = 0;
+        for (int c : {4, 2, 1})
+            if (!CG && (size_t)(1 + 2 * c) * (ny + 1) * 8 <= kLdsBudget) CG = c;
+        if (CG) {
+            { const int rc = ensure_scratch(ctx, 256); if (rc != XC_OK) return rc; }
+            unsigned* flag = (unsigned*)ctx->scratch;
+            XC_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_lwa_check, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, Q, coord, (int)ny, increase, flag);
+            XC_HIP(ctx, hipGetLastError());
+            if (!ctx->pinned_flag) XC_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_flag, 64, hipHostMallocDefault));
+            volatile unsigned& h_flag = *ctx->pinned_flag;
+            h_flag = 1;
+            XC_HIP(ctx, hipMemcpyAsync(ctx->pinned_flag, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+            XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->last_lwa_path = h_flag == 0 ? 1 : 2;
+            if (h_flag == 0) {
+                const size_t lds = (size_t)(1 + 2 * CG) * (ny + 1) * 8;
+                // part (core.py:773-784): 'upper' keeps mask3 > 0 (the near side) if increase else mask3 < 0 (the far side)
+                const int side = part == 0 ? 0 : (((part == 1) == (increase != 0)) ? 1 : 2);
+                const dim3 grid((unsigned)((nx + CG - 1) / CG), (unsigned)nslab);
+#define XC_LWAF(T) do { \
+                    const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(k_lwa_fast<T>), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; \
+                    hipLaunchKernelGGL((k_lwa_fast<T>), grid, dim3(1024), lds, ctx->stream, (const T*)q, Q, dA, dA_rank, dA_max, \
+                                       M, M_rank, (int)ny, nx, increase, side, CG, out_lwa); } while (0)
+                if (q_dtype == XC_F64) XC_LWAF(double); else XC_LWAF(float);
+#undef XC_LWAF
+                XC_HIP(ctx, hipGetLastError());
+                goto masks;
+            }
+        }
+    } else ctx->last_lwa_path = 0;
     {
         // ---- one launch with the 64-column strip of the tracer in LDS when it fits
         const double* Mt = M_rank == XC_DA_NONE ? dA : M;
