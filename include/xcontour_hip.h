@@ -220,11 +220,12 @@ int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const doubl
 /* Planes of more than 512 rows take an O(ny log ny)-per-column path (variant 0): because the sorted reference state Q is
  * monotone, the targets j a cell contributes to form one interval, so one binary search in Q and four adds into a
  * difference array replace the walk over every (target, row) pair; per-column prefix sums finish.  The premises -- no NaN in
- * Q, s*Q non-decreasing (s = +1 if increase else -1), the coordinate strictly monotone -- are checked on the device first and
- * read back (the ONE host round trip of these calls, also the _dev form); if they fail the band walk runs.  Same sums in
+ * Q, s*Q non-decreasing (s = +1 if increase else -1), the coordinate strictly monotone -- are checked ON THE DEVICE first (a
+ * flag the kernels gate themselves on: no host round trip, the _dev form stays asynchronous); if they fail the band walk
+ * enqueued behind the interval kernel runs instead.  Same sums in
  * another order: agreement with the band walk ~1e-13 of the column's largest value (tests 1e-9), not bit for bit.
  * xc_set_lwa_exact(ctx, 1) keeps the bit-exact band walk for every plane.  xc_last_lwa_path: 0 band walk, 1 interval
- * kernel, 2 its premises failed the check. */
+ * kernel, 2 its premises failed the check (waits for the call when the device decided). */
 int xc_set_lwa_exact(xc_ctx* ctx, int exact);
 int xc_last_lwa_path(xc_ctx* ctx, int* out_path);
 

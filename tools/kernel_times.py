@@ -129,7 +129,8 @@ def cmd_lwa(ctx, T):
     dy = np.gradient(np.deg2rad(lat)) * 6371200.0
     dQ, dc, dd, dM = ctx.to_device(Q), ctx.to_device(lat), ctx.to_device(dA), ctx.to_device(dy)
     out = ctx.alloc(NY * NX * 8)
-    fn = lambda: ctx._check(ctx.lib.xc_lwa_dev(ctx.handle, qb.ptr, nat.XC_F64, dQ.ptr, dc.ptr, dd.ptr, nat.XC_DA_PLANE, float(dA.max()),
+    dmax = float(dA.max())             # (outside the timed call: the max of a 52 MB host array is a millisecond of numpy)
+    fn = lambda: ctx._check(ctx.lib.xc_lwa_dev(ctx.handle, qb.ptr, nat.XC_F64, dQ.ptr, dc.ptr, dd.ptr, nat.XC_DA_PLANE, dmax,
                                               dM.ptr, nat.XC_DA_ROW, 1, NY, NX, 1, 0, 0, None, 0, out.ptr, None))
     wei = dA / dA.max()
     rows = {}
@@ -140,7 +141,7 @@ def cmd_lwa(ctx, T):
         rows[j] = -np.nansum(qe * mask3 * wei * dy[:, None], axis=0)
     for exact in (0, 1):                                           # the O(ny log ny) interval kernel (default for ny > 512), then the band walk
         ctx._check(ctx.lib.xc_set_lwa_exact(ctx.handle, exact))
-        ms = T.ms(fn, reps=3, warm=1)
+        ms = T.ms(fn, reps=10, warm=2)
         got = out.download((NY, NX), np.float64)
         path = ctx.last_lwa_path()
         scale = max(float(np.abs(r).max()) for r in rows.values())

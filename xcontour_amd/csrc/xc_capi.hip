@@ -211,6 +211,7 @@ int xc_destroy(xc_ctx* ctx)
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->pinned_flag) (void)hipHostFree(ctx->pinned_flag);
+    if (ctx->lwa_flag) (void)hipFree(ctx->lwa_flag);
     for (auto& e : ctx->resident) (void)hipFree(e.dev);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ev_compute) (void)hipEventDestroy(ctx->ev_compute);
@@ -863,6 +864,13 @@ int xc_set_lwa_exact(xc_ctx* ctx, int exact)
 int xc_last_lwa_path(xc_ctx* ctx, int* out_path)
 {
     if (!ctx || !out_path) return fail(ctx, XC_EBADARG, "xc_last_lwa_path: bad arguments");
+    if (ctx->last_lwa_path < 0) {                                      // decided by the device-side check of the last call: read its flag
+        unsigned f = 0;
+        XC_HIP(ctx, hipSetDevice(ctx->device));
+        XC_HIP(ctx, hipMemcpyAsync(&f, ctx->lwa_flag, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
+        XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->last_lwa_path = (f == ctx->lwa_epoch) ? 2 : 1;
+    }
     *out_path = ctx->last_lwa_path;
     return XC_OK;
 }

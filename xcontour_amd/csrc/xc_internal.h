@@ -54,7 +54,9 @@ struct xc_ctx {
     int mm_cur = 0, mm_valid = 0, mm_P = 0, mm_dtype = 0;
     const void* mm_q = nullptr;  int64_t mm_nslab = 0, mm_ny = 0, mm_nx = 0;  int mm_gen = 0;
     int lwa_exact = 0;          // xc_set_lwa_exact: keep the bit-exact band walk for every plane
-    int last_lwa_path = 0;      // K7, last call: 0 band walk, 1 interval kernel, 2 its premises failed the check (band walk)
+    int last_lwa_path = 0;      // K7, last call: 0 band walk, 1 interval kernel, 2 its premises failed the check (band walk), -1 decided on the device (read lwa_flag)
+    unsigned lwa_epoch = 0;
+    unsigned* lwa_flag = nullptr;   // device word written by k_lwa_check: the interval kernel and the band walk gate themselves on it
     int last_sort_path = 0;     // K8, last call: 0 eight / four key passes, 1 three range-key passes sufficed, 2 they did not (re-sorted)
 };
 

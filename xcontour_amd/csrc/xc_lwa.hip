@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256)
 void k_lwa_prep(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
                 const double* __restrict__ dA, int dA_rank, double dA_max,
                 int64_t ny, int64_t nx, int64_t nstrip, double* __restrict__ wei, double* __restrict__ rowinfo,
-                double* __restrict__ stripmm)
+                double* __restrict__ stripmm, const unsigned* __restrict__ gate, unsigned epoch)
 {
+    if (gate && *gate != epoch) return;      // the interval kernel (K7F) took this call: its premises held (k_lwa_check)
     const int64_t y = blockIdx.x, slab = blockIdx.y;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double* ri = rowinfo + ((size_t)slab * (ny + LWA_RB) + y) * 2;
@@ -95,8 +96,9 @@ void k_lwa(const T* __restrict__ q, const double* __restrict__ Q, const double* 
            const double* __restrict__ wei_, int dA_rank,
            const double* __restrict__ M, int M_rank, const double* __restrict__ rowinfo,
            const double* __restrict__ stripmm,
-           int64_t ny, int64_t nx, int increase, int part, double* __restrict__ out)
+           int64_t ny, int64_t nx, int increase, int part, double* __restrict__ out, const unsigned* __restrict__ gate, unsigned epoch)
 {
+    if (gate && *gate != epoch) return;      // (see k_lwa_prep)
     const int coord_incre = !(coord[ny - 1] < coord[0]);                 // core.py:736-738
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t x = (int64_t)blockIdx.x * 64 + lane;
@@ -214,8 +216,10 @@ template <typename T, bool V2>
 __global__ __launch_bounds__(64 * LWA_SW)
 void k_lwa_strip(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ coord,
                  const double* __restrict__ dA, int dA_rank, double dA_max, const double* __restrict__ M, int M_rank,
-                 int64_t ny_, int64_t nx_, int increase, int part, int tper, int wchunk, double* __restrict__ out)
+                 int64_t ny_, int64_t nx_, int increase, int part, int tper, int wchunk, double* __restrict__ out,
+                 const unsigned* __restrict__ gate, unsigned epoch)
 {
+    if (gate && *gate != epoch) return;      // (see k_lwa_prep)
     extern __shared__ __align__(16) double sm[];
     const int ny = (int)ny_, nx = (int)nx_;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -393,7 +397,7 @@ void k_lwa_strip(const T* __restrict__ q, const double* __restrict__ Q, const do
 constexpr int kLwaFastMinRows = 512;
 
 __global__ __launch_bounds__(256)
-void k_lwa_check(const double* __restrict__ Q, const double* __restrict__ coord, int ny, int increase, unsigned* __restrict__ flag)
+void k_lwa_check(const double* __restrict__ Q, const double* __restrict__ coord, int ny, int increase, unsigned* __restrict__ flag, unsigned epoch)
 {
     const double* Qs = Q + (size_t)blockIdx.x * ny;
     const double s = increase ? 1.0 : -1.0;
@@ -407,15 +411,16 @@ void k_lwa_check(const double* __restrict__ Q, const double* __restrict__ coord,
             bad |= cinc ? !(coord[j + 1] > coord[j]) : !(coord[j + 1] < coord[j]);
         }
     }
-    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(flag, 1u);
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(flag, epoch);      // the word holds the epoch of the last call whose check failed
 }
 
 template <typename T>
 __global__ __launch_bounds__(1024)
 void k_lwa_fast(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ dA, int dA_rank, double dA_max,
                 const double* __restrict__ M, int M_rank, int ny, int64_t nx, int increase, int side, int CG,
-                double* __restrict__ out)
+                double* __restrict__ out, const unsigned* __restrict__ gate, unsigned epoch)
 {
+    if (*gate == epoch) return;                  // k_lwa_check found a premise broken: the band walk enqueued behind this kernel runs instead
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x, nthr = blockDim.x, slab = blockIdx.y;
     const int64_t x0 = (int64_t)blockIdx.x * CG;
@@ -538,39 +543,38 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     if (ny > 65535 || nslab * (nmask > 0 ? nmask : 1) > 65535) return fail(ctx, XC_EBADARG, "xc_lwa: ny / nslab too large");
     if (variant != 0 && variant != 1) return fail(ctx, XC_EBADARG, "xc_lwa: variant must be 0 or 1");
     if (q_dtype != XC_F32 && q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
+    const unsigned* gate = nullptr;          // set: the exact kernels below run only if the device-side check FAILED
+    unsigned epoch = 0;
+    ctx->last_lwa_path = 0;
     if (variant == 0 && !ctx->lwa_exact && ctx->knobs.lwa_fast && (ny > kLwaFastMinRows || ctx->knobs.lwa_fast > 1) && nx <= 0x7fffffff) {
-        // ---- large planes: the O(ny log ny) interval kernel, once its premises are proved (one host round trip: the flag)
+        // ---- large planes: the O(ny log ny) interval kernel, gated ON THE DEVICE by the check of its premises -- no host round
+        // trip (a stream synchronise in the middle of the call cost ~1 ms of host latency against 0.16 ms of kernel): the check
+        // writes a flag, the interval kernel returns at once if it is set, the band walk enqueued behind it returns at once if
+        // it is not (two empty launches, a few microseconds)
         int CG = 0;
         for (int c : {4, 2, 1})
             if (!CG && (size_t)(1 + 2 * c) * (ny + 1) * 8 <= kLdsBudget) CG = c;
         if (CG) {
-            { const int rc = ensure_scratch(ctx, 256); if (rc != XC_OK) return rc; }
-            unsigned* flag = (unsigned*)ctx->scratch;
-            XC_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(k_lwa_check, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, Q, coord, (int)ny, increase, flag);
+            if (!ctx->lwa_flag) { XC_HIP(ctx, hipMalloc((void**)&ctx->lwa_flag, 256)); XC_HIP(ctx, hipMemset(ctx->lwa_flag, 0, 256)); ctx->lwa_epoch = 0; }
+            unsigned* flag = ctx->lwa_flag;
+            epoch = ++ctx->lwa_epoch;            // a failed check stamps the word with its call's epoch: no memset per call
+            hipLaunchKernelGGL(k_lwa_check, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, Q, coord, (int)ny, increase, flag, epoch);
             XC_HIP(ctx, hipGetLastError());
-            if (!ctx->pinned_flag) XC_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_flag, 64, hipHostMallocDefault));
-            volatile unsigned& h_flag = *ctx->pinned_flag;
-            h_flag = 1;
-            XC_HIP(ctx, hipMemcpyAsync(ctx->pinned_flag, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-            XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->last_lwa_path = h_flag == 0 ? 1 : 2;
-            if (h_flag == 0) {
-                const size_t lds = (size_t)(1 + 2 * CG) * (ny + 1) * 8;
-                // part (core.py:773-784): 'upper' keeps mask3 > 0 (the near side) if increase else mask3 < 0 (the far side)
-                const int side = part == 0 ? 0 : (((part == 1) == (increase != 0)) ? 1 : 2);
-                const dim3 grid((unsigned)((nx + CG - 1) / CG), (unsigned)nslab);
+            const size_t lds = (size_t)(1 + 2 * CG) * (ny + 1) * 8;
+            // part (core.py:773-784): 'upper' keeps mask3 > 0 (the near side) if increase else mask3 < 0 (the far side)
+            const int side = part == 0 ? 0 : (((part == 1) == (increase != 0)) ? 1 : 2);
+            const dim3 grid((unsigned)((nx + CG - 1) / CG), (unsigned)nslab);
 #define XC_LWAF(T) do { \
-                    const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(k_lwa_fast<T>), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; \
-                    hipLaunchKernelGGL((k_lwa_fast<T>), grid, dim3(1024), lds, ctx->stream, (const T*)q, Q, dA, dA_rank, dA_max, \
-                                       M, M_rank, (int)ny, nx, increase, side, CG, out_lwa); } while (0)
-                if (q_dtype == XC_F64) XC_LWAF(double); else XC_LWAF(float);
+                const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(k_lwa_fast<T>), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; \
+                hipLaunchKernelGGL((k_lwa_fast<T>), grid, dim3(1024), lds, ctx->stream, (const T*)q, Q, dA, dA_rank, dA_max, \
+                                   M, M_rank, (int)ny, nx, increase, side, CG, out_lwa, flag, epoch); } while (0)
+            if (q_dtype == XC_F64) XC_LWAF(double); else XC_LWAF(float);
 #undef XC_LWAF
-                XC_HIP(ctx, hipGetLastError());
-                goto masks;
-            }
+            XC_HIP(ctx, hipGetLastError());
+            gate = flag;
+            ctx->last_lwa_path = -1;         // decided on the device: xc_last_lwa_path reads the flag
         }
-    } else ctx->last_lwa_path = 0;
+    }
     {
         // ---- one launch with the 64-column strip of the tracer in LDS when it fits
         const double* Mt = M_rank == XC_DA_NONE ? dA : M;
@@ -595,7 +599,7 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
 #define XC_LWAS(T, V) do { \
                     const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(k_lwa_strip<T, V>), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; \
                     hipLaunchKernelGGL((k_lwa_strip<T, V>), grid, dim3(64 * LWA_SW), lds, ctx->stream, (const T*)q, Q, coord, dA, dA_rank, dA_max, \
-                                       Mt, Mr, ny, nx, increase, part, (int)tper, wchunk, out_lwa); } while (0)
+                                       Mt, Mr, ny, nx, increase, part, (int)tper, wchunk, out_lwa, gate, epoch); } while (0)
                 if (q_dtype == XC_F64) { if (variant) XC_LWAS(double, true); else XC_LWAS(double, false); }
                 else { if (variant) XC_LWAS(float, true); else XC_LWAS(float, false); }
 #undef XC_LWAS
@@ -616,16 +620,16 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     if ((nstrip + 63) / 64 > 65535) return fail(ctx, XC_EBADARG, "xc_lwa: nx too large");
     const dim3 gp((unsigned)(ny + LWA_RB), (unsigned)nslab, (unsigned)((nstrip + 63) / 64));
     if (q_dtype == XC_F64)
-        hipLaunchKernelGGL(k_lwa_prep<double>, gp, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, nstrip, wei, rowinfo, stripmm);
+        hipLaunchKernelGGL(k_lwa_prep<double>, gp, dim3(256), 0, ctx->stream, (const double*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, nstrip, wei, rowinfo, stripmm, gate, epoch);
     else if (q_dtype == XC_F32)
-        hipLaunchKernelGGL(k_lwa_prep<float>, gp, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, nstrip, wei, rowinfo, stripmm);
+        hipLaunchKernelGGL(k_lwa_prep<float>, gp, dim3(256), 0, ctx->stream, (const float*)q, Q, coord, dA, dA_rank, dA_max, ny, nx, nstrip, wei, rowinfo, stripmm, gate, epoch);
     else return fail(ctx, XC_EBADARG, "xc_lwa: q_dtype must be XC_F32 or XC_F64");
     if (M_rank == XC_DA_NONE) { M = dA; M_rank = dA_rank; }
     const bool small = (double)ny * (double)ny * (double)nx * (double)nslab < 2.0e8;
     const int jt = small ? 1 : 4;
     dim3 grid((unsigned)((nx + 63) / 64), (unsigned)((ny + 4 * jt - 1) / (4 * jt)), (unsigned)nslab);
 #define XC_LWA2(T, V, J) hipLaunchKernelGGL((k_lwa<T, V, J>), grid, dim3(256), 0, ctx->stream, (const T*)q, Q, coord, wei, dA_rank, \
-                           M, M_rank, rowinfo, stripmm, ny, nx, increase, part, out_lwa)
+                           M, M_rank, rowinfo, stripmm, ny, nx, increase, part, out_lwa, gate, epoch)
 #define XC_LWA(T, V) do { if (small) XC_LWA2(T, V, 1); else XC_LWA2(T, V, 4); } while (0)
     if (q_dtype == XC_F64) { if (variant) XC_LWA(double, true); else XC_LWA(double, false); }
     else { if (variant) XC_LWA(float, true); else XC_LWA(float, false); }
