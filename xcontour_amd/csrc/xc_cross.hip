@@ -105,7 +105,7 @@ template <> __device__ __forceinline__ double sqrt_like_numpy<double>(double a) 
 template <typename TA, bool CNT>
 __device__ __forceinline__ void box_done(const double* __restrict__ cx, int N, double mn, double mx, TA araw, bool nanfill,
                                          double fs, double c_first, double inv_step, double zlo, int& g,
-                                         double* __restrict__ my_len, unsigned* __restrict__ my_cnt, double* __restrict__ s_dir)
+                                         double* __restrict__ my_len, unsigned* __restrict__ my_cnt, double* __restrict__ s_dir, int cshift)
 {
     if (!(mn < mx)) return;                            // one value, or no valid corner at all
     if (inv_step > 0.0) {
@@ -124,10 +124,10 @@ __device__ __forceinline__ void box_done(const double* __restrict__ cx, int N, d
         if (nanfill) w = __longlong_as_double(0x7ff8000000000000LL);
 #ifndef XC_CROSS_NOATOM
         if (w == w) {                                      // np.nansum skips NaN (negative or NaN area)
-            if (w < __longlong_as_double(0x7ff0000000000000LL)) { atomicAdd(&my_len[klo], w); atomicAdd(&my_len[khi], -w); }
+            if (w < __longlong_as_double(0x7ff0000000000000LL)) { atomicAdd(&my_len[(klo) << cshift], w); atomicAdd(&my_len[(khi) << cshift], -w); }
             else for (int t = klo; t < khi; ++t) atomicAdd(&s_dir[t], w);        // an infinite area: +inf / -inf differences would turn into NaN
         }
-        if (CNT) { atomicAdd(&my_cnt[klo], 1u); atomicAdd(&my_cnt[khi], 0xffffffffu); }
+        if (CNT) { atomicAdd(&my_cnt[(klo) << cshift], 1u); atomicAdd(&my_cnt[(khi) << cshift], 0xffffffffu); }
 #endif
         return;
     }
@@ -143,10 +143,10 @@ __device__ __forceinline__ void box_done(const double* __restrict__ cx, int N, d
     const bool add = (w == w);
     do {                                               // the +inf sentinel ends the scan
 #ifndef XC_CROSS_NOATOM
-        if (add) atomicAdd(&my_len[k], w);
-        if (CNT) atomicAdd(&my_cnt[k], 1u);
+        if (add) atomicAdd(&my_len[(k) << cshift], w);
+        if (CNT) atomicAdd(&my_cnt[(k) << cshift], 1u);
 #else
-        if (add && w == 1.2345) my_len[k] = w;         // diagnostic build: the loop without its atomics
+        if (add && w == 1.2345) my_len[(k) << cshift] = w;         // diagnostic build: the loop without its atomics
 #endif
         ++k; ck = cx[k + 1];
     } while (ck < mx);
@@ -159,7 +159,7 @@ template <typename TA, bool CNT, int G>
 __device__ __forceinline__ void boxes_group(const double* __restrict__ cx, int N, const double (&mn)[G], const double (&mx)[G],
                                             const TA (&araw)[G], const bool (&valid)[G], bool nanfill, double fs, double c_first,
                                             double inv_step, double zlo, double* __restrict__ my_len, unsigned* __restrict__ my_cnt,
-                                            double* __restrict__ s_dir)
+                                            double* __restrict__ s_dir, int cshift)
 {
     int klo[G], khi[G];
     bool cross[G];
@@ -183,10 +183,10 @@ __device__ __forceinline__ void boxes_group(const double* __restrict__ cx, int N
     for (int i = 0; i < G; ++i) {
         if (cross[i]) {
             if (w[i] == w[i]) {                            // np.nansum skips NaN (negative or NaN area)
-                if (w[i] < __longlong_as_double(0x7ff0000000000000LL)) { atomicAdd(&my_len[klo[i]], w[i]); atomicAdd(&my_len[khi[i]], -w[i]); }
+                if (w[i] < __longlong_as_double(0x7ff0000000000000LL)) { atomicAdd(&my_len[klo[i] << cshift], w[i]); atomicAdd(&my_len[khi[i] << cshift], -w[i]); }
                 else for (int t = klo[i]; t < khi[i]; ++t) atomicAdd(&s_dir[t], w[i]);
             }
-            if (CNT) { atomicAdd(&my_cnt[klo[i]], 1u); atomicAdd(&my_cnt[khi[i]], 0xffffffffu); }
+            if (CNT) { atomicAdd(&my_cnt[klo[i] << cshift], 1u); atomicAdd(&my_cnt[khi[i] << cshift], 0xffffffffu); }
         }
     }
 #endif
@@ -218,8 +218,16 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
     for (int k = tid; k < ncopy * np; k += CROSS_TPB) { s_len[k] = 0.0; if (CNT) s_cnt[k] = 0u; }
     for (int k = tid; k < N; k += CROSS_TPB) s_dir[k] = 0.0;
     __syncthreads();
-    double* my_len = s_len + (size_t)(tid & (ncopy - 1)) * np;
-    unsigned* my_cnt = s_cnt + (size_t)(tid & (ncopy - 1)) * np;
+    // cell k of copy c sits at [k * ncopy + c] (level-major, round 4): the lanes of a wave hold `ncopy` different copies and
+    // levels a few positions apart, i.e. addresses spread over ncopy * (a few) consecutive words -- distinct banks.  Rounds 1-3
+    // kept the copies apart by an odd pitch (copies 0 / 3 / 6, 1 / 4 / 7 and 2 / 5 came out two banks apart) and the round-3
+    // review blamed the 40 % conflict cycles of a noisy field on that.  Measured: 22.76 -> 22.72 us per noisy cfg2 slab, i.e.
+    // NOTHING -- the conflict cycles are the eight lanes that share a copy adding to the SAME cell (neighbouring boxes cross the
+    // same levels), which no layout removes; 4 / 16 / 32 copies: 25.8 / 25.5 / 25.1 us (fewer copies collide more, more copies
+    // cost occupancy).  The layout stays (it is never worse and needs no pitch rule).
+    const int cshift = __builtin_ctz((unsigned)ncopy);
+    double* my_len = s_len + (tid & (ncopy - 1));
+    unsigned* my_cnt = s_cnt + (tid & (ncopy - 1));
 
     const int s = S > 0 ? S : s_rt;
     const TQ* qs = q + (size_t)slab * ny * nx;
@@ -296,7 +304,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                         int P = 1;                                          // sliding window of w lanes: doubling, then one overlap step
                         for (; 2 * P <= w; P *= 2) { vmn = fmin(vmn, __shfl_down(vmn, P)); vmx = fmax(vmx, __shfl_down(vmx, P)); }
                         if (w != P) { vmn = fmin(vmn, __shfl_down(vmn, w - P)); vmx = fmax(vmx, __shfl_down(vmx, w - P)); }
-                        if (box) box_done<TA, CNT>(s_cx, N, vmn, vmx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
+                        if (box) box_done<TA, CNT>(s_cx, N, vmn, vmx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir, cshift);
                         ++j; inbox = 0; vmn = cmn; vmx = cmx;
                     }
                 }
@@ -353,7 +361,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                             cmn = rmn; cmx = rmx;
                             ab[i] = av[b]; vb[i] = box && (jb + b < j1);
                         }
-                        boxes_group<TA, CNT, G>(s_cx, N, mnb, mxb, ab, vb, nanfill, fs, c_first, inv_step, zlo, my_len, my_cnt, s_dir);
+                        boxes_group<TA, CNT, G>(s_cx, N, mnb, mxb, ab, vb, nanfill, fs, c_first, inv_step, zlo, my_len, my_cnt, s_dir, cshift);
                     }
                     continue;
                 }
@@ -364,7 +372,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                     const double rmn = fmin(fmin(inf, x), xr), rmx = fmax(fmax(-inf, x), xr);
                     const double mn = fmin(cmn, rmn), mx = fmax(cmx, rmx);
                     cmn = rmn; cmx = rmx;
-                    if (box) box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
+                    if (box) box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir, cshift);
                 }
             }
             continue;
@@ -386,7 +394,7 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
                 cmn = inf; cmx = -inf;
                 row_segment(qs + (size_t)(j * s + s) * nx, c0, s, nx, pad_mode, cmn, cmx);
                 mn = fmin(mn, cmn); mx = fmax(mx, cmx);
-                box_done<TA, CNT>(s_cx, N, mn, mx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
+                box_done<TA, CNT>(s_cx, N, mn, mx, as[(size_t)j * nx + ac], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir, cshift);
             }
         } else if constexpr (S > 0) {
             constexpr int B = S == 1 ? 8 : S == 2 ? 4 : S == 3 ? 2 : 1;     // boxes per load batch
@@ -422,20 +430,27 @@ void k_crossing(const TQ* __restrict__ q, int64_t ny, int64_t nx, int pad_mode,
 #pragma unroll
                     for (int d = 0; d <= S; ++d) { const double x = pnan[d] ? qnan : (double)v[b][S - 1][d]; cmn = fmin(cmn, x); cmx = fmax(cmx, x); }
                     mn = fmin(mn, cmn); mx = fmax(mx, cmx);
-                    box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir);
+                    box_done<TA, CNT>(s_cx, N, mn, mx, av[b], nanfill, fs, c_first, inv_step, zlo, g, my_len, my_cnt, s_dir, cshift);
                 }
             }
         }
     }
     __syncthreads();
-    // copies -> copy 0 (thread k touches index k of every copy only)
-    for (int k = tid; k <= N; k += CROSS_TPB) {
+    // copies -> one compact array s_len[0 .. N] (s_cnt likewise), a chunk of CROSS_TPB levels at a time: the compact cells of a
+    // chunk lie below every interleaved cell that is still unread (k <= k * ncopy), and a barrier separates a chunk's reads
+    // from its writes
+    for (int k0 = 0; k0 <= N; k0 += CROSS_TPB) {
+        const int k = k0 + tid;
         double l = 0.0; unsigned n = 0;
-        for (int c = 0; c < ncopy; ++c) { l += s_len[(size_t)c * np + k]; if (CNT) n += s_cnt[(size_t)c * np + k]; }
-        s_len[k] = l;
-        if (CNT) s_cnt[k] = n;
+        if (k <= N)
+            for (int c = 0; c < ncopy; ++c) {
+                const int cc = (c + tid) & (ncopy - 1);                // rotated start: the lanes of a wave read distinct banks
+                l += s_len[((size_t)k << cshift) + cc]; if (CNT) n += s_cnt[((size_t)k << cshift) + cc];
+            }
+        __syncthreads();
+        if (k <= N) { s_len[k] = l; if (CNT) s_cnt[k] = n; }
+        __syncthreads();
     }
-    __syncthreads();
     if (inv_step > 0.0 && tid < 64) {
         // equally spaced levels: the cells hold DIFFERENCES D[0..N] (box_done) whose total is zero, so the sum at level k is
         // both the prefix D[0] + .. + D[k] and minus the suffix D[k+1] + .. + D[N].  The lower half of the levels takes the
