@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/collect_profiles.sh ROUND COMMIT  (run on the GPU box via gpurun, ~10 min): everything profiles/ holds for a round,
 # re-taken at one commit.  Writes gpurun_out/rNN_*; copy what should be judged into profiles/.
-R=$GRAFT_REPO_ROOT; cd $R; RD=${1:-r03}; COMMIT=${2:-unknown}; O=$R/gpurun_out
+R=$GRAFT_REPO_ROOT; cd $R; RD=${1:-r04}; COMMIT=${2:-unknown}; O=$R/gpurun_out
 echo "== bench variants"
 : > $O/${RD}_bench_variants.jsonl
 for a in "--no-chain" "--slab-dA" "--row-dA" "--deterministic" "--variant 1" "--variant 2" "--dtype f32" "--dtype f32 --no-chain"; do
