@@ -167,6 +167,44 @@ def case_lwa():
         tick('lwa')
 
 
+def case_lwa_interval():
+    """planes of more than 512 rows: the O(ny log ny) interval kernel (monotone reference state) against the oracle's loop, <= 1e-11
+    of the plane's largest value; a reference state that is not monotone must take the bit-exact band walk"""
+    S, ny, nx = int(rng.integers(1, 3)), int(rng.integers(513, 640)), int(rng.integers(1, 40))
+    dt = rng.choice([np.float32, np.float64])
+    q = field(S, ny, nx, dt)
+    up = bool(rng.random() < 0.5)
+    coord = np.linspace(-50, 50, ny) * (1 if up else -1)
+    inc = bool(rng.random() < 0.5)
+    Q = np.sort(rng.standard_normal((S, ny)) * rng.uniform(0.3, 2), axis=1)
+    if rng.random() < 0.3:
+        Q[:, rng.integers(1, ny)] = Q[:, 0]                               # ties inside Q
+        Q = np.sort(Q, axis=1)
+    if not inc:
+        Q = Q[:, ::-1].copy()
+    idx = rng.integers(0, q.size, 50)
+    q.reshape(-1)[idx] = Q[0, rng.integers(0, ny, 50)].astype(dt)        # cells exactly on reference levels
+    broken = rng.random() < 0.2
+    if broken:
+        Q[0, [3, 4]] = Q[0, [4, 3]] + (0.1 if inc else -0.1) * np.array([1, -1])
+    dA = rng.random((ny, nx)) + 0.3
+    M = None if rng.random() < 0.4 else (rng.random(ny) + 0.5 if rng.random() < 0.5 else rng.random((ny, nx)) + 0.5)
+    pc = int(rng.integers(0, 3))
+    out, _ = ctx.lwa(q, Q, coord, dA, dA.max(), M=M, increase=inc, part=pc, variant=0)
+    path = ctx.last_lwa_path()
+    mono = all(np.all(np.diff(Q[s] if inc else -Q[s]) >= 0) for s in range(S))
+    assert path == (1 if mono else 2), 'lwa interval path %d, monotone %r' % (path, mono)
+    for s in range(S):
+        with np.errstate(invalid='ignore'):
+            ref = O.cal_local_wave_activity(q[s], Q[s], coord, dA, inc, ('all', 'upper', 'lower')[pc], metric=M)
+        if path == 2 and nx > 1:
+            assert np.array_equal(out[s], ref, equal_nan=True), 'lwa band walk behind a failed check'
+        else:
+            scale = max(float(np.abs(ref).max()), 1e-300)
+            assert float(np.abs(out[s] - ref).max()) <= 1e-11 * scale, 'lwa interval %r: %g' % ((S, ny, nx, inc, up, pc), float(np.abs(out[s] - ref).max()) / scale)
+        tick('lwa_interval')
+
+
 def case_sort():
     S, ny, nx = int(rng.integers(1, 4)), int(rng.integers(1, 70 * SC)), int(rng.integers(1, 300 * SC))
     dt = rng.choice([np.float32, np.float64])
@@ -243,7 +281,7 @@ def case_facade():
     tick('facade')
 
 
-cases = [case_hist, case_keff, case_crossing, case_lwa, case_sort, case_facade]
+cases = [case_lwa_interval, case_hist, case_keff, case_crossing, case_lwa, case_sort, case_facade]
 
 
 def run(seconds, seed=None):
