@@ -167,7 +167,13 @@ class Contour2D(object):
     def _dA_array(self, ny, nx, nslab):
         """self.dA -> (float64 ndarray of shape (ny,), (ny,nx) or (nslab,ny,nx), was_f32)"""
         if self.resident:
-            return self._keep(('dA', ny, nx, nslab), self.dA, lambda: self._dA_array_of(ny, nx, nslab))
+            # one mirror per (ny, nx) unless the weights carry leading (time, ...) dims: a (ny,) / (ny, nx) result does not depend on nslab
+            if lb.is_labeled(self.dA):
+                raw, dd, _, _ = lb.unwrap(self.dA, lazy=True)
+                stack = len([d for d, n in zip(dd, raw.shape) if d in self.dimVs or n != 1]) > 2
+            else:
+                stack = np.ndim(self.dA) > 2
+            return self._keep(('dA', ny, nx, nslab if stack else 0), self.dA, lambda: self._dA_array_of(ny, nx, nslab))
         return self._dA_array_of(ny, nx, nslab)
 
     def _dA_array_of(self, ny, nx, nslab):
