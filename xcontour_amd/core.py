@@ -224,7 +224,11 @@ class Contour2D(object):
         dA, _ = self._dA_array(ny, nx, 1)
         if dA.ndim == 3:
             dA = dA[0]
-        return self.ctx.rowsum(self._float(m[0]), dA, ny, nx, multiply=multiply)
+        m0 = self._float(np.asarray(m[0]))
+        if self.resident:
+            # the mask is time-invariant by contract (core.py:156): with resident inputs it crosses PCIe once, like tracer and weights
+            m0 = self._keep(('mask',), mask, lambda: (np.ascontiguousarray(m0),))[0]
+        return self.ctx.rowsum(m0, dA, ny, nx, multiply=multiply)
 
     def cal_area_eqCoord_table(self, mask):
         """
