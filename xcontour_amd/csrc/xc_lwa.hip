@@ -423,7 +423,16 @@ void k_lwa_fast(const T* __restrict__ q, const double* __restrict__ Q, const dou
     if (*gate == epoch) return;                  // k_lwa_check found a premise broken: the band walk enqueued behind this kernel runs instead
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x, nthr = blockDim.x, slab = blockIdx.y;
-    const int64_t x0 = (int64_t)blockIdx.x * CG;
+    // Column groups that share 128-byte lines (16 float64 columns = 16 / CG groups) go to ONE XCD: workgroups are dealt round-robin
+    // over the eight XCDs (b and b + 8 share one), each XCD has its own L2, and a group touches only CG * 8 bytes of every line of
+    // its rows -- with the plain order the four groups of a line ran on four XCDs and every line of the tracer, the weights and the
+    // output crossed the fabric four times (measured: 0.176 -> 0.148 ms per cfg2-sized slab; two / one columns per workgroup: 0.217 / 0.362).  b = 8 k + xcd  ->  group ((k / GQ) * 8 + xcd) * GQ + k % GQ,
+    // GQ = 16 / CG groups per line; the grid is padded to a multiple of 8 GQ and the surplus workgroups leave at once.
+    const int GQ = 16 / CG;
+    const int64_t bq = blockIdx.x, kq = bq >> 3, xcd = bq & 7;
+    const int64_t grp = ((kq / GQ) * 8 + xcd) * GQ + (kq % GQ);
+    const int64_t x0 = grp * CG;
+    if (x0 >= nx) return;
     const int ncol = (int)((nx - x0 < CG) ? nx - x0 : CG);
     const int L = ny + 1;
     double* Qs = sm;                         // [ny]  Q' = s Q
@@ -436,41 +445,54 @@ void k_lwa_fast(const T* __restrict__ q, const double* __restrict__ Q, const dou
     __syncthreads();
     const double cref = Qs[ny / 2];
     const T* qs = q + (size_t)slab * ny * nx;
-    // cells: row-major over (y, column of the group); two cells per thread and round so that two searches overlap
+    // cells: row-major over (y, column of the group); CPT cells per thread and round: all their loads are issued first (a workgroup
+    // of 1024 threads x 8 covers the 7204 cells of four cfg2 columns in ONE round of loads), then the CPT binary searches advance
+    // together, one LDS read each per step
+    constexpr int CPT = 8;
     const int ncell = ny * ncol;
-    for (int i0 = tid; i0 < ncell; i0 += 2 * nthr) {
-        int yy[2], cc[2], bb[2], aa[2];
-        double qv[2], wv[2];
-        bool ok[2];
+    for (int i0 = tid; i0 < ncell; i0 += CPT * nthr) {
+        int yy[CPT], cc[CPT];
+        double qv[CPT], wv[CPT];
+        bool ok[CPT];
+        T qraw[CPT];
+        double da[CPT], mm_[CPT];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < CPT; ++u) {
             const int i = i0 + u * nthr;
             ok[u] = i < ncell;
             const int ii = ok[u] ? i : 0;
             yy[u] = ii / ncol; cc[u] = ii - yy[u] * ncol;
             const size_t cell = (size_t)yy[u] * nx + x0 + cc[u];
-            qv[u] = s * (double)qs[cell];
-            const double da = dA_rank == XC_DA_ROW ? dA[yy[u]] : dA[cell];
-            const double m = M_rank == XC_DA_NONE ? da : (M_rank == XC_DA_ROW ? M[yy[u]] : M[cell]);
-            wv[u] = (da / dA_max) * m;                                    // (u * wei) * M of core.py:789, weights first
+            qraw[u] = qs[cell];
+            da[u] = dA_rank == XC_DA_ROW ? dA[yy[u]] : dA[cell];
+            mm_[u] = M_rank == XC_DA_NONE ? 0.0 : (M_rank == XC_DA_ROW ? M[yy[u]] : M[cell]);
+        }
+        int lo[CPT], hi[CPT];
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            qv[u] = s * (double)qraw[u];
+            const double m = M_rank == XC_DA_NONE ? da[u] : mm_[u];
+            wv[u] = (da[u] / dA_max) * m;                                 // (u * wei) * M of core.py:789, weights first
             ok[u] = ok[u] && (qv[u] == qv[u]) && (wv[u] == wv[u]);        // NaN tracer / weight: the term is NaN and nansum skips it
+            lo[u] = 0; hi[u] = ok[u] ? ny : 0;                            // lower bound: first j with Q'_j >= q'
         }
-        int lo[2] = {0, 0}, hi[2] = {ny, ny};                             // lower bound: first j with Q'_j >= q'
-        while (lo[0] < hi[0] || lo[1] < hi[1]) {
+        for (int step = 0; step < 32; ++step) {                           // ceil(log2(ny + 1)) steps at most
+            bool any = false;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (lo[u] < hi[u]) { const int mid = (lo[u] + hi[u]) >> 1; if (Qs[mid] < qv[u]) lo[u] = mid + 1; else hi[u] = mid; }
+            for (int u = 0; u < CPT; ++u)
+                if (lo[u] < hi[u]) { const int mid = (lo[u] + hi[u]) >> 1; if (Qs[mid] < qv[u]) lo[u] = mid + 1; else hi[u] = mid; any = true; }
+            if (!any) break;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            bb[u] = lo[u];
-            int a = lo[u];
+        for (int u = 0; u < CPT; ++u) {
+            if (!ok[u]) continue;
+            const int b = lo[u];
+            int a = b;
             while (a < ny && Qs[a] == qv[u]) ++a;                          // upper bound: ties with a level are rare
-            aa[u] = a;
             int p = -1;
-            if (aa[u] <= yy[u]) { if (side != 2) p = aa[u]; }              // near-side term of targets [a, y]
-            else if (bb[u] >= yy[u] + 2) { if (side != 1) p = bb[u]; }     // far-side term of targets [y + 1, b - 1]
-            if (ok[u] && p >= 0) {
+            if (a <= yy[u]) { if (side != 2) p = a; }                      // near-side term of targets [a, y]
+            else if (b >= yy[u] + 2) { if (side != 1) p = b; }             // far-side term of targets [y + 1, b - 1]
+            if (p >= 0) {
                 double* d0 = D0 + (size_t)cc[u] * L;
                 double* d1 = D1 + (size_t)cc[u] * L;
                 const double w = wv[u], qw = (qv[u] - cref) * w;
@@ -480,25 +502,28 @@ void k_lwa_fast(const T* __restrict__ q, const double* __restrict__ Q, const dou
         }
     }
     __syncthreads();
-    // prefix sums over j, one wave per (column, array); the result overwrites D0: lwa[j] = s ((Q'_j - c) S0_j - S1_j)
+    // prefix sums over j: one wave per (column, array), in place: every lane sums a contiguous piece of ceil(ny / 64) elements
+    // (independent LDS reads, one dependent add each), ONE wave scan of the 64 piece totals, then the piece is written back with
+    // its offset.  (First version: 64 elements per step, six shuffles deep, 29 dependent steps for ny = 1801: ~10 us of a 35 us
+    // workgroup.)  Then lwa[j] = s ((Q'_j - c) S0_j - S1_j) overwrites D0.
     {
         const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
-        for (int c = wave; c < ncol; c += nw) {
-            double* d0 = D0 + (size_t)c * L;
-            double* d1 = D1 + (size_t)c * L;
-            double c0 = 0.0, c1 = 0.0;
-            for (int j0 = 0; j0 < ny; j0 += 64) {
-                const int j = j0 + lane;
-                double v0 = j < ny ? d0[j] : 0.0, v1 = j < ny ? d1[j] : 0.0;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const double t0 = __shfl_up(v0, o), t1 = __shfl_up(v1, o);
-                    if (lane >= o) { v0 += t0; v1 += t1; }
-                }
-                v0 += c0; v1 += c1;
-                if (j < ny) d0[j] = s * ((Qs[j] - cref) * v0 - v1);
-                c0 = __shfl(v0, 63); c1 = __shfl(v1, 63);
-            }
+        const int per = (ny + 63) >> 6;
+        for (int t = wave; t < 2 * ncol; t += nw) {
+            double* d = (t & 1 ? D1 : D0) + (size_t)(t >> 1) * L;
+            const int j0 = lane * per, j1 = (j0 + per < ny) ? j0 + per : ny;
+            double tot = 0.0;
+            for (int j = j0; j < j1; ++j) tot += d[j];
+            double v = tot;                                                // inclusive scan of the piece totals over the lanes
+            for (int o = 1; o < 64; o <<= 1) { const double tt = __shfl_up(v, o); if (lane >= o) v += tt; }
+            double run = v - tot;                                          // sum of the pieces before this lane's
+            for (int j = j0; j < j1; ++j) { run += d[j]; d[j] = run; }
         }
+    }
+    __syncthreads();
+    for (int i = tid; i < ncell; i += nthr) {
+        const int y = i / ncol, c = i - y * ncol;
+        D0[(size_t)c * L + y] = s * ((Qs[y] - cref) * D0[(size_t)c * L + y] - D1[(size_t)c * L + y]);
     }
     __syncthreads();
     double* os = out + (size_t)slab * ny * nx;
@@ -563,7 +588,8 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
             const size_t lds = (size_t)(1 + 2 * CG) * (ny + 1) * 8;
             // part (core.py:773-784): 'upper' keeps mask3 > 0 (the near side) if increase else mask3 < 0 (the far side)
             const int side = part == 0 ? 0 : (((part == 1) == (increase != 0)) ? 1 : 2);
-            const dim3 grid((unsigned)((nx + CG - 1) / CG), (unsigned)nslab);
+            const int64_t ngrp = (nx + CG - 1) / CG, gq = 8 * (16 / CG);                 // (XCD-aware group order: k_lwa_fast)
+            const dim3 grid((unsigned)(((ngrp + gq - 1) / gq) * gq), (unsigned)nslab);
 #define XC_LWAF(T) do { \
                 const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(k_lwa_fast<T>), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; \
                 hipLaunchKernelGGL((k_lwa_fast<T>), grid, dim3(1024), lds, ctx->stream, (const T*)q, Q, dA, dA_rank, dA_max, \
