@@ -112,7 +112,7 @@ __device__ __forceinline__ void load_pairs(const TQ* __restrict__ q, const TM* _
 struct PairSrc {                 // where pass 0 finds its input (per-slab strides applied by the kernels)
     const void* q; const void* mask; const double* dA;
     int dA_rank, negate; int64_t nx, mask_stride, dA_stride;
-    const double* mm;            // [nslab][2] min / max of the tracer (K1): the range-key passes only
+    const double* mm;            // [nslab][4] min, max, robust low, robust high of the tracer (K1 + k_range_bounds): the range-key passes only
     const unsigned* rtab;        // [nslab][2 * RANGE_NB] first range key and number of range keys of every coarse bin
 };
 
@@ -127,13 +127,27 @@ constexpr unsigned RANGE_INVALID = 0xFFFFFFu;
 constexpr int RANGE_NB = 256;
 constexpr int RANGE_SAMPLE = 16;       // k_range_hist looks at one 2048-cell chunk in 16: any positive widths give a monotone map, the
                                         // populations only have to be roughly right for the runs to come out short
-struct RangeMap { double lo, scale; const unsigned* tab; };      // tab: the slab's table, staged in LDS by the kernel
-__device__ __forceinline__ void range_lo_scale(const double* __restrict__ mm, int slab, int negate, double& lo, double& scale)
+// Three zones (round 4).  The 256 equalised coarse bins cover the ROBUST range [rlo, rhi] of the plane -- the 9th smallest of
+// the K1 block minima to the 9th largest of the block maxima (k_range_bounds) -- and the cells outside it (a handful: the block
+// extrema are extreme order statistics of the plane) get 2^16 keys each, linear over [min, rlo) and (rhi, max].  With the exact
+// min / max as the ends of the equalised range (round 3) ONE stray cell -- an unmasked fill value, a spike -- stretched the range,
+// the whole field fell into one coarse bin and the sort fell back to eight passes (0.95 ms against 0.38).  Monotone as before:
+// the zones are ordered, each map is monotone inside its zone.
+constexpr unsigned RANGE_WOUT = 65536u;                                   // keys of each outer zone
+constexpr unsigned RANGE_WIN = 16777215u - 2u * RANGE_WOUT;               // keys of the equalised inner zone: [WOUT, WOUT + WIN)
+struct RangeMap { double lo, scale, mn, s_lo, hi, s_hi; const unsigned* tab; };      // tab: the slab's table, staged in LDS by the kernel
+__device__ __forceinline__ void range_params(const double* __restrict__ mm, int slab, int negate, RangeMap& r)
 {
-    const double mn = mm[2 * slab], mx = mm[2 * slab + 1];
-    lo = negate ? -mx : mn;
-    const double hi = negate ? -mn : mx, w = hi - lo;
-    scale = (w > 0.0 && w < __longlong_as_double(0x7ff0000000000000LL)) ? (double)RANGE_NB / w : 0.0;   // constant / empty / infinite range: one bin
+    const double a = mm[4 * slab], b = mm[4 * slab + 1], c = mm[4 * slab + 2], d = mm[4 * slab + 3];    // min, max, robust low, robust high
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    r.mn = negate ? -b : a;
+    const double mx = negate ? -a : b;
+    r.lo = negate ? -d : c;
+    r.hi = negate ? -c : d;
+    const double w = r.hi - r.lo, wl = r.lo - r.mn, wh = mx - r.hi;
+    r.scale = (w > 0.0 && w < inf) ? (double)RANGE_NB / w : (w == 0.0 ? 1e300 : 0.0);   // constant robust range: strays still leave it (x = +-huge); empty / infinite range: one bin
+    r.s_lo = (wl > 0.0 && wl < inf) ? (double)RANGE_WOUT / wl : 0.0;
+    r.s_hi = (wh > 0.0 && wh < inf) ? (double)RANGE_WOUT / wh : 0.0;
 }
 __device__ __forceinline__ int range_bin(double v, double lo, double scale, double& x)
 {
@@ -145,7 +159,7 @@ __device__ __forceinline__ int range_bin(double v, double lo, double scale, doub
 __device__ __forceinline__ RangeMap range_map(const PairSrc& src, int slab, unsigned* s_tab)
 {
     RangeMap r;
-    range_lo_scale(src.mm, slab, src.negate, r.lo, r.scale);
+    range_params(src.mm, slab, src.negate, r);
     const unsigned* g = src.rtab + (size_t)slab * 2 * RANGE_NB;
     for (int i = threadIdx.x; i < 2 * RANGE_NB; i += blockDim.x) s_tab[i] = g[i];
     r.tab = s_tab;
@@ -155,18 +169,89 @@ template <typename K>
 __device__ __forceinline__ unsigned range_key(K key, const RangeMap& m)
 {
     if (key == KeyTraits<K>::invalid()) return RANGE_INVALID;
-    double x;
-    const int b = range_bin(KeyTraits<K>::decode(key), m.lo, m.scale, x);
+    const double v = KeyTraits<K>::decode(key);
+    // the zone follows from x = (v - rlo) * scale itself: x < 0 below the robust range, x > 256 above it (a value a rounding
+    // away from an end may stay inside: it then shares the end key, which keeps the map monotone); one compare on the hot path.
+    // A degenerate robust range (a constant field with strays) has scale = 1e300 (range_params): x is 0 or +-huge.
+    const double x = (v - m.lo) * m.scale;                              // NaN (inf - inf, 0 * inf) -> inner bin 0 below
+    const double xc = fmin(fmax(x, 0.0), (double)RANGE_NB);
+    const int b = (int)fmin(xc, (double)(RANGE_NB - 1));
     const unsigned first = m.tab[2 * b], width = m.tab[2 * b + 1];
-    const double f = fmin(fmax(x - (double)b, 0.0), 1.0) * (double)width;      // (clamped at the ends of the range)
+    const double f = fmin(xc - (double)b, 1.0) * (double)width;          // (x - b in [0, 1]; the last bin takes x = 256)
     const unsigned off = (unsigned)f;
-    return first + (off < width ? off : width - 1u);
+    unsigned k = first + (off < width ? off : width - 1u);
+    // a cell outside the robust range (x NaN: stays in bin 0).  The test is made WAVE-uniform so that it stays a branch: written
+    // per lane, the compiler predicates the two outer-zone maps into every key evaluation (+14 instructions per key and pass:
+    // measured +30 us on the 6.48 M-pair sort); a handful of waves per plane ever take it.
+    if (__ballot(xc != x) != 0ull) {
+        if (x < 0.0) k = (unsigned)fmin(fmax((v - m.mn) * m.s_lo, 0.0), (double)(RANGE_WOUT - 1u));
+        else if (x > (double)RANGE_NB) k = RANGE_WOUT + RANGE_WIN + (unsigned)fmin(fmax((v - m.hi) * m.s_hi, 0.0), (double)(RANGE_WOUT - 1u));
+    }
+    return k;
 }
 template <typename K, int MODE>
 __device__ __forceinline__ unsigned digit_of(K key, int shift, const RangeMap& m)
 {
     if (MODE == 0) return (unsigned)((key >> shift) & (K)255);
     return (range_key<K>(key, m) >> shift) & 255u;
+}
+
+// min, max and the ROBUST range of every plane from the per-block partials of K1 ([nslab][P][2]; a block = a contiguous piece
+// of the plane): consecutive blocks are folded into at most 512 groups, dealt round-robin to the eight waves of the workgroup;
+// every wave names its TWO smallest group minima and two largest group maxima (two rounds of a shuffle tree with retirement), and
+// the T-th smallest / largest of those 16 candidates (T = 9; fewer than 72 groups: an eighth of them, at least 1 = the exact
+// extrema) bounds the robust range: up to eight stray-holding groups are trimmed wherever they sit, and a candidate is never
+// below the true T-th smallest group minimum, so the handful of cells outside [rlo, rhi] only grows by a few groups' worth when
+// the extremes cluster in one wave's share.  (Exact selection by rank counting over all groups: 11-24 us per call; this: ~3.)
+// out: [nslab][4] = min, max, rlo, rhi (all-NaN plane: NaN).
+__global__ __launch_bounds__(512)
+void k_range_bounds(const double* __restrict__ part, int P, double* __restrict__ out)
+{
+    __shared__ double s_c[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* mp = part + (size_t)blockIdx.x * P * 2;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    const int per = (P + 511) / 512, ng = (P + per - 1) / per;           // groups of `per` consecutive blocks
+    const int g = lane * 8 + wave;                                       // group of this thread: round-robin over the waves
+    double a = inf, b = -inf;
+    if (g < ng)
+        for (int i = g * per; i < (g + 1) * per && i < P; ++i) { a = fmin(a, mp[2 * i]); b = fmax(b, mp[2 * i + 1]); }
+    for (int r = 0; r < 2; ++r) {
+        double lo = a, hi = b;
+        for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+        if (lane == 0) { s_c[0][wave * 2 + r] = lo; s_c[1][wave * 2 + r] = hi; }
+        const unsigned long long wa = __ballot(a == lo), wb = __ballot(b == hi);          // retire ONE holder of each extreme
+        if (wa && lane == __builtin_ctzll(wa)) a = inf;
+        if (wb && lane == __builtin_ctzll(wb)) b = -inf;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const double ca = s_c[0][tid], cb = s_c[1][tid];
+        int below = 0, above = 0;                                         // strict rank among the 16 candidates, index as the tie-break
+        for (int i = 0; i < 16; ++i) {
+            const double x = s_c[0][i], y = s_c[1][i];
+            below += (x < ca) || (x == ca && i < tid);
+            above += (y > cb) || (y == cb && i < tid);
+        }
+        const int T = ng >= 72 ? 9 : (ng / 8 > 0 ? ng / 8 : 1);
+        double* o = out + (size_t)blockIdx.x * 4;
+        if (below == 0) o[0] = ca;
+        if (above == 0) o[1] = cb;
+        if (below == T - 1) o[2] = ca;
+        if (above == T - 1) o[3] = cb;
+    }
+    __syncthreads();                                                      // (same workgroup: the stores above are visible to thread 0 below)
+    if (tid == 0) {
+        double* o = out + (size_t)blockIdx.x * 4;
+        double lo0 = o[0], hi0 = o[1], c = o[2], d = o[3];
+        if (lo0 == inf && hi0 == -inf) { lo0 = hi0 = c = d = __longlong_as_double(0x7ff8000000000000LL); }     // no valid cell
+        else {
+            if (!(c >= lo0) || c == inf || c == -inf) c = lo0;           // candidates without a valid cell carry +inf / -inf: fall back to the extrema
+            if (!(d <= hi0) || d == inf || d == -inf) d = hi0;
+            if (!(c <= d)) { c = lo0; d = hi0; }
+        }
+        o[0] = lo0; o[1] = hi0; o[2] = c; o[3] = d;
+    }
 }
 
 // population of the RANGE_NB coarse bins (valid cells only, the validity rule of load_pairs); hist zeroed by the caller
@@ -176,8 +261,9 @@ void k_range_hist(int64_t n, const PairSrc src, unsigned* __restrict__ hist)
 {
     __shared__ unsigned s_h[RANGE_NB];
     for (int i = threadIdx.x; i < RANGE_NB; i += 256) s_h[i] = 0;
-    double lo, scale;
-    range_lo_scale(src.mm, blockIdx.y, src.negate, lo, scale);
+    RangeMap rp;
+    range_params(src.mm, blockIdx.y, src.negate, rp);
+    const double lo = rp.lo, hi = rp.hi, scale = rp.scale;
     const TQ* q = (const TQ*)src.q + (size_t)blockIdx.y * n;
     const TM* mask = src.mask ? (const TM*)src.mask + (size_t)blockIdx.y * src.mask_stride : nullptr;
     __syncthreads();
@@ -196,7 +282,7 @@ void k_range_hist(int64_t n, const PairSrc src, unsigned* __restrict__ hist)
         for (int u = 0; u < U; ++u) {
             const int64_t i = (s0 + u) * 256 * samp + threadIdx.x;
             const double v = src.negate ? -(double)qv[u] : (double)qv[u];
-            if (s0 + u < nseg && i < n && v == v && (!mask || mv[u] == (TM)1)) { double x; atomicAdd(&s_h[range_bin(v, lo, scale, x)], 1u); }
+            if (s0 + u < nseg && i < n && v >= lo && v <= hi && (!mask || mv[u] == (TM)1)) { double x; atomicAdd(&s_h[range_bin(v, lo, scale, x)], 1u); }   // (the robust range only; NaN fails both compares)
         }
     }
     __syncthreads();
@@ -220,13 +306,13 @@ void k_range_table(const unsigned* __restrict__ hist, unsigned* __restrict__ rta
     __syncthreads();
     if (lane == 0) atomicAdd(&s_tot, t);
     __syncthreads();
-    const unsigned long long tot = s_tot, even = 8388608ull / RANGE_NB, budget = 16777215ull - even * RANGE_NB;
+    const unsigned long long tot = s_tot, even = (RANGE_WIN / 2u) / RANGE_NB, budget = (unsigned long long)RANGE_WIN - even * RANGE_NB;
     const unsigned width = (unsigned)even + (tot ? (unsigned)((unsigned long long)c * budget / tot) : 0u);
     unsigned x = width;                                                 // exclusive scan of the widths
     for (int o = 1; o < 64; o <<= 1) { const unsigned y = __shfl_up(x, o); if (lane >= o) x += y; }
     if (lane == 63) s_w[wave] = x;
     __syncthreads();
-    unsigned first = x - width;
+    unsigned first = RANGE_WOUT + x - width;                            // behind the lower outer zone
     for (int w = 0; w < wave; ++w) first += s_w[w];
     rtab[((size_t)blockIdx.x * RANGE_NB + b) * 2] = first;
     rtab[((size_t)blockIdx.x * RANGE_NB + b) * 2 + 1] = width;
@@ -268,7 +354,7 @@ void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = blockIdx.x;
     __shared__ unsigned s_rt[MODE == 1 ? 2 * RANGE_NB : 1];
-    RangeMap rm = {0.0, 0.0, nullptr};
+    RangeMap rm = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr};
     if (MODE == 1) rm = range_map(src, blockIdx.y, s_rt);
     keys += (size_t)blockIdx.y * n; hist += (size_t)blockIdx.y * 256 * ntiles;
     for (int i = lane; i < 256; i += 64) s_cnt[wave][i] = 0;
@@ -380,7 +466,7 @@ void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x;
     __shared__ unsigned s_rt[MODE == 1 ? 2 * RANGE_NB : 1];
-    RangeMap rm = {0.0, 0.0, nullptr};
+    RangeMap rm = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, nullptr};
     if (MODE == 1) { rm = range_map(src, blockIdx.y, s_rt); __syncthreads(); }
     { const size_t so = (size_t)blockIdx.y * n; kin += so; vin += so; kout += so; vout += so; }
     hist += (size_t)blockIdx.y * 256 * ntiles; totals += (size_t)blockIdx.y * 256;
@@ -780,7 +866,7 @@ size_t sort_workspace_bytes(int64_t n, int64_t nslab)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t S = (size_t)nslab;
     return 4 * al(S * n * 8) + al(S * 256 * ntiles * 4) + al(S * 256 * 4) + al(S * 4) + al(S * nb * 8) + al(S * BPE_BLOCKS * 8) +
-           al(S * kMinmaxBlocks * 2 * 8) + al(S * 2 * 8) + 256 + al(S * RANGE_NB * 4) + al(S * RANGE_NB * 8);
+           al(S * kMinmaxBlocks * 2 * 8) + al(S * 4 * 8) + 256 + al(S * RANGE_NB * 4) + al(S * RANGE_NB * 8);
 }
 
 template <typename TQ, typename K>
@@ -806,7 +892,7 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
     double* bsum = (double*)w; w += al(S * nb * 8);
     double* parts = (double*)w; w += al(S * BPE_BLOCKS * 8);
     double* mmpart = (double*)w; w += al(S * kMinmaxBlocks * 2 * 8);
-    double* mm = (double*)w; w += al(S * 2 * 8);
+    double* mm = (double*)w; w += al(S * 4 * 8);
     unsigned* flag = (unsigned*)w; w += 256;
     unsigned* rhist = (unsigned*)w; w += al(S * RANGE_NB * 4);
     unsigned* rtab = (unsigned*)w;
@@ -883,7 +969,7 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
             // ---- three passes over the 24-bit range key, then the short runs (see the head of this file)
             XC_TRY_(launch_minmax_partial(ctx, q, q_dtype, nslab, n, mmpart));
             XC_HIP(ctx, hipMemsetAsync(flag, 0, 256 + S * RANGE_NB * 4, ctx->stream));      // the flag and the coarse histogram behind it
-            XC_TRY_(launch_minmax_final(ctx, mmpart, nslab, minmax_blocks(n, nslab), mm));
+            hipLaunchKernelGGL(k_range_bounds, dim3(ns), dim3(512), 0, ctx->stream, mmpart, minmax_blocks(n, nslab), mm);
             {
                 const int64_t samp = n > (int64_t)256 * RANGE_SAMPLE * 64 ? RANGE_SAMPLE : 1;
                 int64_t hb = ((n + 256 * samp - 1) / (256 * samp) + 7) / 8;                  // eight 256-cell segments per block and round
