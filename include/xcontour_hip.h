@@ -248,9 +248,10 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
                     const double* targets, int J, const double* tbl, const double* coord, int ntbl,
                     double* out_Q, double* out_qsorted, double* out_acum, uint32_t* out_nvalid, double* out_bpe);
 
-/* float64 tracers take a three-pass path: a stable LSD sort on a 24-bit RANGE key -- a monotone, piecewise-linear map of
- * (q - min) / (max - min) onto [0, 2^24 - 2] that gives densely populated parts of the range more keys (sampled histogram
- * equalisation) -- then a repair pass that puts every run of equal range key into exact order (stable rank inside the run, in
+/* float64 tracers take a three-pass path: a stable LSD sort on a 24-bit RANGE key -- a monotone, piecewise-linear map of the
+ * value range onto [0, 2^24 - 2] that gives densely populated parts of the range more keys (sampled histogram equalisation over
+ * the plane's ROBUST range, the 9th smallest / largest of its block extrema; the few cells outside it -- a stray fill value -- get
+ * 2^16 linear keys on either side instead of stretching the range) -- then a repair pass that puts every run of equal range key into exact order (stable rank inside the run, in
  * LDS) and proves the result sorted; its flag is read back -- the ONE host round trip these calls (also the _dev ones) make;
  * a stack that fails it (more than 128 distinct values inside one range key) is sorted again with the eight key passes.  The result is the same stable sort either way.  xc_last_sort_path: 0 = key passes only (float32
  * tracers, or XC_SORT_RANGE=0 in the environment at xc_create), 1 = range-key path, 2 = range-key path failed the check. */
