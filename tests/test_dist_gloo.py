@@ -287,3 +287,65 @@ def test_socket_group_rejects_strangers_and_bad_ranks():
     t.join(timeout=30)
     assert res['parts'] == [b'zero', b'one']
     assert 'pickle' not in _imports_of(os.path.join(ROOT, 'xcontour_amd', 'distributed.py'))
+
+
+# ---------------------------------------------------------------- SocketGroup.init_device: every rank learns every rank's verdict
+class _FakeCtx(object):
+    """stands in for a device context: the unique id is 128 bytes, comm_init fails on the ranks named in `bad`"""
+
+    def __init__(self, rank, bad):
+        self.rank, self.bad, self.inited, self.finalized = rank, bad, None, False
+
+    def comm_unique_id(self):
+        if 'id' in self.bad:
+            raise RuntimeError('cannot load librccl')
+        return bytes(range(128))
+
+    def comm_init(self, world, rank, uid):
+        assert len(uid) == 128 and uid == bytes(range(128)) and rank == self.rank
+        if rank in self.bad:
+            raise RuntimeError('ncclCommInitRank: invalid usage (duplicate GPU)')
+        self.inited = (world, rank)
+
+    def comm_finalize(self):
+        self.finalized = True
+
+
+def _init_device_worker(rank, world, port, bad, q):
+    sys.path.insert(0, ROOT)
+    from xcontour_amd.distributed import SocketGroup
+    g = SocketGroup(rank, world, '127.0.0.1', port, token='t')
+    ctx = _FakeCtx(rank, bad)
+    try:
+        g.init_device(ctx)
+        out = ('ok', ctx.inited)
+    except Exception as e:
+        out = ('error', str(e), ctx.finalized)
+    g.barrier()                                   # the group is still usable after a failed device init (the host carrier takes over)
+    q.put((rank, out))
+    g.close()
+
+
+@pytest.mark.parametrize('bad', [(), (1,), (0, 2), ('id',)])
+def test_init_device_reaches_a_consensus(bad):
+    """the RCCL communicator either exists on EVERY rank or on none: a rank whose ncclCommInitRank fails (or rank 0 that cannot
+    create the id) makes every rank raise the same error -- nobody waits in a collective that will never complete -- and the
+    sockets stay usable for the host carrier bench.py falls back to"""
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_init_device_worker, args=(r, world, port, tuple(bad), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if not bad:
+        assert all(got[r] == ('ok', (world, r)) for r in range(world))
+    else:
+        assert all(got[r][0] == 'error' and got[r][2] for r in range(world))            # everyone raised, everyone finalised
+        msgs = set(got[r][1] for r in range(world))
+        assert len(msgs) == 1                                                            # the same verdict everywhere
+        assert ('librccl' in got[0][1]) if 'id' in bad else all(('rank %d' % b) in got[0][1] for b in bad)
