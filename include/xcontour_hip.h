@@ -319,7 +319,7 @@ typedef struct xc_keff_desc {
     double        lmin_scale;   /* 2*pi*R: Lmin = lmin_scale*cos(deg2rad(latEq))            */
     double*       ctr;          double* area;   double* intgrdS; double* latEq;
     double*       dqdA;         double* dintSdA; double* Leq2;   double* Lmin;  double* nkeff;
-    uint64_t*     counts;       /* uint64[nslab][N] */
+    uint64_t*     counts;       /* uint64[nslab][N]; NULL: not wanted -- the histogram pass then skips the count adds (a third of its LDS atomics) */
     double*       interp;       /* double[nslab][9][npre]: ctr, area, intgrdS, latEq, dintSdA, dqdA, Leq2, Lmin, nkeff on preY */
     int32_t*      status;       /* int32[nslab] 0 ok, 1 degenerate levels ('non monotonic bins', core.py:1233) */
     const void*   q_next;       /* optional: the batch the NEXT xc_keff_dev call will process (same dtype and

@@ -424,3 +424,39 @@ def test_lwa_interval_kernel_premises_and_stacks(ctx):
     small = _lwa_case(rng, 256, 128, np.float64, True, True, False)
     g2, _ = ctx.lwa(small[1][None], small[2][None], small[0], small[3], float(small[3].max()))
     assert ctx.last_lwa_path() == 0 and np.array_equal(g2[0], O.cal_local_wave_activity(small[1], small[2], small[0], small[3], True, 'all'))
+
+
+def test_keff_without_counts_gives_the_same_vectors(ctx):
+    """KeffPlan(counts=False) / xc_keff_desc.counts = NULL: the histogram pass skips the count adds (the reference's Keff
+    sequence never looks at counts; Contour2D.keff runs this way) -- the nine vectors are the same bits with deterministic
+    sums, float32 (E32) and float64, chained and not; xc_hist without 'counts' likewise"""
+    from xcontour_amd.pipeline import KeffPlan, OUT_NAMES
+    from xcontour_amd.utils import cell_area, table_from_rowsums
+    ny, nx, N, S = 91, 1280, 61, 4
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * (360.0 / nx)
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(dA.sum(1), True)
+    for dt in (np.float64, np.float32):
+        kw = dict(dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, deterministic=True, nslots=2)
+        a = KeffPlan(ctx, S, ny, nx, N, dt, dt, **kw)
+        a.synth(lat, lon, 3, 0)
+        b = KeffPlan(ctx, S, ny, nx, N, dt, dt, alloc_q=False, counts=False, **kw)
+        b.set_q_device(a._q_ptr)
+        for slot, (group, chain) in enumerate(((None, False), (2, True))):
+            a.run(slot, group, chain=chain); b.run(slot, group, chain=chain)
+            ra, rb = a.fetch(slot=slot), b.fetch(slot=slot)
+            for k in OUT_NAMES:
+                assert np.array_equal(bits(ra[k]), bits(rb[k])), (k, dt, chain)
+        q = a.download_q()
+        r = O.keff_pipeline(q[1], dA, lat, N, lon=lon, increase=True, lt=True, dtype=dt)
+        assert np.array_equal(ra['counts'][1].astype(np.int64), r['counts']) and rel(rb['area'][1], r['area']) < TIGHT
+        a.free(); b.free()
+    rng = np.random.default_rng(2)
+    qh = rng.standard_normal((2, 40, 130))
+    ed = np.linspace(-4, 4, 33)
+    w = rng.random((40, 130))
+    full = ctx.hist(qh, ed, dA=w, want=('pdf', 'cdf', 'counts'), deterministic=True)
+    part = ctx.hist(qh, ed, dA=w, want=('pdf', 'cdf'), deterministic=True)
+    assert np.array_equal(bits(full['pdf']), bits(part['pdf'])) and np.array_equal(bits(full['cdf']), bits(part['cdf']))
+    plain = ctx.hist(qh, ed, dA=w, want=('cdf',))
+    assert rel(plain['cdf'], full['cdf']) < 1e-13

@@ -833,7 +833,8 @@ class Contour2D(object):
                             increase=self.increase, lt=self.lt, right_edge=self.right_edge,
                             nkeff_mask=nkeff_mask, grdS_dtype=None if g is None else g.dtype,
                             prod_f32=bool(g is not None and g.dtype == np.float32 and dA_f32),
-                            detect_row_dA=not slab_dA, deterministic=self.deterministic, out_slabs=batch, nslots=nbuf)
+                            detect_row_dA=not slab_dA, deterministic=self.deterministic, out_slabs=batch, nslots=nbuf,
+                            counts=False)                      # (Keff never looks at the cell counts: a third of K3's LDS atomics saved)
         if slab_dA:
             plan.desc.dA_pos_finite = int(bool(np.isfinite(dA).all() and (dA >= 0).all()))
         ctx = self.ctx

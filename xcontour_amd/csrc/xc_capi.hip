@@ -580,7 +580,7 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     a.prod_f32 = d->prod_f32;
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
-    a.part_h = (double*)ctx->scratch; a.part_c = (unsigned*)((char*)ctx->scratch + ph);
+    a.part_h = (double*)ctx->scratch; a.part_c = (d->counts || d->deterministic) ? (unsigned*)((char*)ctx->scratch + ph) : nullptr;   // (no counts wanted: no count adds)
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = a.part_h; f.part_c = a.part_c; f.bps = g.bps; f.nch = nch; f.nbin = nbin;
     f.red_h = (double*)((char*)ctx->scratch + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + ph + pc + rh);
@@ -1011,6 +1011,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     a.prod_f32 = d->prod_f32;
     a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
     a.ny = d->ny; a.nx = d->nx; a.nstrip = g.nstrip; a.ncopy = g.ncopy;
+    if (!d->counts && !det) part_c = nullptr;            // nobody asked for counts: the histogram pass skips their LDS adds (a third of its atomics)
     a.part_h = part_h; a.part_c = part_c; a.ctr_out = d->ctr; a.ctr_stride = vstride; a.status = d->status;
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = part_h; f.part_c = part_c; f.bps = g.bps; f.nch = nch; f.nbin = N;

@@ -291,6 +291,7 @@ void k_hist(const HistArgs a)
         uni = !__syncthreads_or(bad);
     }
     const int negate = a.negate;
+    const bool want_cnt = DET != 0 || a.part_c != nullptr;         // counts are an OUTPUT only: the float64-atomics pass skips their adds when none is wanted
     const bool wpos = FAST ? true : (a.dA_pos_finite != 0);
     if (DET == 2) {
         const int* sc = a.det_scale + (size_t)slab * NCH * N;                     // [NCH][N], written by k_det_scales
@@ -313,7 +314,7 @@ void k_hist(const HistArgs a)
             double* cp = s_cell + (unsigned)(cur * ncopy + copy) * (unsigned)CW;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) lds_add(cp + c, acc[c]);
-            lds_add(reinterpret_cast<unsigned*>(cp + NCH), cnt);
+            if (want_cnt) lds_add(reinterpret_cast<unsigned*>(cp + NCH), cnt);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[c] = 0.0;
@@ -421,7 +422,7 @@ void k_hist(const HistArgs a)
                 if (DET == 0) {
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) lds_add(cp + ch, w[ch][c]);
-                    lds_add(reinterpret_cast<unsigned*>(cp + NCH), 1u);
+                    if (want_cnt) lds_add(reinterpret_cast<unsigned*>(cp + NCH), 1u);       // (wave-uniform: a third of the LDS atomics when nobody asked for counts)
                 } else if (DET == 1) {
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch)
@@ -517,7 +518,7 @@ void k_hist(const HistArgs a)
         }
     }
     unsigned* pc = a.part_c + pb * N;
-    if (DET != 2)                                     // the fixed-point pass takes the counts of the max pass
+    if (DET != 2 && a.part_c)                                     // the fixed-point pass takes the counts of the max pass
     for (int b = tid; b < N; b += blockDim.x) {
         unsigned sum = 0u;
         for (int c = 0; c < ncopy; ++c)

@@ -230,7 +230,7 @@ void k_reduce_partials(const double* __restrict__ part_h, const unsigned* __rest
         for (int b = l; b < bps; b += 32) sum += p[(size_t)b * nvh];
         for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         if (l == 0) red_h[(size_t)slab * nvh + v] = sum;
-    } else if (v < nvh + nbin) {
+    } else if (part_c && v < nvh + nbin) {
         const int k = v - nvh;
         const unsigned* p = part_c + (size_t)slab * bps * nbin + k;
         unsigned long long sum = 0;

@@ -38,7 +38,7 @@ class KeffPlan(object):
                  tbl=None, tbl_coord=None, preY=None, increase=True, lt=True,
                  right_edge='xhistogram', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
                  prod_f32=False, alloc_q=True, nslots=1, out_ptr=None, detect_row_dA=False,
-                 out_slabs=None, replicate_dA=False, deterministic=False, slab_major=False):
+                 out_slabs=None, replicate_dA=False, deterministic=False, slab_major=False, counts=True):
         """dA: None | (ny,) | (ny,nx) | (nslab,ny,nx) f64 (the last: weights that change with the leading
         (time, level) index, which the reference allows -- core.py:1271-1274).  Gradient metrics either `rdx, rdy`
         (per-row reciprocals) or derived from `lat, lon` (sphere).  If
@@ -54,6 +54,8 @@ class KeffPlan(object):
         `slab_major`: lay the nine result vectors of a slot out as ONE [out_slabs][9][N] block (pipeline.OUT_NAMES order,
         xc_keff_desc.out_stride = 9 N) instead of nine [out_slabs][N] arrays: the head of the slot IS the block a rank hands to
         the one gather at the end of a job, no repacking pass; `head_bytes` is its size.
+        `counts=False`: the per-bin cell counts are not wanted (the reference's Keff sequence never looks at them): the histogram
+        pass then skips their LDS adds -- a third of its atomics; `fetch()['counts']` is meaningless.
         `deterministic`: order-free fixed-point sums (xc_keff_desc.deterministic): area / intgrdS and everything derived
         from them are bit-identical between runs, launch-set sizes and ranks, chained (q_next) or not."""
         self.ctx = ctx
@@ -136,6 +138,7 @@ class KeffPlan(object):
         # (out_slabs < nslab: the tracer buffer holds several batches, a slot one batch)
         self.out_slabs = self.nslab if out_slabs is None else int(out_slabs)
         self.slab_major = bool(slab_major)
+        self.want_counts = bool(counts)
         nN = self.out_slabs * self.N
         self._off = {}
         off = 0
@@ -175,7 +178,7 @@ class KeffPlan(object):
         base = self.out_ptr + slot * self.slot_bytes
         for name in OUT_NAMES:
             setattr(d, name, base + self._off[name] + o0 * self._vstep)
-        d.counts = base + self._off['counts'] + o0 * self.N * 8
+        d.counts = (base + self._off['counts'] + o0 * self.N * 8) if self.want_counts else None
         d.interp = (base + self._off['interp'] + o0 * 9 * self.npre * 8) if self.npre else None
         d.status = base + self._off['status'] + o0 * 4
         d.nslab = n
