@@ -33,6 +33,24 @@ m = lb.merge([w, w.rename('other')], w)
 assert isinstance(m, xr.Dataset) and sorted(m) == ['ctr', 'other']
 mine = lb.wrap(np.arange(3.0), ('contour',), {'contour': np.arange(3.0)}, 'ctr', xa.DataArray(q0, ('latitude', 'longitude'), c2))
 assert isinstance(mine, xa.DataArray) and isinstance(lb.merge([mine], mine), xa.Dataset)
+# a dask-like (lazy) array behind an xarray object stays lazy all the way into the facade's plumbing
+class _Lazy(object):
+    def __init__(self, a):
+        self.a, self.shape, self.dtype, self.reads = a, a.shape, a.dtype, 0
+
+    def __getitem__(self, k):
+        self.reads += 1
+        return self.a[k]
+
+
+lz = _Lazy(np.stack([q0, 2 * q0]))
+xl = xr.DataArray(lz, coords=dict(c2, time=np.arange(2)), dims=('time', 'latitude', 'longitude'), name='pv')
+raw, d_, c_, n_ = lb.unwrap(xl, lazy=True)
+assert raw is lz and d_ == ('time', 'latitude', 'longitude') and n_ == 'pv' and lz.reads == 0
+cm = xa.Contour2D(xl, xr.DataArray(np.ones_like(q0), coords=c2, dims=('latitude', 'longitude')), dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'})
+st, lead, lshape, _ = cm._plane(cm.tracer)
+assert isinstance(st, lb.LazyStack) and st.shape == (2,) + q0.shape and lead == ('time',) and lz.reads == 0
+assert np.array_equal(st[1], 2 * q0) and lz.reads == 1
 if sys.argv[1] == 'cpu':
     print('ok cpu')
     sys.exit(0)
