@@ -185,7 +185,7 @@ int xc_create(int device_id, xc_ctx** out)
         k.threads = env_int("XC_HIST_THREADS", 0); k.ncopy = env_int("XC_HIST_NCOPY", 0); k.rows = env_int("XC_HIST_ROWS", 0);
         k.bps = env_int("XC_HIST_BPS", 0);
         k.cross_ncopy = env_int("XC_CROSS_NCOPY", 0); k.cross_blocks = env_int("XC_CROSS_BLOCKS", 0);
-        k.sort_range = env_int("XC_SORT_RANGE", 1); k.lwa_fast = env_int("XC_LWA_FAST", 1); k.lwa_strip = env_int("XC_LWA_STRIP", 1);
+        k.sort_range = env_int("XC_SORT_RANGE", 1); k.lwa_fast = env_int("XC_LWA_FAST", 1); k.k1_nt = env_int("XC_K1_NT", 0); k.lwa_strip = env_int("XC_LWA_STRIP", 1);
     }
     ctx->cus = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {

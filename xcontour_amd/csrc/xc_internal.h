@@ -21,6 +21,7 @@ struct HistKnobs {
     int rows = 0;        // XC_HIST_ROWS     (strip, row) pairs per wave
     int bps = 0;         // XC_HIST_BPS      blocks per slab
     int cross_ncopy = 0, cross_blocks = 0;   // XC_CROSS_NCOPY, XC_CROSS_BLOCKS (K9)
+    int k1_nt = 0;       // XC_K1_NT         K1: 1 forces the non-temporal loads also for launches that fit the Infinity Cache
     int lwa_fast = 1;    // XC_LWA_FAST      K7: the O(ny log ny) interval kernel for planes of more than 512 rows (0: never, 2: for every plane)
     int lwa_strip = 1;   // XC_LWA_STRIP     K7: the one-launch kernel with the strip in LDS where it fits (0: always prep + streaming kernel)
     int sort_range = 1;  // XC_SORT_RANGE    K8: three range-key passes + short-run repair for float64 tracers (0: always eight passes)

@@ -40,7 +40,9 @@ __device__ __forceinline__ void mmv(double& mn, double& mx, const float4& v)
     mn = fmin(mn, (double)lo); mx = fmax(mx, (double)hi);
 }
 
-template <typename T>
+// NT: the streaming hint (a pass over more bytes than the 256 MiB Infinity Cache holds: nothing read here is read again before it would be
+// evicted anyway).  Without it -- a launch of a few slabs -- the tracer stays in the Infinity Cache for the histogram pass that follows.
+template <typename T, bool NT>
 __global__ __launch_bounds__(256)
 void k_minmax_partial(const T* __restrict__ q, int64_t ncell, double* __restrict__ part)
 {
@@ -62,11 +64,11 @@ void k_minmax_partial(const T* __restrict__ q, int64_t ncell, double* __restrict
     for (; i + 7 * 256 < v1; i += 8 * 256) {
         V a[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = ld16_nt<T>(qv + i + u * 256);
+        for (int u = 0; u < 8; ++u) a[u] = NT ? ld16_nt<T>(qv + i + u * 256) : qv[i + u * 256];
 #pragma unroll
         for (int u = 0; u < 8; ++u) mmv(mn, mx, a[u]);
     }
-    for (; i < v1; i += 256) { const V a0 = ld16_nt<T>(qv + i); mmv(mn, mx, a0); }
+    for (; i < v1; i += 256) { const V a0 = NT ? ld16_nt<T>(qv + i) : qv[i]; mmv(mn, mx, a0); }
     if (b == 0) {
         for (int64_t j = tid; j < head; j += 256) mm(mn, mx, (double)qs[j]);
         for (int64_t j = head + nvec * VN + tid; j < ncell; j += 256) mm(mn, mx, (double)qs[j]);
@@ -519,10 +521,14 @@ int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab
     if (!q || !part || nslab < 1 || ncell < 1) return fail(ctx, XC_EBADARG, "xc_minmax: bad arguments");
     if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_minmax: at most 65535 slabs per launch");
     dim3 grid((unsigned)minmax_blocks(ncell, nslab), (unsigned)nslab);      // partials: [nslab][minmax_blocks(ncell, nslab)][2]
-    if (q_dtype == XC_F64)
-        hipLaunchKernelGGL(k_minmax_partial<double>, grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part);
-    else if (q_dtype == XC_F32)
-        hipLaunchKernelGGL(k_minmax_partial<float>, grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part);
+    const bool nt = (double)nslab * (double)ncell * (q_dtype == XC_F64 ? 8.0 : 4.0) > 128.0 * 1048576.0 || ctx->knobs.k1_nt > 0;
+    if (q_dtype == XC_F64) {
+        if (nt) hipLaunchKernelGGL((k_minmax_partial<double, true>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part);
+        else hipLaunchKernelGGL((k_minmax_partial<double, false>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part);
+    } else if (q_dtype == XC_F32) {
+        if (nt) hipLaunchKernelGGL((k_minmax_partial<float, true>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part);
+        else hipLaunchKernelGGL((k_minmax_partial<float, false>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part);
+    }
     else return fail(ctx, XC_EBADARG, "xc_minmax: q_dtype must be XC_F32 or XC_F64");
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
