@@ -18,7 +18,9 @@ static int fail(const char* what, xc_ctx* ctx) { fprintf(stderr, "FAIL %s: %s\n"
 int main(void)
 {
     xc_ctx* ctx = NULL;
+    { int ndev = -1; if (xc_device_count(&ndev) != XC_OK || ndev < 1) { fprintf(stderr, "FAIL xc_device_count: %d\n", ndev); return 1; } }
     if (xc_create(0, &ctx) != XC_OK) return fail("xc_create", NULL);
+    { int path = -1; if (xc_set_lwa_exact(ctx, 0) != XC_OK || xc_last_lwa_path(ctx, &path) != XC_OK || path != 0) { fprintf(stderr, "FAIL lwa mode calls\n"); return 1; } }
     static float q[2][NY][NX];
     static double dA[NY][NX];
     uint64_t s = 88172645463325252ull;
