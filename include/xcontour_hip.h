@@ -224,7 +224,9 @@ int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const doubl
  * flag the kernels gate themselves on: no host round trip, the _dev form stays asynchronous); if they fail the band walk
  * enqueued behind the interval kernel runs instead.  Same sums in
  * another order: agreement with the band walk ~1e-13 of the column's largest value (tests 1e-9), not bit for bit.
- * xc_set_lwa_exact(ctx, 1) keeps the bit-exact band walk for every plane.  xc_last_lwa_path: 0 band walk, 1 interval
+ * xc_set_lwa_exact(ctx, mode): 0 automatic (above), 1 the bit-exact band walk for every plane, 2 the interval kernel for every plane
+ * (checked on the device), 3 the same with the premises vouched for by the caller -- it has looked at Q and the coordinate on the
+ * host: one launch, no check (a plane of 256 x 512: 15.8 us for the band walk, see DESIGN.md for the interval kernel).  xc_last_lwa_path: 0 band walk, 1 interval
  * kernel, 2 its premises failed the check (waits for the call when the device decided). */
 int xc_set_lwa_exact(xc_ctx* ctx, int exact);
 int xc_last_lwa_path(xc_ctx* ctx, int* out_path);

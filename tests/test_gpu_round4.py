@@ -422,8 +422,14 @@ def test_lwa_interval_kernel_premises_and_stacks(ctx):
         assert np.abs(got[s] - ref).max() <= 1e-11 * np.abs(ref).max()
         assert np.array_equal(masks[s, 0], mref[0]) and np.array_equal(masks[s, 1], mref[1])
     small = _lwa_case(rng, 256, 128, np.float64, True, True, False)
+    sref = O.cal_local_wave_activity(small[1], small[2], small[0], small[3], True, 'all')
     g2, _ = ctx.lwa(small[1][None], small[2][None], small[0], small[3], float(small[3].max()))
-    assert ctx.last_lwa_path() == 0 and np.array_equal(g2[0], O.cal_local_wave_activity(small[1], small[2], small[0], small[3], True, 'all'))
+    assert ctx.last_lwa_path() == 0 and np.array_equal(g2[0], sref)
+    # exact=False: the premises are checked on the host and vouched for -- ONE launch of the interval kernel, any plane size
+    g3, _ = ctx.lwa(small[1][None], small[2][None], small[0], small[3], float(small[3].max()), exact=False)
+    assert ctx.last_lwa_path() == 1 and np.abs(g3[0] - sref).max() <= 1e-11 * np.abs(sref).max() and not np.array_equal(g3[0], sref)
+    g4, _ = ctx.lwa(q[None], Qbad[None], lat, dA, float(dA.max()), exact=False)            # not monotone: the host check sends it to the band walk
+    assert ctx.last_lwa_path() == 0 and np.array_equal(g4[0], O.cal_local_wave_activity(q, Qbad, lat, dA, True, 'all'))
 
 
 def test_keff_without_counts_gives_the_same_vectors(ctx):

@@ -116,6 +116,15 @@ def cmd_lwa(ctx, T):
         ref = O.cal_local_wave_activity(q, L['Q'], lat, dA, True, 'all', metric=L['dy'])
         emit(kernel='K7 lwa', config='cfg3 barotropic 256x512 f32, J = 256', slabs=S, us_per_call=ms * 1e3, us_per_slab=ms / S * 1e3,
              cell_rows_per_s=S * 256 * 256 * 512 / ms * 1e3, bit_identical_to_oracle=bool(all(np.array_equal(got[s], ref) for s in range(S))))
+        if S == 1:
+            # the same plane through the interval kernel with its premises vouched for (mode 3: what `exact=False` does after looking
+            # at Q on the host): one launch
+            ctx._check(ctx.lib.xc_set_lwa_exact(ctx.handle, 3))
+            ms3 = T.ms(fn, reps=20, warm=3)
+            got3 = out.download((S, 256, 512), np.float64)
+            ctx._check(ctx.lib.xc_set_lwa_exact(ctx.handle, 0))
+            emit(kernel='K7 lwa', config='cfg3 barotropic 256x512 f32, J = 256, interval kernel (exact=False)', slabs=S, us_per_call=ms3 * 1e3,
+                 max_err_over_max_value=float(np.abs(got3[0] - ref).max() / np.abs(ref).max()))
         for b in (dq, dQ, out):
             b.free()
     # one cfg2-sized slab, all J = 1801 target rows; six rows spot-checked bit for bit against the formula (core.py:752-789)

@@ -636,7 +636,7 @@ class Contour2D(object):
         return re if isiterable else re[0]
 
     # ------------------------------------------------------------------ local wave activity
-    def cal_local_wave_activity(self, q, Q, mask_idx=None, part='all', metric=None, exact=False):
+    def cal_local_wave_activity(self, q, Q, mask_idx=None, part='all', metric=None, exact=None):
         """
         Local finite-amplitude wave activity density (reference core.py:696-799;
         Huang and Nakamura 2016).  The J-iteration python loop of the reference is one
@@ -644,7 +644,7 @@ class Contour2D(object):
         1-D length metric (e.g. dy) for the legacy grid.get_metric form (core.py:787-788).
         Planes of up to 512 rows are summed in numpy's own order (bit-identical to the reference's nansum); larger ones take
         an O(ny log ny)-per-column path that needs a monotone Q (checked; else the exact walk runs) and agrees to ~1e-13;
-        `exact=True` keeps the bit-exact walk everywhere.
+        `exact=True` keeps the bit-exact walk everywhere, `exact=False` takes the interval path for every plane with a monotone Q.
         """
         return self._lwa(q, Q, mask_idx, part, metric, 'LWA', exact=exact)
 
@@ -653,11 +653,11 @@ class Contour2D(object):
         with the opposite sign convention; same GPU kernel family."""
         return self._lwa(q, Q, mask_idx, part, metric, 'LWA', variant=1)
 
-    def cal_local_APE(self, q, Q, mask_idx=None, part='all', metric=None, exact=False):
+    def cal_local_APE(self, q, Q, mask_idx=None, part='all', metric=None, exact=None):
         """Local available potential energy density (reference core.py:908-942)."""
         return self._lwa(q, Q, mask_idx, part, metric, 'LAPE', exact=exact)
 
-    def _lwa(self, q, Q, mask_idx, part, metric, name, variant=0, exact=False):
+    def _lwa(self, q, Q, mask_idx, part, metric, name, variant=0, exact=None):
         part = part.lower()
         if part not in ['all', 'upper', 'lower']:
             raise Exception('invalid part, should be in [\'all\', \'upper\', \'lower\']')

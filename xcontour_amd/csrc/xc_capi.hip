@@ -857,7 +857,8 @@ int xc_sort_profile(xc_ctx* ctx, const void* q, int q_dtype, const void* mask, i
 int xc_set_lwa_exact(xc_ctx* ctx, int exact)
 {
     if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
-    ctx->lwa_exact = exact ? 1 : 0;
+    if (exact < 0 || exact > 3) return fail(ctx, XC_EBADARG, "xc_set_lwa_exact: mode must be 0 (automatic), 1 (band walk), 2 (interval kernel, checked) or 3 (interval kernel, premises vouched for)");
+    ctx->lwa_exact = exact;
     return XC_OK;
 }
 

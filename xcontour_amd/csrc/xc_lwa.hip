@@ -420,7 +420,7 @@ void k_lwa_fast(const T* __restrict__ q, const double* __restrict__ Q, const dou
                 const double* __restrict__ M, int M_rank, int ny, int64_t nx, int increase, int side, int CG,
                 double* __restrict__ out, const unsigned* __restrict__ gate, unsigned epoch)
 {
-    if (*gate == epoch) return;                  // k_lwa_check found a premise broken: the band walk enqueued behind this kernel runs instead
+    if (gate && *gate == epoch) return;          // k_lwa_check found a premise broken: the band walk enqueued behind this kernel runs instead (gate NULL: the caller vouches)
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x, nthr = blockDim.x, slab = blockIdx.y;
     // Column groups that share 128-byte lines (16 float64 columns = 16 / CG groups) go to ONE XCD: workgroups are dealt round-robin
@@ -571,20 +571,24 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     const unsigned* gate = nullptr;          // set: the exact kernels below run only if the device-side check FAILED
     unsigned epoch = 0;
     ctx->last_lwa_path = 0;
-    if (variant == 0 && !ctx->lwa_exact && ctx->knobs.lwa_fast && (ny > kLwaFastMinRows || ctx->knobs.lwa_fast > 1) && nx <= 0x7fffffff) {
-        // ---- large planes: the O(ny log ny) interval kernel, gated ON THE DEVICE by the check of its premises -- no host round
-        // trip (a stream synchronise in the middle of the call cost ~1 ms of host latency against 0.16 ms of kernel): the check
-        // writes a flag, the interval kernel returns at once if it is set, the band walk enqueued behind it returns at once if
-        // it is not (two empty launches, a few microseconds)
+    // ctx->lwa_exact (xc_set_lwa_exact): 0 automatic (planes of more than kLwaFastMinRows rows take the interval kernel behind its
+    // device-side check), 1 the band walk everywhere, 2 the interval kernel for every plane (checked), 3 the same with the premises
+    // vouched for by the caller (it looked at Q and the coordinate on the host): ONE launch, no check, no gated band walk behind it
+    const int mode = ctx->lwa_exact;
+    const bool want_fast = mode >= 2 || (mode == 0 && ctx->knobs.lwa_fast && (ny > kLwaFastMinRows || ctx->knobs.lwa_fast > 1));
+    if (variant == 0 && want_fast && nx <= 0x7fffffff) {
         int CG = 0;
         for (int c : {4, 2, 1})
             if (!CG && (size_t)(1 + 2 * c) * (ny + 1) * 8 <= kLdsBudget) CG = c;
         if (CG) {
-            if (!ctx->lwa_flag) { XC_HIP(ctx, hipMalloc((void**)&ctx->lwa_flag, 256)); XC_HIP(ctx, hipMemset(ctx->lwa_flag, 0, 256)); ctx->lwa_epoch = 0; }
-            unsigned* flag = ctx->lwa_flag;
-            epoch = ++ctx->lwa_epoch;            // a failed check stamps the word with its call's epoch: no memset per call
-            hipLaunchKernelGGL(k_lwa_check, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, Q, coord, (int)ny, increase, flag, epoch);
-            XC_HIP(ctx, hipGetLastError());
+            unsigned* flag = nullptr;
+            if (mode != 3) {
+                if (!ctx->lwa_flag) { XC_HIP(ctx, hipMalloc((void**)&ctx->lwa_flag, 256)); XC_HIP(ctx, hipMemset(ctx->lwa_flag, 0, 256)); ctx->lwa_epoch = 0; }
+                flag = ctx->lwa_flag;
+                epoch = ++ctx->lwa_epoch;        // a failed check stamps the word with its call's epoch: no memset per call
+                hipLaunchKernelGGL(k_lwa_check, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, Q, coord, (int)ny, increase, flag, epoch);
+                XC_HIP(ctx, hipGetLastError());
+            }
             const size_t lds = (size_t)(1 + 2 * CG) * (ny + 1) * 8;
             // part (core.py:773-784): 'upper' keeps mask3 > 0 (the near side) if increase else mask3 < 0 (the far side)
             const int side = part == 0 ? 0 : (((part == 1) == (increase != 0)) ? 1 : 2);
@@ -597,6 +601,7 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
             if (q_dtype == XC_F64) XC_LWAF(double); else XC_LWAF(float);
 #undef XC_LWAF
             XC_HIP(ctx, hipGetLastError());
+            if (mode == 3) { ctx->last_lwa_path = 1; goto masks; }           // vouched for: nothing else to enqueue
             gate = flag;
             ctx->last_lwa_path = -1;         // decided on the device: xc_last_lwa_path reads the flag
         }
