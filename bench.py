@@ -18,9 +18,12 @@ distinct slabs resident in HBM; two such batches alternate (each larger than the
 Infinity Cache, so every step really reads its tracer from HBM, and the batch whose min/max is
 folded into a histogram pass is different data).  Metric: lat-lon cells x contours per second,
 whole job.  N > 1: every rank owns its own batch of independent slabs (weak scaling), no
-data-path collective during compute, ONE RCCL all-gather (the library's own communicator, xc_comm_*, over xGMI) of all
-per-slab result vectors at the end of the timed region.  `--backend gloo` carries that one gather through the
-host (sockets) instead: for rehearsing the N > 1 path on a box with fewer GPUs than ranks.
+data-path collective during compute, ONE gather of all per-slab result vectors to rank 0 at the end of the timed region
+(SURVEY 8e).  Carriers of that gather, in the order they are tried (class Gather): RCCL over xGMI (grouped ncclSend / ncclRecv
+through the library's own communicator, xc_comm_*), HIP IPC pushes into the root's receive buffer (no RCCL; works with several
+ranks on ONE GPU too: the rehearsal this file's tests run), the rendezvous sockets (host; last resort).  Every first contact
+-- ncclCommInitRank, the first transfers -- runs under a deadline; the launcher has one for the whole job (`--deadline-s`)
+and reports every rank's last stage when it expires.  A < 10 s preflight goes to stderr before any timed work.
 
 Steady-state schedule (default, `--chain`): the stack is processed as a software pipeline -- the
 histogram pass of step k also streams the batch of step k+1 and leaves its min/max partials
@@ -41,9 +44,9 @@ After the timed region rank 0's line also carries (all outside the timed region,
     ranks) and a `budget` of where each rank's job time goes.
 
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel = the histogram pass, timed
-with HIP events on its own stream around every launch of the timed region) and, at N=1,
+with HIP events on its own stream around every launch of the timed region) and
 `cpu_baseline` (the numpy oracle = a port of the reference's xarray/xhistogram call
-sequence, timed on this host's cores on a bounded sample of the same slabs).
+sequence, timed on this host's cores by rank 0 on a bounded sample of the same slabs).
 """
 import argparse
 import json
@@ -118,7 +121,7 @@ def _compare_with_oracle(gpu, ref, s):
         raise RuntimeError('bench parity check against the oracle FAILED for slab %d: %s' % (s, ', '.join(bad)))
 
 
-def cpu_baseline(q_host, gpu_out, ncheck, cdt='float64'):
+def cpu_baseline(q_host, gpu_out, ncheck, cdt='float64', max_workers=0):
     """Oracle on a bounded sample: single-thread time per slab, then every logical core of the host in parallel
     (bounded by memory: ~1.2 GB of numpy temporaries per worker).  The first `ncheck` slabs' vectors are compared
     with the GPU's (`gpu_out`, same slabs) -- the CPU leg is the checker of the timed GPU result, not only a clock."""
@@ -127,6 +130,8 @@ def cpu_baseline(q_host, gpu_out, ncheck, cdt='float64'):
     import tempfile
     cores = os.cpu_count() or 1
     workers = max(1, min(cores, int(_mem_available_bytes() * 0.5 // (1.2 * (1 << 30)))))
+    if max_workers > 0:
+        workers = min(workers, int(max_workers))                     # (--cpu-workers: tests bound the leg's time)
     nd = q_host.shape[0]
     # the host's real best: all logical cores, and (this path is memory-bound numpy: more processes than memory channels
     # slow it down) 1/2, 1/4, 1/8, 1/16 of them; the best rate is `value`, every tried count goes into `by_workers`
@@ -228,26 +233,56 @@ def rel_err(a, b):
 
 
 # ----------------------------------------------------------------------------- launcher + the ranks' process group
-def launch_ranks(n, argv):
+# HSA_ENABLE_IPC_MODE_LEGACY=0: on this driver stack (ROCm 7.2 user space over a host kernel driver that only implements dmabuf
+# IPC) the ROCr default, the legacy KFD IPC ioctls, is refused: hipIpcGetMemHandle fails with "invalid argument", and with it
+# everything that shares device memory between processes -- RCCL's intra-node P2P transport and this file's own HIP IPC carrier.
+# The image exports the variable already; the launcher and every rank set it if it is missing (never overriding a value the
+# environment chose), because a rank started by some other launcher with a scrubbed environment would otherwise lose both device
+# carriers and fall to the host carrier.  It has no effect on single-process work.
+IPC_ENV = ('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+STAGE_ENV = 'XC_BENCH_STAGE_DIR'
+
+
+def stage(word):
+    """one word saying where this rank is, into $XC_BENCH_STAGE_DIR/rank<r> (set by the launcher): what the launcher reports for
+    every rank when its deadline expires.  Nothing happens without the variable."""
+    d = os.environ.get(STAGE_ENV)
+    if not d:
+        return
+    try:
+        with open(os.path.join(d, 'rank%s' % os.environ.get('RANK', '0')), 'w') as f:
+            f.write('%s %.1f\n' % (word, time.time()))
+    except OSError:
+        pass
+
+
+def launch_ranks(n, argv, deadline_s=480.0, program=None):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh rank processes (one per GPU), each a
     new interpreter running this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, and return the
     worst exit code.  This process imports nothing that can touch the GPU and never execs: the ranks are children.
-    Rank 0's JSON line goes to this process's stdout (inherited); a rank that dies takes the others down with it."""
+    Rank 0's JSON line goes to this process's stdout (inherited); a rank that dies takes the others down with it.
+    `deadline_s`: the whole job's time limit.  When it expires the children still alive are terminated BY PID, the launcher says
+    on stderr which ranks were alive and the last stage each rank reported (`stage()`), and returns 124 -- a job that hangs in a
+    first contact with a collective ends with a diagnosis inside the driver's own limit instead of with its kill."""
     import secrets
+    import shutil
     import socket
     import subprocess
+    import tempfile
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:      # a free port pair: P for a launcher's store (unused here), P + 1 for SocketGroup
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     port = port - 1 if port > 1024 else port
+    sdir = tempfile.mkdtemp(prefix='xc_bench_stage_')
     env = dict(os.environ)
     env.update({'WORLD_SIZE': str(n), 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'XC_DIST_TOKEN': secrets.token_hex(16),
-                'HSA_ENABLE_IPC_MODE_LEGACY': env.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), 'XC_BENCH_LAUNCHED': '1'})
+                IPC_ENV[0]: env.get(IPC_ENV[0], IPC_ENV[1]), 'XC_BENCH_LAUNCHED': '1', STAGE_ENV: sdir})
     procs = []
     for r in range(n):
         e = dict(env)
         e.update({'RANK': str(r), 'LOCAL_RANK': str(r)})
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+        procs.append(subprocess.Popen([sys.executable, program or os.path.abspath(__file__)] + list(argv), env=e))
+    t_end = time.time() + float(deadline_s)
     rc, alive = 0, list(procs)
     while alive:
         time.sleep(0.2)
@@ -260,59 +295,255 @@ def launch_ranks(n, argv):
                 rc = c if c > 0 else 1
                 for q in alive:                                        # exactly the processes started above, by PID
                     q.terminate()
+        if alive and time.time() > t_end:
+            stages = {}
+            for r in range(n):
+                try:
+                    w = open(os.path.join(sdir, 'rank%d' % r)).read().split()
+                    stages[r] = '%s (%.0f s ago)' % (w[0], time.time() - float(w[1]))
+                except (OSError, IndexError, ValueError):
+                    stages[r] = 'no stage reported'
+            live = [procs.index(p) for p in alive]
+            print('bench.py launcher: deadline of %.0f s expired; ranks still alive: %s; last stage per rank: %s -- terminating them'
+                  % (deadline_s, live, ', '.join('rank %d: %s' % (r, stages[r]) for r in range(n))), file=sys.stderr, flush=True)
+            for q in alive:
+                q.terminate()
+            rc = 124
+            break
     for p in procs:
         try:
-            p.wait(timeout=30)
+            p.wait(timeout=15)
         except subprocess.TimeoutExpired:
             p.kill()
+            p.wait()
+    shutil.rmtree(sdir, ignore_errors=True)
     return rc
 
 
-class Gather(object):
-    """The one collective of a job: an all-gather of equal device blocks.  Carrier 'rccl': the library's own RCCL communicator
-    (xc_comm_*, ncclAllGather over xGMI on the context's stream).  Carrier 'host': device -> host, SocketGroup.allgather,
-    the result stays on the host (`--backend gloo`; also what a job falls back to -- loudly, in the JSON line -- if the
-    communicator cannot be created, e.g. more ranks than GPUs)."""
+class RecvBlock(object):
+    """where the root collects the ranks' blocks: `stride` bytes per rank.  Device carriers: a device buffer on the root (`buf`),
+    `dst` = its address as THIS rank sees it (the root: its own pointer; HIP IPC: the mapping opened from the root's handle; RCCL:
+    nothing, the library addresses the root by rank).  Host carrier: `host` on the root after finish()."""
 
-    def __init__(self, ctx, group, backend):
-        self.ctx, self.group, self.note = ctx, group, None
-        self.carrier = 'none' if group.world == 1 else ('rccl' if backend in ('nccl', 'rccl') else 'host')
-        if self.carrier == 'rccl':
+    def __init__(self, stride):
+        self.stride, self.buf, self.dst, self.opened, self.host, self.pending = int(stride), None, None, None, None, []
+
+
+class Gather(object):
+    """The one collective of a job: every rank's result block to rank 0 (north_star: "RCCL gather"; SURVEY 8e: "all-gather or
+    gather-to-root").  A rank PUSHES pieces of its block as they become final -- a launch set's results leave on the context's
+    comm stream, behind an event, while the next launch set computes -- and `finish()` ends the job: only the last piece is exposed.
+    Carriers, tried in this order (`--backend nccl`, the default) until one passes its trial on EVERY rank:
+      'rccl'  grouped ncclSend / ncclRecv over xGMI through the library's own communicator (xc_comm_gather_dev);
+      'ipc'   HIP IPC: the root's receive buffer mapped into every rank, device-to-device pushes (peer writes over xGMI between
+              GPUs; plain copies when ranks share one GPU in a rehearsal) -- needs no RCCL;
+      'host'  device -> host, the rendezvous sockets to rank 0 (TCP; rehearsal only: ~0.5 s per 274 MB).
+    A trial = communicator / mapping set-up under a deadline + a 1 MB and a 32 MB gather whose bytes the root checks, each with a
+    deadline on the stream wait (xc_streams_idle polling: never a blocking sync on a collective that has not proved itself).
+    `self.trials` records what was tried, how long it took and why a carrier was passed over; it goes into the JSON line."""
+
+    ORDER = {'nccl': ('rccl', 'ipc', 'host'), 'rccl': ('rccl', 'ipc', 'host'), 'ipc': ('ipc', 'host'), 'gloo': ('host',), 'host': ('host',),
+             'auto': ('rccl', 'ipc', 'host')}
+
+    def __init__(self, ctx, group, backend, timeout=None):
+        self.ctx, self.group, self.note, self.trials = ctx, group, None, {}
+        self.timeout = float(os.environ.get('XC_COMM_TIMEOUT_S', 60)) if timeout is None else float(timeout)
+        self.carrier = 'none'
+        if group.world == 1:
+            return
+        passed, notes = [], []
+        for c in self.ORDER[backend]:
+            ok, why = self._try(c)
+            if ok:
+                passed.append(c)
+                if backend != 'auto':
+                    break
+            else:
+                notes.append('%s unavailable (%s)' % (c, why))
+        if not passed:
+            raise RuntimeError('bench.py: no carrier for the gather works: ' + '; '.join(notes))
+        if backend == 'auto' and len(passed) > 1:                     # the fastest 32 MB trial wins (rank 0's clock, same answer everywhere)
+            best = min(passed, key=lambda c: self.trials[c].get('ms_32MB', 1e9))
+            passed = [group.broadcast_bytes(best.encode() if group.rank == 0 else b'').decode()]
+        self.carrier = passed[0]
+        if self.carrier != 'rccl' and not group.stuck:
             try:
-                group.init_device(ctx)
-            except Exception as e:                                     # every rank gets the same verdict (SocketGroup.init_device)
-                self.carrier, self.note = 'host', 'RCCL communicator unavailable, gathered through the host instead: %s' % e
-                if group.rank == 0:
-                    print('warning: ' + self.note, file=sys.stderr)
+                ctx.comm_finalize()                                     # (a no-op without a communicator)
+            except Exception:                                           # noqa: BLE001
+                pass
+        if notes:
+            self.note = '; '.join(notes) + ' -> gathered over ' + self.carrier
+            if group.rank == 0:
+                print('warning: ' + self.note, file=sys.stderr)
+
+    # -- set-up + trial of one carrier; the verdict is the same on every rank
+    def _try(self, c):
+        g, ctx, t = self.group, self.ctx, {}
+        self.trials[c] = t
+        t0 = time.perf_counter()
+        try:
+            if c == 'rccl':
+                g.init_device(ctx, timeout=self.timeout)               # consensus inside: raises on every rank or on none
+            t['setup_ms'] = (time.perf_counter() - t0) * 1e3
+        except Exception as e:                                          # noqa: BLE001
+            t['error'] = str(e)
+            return False, str(e)
+        self.carrier = c
+        why = ''
+        try:
+            for mb in (1, 32):
+                ms, ok = self._trial(int(mb) << 20)
+                if not ok:
+                    why = 'the %d MB trial gather %s' % (mb, 'did not finish within %.0f s' % self.timeout if ms is None else 'delivered wrong bytes')
+                    break
+                t['ms_%dMB' % mb] = ms
+        except Exception as e:                                          # noqa: BLE001 -- this rank's failure; the others learn it below
+            why = str(e)
+        bad = [p.decode('utf-8', 'replace') for p in g.allgather_bytes(why.encode())]
+        self.carrier = 'none'
+        if any(bad):
+            why = '; '.join('rank %d: %s' % (r, w) for r, w in enumerate(bad) if w)
+            t['error'] = why
+            if c == 'rccl':
+                try:
+                    ctx.comm_abort()                                    # never wait for a collective that did not finish
+                except Exception:                                       # noqa: BLE001
+                    pass
+            return False, why
+        return True, ''
+
+    def _trial(self, nbytes):
+        """one gather of `nbytes` per rank with a known pattern; the root compares every byte.  Returns (ms or None on a timeout, ok)."""
+        g, ctx = self.group, self.ctx
+        pat = (np.arange(nbytes // 8, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(g.rank + 1)).view(np.uint8)
+        send = ctx.to_device(pat)
+        rb = self.recv_block(nbytes)
+        if g.rank == 0 and rb.buf is not None:
+            ctx._check(ctx.lib.xc_memset(ctx.handle, rb.buf.ptr, 0xA5, g.world * nbytes))     # stale lines in the root's caches on purpose
+        ctx.sync()
+        g.barrier()
+        t0 = time.perf_counter()
+        self.push(rb, send.ptr, nbytes)
+        done = self.finish(rb, deadline=self.timeout)
+        ms = (time.perf_counter() - t0) * 1e3
+        ok = True
+        if done and g.rank == 0:
+            got = self.fetch(rb)
+            for r in range(g.world):
+                e = (np.arange(nbytes // 8, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(r + 1)).view(np.uint8)
+                ok = ok and bool(np.array_equal(got[r], e))
+        if done:
+            self.free_block(rb)
+            send.free()
+        return (ms if done else None), (ok and done)
 
     def describe(self):
-        return {'none': 'single rank (no collective)', 'rccl': 'ncclAllGather over xGMI (library communicator xc_comm_*, RCCL), on the compute stream',
-                'host': 'device -> host, TCP all-gather through rank 0 (xcontour_amd.distributed.SocketGroup), host result'}[self.carrier]
+        return {'none': 'single rank (no collective)',
+                'rccl': 'gather to rank 0 over xGMI: grouped ncclSend / ncclRecv (library communicator xc_comm_*, RCCL) on a comm stream, one piece per launch set',
+                'ipc': 'gather to rank 0 by HIP IPC: the root\'s receive buffer mapped into every rank, device-to-device pushes on a comm stream, one piece per launch set',
+                'host': 'device -> host, TCP gather to rank 0 (xcontour_amd.distributed.SocketGroup), host result'}[self.carrier]
 
-    def run(self, send_ptr, nbytes, recv_buf):
-        """enqueue / perform the gather of `nbytes` at device `send_ptr` from every rank; returns None (rccl: result in
-        `recv_buf` on the device after ctx.sync()) or the gathered host array (world, nbytes) uint8 (host carrier)"""
-        if self.carrier == 'none':
-            return None                                                # a single rank: the block stays where it is, on the device
+    # -- the job's interface
+    def recv_block(self, stride):
+        """collective: the root's landing area for `stride` bytes per rank"""
+        rb = RecvBlock(stride)
+        g, ctx = self.group, self.ctx
+        if self.carrier in ('rccl', 'ipc') and g.rank == 0:
+            rb.buf = ctx.alloc(g.world * rb.stride)
+            rb.dst = rb.buf.ptr
+        if self.carrier == 'ipc':
+            h = g.broadcast_bytes(ctx.ipc_export(rb.buf.ptr) if g.rank == 0 else b'')
+            if g.rank != 0:
+                rb.opened = ctx.ipc_open(h)
+                rb.dst = rb.opened
+        return rb
+
+    def push(self, rb, src_ptr, nbytes, offset=0):
+        """enqueue: bytes [src_ptr, + nbytes) of this rank -> the root's block at rank * stride + offset, behind everything enqueued
+        on the compute stream so far; returns at once.  Every rank pushes the same sizes in the same order."""
+        ctx, r = self.ctx, self.group.rank
+        if self.carrier == 'none' or nbytes <= 0:
+            return
+        if self.carrier == 'host':
+            rb.pending.append((int(src_ptr), int(nbytes), int(offset)))
+            return
+        ctx.comm_wait_compute()
         if self.carrier == 'rccl':
-            self.ctx.comm_allgather(send_ptr, recv_buf.ptr, nbytes)
-            return None
-        self.ctx.sync()
-        return self.group.allgather(self._d2h(send_ptr, nbytes))
+            ctx.comm_gather(src_ptr, nbytes, (rb.dst + offset) if r == 0 else None, rb.stride, 0)
+        else:
+            ctx.comm_memcpy_d2d(rb.dst + r * rb.stride + offset, src_ptr, nbytes)
 
-    def _d2h(self, ptr, nbytes):
-        h = np.empty(nbytes, dtype=np.uint8)
-        self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, h.ctypes.data, ptr, nbytes))
-        return h
-
-    def fetch(self, send_ptr, recv_buf, nbytes, host_result):
-        """the gathered bytes on the host, (world, nbytes) uint8, after the job (outside every timed region)"""
-        if host_result is not None:
-            return host_result
-        self.ctx.sync()
+    def finish(self, rb, deadline=None):
+        """the end of the job on this rank: its pushes have landed (and, on the root, everybody's).  `deadline`: give up after that many
+        seconds instead of blocking (trials); returns False then."""
+        ctx, g = self.ctx, self.group
         if self.carrier == 'none':
-            return self._d2h(send_ptr, nbytes)[None]
-        return recv_buf.download((self.group.world, nbytes), np.uint8)
+            ctx.sync()
+            return True
+        if self.carrier == 'host':
+            ctx.sync()
+            mine = np.zeros(rb.stride, dtype=np.uint8)
+            for src, n, off in rb.pending:
+                ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, mine[off:].ctypes.data, src, n))
+            del rb.pending[:]
+            parts = g.gather_bytes(mine.tobytes())
+            if g.rank == 0:
+                rb.host = np.stack([np.frombuffer(p, dtype=np.uint8) for p in parts])
+            return True
+        ctx.compute_wait_comm()
+        if deadline is None:
+            ctx.sync()
+        elif not ctx.sync_within(deadline):
+            return False
+        if self.carrier == 'ipc':
+            g.barrier()                                                # the root learns that every rank's pushes have landed
+        return True
+
+    def fetch(self, rb):
+        """root: the gathered bytes on the host, (world, stride) uint8 (outside every timed region)"""
+        if rb.host is not None:
+            return rb.host
+        return rb.buf.download((self.group.world, rb.stride), np.uint8)
+
+    def free_block(self, rb):
+        """collective"""
+        if rb.opened is not None:
+            self.ctx.ipc_close(rb.opened)
+            rb.opened = None
+        if self.carrier == 'ipc':
+            self.group.barrier()                                        # nobody still maps the buffer the root is about to free
+        if rb.buf is not None:
+            rb.buf.free()
+            rb.buf = None
+
+
+def preflight(ctx, nat, group, dev, nd):
+    """< 10 s, before any timed work, to stderr (rank 0): what this node offers the N > 1 path -- devices, librccl, the peer-access
+    matrix row of every rank's device.  (The carriers' trial gathers, with their times, follow in Gather.)"""
+    import ctypes as C
+    info = {'rank': group.rank, 'devices_visible': nd, 'device': dev, 'name': ctx.device_name()}
+    try:
+        C.CDLL('librccl.so.1')
+        info['librccl'] = True
+    except OSError as e:
+        info['librccl'] = str(e)
+    row = []
+    for j in range(nd):
+        v = C.c_int(0)
+        nat.load().xc_device_can_access_peer(dev, j, C.byref(v))
+        row.append(int(v.value))
+    info['peer_access'] = row
+    info[IPC_ENV[0]] = os.environ.get(IPC_ENV[0])
+    allinfo = [json.loads(p.decode()) for p in group.allgather_bytes(json.dumps(info).encode())]
+    if group.rank == 0:
+        print('[preflight] world %d, %d device(s) visible to rank 0%s' % (group.world, nd, '' if nd >= group.world else
+              ' -- FEWER than ranks: ranks share GPUs (a rehearsal; RCCL refuses that, the gather will use HIP IPC)'), file=sys.stderr)
+        for i in allinfo:
+            print('[preflight] rank %d -> device %d (%s), librccl %s, peer access %s, %s=%s'
+                  % (i['rank'], i['device'], i['name'], 'loadable' if i['librccl'] is True else 'NOT loadable: %s' % i['librccl'],
+                     i['peer_access'], IPC_ENV[0], i[IPC_ENV[0]]), file=sys.stderr)
+        sys.stderr.flush()
+    return allinfo
 
 
 # ----------------------------------------------------------------------------- cfg4: strong scaling over the ranks
@@ -352,8 +583,10 @@ def cfg4_strong(ctx, nat, a, group, gather):
     per = -(-S // world)
     lo, hi = shard_slabs(S, rank, world)
     n = hi - lo
-    Cn = min(int(a.cfg4_chunk) if a.cfg4_chunk > 0 else cfg4_launch_set(n), max(n, 1))
-    nchunk = -(-n // Cn) if n else 0
+    # launch sets are cut from the PADDED block (per slabs on every rank, a short last block ends in zero rows): every rank pushes
+    # the same piece sizes in the same order, whatever it owns
+    Cn = min(int(a.cfg4_chunk) if a.cfg4_chunk > 0 else cfg4_launch_set(per), max(per, 1))
+    nchunk = -(-per // Cn)
     slab_bytes = NY4 * NX4 * 8
     qbuf, err = None, ''
     try:
@@ -372,61 +605,75 @@ def cfg4_strong(ctx, nat, a, group, gather):
     ctx.sync()
     # ONE result slot of `per` slabs, slab-major: its head is the rank's (per, 9, N) block (short blocks: zero padding)
     plan = KeffPlan(ctx, Cn, NY4, NX4, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
-                    increase=True, lt=True, nslots=1, out_slabs=per, alloc_q=False, right_edge='xhistogram', slab_major=True)
+                    increase=True, lt=True, nslots=1, out_slabs=per, alloc_q=False, right_edge='xhistogram', slab_major=True,
+                    deterministic=a.deterministic)
     block_bytes = plan.head_bytes                                # per * 9 * N * 8
     ctx._check(ctx.lib.xc_memset(ctx.handle, plan.out_ptr, 0, plan.slot_bytes))
-    recv = ctx.alloc(world * block_bytes) if gather.carrier == 'rccl' else None
+    rb = gather.recv_block(block_bytes)
+    sb = 9 * NCONT * 8                                           # result bytes per slab
+    sets = [(c0, min(Cn, n - c0), min(Cn, per - c0)) for c0 in range(0, per, Cn)]     # (first slab, slabs computed here, slabs pushed)
 
-    def sweep():
-        for ci in range(nchunk):
-            c0 = ci * Cn
-            m = min(Cn, n - c0)
-            plan.set_q_device(qbuf.ptr + c0 * slab_bytes)
-            nxt = ((ci + 1) % nchunk) * Cn
-            chain = min(Cn, n - nxt) == m                          # equal-shape launch sets chain their min/max (q_next)
-            plan._point(0, 0, m, out_s0=c0)                        # results of slab c0 + i -> block[c0 + i][:][:]
-            plan.desc.q_next = (qbuf.ptr + nxt * slab_bytes) if chain else None
-            ctx._check(ctx.lib.xc_keff_dev(ctx.handle, C.byref(plan.desc)))
+    def sweep(push=True):
+        for ci, (c0, m, mp) in enumerate(sets):
+            if m > 0:
+                plan.set_q_device(qbuf.ptr + c0 * slab_bytes)
+                nc0, nm, _ = sets[(ci + 1) % nchunk]
+                plan._point(0, 0, m, out_s0=c0)                    # results of slab c0 + i -> block[c0 + i][:][:]
+                plan.desc.q_next = (qbuf.ptr + nc0 * slab_bytes) if nm == m else None   # equal-shape launch sets chain their min/max
+                ctx._check(ctx.lib.xc_keff_dev(ctx.handle, C.byref(plan.desc)))
+            if push:                                               # this set's rows leave on the comm stream while the next set computes
+                gather.push(rb, plan.out_ptr + c0 * sb, mp * sb, c0 * sb)
 
     def job():
         sweep()
-        h = gather.run(plan.out_ptr, block_bytes, recv)          # the ONE collective: same stream, right behind the last launch set
-        ctx.sync()
-        return h
+        gather.finish(rb)                                          # only the last set's piece is exposed
 
-    host = job()                                                 # warm-up: kernels, scratch growth, the communicator's channels
+    stage('cfg4_warmup')
+    job()                                                        # warm-up: kernels, scratch growth, the carrier's channels
     group.barrier()
     ctx.sync()
+    stage('cfg4_timed')
     t0 = time.perf_counter()
     for _ in range(R):
-        host = job()
+        job()
     group.barrier()
     el = group.allreduce_max(time.perf_counter() - t0)
-    # where a job's time goes: one extra job per rank, device events around the sweep and around the gather (no sync between
-    # them), host clock around the whole; every rank reports, rank 0 prints the per-rank lists and the worst of each
+    # where a job's time goes: one extra job per rank, device events around the sweep and behind the gather's last piece (no sync
+    # between them), host clock around the whole; every rank reports, rank 0 prints the per-rank lists and the worst of each
+    stage('cfg4_budget')
     e0, e1, e2 = ctx.event(), ctx.event(), ctx.event()
     group.barrier()
     ts = time.perf_counter()
     ctx.record(e0); sweep(); ctx.record(e1)
     tg = time.perf_counter()
-    host = gather.run(plan.out_ptr, block_bytes, recv)
-    ctx.record(e2); ctx.sync()
+    if gather.carrier in ('rccl', 'ipc'):
+        ctx.compute_wait_comm()                                  # (what finish() does first: e2 then marks the last piece's arrival / departure)
+    ctx.record(e2)
+    gather.finish(rb)
     t_end = time.perf_counter()
     sweep_ms = ctx.elapsed_ms(e0, e1)
-    gather_ms = ctx.elapsed_ms(e1, e2) if gather.carrier != 'host' else (t_end - tg) * 1e3
-    st = np.array([sweep_ms, gather_ms, (t_end - ts) * 1e3])
-    stages = group.allgather(st)                                 # (world, 3)
+    gather_ms = (t_end - tg) * 1e3 if gather.carrier == 'host' else ctx.elapsed_ms(e1, e2)
+    st = np.array([sweep_ms, gather_ms, (t_end - ts) * 1e3, (t_end - tg) * 1e3])
+    stages = group.allgather(st)                                 # (world, 4)
     block = None
     if rank == 0:
-        full = gather.fetch(plan.out_ptr, recv, block_bytes, host).view(np.float64).reshape(world * per, 9, NCONT)[:S]
+        if world == 1:
+            full = np.empty(plan.head_bytes, dtype=np.uint8)
+            ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, full.ctypes.data, plan.out_ptr, plan.head_bytes))
+            full = full[None]
+        else:
+            full = gather.fetch(rb)
+        full = full.view(np.float64).reshape(world * per, 9, NCONT)[:S]
         mine = plan.fetch(check=False)
         mine_blk = np.stack([mine[k] for k in OUT_NAMES], axis=1)[:n]
+        if a.dump_cfg4:
+            np.save(a.dump_cfg4, full)                               # (tests: an N-rank job against the 1-rank job, bit for bit with --deterministic)
         fb = full.view(np.int64)                                   # bit patterns: the vectors hold NaNs
         assert np.array_equal(fb[lo:hi], mine_blk.view(np.int64)), 'rank 0 block is not where it belongs'
         # every other rank's block sits at its place with that rank's data: recompute the FIRST slab of each block here
         checked = []
         one = KeffPlan(ctx, 1, NY4, NX4, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
-                       increase=True, lt=True, right_edge='xhistogram')
+                       increase=True, lt=True, right_edge='xhistogram', deterministic=a.deterministic)
         for r in range(world):
             rlo, rhi = shard_slabs(S, r, world)
             if rhi <= rlo:
@@ -462,24 +709,28 @@ def cfg4_strong(ctx, nat, a, group, gather):
             'slabs': S, 'slab_shape': [NY4, NX4], 'slabs_per_gpu': per, 'slabs_per_launch': Cn,
             'us_per_slab_per_gpu': el / R / max(1, per) * 1e6,
             'budget': {'sweep_ms_by_rank': [float(x) for x in stages[:, 0]], 'gather_ms_by_rank': [float(x) for x in stages[:, 1]],
-                       'job_ms_by_rank': [float(x) for x in stages[:, 2]], 'pack_ms': 0.0,
+                       'job_ms_by_rank': [float(x) for x in stages[:, 2]], 'finish_host_ms_by_rank': [float(x) for x in stages[:, 3]], 'pack_ms': 0.0,
                        'sweep_ms_max': float(stages[:, 0].max()), 'gather_ms_max': float(stages[:, 1].max()),
-                       'note': 'one extra job after the timed ones: HIP events around the sweep and (RCCL carrier) around the gather on the '
-                               'same stream, host clock around the job; no pack stage: the launch sets write [slab][9][N] straight into the send block'},
-            'gathered_bytes': int(world * block_bytes), 'gather': gather.describe(), 'gather_note': gather.note,
+                       'note': 'one extra job after the timed ones.  sweep_ms: HIP events around the launch sets.  gather_ms: what the gather ADDS behind the '
+                               'sweep\'s last kernel -- every launch set\'s rows leave on the comm stream while the next set computes, so this is the last '
+                               'piece (device carriers: event behind the comm stream\'s last piece minus the sweep\'s end; host carrier: host clock around '
+                               'the whole staged gather).  finish_host_ms: host clock from the last enqueue to the end of finish() (stream wait + the one '
+                               'rendezvous barrier of the HIP IPC carrier).  No pack stage: the launch sets write [slab][9][N] straight into the send block'},
+            'gathered_bytes': int(world * block_bytes), 'gather_to': 'rank 0', 'pieces_per_job': len(sets),
+            'gather': gather.describe(), 'gather_note': gather.note,
             'algorithmic_bytes': int(S * NY4 * NX4 * BYTES_PER_CELL), 'pipeline_frac': (S * NY4 * NX4 * BYTES_PER_CELL * R / el / 1e9) / HBM_PEAK_GBS / world,
             'checks': {'rank0_block_bit_identical': True, 'first_slab_of_each_rank_recomputed': checked,
                        'oracle_checked_slabs': oracle_checked, 'finite_nkeff_fraction': float(np.isfinite(nk).mean())},
             'config': 'cfg4: %d slabs of %dx%d float64 (seed + slab id), %d contours, per-slab levels, contiguous blocks of '
-                      'ceil(S/G) slabs per rank, chained launch sets of %d writing slab-major, ONE all-gather of (S, 9, N) f64 inside the timed job'
+                      'ceil(S/G) slabs per rank, chained launch sets of %d writing slab-major, ONE gather of (S, 9, N) f64 to rank 0 inside the timed job '
+                      '(a piece per launch set, overlapped with the next set)'
                       % (S, NX4, NY4, NCONT, Cn),
         }
     for e in (e0, e1, e2):
         ctx.lib.xc_event_destroy(ctx.handle, e)
     plan.free()
     qbuf.free(); lat_b.free(); lon_b.free()
-    if recv is not None:
-        recv.free()
+    gather.free_block(rb)
     return block
 
 
@@ -513,10 +764,15 @@ def parse_args(argv=None):
                     help='order-free fixed-point accumulation (xc_keff_desc.deterministic): bit-reproducible sums at about twice the '
                          'histogram cost')
     ap.add_argument('--native-rccl', action='store_true', help='(kept for old command lines: the library communicator is the default now)')
-    ap.add_argument('--backend', default='nccl', choices=['nccl', 'rccl', 'gloo', 'host'],
-                    help="carrier of the ONE end-of-job gather: 'nccl' = 'rccl' (default): ncclAllGather over xGMI through the "
-                         "library's own communicator (xc_comm_*); 'gloo' = 'host': staged through the host over the rendezvous "
-                         'sockets -- only for exercising the multi-rank path on a box with fewer GPUs than ranks')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'rccl', 'ipc', 'gloo', 'host', 'auto'],
+                    help="carrier of the ONE gather of a job (to rank 0): 'nccl' = 'rccl' (default): grouped ncclSend / ncclRecv over xGMI "
+                         "through the library's own communicator (xc_comm_*), falling back -- loudly, in the JSON line -- to 'ipc' and then "
+                         "'host' if a carrier does not pass its deadline-bounded trial on every rank; 'ipc': HIP IPC pushes into the root's "
+                         "receive buffer (no RCCL; also works with several ranks on one GPU); 'gloo' = 'host': staged through the host over "
+                         "the rendezvous sockets (slow; a last resort); 'auto': whichever of rccl / ipc moved its 32 MB trial faster")
+    ap.add_argument('--deadline-s', type=float, default=480.0,
+                    help='launcher only (`--gpus N` without WORLD_SIZE): the whole job\'s time limit; on expiry the ranks are terminated '
+                         'by PID, the launcher reports every rank\'s last stage on stderr and exits 124')
     ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3', 'cfg4', 'cfg5'],
                     help="BASELINE.json configuration: cfg2 (default, the headline metric's), or one of the secondary ones as "
                          'a bench line of the same contract (tools/bench_configs.py; single GPU; --steps / --warmup apply)')
@@ -525,12 +781,14 @@ def parse_args(argv=None):
                          'contours, the dtype of the files the reference ships and its default `dtype` (core.py:21); algorithmic bytes 4 + 8 per cell')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--cpu-slabs', type=int, default=0, help='distinct slabs in the CPU sample, all parity-checked (0: 8)')
+    ap.add_argument('--cpu-workers', type=int, default=0, help='upper bound on the CPU sample\'s concurrent processes (0: as many as cores and memory allow)')
     ap.add_argument('--no-extras', action='store_true', help='skip variants / long_run / unchained after the timed region')
     ap.add_argument('--long-run-s', type=float, default=4.0, help='seconds of extra steps with per-launch events (long_run)')
     ap.add_argument('--no-cfg4', action='store_true', help='skip the cfg4 strong-scaling block')
     ap.add_argument('--cfg4-slabs', type=int, default=512 * 37)
     ap.add_argument('--cfg4-chunk', type=int, default=0, help='slabs per launch set of the cfg4 sweep (0: chosen by cfg4_launch_set: a size that tiles the rank\'s block and fills whole rounds of workgroups)')
     ap.add_argument('--cfg4-reps', type=int, default=2, help='timed cfg4 jobs (sweep + gather)')
+    ap.add_argument('--dump-cfg4', default='', help='rank 0 saves the gathered (S, 9, N) cfg4 result to this .npy file')
     return ap.parse_args(argv)
 
 
@@ -540,12 +798,13 @@ def main():
         # the driver's plain `python3 bench.py --gpus N`: become the launcher, BEFORE anything that could touch a GPU
         if a.config != 'cfg2':
             raise SystemExit('--config %s is a single-GPU line; the multi-GPU cfg4 job is the `cfg4_strong` block of the default run' % a.config)
-        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:], a.deadline_s))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault(*IPC_ENV)                               # see IPC_ENV above: dmabuf IPC, or no device carrier between processes
+    stage('start')
     if a.gpus != world:
         raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks (the two must agree: `value` is the '
                          'whole-job aggregate over --gpus GPUs)' % (a.gpus, world))
@@ -571,7 +830,9 @@ def main():
         raise RuntimeError('bench.py needs an MI355X (no CPU fallback)')
     dev = local if local < nd else local % nd     # a launcher may expose one device per rank; a rehearsal has fewer GPUs than ranks
     ctx = nat.Context(dev)
+    stage('rendezvous')
     group = SocketGroup(rank, world)
+    pre = preflight(ctx, nat, group, dev, nd) if world > 1 else None
     if a.config != 'cfg2':
         if world > 1:
             raise SystemExit('--config %s is a single-GPU line; the multi-GPU cfg4 job is the `cfg4_strong` block of the default run' % a.config)
@@ -580,7 +841,11 @@ def main():
         print(json.dumps(bench_configs.run(a.config, ctx, a.steps, a.warmup)), flush=True)
         ctx.close()
         return
+    stage('carrier')
     gather = Gather(ctx, group, a.backend)
+    if world > 1 and rank == 0:
+        print('[preflight] carrier: %s; trials %s' % (gather.carrier, json.dumps(gather.trials)), file=sys.stderr, flush=True)
+    stage('setup')
     B, K, W = a.batch, a.steps, a.warmup
     qdt = np.dtype(np.float32 if a.dtype == 'f32' else np.float64)
     bpc = qdt.itemsize + 8                                        # algorithmic bytes per cell: tracer once + 2-D f64 dA once
@@ -615,6 +880,7 @@ def main():
             g1 = g0 + grp if g0 + grp < s0 + B else nxt          # what runs after this launch set
             pl.run_range(slot_idx, g0, n, g1 if (ch and min(grp, B) == n) else None, out_s0=g0 - s0)
 
+    stage('warmup')
     plan.out_ptr = wres.ptr
     for k in range(-W, 0):                                        # ends on batch B; its pass carries batch A's min/max
         step(k, 0)
@@ -622,16 +888,18 @@ def main():
     ctx.sync()
     ev = [(ctx.event(), ctx.event()) for _ in range(K)]
     nres = slot * K
-    gathered = ctx.alloc(nres * world) if gather.carrier == 'rccl' else None
+    rb = gather.recv_block(nres) if world > 1 else None           # the root's landing area: (world, nres) bytes
     if world > 1:
-        # warm-up of the collective, like the W warm-up steps of the compute: the first all-gather of a communicator sets up
-        # its channels / proxy connections (tens of ms), which is start-up cost and not part of a steady-state job
-        gather.run(res.ptr, nres, gathered)
-        ctx.sync()
+        # warm-up of the collective, like the W warm-up steps of the compute: a carrier's first transfer into a new buffer sets up
+        # channels / mappings, which is start-up cost and not part of a steady-state job
+        gather.push(rb, res.ptr, nres)
+        gather.finish(rb)
         ctx._check(ctx.lib.xc_memset(ctx.handle, res.ptr, 0, nres))                     # the timed region fills them again
-        if gathered is not None:
-            ctx._check(ctx.lib.xc_memset(ctx.handle, gathered.ptr, 0, nres * world))
+        if rb.buf is not None:
+            ctx._check(ctx.lib.xc_memset(ctx.handle, rb.buf.ptr, 0, nres * world))
+        ctx.sync()
 
+    stage('timed')
     group.barrier()
     ctx.sync()
     t0 = time.perf_counter()
@@ -639,17 +907,22 @@ def main():
         if grp == B:
             ctx.set_hist_events(ev[k][0], ev[k][1])               # events around the K3 launch only
         step(k, k)
-    hostg = gather.run(res.ptr, nres, gathered) if world > 1 else None    # the one collective: same stream, behind the last step
-    ctx.sync()                                                    # the library's own HIP stream (every kernel and the gather run on it)
+    if world > 1:
+        gather.push(rb, res.ptr, nres)                            # the one collective: every step's vectors to rank 0, behind the last step
+        gather.finish(rb)
+    ctx.sync()                                                    # the library's own HIP streams (every kernel and the gather run on them)
     group.barrier()
     t1 = time.perf_counter()
     el = group.allreduce_max(t1 - t0)
+    stage('checks')
     if world > 1 and rank == 0:
         # every rank's block arrived, in rank order, and rank r's slabs differ from rank 0's (seed + r*2B + s)
-        g = gather.fetch(res.ptr, gathered, nres, hostg)
+        g = gather.fetch(rb)
         mine = res.download((nres,), np.uint8)
         assert np.array_equal(g[0], mine) and all(not np.array_equal(g[r], g[0]) for r in range(1, world)), 'gathered blocks are not in rank order'
         del g, mine
+    if world > 1:
+        gather.free_block(rb)
 
     line = None
     if rank == 0:
@@ -666,7 +939,8 @@ def main():
                        'slabs_per_step_per_gpu': B, 'slabs_per_launch': grp, 'resident_batches': NB, 'variant': a.variant, 'dA': dA_kind,
                        'minmax': 'folded into the previous histogram pass (q_next)' if chain else 'stand-alone K1 pass',
                        'sums': 'order-free fixed point (deterministic)' if a.deterministic else 'float64 LDS atomics',
-                       'parallelism': ('independent slabs per GPU, one all-gather at the end: ' + gather.describe()) if world > 1 else 'single GPU',
+                       'parallelism': ('independent slabs per GPU (dp%d), one gather to rank 0 at the end; carrier %s: %s' % (world, gather.carrier, gather.describe())) if world > 1 else 'single GPU',
+                       'carrier_trials': gather.trials if world > 1 else None, 'preflight': pre,
                        'launcher': ('bench.py itself (one child process per rank)' if os.environ.get('XC_BENCH_LAUNCHED') else 'external (RANK / WORLD_SIZE from the environment)') if world > 1 else 'none',
                        'collective_note': gather.note,
                        'host_code': 'python + ctypes, no torch', 'device': ctx.device_name()},
@@ -797,30 +1071,40 @@ def main():
             finally:
                 if p2 is not None:
                     p2.free()
-        if world == 1 and not a.no_cpu:
-            # the oracle on slabs of the LAST timed step's batch; their vectors are compared with that step's GPU result
-            nd_ = max(1, min(a.cpu_slabs or 8, B))
+        if not a.no_cpu:
+            # the oracle on slabs of the LAST timed step's batch; their vectors are compared with that step's GPU result.  N > 1: rank 0
+            # alone, a smaller sample (the other ranks wait at a barrier whose timeout covers it, below): a line without a CPU
+            # baseline beside it reads as unmeasured
+            stage('cpu_baseline')
+            nd_ = max(1, min(a.cpu_slabs or (8 if world == 1 else 4), B))
             s0 = ((K - 1) % NB) * B
             esz = NY * NX * qdt.itemsize
             qh = np.empty((nd_, NY, NX), dtype=qdt)
             ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, plan._q_ptr + s0 * esz, nd_ * esz))
-            line['cpu_baseline'] = cpu_baseline(qh, out, nd_, qdt.name)
+            line['cpu_baseline'] = cpu_baseline(qh, out, nd_, qdt.name, a.cpu_workers)
+    if world > 1:
+        group.barrier(timeout=900.0)                              # rank 0 has been timing the CPU baseline meanwhile
     plan.free()
     res.free(); wres.free()
-    if gathered is not None:
-        gathered.free()
     if rank == 0 and world == 1 and a.dtype == 'f64' and grp == B and not a.no_extras and not (a.slab_dA or a.row_dA or a.deterministic):
         # float32 tracers and contours -- the reference's default `dtype` and the dtype of the files it ships -- through the same
         # chained schedule, so that the driver's line carries them; two slabs of its last step against the oracle
         line.setdefault('variants', {})['f32'] = variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain)
     # ---- cfg4 strong scaling: every rank takes part (its own timed region, after the cfg2 buffers are gone)
     if not a.no_cfg4 and a.dtype == 'f64':
+        stage('cfg4')
         blk = cfg4_strong(ctx, nat, a, group, gather)
         if rank == 0:
             line['cfg4_strong'] = blk
+    stage('done')
     if rank == 0:
         print(json.dumps(line), flush=True)
     group.barrier()
+    if group.stuck:
+        # a helper thread never came back from ncclCommInitRank (SocketGroup.init_device): the results are out, and an interpreter
+        # that waits for that thread -- or a library destructor that waits for its bootstrap -- would hang the finished job
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
     ctx.close()
     group.close()
 

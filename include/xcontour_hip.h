@@ -110,6 +110,8 @@ int xc_event_create(xc_ctx* ctx, void** out_event);
 int xc_event_destroy(xc_ctx* ctx, void* event);
 int xc_event_record(xc_ctx* ctx, void* event);
 int xc_event_elapsed_ms(xc_ctx* ctx, void* start, void* stop, float* out_ms);  /* waits for `stop` */
+int xc_event_record_copies(xc_ctx* ctx, void* event);   /* record on the COPY stream: done once the uploads issued so far have landed */
+int xc_event_query(xc_ctx* ctx, void* event, int* out_done);   /* 1 when the event has completed, 0 while it has not; never blocks */
 
 /* ------------------------------------------------------------------ K1  min / max
  * Replaces tracer.min(dim=dimVs), tracer.max(dim=dimVs)            core.py:224-225
@@ -219,14 +221,15 @@ int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const doubl
 
 /* Planes of more than 512 rows take an O(ny log ny)-per-column path (variant 0): because the sorted reference state Q is
  * monotone, the targets j a cell contributes to form one interval, so one binary search in Q and four adds into a
- * difference array replace the walk over every (target, row) pair; per-column prefix sums finish.  The premises -- no NaN in
- * Q, s*Q non-decreasing (s = +1 if increase else -1), the coordinate strictly monotone -- are checked ON THE DEVICE first (a
+ * difference array replace the walk over every (target, row) pair; per-column prefix sums finish.  The premises -- Q finite
+ * (no NaN, no infinity), s*Q non-decreasing (s = +1 if increase else -1), the coordinate strictly monotone, no INFINITE tracer cell
+ * (found by the interval kernel itself; NaN cells are fine) -- are checked ON THE DEVICE first (a
  * flag the kernels gate themselves on: no host round trip, the _dev form stays asynchronous); if they fail the band walk
  * enqueued behind the interval kernel runs instead.  Same sums in
  * another order: agreement with the band walk ~1e-13 of the column's largest value (tests 1e-9), not bit for bit.
  * xc_set_lwa_exact(ctx, mode): 0 automatic (above), 1 the bit-exact band walk for every plane, 2 the interval kernel for every plane
- * (checked on the device), 3 the same with the premises vouched for by the caller -- it has looked at Q and the coordinate on the
- * host: one launch, no check (a plane of 256 x 512: 15.8 us for the band walk, see DESIGN.md for the interval kernel).  xc_last_lwa_path: 0 band walk, 1 interval
+ * (checked on the device), 3 the same with the premises vouched for by the caller -- it has looked at Q, the coordinate and the
+ * tracer (no infinite cell) on the host: one launch, no check (a plane of 256 x 512: 15.8 us for the band walk, see DESIGN.md for the interval kernel).  xc_last_lwa_path: 0 band walk, 1 interval
  * kernel, 2 its premises failed the check (waits for the call when the device decided). */
 int xc_set_lwa_exact(xc_ctx* ctx, int exact);
 int xc_last_lwa_path(xc_ctx* ctx, int* out_path);
@@ -385,6 +388,35 @@ int xc_comm_unique_id(xc_ctx* ctx, void* out_id128);
 int xc_comm_init(xc_ctx* ctx, int nranks, int rank, const void* id128);
 int xc_comm_allgather_dev(xc_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
 int xc_comm_finalize(xc_ctx* ctx);
+/* Gather to ONE root (north_star: "RCCL gather"; SURVEY 8e "or gather-to-root"): every rank's `bytes` at `send` arrive at
+ * recv + r * rank_stride on rank `root` (grouped ncclSend / ncclRecv; the root's own block is a device-to-device copy).  Moves
+ * 1 / nranks of the all-gather's bytes.  Enqueued on the context's COMM stream (below), not on the compute stream. */
+int xc_comm_gather_dev(xc_ctx* ctx, const void* send, size_t bytes, void* recv, size_t rank_stride, int root);
+/* Give up on a communicator whose collective does not finish (ncclCommAbort): the first contact with RCCL on a new node runs
+ * under a deadline (bench.py), and a job must be able to move on to the next carrier instead of hanging. */
+int xc_comm_abort(xc_ctx* ctx);
+
+/* The COMM stream: a third HIP stream of the context (beside compute and upload), created on first use.  A rank's result
+ * block leaves on it -- an RCCL send or a device-to-device push -- while the next launch set computes.
+ *   xc_comm_wait_compute  everything enqueued on the comm stream AFTER the call waits for the compute work enqueued so far
+ *   xc_compute_wait_comm  later compute-stream work (and therefore xc_sync) waits for the comm work enqueued so far
+ *   xc_comm_memcpy_d2d    device-to-device copy on the comm stream (dst may be another process's memory opened by xc_ipc_open)
+ *   xc_streams_idle       *out_idle = 1 once both streams have drained, 0 while they have not; never blocks */
+int xc_comm_wait_compute(xc_ctx* ctx);
+int xc_compute_wait_comm(xc_ctx* ctx);
+int xc_comm_memcpy_d2d(xc_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+int xc_streams_idle(xc_ctx* ctx, int* out_idle);
+
+/* HIP IPC carrier of the same gather (no RCCL involved; no reference call site): the root exports the base pointer of its
+ * receive buffer (an xc_malloc allocation) as a 64-byte handle, the rendezvous hands it to every rank, every rank opens it
+ * and pushes its block with xc_comm_memcpy_d2d -- a peer write over xGMI between GPUs, a plain copy between ranks that share
+ * one GPU.  Needs dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment on this driver stack (see bench.py).
+ *   xc_ipc_export  handle of the ALLOCATION that starts at dptr        xc_ipc_open  map it (returns its base address)
+ *   xc_ipc_close   unmap (drains the comm stream first)                xc_device_can_access_peer  hipDeviceCanAccessPeer */
+int xc_ipc_export(xc_ctx* ctx, const void* dptr, void* out_handle64);
+int xc_ipc_open(xc_ctx* ctx, const void* handle64, void** out_dptr);
+int xc_ipc_close(xc_ctx* ctx, void* dptr);
+int xc_device_can_access_peer(int device, int peer, int* out_can);
 
 /* ------------------------------------------------------------------ synthetic slabs (bench / tests)
  * PV-like tracer q = sin(phi) + 0.25 sum_k a_k cos(k lambda + theta_k) cos^2(phi) + 0.02 eps

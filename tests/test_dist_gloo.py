@@ -224,17 +224,14 @@ def test_bench_launcher_starts_the_ranks_and_reports_failure(tmp_path):
         "open(os.path.join(%r, 'rank%%d' %% g.rank), 'w').write(sys.argv[1])\n"
         "g.barrier(); g.close()\n"
         "sys.exit(3 if (sys.argv[1] == 'fail' and g.rank == 1) else 0)\n" % (ROOT, str(tmp_path)))
-    old = m.__file__
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'XC_DIST_TOKEN')}
     saved = dict(os.environ)
     try:
         os.environ.clear(); os.environ.update(env)
-        m.__file__ = str(prog)
-        assert m.launch_ranks(3, ['ok']) == 0
+        assert m.launch_ranks(3, ['ok'], program=str(prog)) == 0
         assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith('rank') and f != 'rank.py') == ['rank0', 'rank1', 'rank2']
-        assert m.launch_ranks(2, ['fail']) == 3
+        assert m.launch_ranks(2, ['fail'], program=str(prog)) == 3
     finally:
-        m.__file__ = old
         os.environ.clear(); os.environ.update(saved)
     # and the real file: without a GPU every rank fails loudly and so does the launcher, in seconds
     import torch
@@ -242,6 +239,64 @@ def test_bench_launcher_starts_the_ranks_and_reports_failure(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu'],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=120)
         assert r.returncode != 0 and 'no CPU fallback' in r.stderr and r.stdout.strip() == ''
+
+
+def test_launcher_deadline_ends_a_hung_job_with_a_stage_report(tmp_path):
+    """a rank that never reaches the collective (here: a stand-in that reports its stage and then sleeps, like a process stuck in a
+    bootstrap that will never complete): the launcher's deadline expires, it terminates the ranks BY PID, names the ranks still alive
+    and every rank's last stage on stderr and returns 124 -- well inside the deadline + its grace, no JSON line on stdout"""
+    import subprocess
+    import time as _t
+    prog = tmp_path / 'hang.py'
+    prog.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('bench_mod', %r); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        "m.stage('start')\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    m.stage('comm_init'); time.sleep(600)\n"                    # never calls init: the others would wait for it forever
+        "m.stage('waiting_for_rank1'); time.sleep(600)\n" % (ROOT, os.path.join(ROOT, 'bench.py')))
+    code = ("import sys, importlib.util; spec = importlib.util.spec_from_file_location('bench_mod', %r); m = importlib.util.module_from_spec(spec); "
+            "spec.loader.exec_module(m); sys.exit(m.launch_ranks(3, [], deadline_s=6.0, program=%r))" % (os.path.join(ROOT, 'bench.py'), str(prog)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'XC_DIST_TOKEN')}
+    t0 = _t.time()
+    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=120)
+    assert r.returncode == 124 and _t.time() - t0 < 60, (r.returncode, r.stderr)
+    assert 'deadline of 6 s expired' in r.stderr and 'ranks still alive: [0, 1, 2]' in r.stderr
+    assert 'rank 1: comm_init' in r.stderr and 'rank 0: waiting_for_rank1' in r.stderr and 'rank 2: waiting_for_rank1' in r.stderr
+    assert r.stdout.strip() == ''
+
+
+def test_socket_group_needs_a_token_off_loopback():
+    """round-4 advisor: with no token the HMAC proofs are keyed with b'' and any process that reaches the port passes -- accepted on a
+    loopback rendezvous only (one node); any other address raises before a socket is opened.  world 1 needs nothing"""
+    from xcontour_amd.distributed import SocketGroup, _is_loopback
+    assert _is_loopback('127.0.0.1') and _is_loopback('::1') and _is_loopback('localhost') and not _is_loopback('10.1.2.3')
+    saved = os.environ.pop('XC_DIST_TOKEN', None)
+    try:
+        with pytest.raises(Exception, match='needs a job token'):
+            SocketGroup(1, 2, '10.1.2.3', 29999, timeout=1)
+        with pytest.raises(Exception, match='needs a job token'):
+            SocketGroup(0, 2, '192.0.2.7', 29999, timeout=1, token='')
+        SocketGroup(0, 1, '10.1.2.3', 29999).close()                # a single rank opens no socket
+    finally:
+        if saved is not None:
+            os.environ['XC_DIST_TOKEN'] = saved
+
+
+def test_run_sharded_single_rank_stays_in_numpy_and_numpy_needs_a_group():
+    """round-4 advisor: world == 1 with no group and no initialised torch process group is numpy in, numpy out (torch not imported by
+    the call); as_numpy=True with world > 1 and no SocketGroup is an error, not a numpy array handed to torch.distributed"""
+    import subprocess
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from xcontour_amd.distributed import run_sharded; "
+            "out = run_sharded(lambda lo, hi: np.arange(lo, hi)[:, None] * np.ones(3), 5, 0, 1); "
+            "assert isinstance(out, np.ndarray) and out.shape == (5, 3) and 'torch' not in sys.modules; print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr
+    from xcontour_amd.distributed import run_sharded
+    with pytest.raises(Exception, match='needs a SocketGroup'):
+        run_sharded(lambda lo, hi: np.zeros((hi - lo, 2)), 4, 0, 2, as_numpy=True)
 
 
 def test_socket_group_rejects_strangers_and_bad_ranks():
@@ -303,6 +358,9 @@ class _FakeCtx(object):
 
     def comm_init(self, world, rank, uid):
         assert len(uid) == 128 and uid == bytes(range(128)) and rank == self.rank
+        if ('hang', rank) in self.bad:
+            import time
+            time.sleep(600)                       # a bootstrap that waits for a rank that never comes
         if rank in self.bad:
             raise RuntimeError('ncclCommInitRank: invalid usage (duplicate GPU)')
         self.inited = (world, rank)
@@ -317,13 +375,16 @@ def _init_device_worker(rank, world, port, bad, q):
     g = SocketGroup(rank, world, '127.0.0.1', port, token='t')
     ctx = _FakeCtx(rank, bad)
     try:
-        g.init_device(ctx)
+        g.init_device(ctx, timeout=3.0 if any(isinstance(b, tuple) for b in bad) else None)
         out = ('ok', ctx.inited)
     except Exception as e:
-        out = ('error', str(e), ctx.finalized)
-    g.barrier()                                   # the group is still usable after a failed device init (the host carrier takes over)
+        out = ('error', str(e), ctx.finalized, len(g.stuck))
+    g.barrier()                                   # the group is still usable after a failed device init (the next carrier takes over)
     q.put((rank, out))
     g.close()
+    if g.stuck:
+        q.close(); q.join_thread()                # (the queue's feeder thread has flushed)
+        os._exit(0)                               # what bench.py does: never wait for a thread that sits in a dead bootstrap
 
 
 @pytest.mark.parametrize('bad', [(), (1,), (0, 2), ('id',)])
@@ -349,3 +410,26 @@ def test_init_device_reaches_a_consensus(bad):
         msgs = set(got[r][1] for r in range(world))
         assert len(msgs) == 1                                                            # the same verdict everywhere
         assert ('librccl' in got[0][1]) if 'id' in bad else all(('rank %d' % b) in got[0][1] for b in bad)
+
+
+def test_init_device_has_a_deadline():
+    """ncclCommInitRank blocks until every rank has joined -- forever if one never does.  It runs in a helper thread with a deadline:
+    the rank whose call did not return reports that as its verdict, EVERY rank raises within the deadline, the stuck thread is
+    remembered (the process then leaves through os._exit) and the sockets still work for the next carrier"""
+    import time as _t
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    t0 = _t.time()
+    procs = [ctx.Process(target=_init_device_worker, args=(r, world, port, (('hang', 1),), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert _t.time() - t0 < 45
+    assert all(got[r][0] == 'error' and 'rank 1: ncclCommInitRank did not return within 3 s' in got[r][1] for r in range(world))
+    assert got[1][3] == 1 and got[0][3] == 0 and got[2][3] == 0                        # the stuck thread is known where it is stuck
+    assert not got[1][2] and got[0][2] and got[2][2]                                   # (that rank must not call into the library's teardown)

@@ -30,7 +30,7 @@ def test_bench_launches_two_ranks_by_itself_on_one_gpu():
     arrived in rank order (asserted inside) and the cfg4 block's checks hold -- rank 1's first slab recomputed on rank 0, two
     slabs against the oracle; no torch in any of the three processes"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
-                        '--batch', '4', '--cfg4-slabs', '64', '--cfg4-reps', '1'],
+                        '--batch', '4', '--cfg4-slabs', '64', '--cfg4-reps', '1', '--cpu-slabs', '1', '--cpu-workers', '2'],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=_clean_env(), timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -159,15 +159,15 @@ def test_native_rccl_allgather_two_ranks_two_gpus(tmp_path):
     saved = dict(os.environ)
     try:
         os.environ.clear(); os.environ.update(_clean_env())
-        m.__file__ = str(prog)
-        assert m.launch_ranks(2, []) == 0
+        assert m.launch_ranks(2, [], program=str(prog)) == 0
     finally:
         os.environ.clear(); os.environ.update(saved)
 
 
-def test_rccl_unavailable_falls_back_to_the_host_carrier_loudly():
+def test_rccl_unavailable_lands_on_the_ipc_carrier_loudly():
     """two ranks on ONE GPU with the default backend: ncclCommInitRank fails on every rank ('duplicate GPU'), every rank
-    learns it (SocketGroup.init_device), the job gathers through the host and the line says so"""
+    learns it (SocketGroup.init_device), the job moves on to the HIP IPC carrier -- a device carrier, not the TCP one of round 4 -- and
+    the line says so, with the trials it made"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2',
                         '--no-cpu', '--no-cfg4'],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=_clean_env(), timeout=600, cwd=ROOT)
@@ -177,11 +177,41 @@ def test_rccl_unavailable_falls_back_to_the_host_carrier_loudly():
     nat.load().xc_device_count(C.byref(n))
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
-    assert d['n_gpus'] == 2
+    assert d['n_gpus'] == 2 and '[preflight] rank 1 -> device' in r.stderr and '[preflight] carrier:' in r.stderr
+    tr = d['config']['carrier_trials']
     if n.value < 2:
-        assert 'RCCL communicator unavailable' in d['config']['collective_note'] and 'host' in d['config']['parallelism']
+        assert 'rccl unavailable' in d['config']['collective_note'] and 'carrier ipc' in d['config']['parallelism']
+        assert 'error' in tr['rccl'] and tr['ipc']['ms_1MB'] > 0 and tr['ipc']['ms_32MB'] > 0 and 'host' not in tr
     else:
-        assert d['config']['collective_note'] is None and 'ncclAllGather' in d['config']['parallelism']
+        assert d['config']['collective_note'] is None and 'carrier rccl' in d['config']['parallelism'] and tr['rccl']['ms_32MB'] > 0
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_bench_ipc_ranks_on_one_gpu_equal_the_one_rank_job(world, tmp_path):
+    """`python3 bench.py --gpus N --backend ipc` (the driver's command form) with N = 2 and 4 ranks sharing this box's GPU: the HIP IPC
+    carrier gathers every rank's block to rank 0 -- a piece per launch set on the comm stream -- and the gathered (S, 9, N) cfg4
+    result equals the ONE-rank job's bit for bit (deterministic sums: a rank count must not change a bit); the gather's exposed
+    time stays in the milliseconds (round 4, through TCP: 400-510 ms); N > 1 lines carry roofline and cpu_baseline"""
+    outs = {}
+    for w in (1, world):
+        f = str(tmp_path / ('cfg4_%d.npy' % w))
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(w), '--steps', '2', '--warmup', '1', '--batch', '2', '--deterministic',
+               '--cfg4-slabs', '100', '--cfg4-chunk', '8', '--cfg4-reps', '1', '--dump-cfg4', f, '--no-extras', '--cpu-slabs', '1', '--cpu-workers', '2']
+        if w > 1:
+            cmd += ['--backend', 'ipc']
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=_clean_env(), timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[w] = (json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0]), np.load(f))
+    d, full = outs[world]
+    assert d['n_gpus'] == world and 'carrier ipc' in d['config']['parallelism'] and d['config']['collective_note'] is None
+    assert d['roofline']['frac'] > 0 and d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['parity_checked_slabs'] >= 1
+    c4 = d['cfg4_strong']
+    per = -(-100 // world)
+    assert c4['n_gpus'] == world and c4['slabs_per_gpu'] == per and c4['pieces_per_job'] == -(-per // 8) and 'HIP IPC' in c4['gather']
+    assert c4['checks']['first_slab_of_each_rank_recomputed'] == [r * per for r in range(world) if r * per < 100]
+    assert c4['budget']['gather_ms_max'] < 5.0, c4['budget']
+    assert full.shape == outs[1][1].shape == (100, 9, 201)
+    assert np.array_equal(bits(full), bits(outs[1][1]))                   # 100 = 4 x 25: ragged launch sets, and at N = 4 pieces of 8, 8, 8, 1
 
 
 # ---------------------------------------------------------------- K3 E32: float32 tracer + float32 levels, float32 bin search

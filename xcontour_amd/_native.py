@@ -90,6 +90,8 @@ PROTOTYPES = {
     'xc_event_destroy': (C.c_int, [_vp, _vp]),
     'xc_event_record': (C.c_int, [_vp, _vp]),
     'xc_event_elapsed_ms': (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
+    'xc_event_record_copies': (C.c_int, [_vp, _vp]),
+    'xc_event_query': (C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
     'xc_minmax_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp]),
     'xc_minmax': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp]),
     'xc_levels_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -131,6 +133,16 @@ PROTOTYPES = {
     'xc_comm_init': (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     'xc_comm_allgather_dev': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     'xc_comm_finalize': (C.c_int, [_vp]),
+    'xc_comm_gather_dev': (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int]),
+    'xc_comm_abort': (C.c_int, [_vp]),
+    'xc_comm_wait_compute': (C.c_int, [_vp]),
+    'xc_compute_wait_comm': (C.c_int, [_vp]),
+    'xc_comm_memcpy_d2d': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    'xc_streams_idle': (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    'xc_ipc_export': (C.c_int, [_vp, _vp, _vp]),
+    'xc_ipc_open': (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
+    'xc_ipc_close': (C.c_int, [_vp, _vp]),
+    'xc_device_can_access_peer': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'xc_synth_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _vp, _u64, C.c_int]),
 }
 
@@ -219,9 +231,13 @@ class DeviceBuffer(object):
         assert offset_bytes + arr.nbytes <= self.nbytes
         # lifetime rule: the source must stay alive until the copy has run.  Pageable sources make hipMemcpyAsync return
         # after the copy today, but that is how the runtime behaves, not a promise (and a pinned source returns at once):
-        # the context holds a reference until its next sync()
-        self.ctx._staged.append(arr)
-        self.ctx._check(self.ctx.lib.xc_memcpy_h2d_async(self.ctx.handle, self.ptr + offset_bytes, _ptr(arr), arr.nbytes))
+        # the context holds a reference until an event recorded on the copy stream behind this copy has completed
+        ctx = self.ctx
+        ctx._reap_staged()
+        ctx._check(ctx.lib.xc_memcpy_h2d_async(ctx.handle, self.ptr + offset_bytes, _ptr(arr), arr.nbytes))
+        ev = ctx._ev_pool.pop() if ctx._ev_pool else ctx.event()
+        ctx._check(ctx.lib.xc_event_record_copies(ctx.handle, ev))
+        ctx._staged.append((arr, ev))
         return self
 
     def download(self, shape, dtype, offset_bytes=0):
@@ -251,7 +267,8 @@ class Context(object):
         self.device = int(device)
         self._buffers = []
         self._resident = {}          # data pointer -> ndarray registered with xc_keep_resident (kept alive here)
-        self._staged = []            # host arrays of asynchronous uploads in flight (DeviceBuffer.upload_async), dropped by sync()
+        self._staged = []            # (host array, event) of asynchronous uploads in flight (DeviceBuffer.upload_async): dropped once the event has completed
+        self._ev_pool = []           # recycled events of completed uploads
         # host-pointer entry points stage at most this many bytes of per-slab data (tracer, integrands, per-slab weights,
         # per-slab outputs) on the device at once: larger stacks go through in batches of whole slabs (the reference's
         # histogram path is lazy / dask-friendly, core.py:158-160, 241-246)
@@ -276,11 +293,23 @@ class Context(object):
             pass
 
     def sync(self):
+        """wait for the COMPUTE stream.  Uploads in flight on the copy stream are not waited for (a download of batch k must not
+        stand behind the upload of batch k + 1): work that needs them says so with stream_wait_copies() before it is enqueued"""
         self._check(self.lib.xc_sync(self.handle))
-        if self._staged:
-            self.stream_wait_copies()
-            self._check(self.lib.xc_sync(self.handle))            # the compute stream now also stands behind every copy issued
-            del self._staged[:]
+        self._reap_staged()
+
+    def _reap_staged(self):
+        """drop the host arrays of asynchronous uploads whose copy has completed (an event per upload, polled: never blocks)"""
+        if not self._staged:
+            return
+        keep, done = [], C.c_int()
+        for arr, ev in self._staged:
+            self._check(self.lib.xc_event_query(self.handle, ev, C.byref(done)))
+            if done.value:
+                self._ev_pool.append(ev)
+            else:
+                keep.append((arr, ev))
+        self._staged = keep
 
     def stream_wait_copies(self):
         self._check(self.lib.xc_stream_wait_copies(self.handle))
@@ -377,6 +406,52 @@ class Context(object):
     def comm_finalize(self):
         self._check(self.lib.xc_comm_finalize(self.handle))
 
+    def comm_gather(self, send_ptr, nbytes, recv_ptr, rank_stride, root=0):
+        """gather to `root` over RCCL (grouped ncclSend / ncclRecv) on the comm stream: rank r's block lands at recv + r * rank_stride"""
+        self._check(self.lib.xc_comm_gather_dev(self.handle, send_ptr, int(nbytes), recv_ptr, int(rank_stride), int(root)))
+
+    def comm_abort(self):
+        self._check(self.lib.xc_comm_abort(self.handle))
+
+    # -- the comm stream (blocks leave while the next launch set computes) and the HIP IPC carrier
+    def comm_wait_compute(self):
+        self._check(self.lib.xc_comm_wait_compute(self.handle))
+
+    def compute_wait_comm(self):
+        self._check(self.lib.xc_compute_wait_comm(self.handle))
+
+    def comm_memcpy_d2d(self, dst_ptr, src_ptr, nbytes):
+        self._check(self.lib.xc_comm_memcpy_d2d(self.handle, dst_ptr, src_ptr, int(nbytes)))
+
+    def streams_idle(self):
+        v = C.c_int()
+        self._check(self.lib.xc_streams_idle(self.handle, C.byref(v)))
+        return bool(v.value)
+
+    def sync_within(self, seconds, poll=0.002):
+        """wait for the compute and comm streams like sync(), but give up after `seconds`: True when they drained"""
+        import time
+        t_end = time.time() + float(seconds)
+        while not self.streams_idle():
+            if time.time() > t_end:
+                return False
+            time.sleep(poll)
+        return True
+
+    def ipc_export(self, ptr):
+        buf = C.create_string_buffer(64)
+        self._check(self.lib.xc_ipc_export(self.handle, ptr, buf))
+        return bytes(buf.raw)
+
+    def ipc_open(self, handle):
+        assert len(handle) == 64
+        p = _vp()
+        self._check(self.lib.xc_ipc_open(self.handle, C.create_string_buffer(handle, 64), C.byref(p)))
+        return p.value
+
+    def ipc_close(self, ptr):
+        self._check(self.lib.xc_ipc_close(self.handle, ptr))
+
     # -- host-pointer compute entry points (numpy in, numpy out)
     def _batches(self, nslab, per_slab_bytes):
         """[(s0, s1), ...]: the slab axis cut into equal batches of whole slabs whose staged bytes stay below
@@ -417,6 +492,7 @@ class Context(object):
         q = _stack_in(q)
         assert q.ndim == 3
         nslab, ny, nx = q.shape
+        integrands = [v if _is_lazy(v) else np.asarray(v) for v in integrands]     # (nested lists are fine, as for q)
         per = ny * nx * (q.dtype.itemsize + sum(np.dtype(v.dtype).itemsize for v in integrands) + (8 if dA is not None and np.ndim(dA) == 3 else 0))
         bt = self._batches(nslab, per)
         if len(bt) > 1:                                      # more than one launch / one arena takes: batches of whole slabs
@@ -602,7 +678,8 @@ class Context(object):
         """`exact`: None (default) -- planes of up to 512 rows are summed in numpy's own order (bit-exact band walk), larger ones by
         the O(ny log ny) interval kernel when the reference state is monotone (checked on the device); True -- the band walk for
         every plane; False -- the interval kernel for every plane whose premises hold: they are checked HERE, on the host copy of
-        Q and the coordinate (no NaN in Q, s Q non-decreasing, the coordinate strictly monotone), and vouched for to the library,
+        Q, the coordinate and the tracer (Q finite, s Q non-decreasing, the coordinate strictly monotone, no infinite tracer
+        cell -- NaN cells are fine), and vouched for to the library,
         so the call is one launch (xc_set_lwa_exact modes 0 / 1 / 3); agreement ~1e-13 of the plane's largest value."""
         q = _stack_in(q)
         assert q.ndim == 3
@@ -632,7 +709,8 @@ class Context(object):
             sg = 1.0 if increase else -1.0
             c64 = np.asarray(coord, dtype=np.float64)
             dq, dc = np.diff(sg * Q, axis=1), np.diff(c64)
-            ok = bool(np.isfinite(Q).all() or (not np.isnan(Q).any())) and bool((dq >= 0).all()) and bool((dc > 0).all() or (dc < 0).all())
+            # FINITE, not only NaN-free: an infinite Q_j would make (Q'_j - c) * S0 = inf * 0 = NaN where the reference sums to 0
+            ok = bool(np.isfinite(Q).all()) and bool((dq >= 0).all()) and bool((dc > 0).all() or (dc < 0).all()) and not bool(np.isinf(q).any())
             mode = 3 if ok else 1
         self._check(self.lib.xc_set_lwa_exact(self.handle, mode))
         try:

@@ -24,7 +24,8 @@ Extensions over the reference (all optional, defaults follow the snapshot):
     runs (xhistogram: last edge + 1e-8 in the edge dtype, half-open), 'numpy' closes the last bin;
   * `cal_squared_gradient`, `keff` (fused pipeline), `metric=` in cal_local_wave_activity;
   * `deterministic=True`: order-free fixed-point sums in every histogram pass (include/xcontour_hip.h, "Deterministic
-    sums"): bit-identical results between runs and shardings, like the reference's np.bincount, at ~2x the pass.
+    sums"): bit-identical results between runs and shardings, like the reference's np.bincount; it also keeps
+    cal_local_wave_activity / cal_local_APE on the band walk that sums in numpy's order (`exact=True`) for every plane size.
 """
 import numpy as np
 
@@ -687,6 +688,8 @@ class Contour2D(object):
         if metric is not None:
             M = np.asarray(lb.unwrap(metric)[0] if lb.is_labeled(metric) else metric, dtype=np.float64).squeeze()
         pcode = {'all': 0, 'upper': 1, 'lower': 2}[part]
+        if exact is None and self.deterministic:
+            exact = True         # deterministic=True promises run-to-run identical bits: the interval kernel's LDS atomics add in arrival order
         lwa, masks = self.ctx.lwa(qv, Qv, eq.astype(np.float64), dA, dmax, M=M, increase=self.increase,
                                   part=pcode, mask_idx=mask_idx, variant=variant, exact=exact)
         qdims = lb.unwrap(q, lazy=True)[1]

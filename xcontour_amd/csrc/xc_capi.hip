@@ -210,6 +210,9 @@ int xc_destroy(xc_ctx* ctx)
     (void)xc_comm_finalize(ctx);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
+    if (ctx->ev_comm_in) (void)hipEventDestroy(ctx->ev_comm_in);
+    if (ctx->ev_comm_out) (void)hipEventDestroy(ctx->ev_comm_out);
     if (ctx->pinned_flag) (void)hipHostFree(ctx->pinned_flag);
     if (ctx->lwa_flag) (void)hipFree(ctx->lwa_flag);
     for (auto& e : ctx->resident) (void)hipFree(e.dev);
@@ -392,6 +395,25 @@ int xc_event_record(xc_ctx* ctx, void* event)
     if (!event) return fail(ctx, XC_EBADARG, "xc_event_record: NULL event");
     XC_HIP(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
     return XC_OK;
+}
+
+int xc_event_record_copies(xc_ctx* ctx, void* event)      // on the COPY stream: completes when the uploads issued so far have landed
+{
+    XC_CTX(ctx);
+    if (!event) return fail(ctx, XC_EBADARG, "xc_event_record_copies: NULL event");
+    XC_HIP(ctx, hipEventRecord((hipEvent_t)event, ctx->copy_stream));
+    return XC_OK;
+}
+
+int xc_event_query(xc_ctx* ctx, void* event, int* out_done)
+{
+    XC_CTX(ctx);
+    if (!event || !out_done) return fail(ctx, XC_EBADARG, "xc_event_query: NULL argument");
+    const hipError_t e = hipEventQuery((hipEvent_t)event);
+    if (e == hipSuccess) { *out_done = 1; return XC_OK; }
+    *out_done = 0;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return XC_OK; }
+    return hipfail(ctx, e, "hipEventQuery");
 }
 
 int xc_event_elapsed_ms(xc_ctx* ctx, void* start, void* stop, float* out_ms)

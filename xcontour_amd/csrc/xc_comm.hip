@@ -1,8 +1,15 @@
-// X1 -- the one collective of the slab-parallel path: an all-gather of the per-slab result
-// vectors over RCCL (xGMI) at the end of a job (SURVEY 8e / 8b `xc_comm_*`).  One process per
-// GPU; the 128-byte unique id is created on rank 0 (xc_comm_unique_id) and distributed by the
-// launcher (bench.py broadcasts it through the torch.distributed store).  librccl is loaded
-// lazily with dlopen so that single-GPU users do not pay for it.
+// X1 -- the one collective of the slab-parallel path: the gather of the per-slab result vectors at the end of a job
+// (SURVEY 8e / 8b `xc_comm_*`).  One process per GPU.  Two device carriers:
+//   * RCCL over xGMI: the 128-byte unique id is created on rank 0 (xc_comm_unique_id) and distributed by the launcher's
+//     rendezvous (xcontour_amd.distributed.SocketGroup); ncclAllGather (every rank gets everything) or a gather to ONE root
+//     (grouped ncclSend / ncclRecv: 1 / world of the all-gather's traffic).  librccl is loaded lazily with dlopen so that
+//     single-GPU users do not pay for it.
+//   * HIP IPC (no RCCL needed): the root exports its receive buffer (hipIpcGetMemHandle), every rank opens it and PUSHES its
+//     block with a device-to-device copy on its own comm stream (a peer write over xGMI on a real node, a same-device copy when
+//     several ranks share one GPU in a rehearsal) -- ordered behind its own kernels by an event, so no cross-process
+//     synchronisation is needed until the one rendezvous barrier at the end of the job.
+// Both run on the context's COMM stream (a third stream beside compute and upload): a launch set's block leaves while the next
+// launch set computes, and only the last set's block is exposed (xc_comm_wait_compute / xc_compute_wait_comm are the fences).
 #include "xc_internal.h"
 #include <dlfcn.h>
 #include <string.h>
@@ -18,11 +25,14 @@ typedef int (*fn_init_rank)(Comm*, int, UniqueId, int);
 typedef int (*fn_allgather)(const void*, void*, size_t, int /*ncclDataType_t*/, Comm, hipStream_t);
 typedef int (*fn_destroy)(Comm);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_sendrecv)(void*, size_t, int /*ncclDataType_t*/, int /*peer*/, Comm, hipStream_t);
+typedef int (*fn_group)(void);
 
 struct Rccl {
     void* h = nullptr;
     fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_allgather allgather = nullptr;
     fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
+    fn_sendrecv send = nullptr, recv = nullptr; fn_group group_start = nullptr, group_end = nullptr; fn_destroy abort = nullptr;
 };
 Rccl g_rccl;
 
@@ -37,6 +47,9 @@ int load_rccl(xc_ctx* ctx)
     g_rccl.allgather = (fn_allgather)dlsym(h, "ncclAllGather");
     g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    g_rccl.send = (fn_sendrecv)dlsym(h, "ncclSend"); g_rccl.recv = (fn_sendrecv)dlsym(h, "ncclRecv");
+    g_rccl.group_start = (fn_group)dlsym(h, "ncclGroupStart"); g_rccl.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
+    g_rccl.abort = (fn_destroy)dlsym(h, "ncclCommAbort");
     if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.allgather || !g_rccl.destroy)
         return fail(ctx, XC_EHIP, "xc_comm: librccl lacks a required symbol");
     g_rccl.h = h;
@@ -49,10 +62,24 @@ int rccl_fail(xc_ctx* ctx, int rc, const char* what)
     return fail(ctx, XC_EHIP, m);
 }
 
+// the comm stream and its two fence events, created on first use
+int ensure_comm_stream(xc_ctx* ctx)
+{
+    if (ctx->comm_stream) return XC_OK;
+    XC_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    XC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_in, hipEventDisableTiming));
+    XC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_out, hipEventDisableTiming));
+    return XC_OK;
+}
+
 }  // namespace
 }  // namespace xc
 
 using namespace xc;
+
+#define XC_COMM_CTX(ctx) do { if (!(ctx)) return fail(nullptr, XC_EBADARG, "null context"); \
+                              hipError_t _e = hipSetDevice((ctx)->device); \
+                              if (_e != hipSuccess) return hipfail((ctx), _e, "hipSetDevice"); } while (0)
 
 extern "C" {
 
@@ -93,11 +120,137 @@ int xc_comm_allgather_dev(xc_ctx* ctx, const void* send, void* recv, size_t byte
     return XC_OK;
 }
 
+// ---- gather to ONE root over RCCL: grouped ncclSend (every other rank) / ncclRecv (the root, one per peer) on the comm stream.
+// The root's own block is copied device to device.  recv + r * rank_stride is where rank r's `bytes` land (root only).
+int xc_comm_gather_dev(xc_ctx* ctx, const void* send, size_t bytes, void* recv, size_t rank_stride, int root)
+{
+    XC_COMM_CTX(ctx);
+    if (!ctx->comm) return fail(ctx, XC_EBADARG, "xc_comm_gather: no communicator (call xc_comm_init)");
+    if (!g_rccl.send || !g_rccl.recv || !g_rccl.group_start || !g_rccl.group_end)
+        return fail(ctx, XC_EHIP, "xc_comm_gather: librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+    if (!send || root < 0 || root >= ctx->comm_nranks || (ctx->comm_rank == root && !recv) || rank_stride < bytes)
+        return fail(ctx, XC_EBADARG, "xc_comm_gather: bad arguments");
+    { const int rc = ensure_comm_stream(ctx); if (rc != XC_OK) return rc; }
+    if (bytes == 0) return XC_OK;
+    if (ctx->comm_rank != root) {
+        const int r = g_rccl.send(const_cast<void*>(send), bytes, 0 /* ncclInt8 */, root, ctx->comm, ctx->comm_stream);
+        if (r != 0) return rccl_fail(ctx, r, "ncclSend");
+        return XC_OK;
+    }
+    XC_HIP(ctx, hipMemcpyAsync((char*)recv + (size_t)root * rank_stride, send, bytes, hipMemcpyDeviceToDevice, ctx->comm_stream));
+    int r = g_rccl.group_start();
+    if (r != 0) return rccl_fail(ctx, r, "ncclGroupStart");
+    for (int p = 0; p < ctx->comm_nranks; ++p) {
+        if (p == root) continue;
+        r = g_rccl.recv((char*)recv + (size_t)p * rank_stride, bytes, 0, p, ctx->comm, ctx->comm_stream);
+        if (r != 0) { (void)g_rccl.group_end(); return rccl_fail(ctx, r, "ncclRecv"); }
+    }
+    r = g_rccl.group_end();
+    if (r != 0) return rccl_fail(ctx, r, "ncclGroupEnd");
+    return XC_OK;
+}
+
+// ---- HIP IPC: a device allocation of one process mapped into another (no RCCL involved)
+int xc_ipc_export(xc_ctx* ctx, const void* dptr, void* out_handle64)
+{
+    XC_COMM_CTX(ctx);
+    if (!dptr || !out_handle64) return fail(ctx, XC_EBADARG, "xc_ipc_export: bad arguments");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t h;
+    XC_HIP(ctx, hipIpcGetMemHandle(&h, const_cast<void*>(dptr)));
+    memcpy(out_handle64, &h, sizeof(h));
+    return XC_OK;
+}
+
+int xc_ipc_open(xc_ctx* ctx, const void* handle64, void** out_dptr)
+{
+    XC_COMM_CTX(ctx);
+    if (!handle64 || !out_dptr) return fail(ctx, XC_EBADARG, "xc_ipc_open: bad arguments");
+    hipIpcMemHandle_t h; memcpy(&h, handle64, sizeof(h));
+    *out_dptr = nullptr;
+    XC_HIP(ctx, hipIpcOpenMemHandle(out_dptr, h, hipIpcMemLazyEnablePeerAccess));
+    return XC_OK;
+}
+
+int xc_ipc_close(xc_ctx* ctx, void* dptr)
+{
+    XC_COMM_CTX(ctx);
+    if (!dptr) return XC_OK;
+    if (ctx->comm_stream) XC_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));      // a push may still be writing through the mapping
+    XC_HIP(ctx, hipIpcCloseMemHandle(dptr));
+    return XC_OK;
+}
+
+// ---- the comm stream: device-to-device pushes and the fences against the compute stream
+int xc_comm_memcpy_d2d(xc_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    XC_COMM_CTX(ctx);
+    if (bytes && (!dst || !src)) return fail(ctx, XC_EBADARG, "xc_comm_memcpy_d2d: NULL pointer");
+    { const int rc = ensure_comm_stream(ctx); if (rc != XC_OK) return rc; }
+    if (bytes) XC_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->comm_stream));
+    return XC_OK;
+}
+
+int xc_comm_wait_compute(xc_ctx* ctx)          // later comm-stream work waits for the compute work enqueued so far
+{
+    XC_COMM_CTX(ctx);
+    { const int rc = ensure_comm_stream(ctx); if (rc != XC_OK) return rc; }
+    XC_HIP(ctx, hipEventRecord(ctx->ev_comm_in, ctx->stream));
+    XC_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_in, 0));
+    return XC_OK;
+}
+
+int xc_compute_wait_comm(xc_ctx* ctx)          // later compute-stream work (and xc_sync) waits for the comm work enqueued so far
+{
+    XC_COMM_CTX(ctx);
+    { const int rc = ensure_comm_stream(ctx); if (rc != XC_OK) return rc; }
+    XC_HIP(ctx, hipEventRecord(ctx->ev_comm_out, ctx->comm_stream));
+    XC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm_out, 0));
+    return XC_OK;
+}
+
+// 1 once everything enqueued on the compute AND comm streams has finished, 0 while it has not: a caller that must not block
+// forever (the first contact with a collective) polls this against its own deadline instead of calling xc_sync
+int xc_streams_idle(xc_ctx* ctx, int* out_idle)
+{
+    XC_COMM_CTX(ctx);
+    if (!out_idle) return fail(ctx, XC_EBADARG, "xc_streams_idle: out is NULL");
+    *out_idle = 0;
+    hipError_t e = hipStreamQuery(ctx->stream);
+    if (e == hipSuccess && ctx->comm_stream) e = hipStreamQuery(ctx->comm_stream);
+    if (e == hipSuccess) { *out_idle = 1; return XC_OK; }
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return XC_OK; }
+    return hipfail(ctx, e, "hipStreamQuery");
+}
+
+int xc_device_can_access_peer(int device, int peer, int* out_can)
+{
+    if (!out_can) return fail(nullptr, XC_EBADARG, "xc_device_can_access_peer: out is NULL");
+    *out_can = 0;
+    if (device == peer) { *out_can = 1; return XC_OK; }
+    int c = 0;
+    if (hipDeviceCanAccessPeer(&c, device, peer) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+    *out_can = c;
+    return XC_OK;
+}
+
+// give up on a communicator whose collective does not finish (ncclCommAbort frees it without waiting for its kernels)
+int xc_comm_abort(xc_ctx* ctx)
+{
+    if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
+    if (ctx->comm) {
+        Comm c = ctx->comm; ctx->comm = nullptr;
+        if (g_rccl.abort) { const int r = g_rccl.abort(c); if (r != 0) return rccl_fail(ctx, r, "ncclCommAbort"); }
+    }
+    return XC_OK;
+}
+
 int xc_comm_finalize(xc_ctx* ctx)
 {
     if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
     if (ctx->comm) {
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
         const int r = g_rccl.destroy(ctx->comm);
         ctx->comm = nullptr;
         if (r != 0) return rccl_fail(ctx, r, "ncclCommDestroy");

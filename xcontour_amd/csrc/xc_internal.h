@@ -32,6 +32,8 @@ struct xc_ctx {
     HistKnobs knobs;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;            // uploads that overlap compute (xc_memcpy_h2d_async)
+    hipStream_t comm_stream = nullptr;            // the gather's blocks leave on it while the next launch set computes (xc_comm_*; created on first use)
+    hipEvent_t ev_comm_in = nullptr, ev_comm_out = nullptr;
     hipEvent_t ev_copy = nullptr, ev_compute = nullptr;
     unsigned* pinned_flag = nullptr;   // 64 bytes of pinned host memory: the sort's one read-back
     struct Resident { const char* host; size_t bytes; void* dev; };

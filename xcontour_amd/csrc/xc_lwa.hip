@@ -405,7 +405,7 @@ void k_lwa_check(const double* __restrict__ Q, const double* __restrict__ coord,
     int bad = 0;
     for (int j = threadIdx.x; j < ny; j += 256) {
         const double v = Qs[j];
-        bad |= (v != v);
+        bad |= !(fabs(v) < __longlong_as_double(0x7ff0000000000000LL));   // finite: NaN fails, and so does an infinite level ((Q'_j - c) * S0 = inf * 0 = NaN in the interval kernel where the reference sums to 0)
         if (j + 1 < ny) {
             bad |= !(s * Qs[j + 1] >= s * v);                          // (a NaN neighbour fails too)
             bad |= cinc ? !(coord[j + 1] > coord[j]) : !(coord[j + 1] < coord[j]);
@@ -418,7 +418,7 @@ template <typename T>
 __global__ __launch_bounds__(1024)
 void k_lwa_fast(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ dA, int dA_rank, double dA_max,
                 const double* __restrict__ M, int M_rank, int ny, int64_t nx, int increase, int side, int CG,
-                double* __restrict__ out, const unsigned* __restrict__ gate, unsigned epoch)
+                double* __restrict__ out, unsigned* __restrict__ gate, unsigned epoch)
 {
     if (gate && *gate == epoch) return;          // k_lwa_check found a premise broken: the band walk enqueued behind this kernel runs instead (gate NULL: the caller vouches)
     extern __shared__ __align__(16) double sm[];
@@ -473,6 +473,10 @@ void k_lwa_fast(const T* __restrict__ q, const double* __restrict__ Q, const dou
             qv[u] = s * (double)qraw[u];
             const double m = M_rank == XC_DA_NONE ? da[u] : mm_[u];
             wv[u] = (da[u] / dA_max) * m;                                 // (u * wei) * M of core.py:789, weights first
+            // an INFINITE tracer cell is a premise this kernel cannot check ahead of time: +-inf into the difference arrays turns every
+            // row behind the cell into inf - inf = NaN, where the reference's per-row sums stay finite.  Stamp the flag: the gated band
+            // walk enqueued behind this kernel then runs and overwrites the plane (mode 3 has no gate: the caller vouched for finite cells)
+            if (gate && ok[u] && fabs(qv[u]) == __longlong_as_double(0x7ff0000000000000LL)) atomicMax(gate, epoch);
             ok[u] = ok[u] && (qv[u] == qv[u]) && (wv[u] == wv[u]);        // NaN tracer / weight: the term is NaN and nansum skips it
             lo[u] = 0; hi[u] = ok[u] ? ny : 0;                            // lower bound: first j with Q'_j >= q'
         }

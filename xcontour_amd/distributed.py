@@ -77,6 +77,20 @@ def _unpack_parts(blob, world):
     return parts
 
 
+def _is_loopback(addr):
+    """True for 127.0.0.0/8, ::1 and names that resolve only to such addresses"""
+    import ipaddress
+    try:
+        return ipaddress.ip_address(addr).is_loopback
+    except ValueError:
+        pass
+    try:
+        infos = socket.getaddrinfo(addr, None)
+    except OSError:
+        return False
+    return bool(infos) and all(ipaddress.ip_address(i[4][0].split('%')[0]).is_loopback for i in infos)
+
+
 class SocketGroup(object):
     """One process per rank, a star over TCP through rank 0.  Built for the rendezvous and ONE small collective at the end of
     a job (a few hundred MB at most), not for bandwidth: the device path is `allgather_device` (RCCL).
@@ -84,7 +98,10 @@ class SocketGroup(object):
     Trust: a peer must present the job's token -- `token` or the environment's XC_DIST_TOKEN (the launcher of bench.py draws a
     random one per job); rank 0 answers with a proof of the same token, so neither side talks to a stranger that merely got to
     the port first.  Frames are length-prefixed byte strings (no pickle); ranks are checked for range and uniqueness and frame
-    lengths against `MAX_FRAME_BYTES` before anything is allocated."""
+    lengths against `MAX_FRAME_BYTES` before anything is allocated.  WITHOUT a token the proofs would be keyed with the empty
+    string and prove nothing: that is accepted only when the rendezvous address is a loopback address (one node, e.g. under
+    `torch.distributed.run --master-addr 127.0.0.1`, where only local processes can reach the port); on any other address a
+    world > 1 without a token raises -- export XC_DIST_TOKEN (the same secret on every rank) or pass `token=`."""
 
     def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0, token=None):
         self.rank = int(os.environ.get('RANK', 0) if rank is None else rank)
@@ -94,10 +111,15 @@ class SocketGroup(object):
         tok = token if token is not None else os.environ.get('XC_DIST_TOKEN', '')
         tok = tok.encode() if isinstance(tok, str) else bytes(tok)
         self._peers, self._up, self._ctx = [], None, None
+        self.timeout = float(timeout)
+        self.stuck = []                  # helper threads that never came back from a blocking library call (init_device)
         if not (0 <= self.rank < self.world):
             raise Exception('SocketGroup: rank %d outside [0, %d)' % (self.rank, self.world))
         if self.world == 1:
             return
+        if not tok and not _is_loopback(addr):
+            raise Exception('SocketGroup: world %d on %s needs a job token (XC_DIST_TOKEN or token=): without one any process that '
+                            'reaches the port passes the handshake; only a loopback rendezvous may go without' % (self.world, addr))
 
         def proof(side, nonce, r):
             return hmac.new(tok, side + nonce + struct.pack('<i', r), hashlib.sha256).digest()
@@ -185,8 +207,19 @@ class SocketGroup(object):
     def broadcast_bytes(self, payload, src=0):
         return self.allgather_bytes(payload if self.rank == src else b'')[src]
 
-    def barrier(self):
-        self.allgather_bytes(b'')
+    def barrier(self, timeout=None):
+        """`timeout`: seconds this one barrier may take (default: the group's) -- e.g. while rank 0 times the CPU baseline"""
+        if timeout is None or self.world == 1:
+            self.allgather_bytes(b'')
+            return
+        socks = self._peers if self.rank == 0 else [self._up]
+        for c in socks:
+            c.settimeout(float(timeout))
+        try:
+            self.allgather_bytes(b'')
+        finally:
+            for c in socks:
+                c.settimeout(self.timeout)
 
     def allreduce_max(self, x):
         return max(struct.unpack('<d', p)[0] for p in self.allgather_bytes(struct.pack('<d', float(x))))
@@ -203,27 +236,57 @@ class SocketGroup(object):
         return np.stack([np.frombuffer(p, dtype=arr.dtype).reshape(arr.shape) for p in parts])
 
     # -- the device path: the library's RCCL communicator over xGMI
-    def init_device(self, ctx):
+    def init_device(self, ctx, timeout=None):
         """create the RCCL communicator of `ctx` (one context = one GPU per rank); the unique id travels through the sockets.
-        Every rank learns whether EVERY rank succeeded (an exception on all of them otherwise: nobody is left waiting)."""
+        Every rank learns whether EVERY rank succeeded (an exception on all of them otherwise: nobody is left waiting).
+        ncclCommInitRank blocks until all ranks have joined its bootstrap -- forever, if one of them never calls it -- so it runs
+        in a helper thread that is given `timeout` seconds (default XC_COMM_TIMEOUT_S, 60): a rank whose call has not returned
+        by then reports 'timed out' as its verdict, the consensus fails on every rank and the caller moves on to another
+        carrier.  The stuck thread is remembered in `self.stuck`: a process that has one must leave through os._exit after
+        printing its results (an interpreter waiting for it at exit would hang the job after all)."""
+        import threading
+        if timeout is None:
+            timeout = float(os.environ.get('XC_COMM_TIMEOUT_S', 60))
         err = ''
         try:
             uid = self.broadcast_bytes(ctx.comm_unique_id() if self.rank == 0 else b'')
         except Exception as e:                                     # rank 0 could not create the id (librccl missing ...)
             uid, err = self.broadcast_bytes(b''), str(e)
         if len(uid) == 128 and not err:
-            try:
-                ctx.comm_init(self.world, self.rank, uid)
-            except Exception as e:
-                err = str(e)
+            box = {}
+
+            def call():
+                try:
+                    ctx.comm_init(self.world, self.rank, uid)
+                    box['ok'] = True
+                except Exception as e:                             # noqa: BLE001 -- the verdict travels to every rank
+                    box['err'] = str(e)
+
+            t = threading.Thread(target=call, name='xc-comm-init', daemon=True)
+            t.start()
+            t.join(timeout)
+            if t.is_alive():
+                self.stuck.append(t)
+                err = 'ncclCommInitRank did not return within %.0f s' % timeout
+            elif 'err' in box:
+                err = box['err']
         elif not err:
             err = 'rank 0 could not create the RCCL unique id'
-        errs = [p.decode('utf-8', 'replace') for p in self.allgather_bytes(err.encode())]
+        # the slowest rank may sit in its deadline while the others already wait here: give the consensus that long
+        socks = self._peers if self.rank == 0 else [self._up]
+        for c in socks:
+            c.settimeout(self.timeout + timeout)
+        try:
+            errs = [p.decode('utf-8', 'replace') for p in self.allgather_bytes(err.encode())]
+        finally:
+            for c in socks:
+                c.settimeout(self.timeout)
         if any(errs):
-            try:
-                ctx.comm_finalize()
-            except Exception:
-                pass
+            if not self.stuck:
+                try:
+                    ctx.comm_finalize()
+                except Exception:
+                    pass
             raise Exception('RCCL communicator not created: ' + '; '.join('rank %d: %s' % (r, e) for r, e in enumerate(errs) if e))
         self._ctx = ctx
 
@@ -307,13 +370,22 @@ def run_sharded(process, nslab, rank, world, device=None, group=None, as_numpy=N
     """Process slabs [lo, hi) on this rank with `process(lo, hi) -> ndarray (hi-lo, ...)`
     (e.g. a KeffPlan over the rank's block) and gather every rank's result.  The CARRIER decides the return type, not the
     world size: with `group` (a SocketGroup) numpy in, numpy out, no torch; without one the torch.distributed process group
-    the caller initialised, a torch tensor on `device` out -- also at world == 1.  `as_numpy=True` asks for the numpy path
-    explicitly (world == 1 needs no group then)."""
+    the caller initialised, a torch tensor on `device` out.  At world == 1 with neither a group nor an initialised torch process
+    group there is nothing to gather through: numpy in, numpy out, torch never imported.  `as_numpy=True` asks for the numpy
+    path explicitly (world > 1 then needs a SocketGroup: anything else raises)."""
     lo, hi = shard_slabs(nslab, rank, world)
     out = np.ascontiguousarray(np.asarray(process(lo, hi)))
     if as_numpy is None:
         as_numpy = group is not None
+        if not as_numpy and world == 1:
+            # a single rank needs no carrier at all: stay in numpy unless the caller lives in an initialised torch process group
+            import sys
+            dist = sys.modules.get('torch.distributed')            # not imported yet: nobody can have initialised a process group
+            as_numpy = not (dist is not None and dist.is_available() and dist.is_initialized())
     if as_numpy:
+        if world > 1 and group is None:
+            raise Exception('run_sharded: as_numpy=True with world > 1 needs a SocketGroup as `group` (numpy blocks cannot travel '
+                            'through torch.distributed)')
         return all_gather_slabs(out, nslab, rank, world, group)
     import torch
     t = torch.from_numpy(out)
