@@ -353,6 +353,8 @@ class Gather(object):
             return
         passed, notes = [], []
         for c in self.ORDER[backend]:
+            if c == 'host' and passed:
+                break                                                   # ('auto': the host carrier only when no device carrier works)
             ok, why = self._try(c)
             if ok:
                 passed.append(c)
