@@ -763,8 +763,8 @@ def parse_args(argv=None):
                          'which the 16 B/cell roofline numerator is exactly the unique HBM traffic (the default run reports it '
                          'as `variants.slab_dA` after the timed region)')
     ap.add_argument('--deterministic', action='store_true',
-                    help='order-free fixed-point accumulation (xc_keff_desc.deterministic): bit-reproducible sums at about twice the '
-                         'histogram cost')
+                    help='order-free fixed-point accumulation (xc_keff_desc.deterministic): bit-reproducible sums in ONE pass, '
+                         'about 1.3x the histogram cost')
     ap.add_argument('--native-rccl', action='store_true', help='(kept for old command lines: the library communicator is the default now)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'rccl', 'ipc', 'gloo', 'host', 'auto'],
                     help="carrier of the ONE gather of a job (to rank 0): 'nccl' = 'rccl' (default): grouped ncclSend / ncclRecv over xGMI "

@@ -174,13 +174,18 @@ int xc_hist(xc_ctx* ctx, const xc_hist_desc* d);
 /* Deterministic sums (`deterministic != 0` in xc_hist_desc / xc_keff_desc).  The reference's per-bin sums come out of
  * np.bincount inside xhistogram (core.py:1284, 1307): the same input gives the same bits.  The default histogram pass
  * adds float64 weights with LDS atomics, so the last bits of pdf / cdf (area, intgrdS) depend on the order in which
- * waves reach the LDS and differ from run to run (~1e-13 relative).  With `deterministic` the pass runs twice:
- * (1) per (bin, channel) maximum |w| and exact counts; (2) every weight becomes the 64-bit integer rint(w * 2^k), k chosen
- * per (bin, channel) from (1) so that the bin's sum stays below 2^62 -- a function of the cell alone -- and the integers
- * are added with ds_add_u64.  Integer addition is associative: results are bit-identical between runs, launch geometries,
- * slabs per launch and numbers of ranks.  Cost: about twice the histogram pass (measured: DESIGN.md).  Precision: 62 -
- * ceil(log2 count) bits below the largest weight of the bin (no worse than float64 summation in any order); a
- * bin that received an infinite weight reports NaN.  Levels, edges and counts are the same bits in both modes. */
+ * waves reach the LDS and differ from run to run (~1e-13 relative).  With `deterministic` every (bin, channel) owns a
+ * fixed-point SUPERACCUMULATOR instead: four 48-bit limbs on a fixed grid below a window top that follows from bounds known
+ * before the pass (max |dA|; for the in-kernel squared gradient 2 ((max - min) max(rdx, rdy))^2 max |dA| from K1's extrema; for a
+ * supplied integrand max |integrand| max |dA|, from one extra min / max pass over it).  A weight is cut once to its leading 49
+ * significant bits -- a function of the cell alone -- and added as two integer chunks (ds_add_u64) to the two adjacent limbs its
+ * bits fall into, whatever its magnitude; the limbs are summed exactly and converted ONCE to float64 (round half to even).
+ * Integer addition is associative: results are bit-identical between runs, launch geometries, slabs per launch and numbers
+ * of ranks.  ONE pass over the cells (rounds 3-4 needed two: a per-bin scale came from a maximum pass): measured 1.3x the
+ * default pass.  Precision: 2^-49 relative per weight anywhere in the 180 bits below the bound (the pole row of
+ * a lat-lon grid carries squared gradients 2^100 times the typical ones: both keep their 49 bits); weights further down
+ * lose their last bits, zeros and denormals contribute nothing; a bin that received an infinite weight reports NaN.
+ * Levels, edges and counts are the same bits in both modes.  oracle/xcontour_oracle.py: deterministic_bin_sums. */
 
 /* ------------------------------------------------------------------ K2  row sums for the A(Yeq) table
  * Replaces the degenerate histogram of cal_area_eqCoord_table_hist   core.py:176-193
@@ -342,6 +347,8 @@ typedef struct xc_keff_desc {
                                    (nine dense [nslab][N] arrays).  9 * N with ctr = base, area = base + N, ... lays the
                                    results out slab-major, [nslab][9][N] -- the block a rank hands to the one gather
                                    with no repacking pass.  counts / interp / status keep their dense layout. */
+    double        dA_max;       /* deterministic sums only: the largest finite |dA| value, if the caller knows it (a static metric: computed once
+                                   on the host); <= 0 or NaN: the library takes it from the device array with one extra min / max pass over dA per call */
 } xc_keff_desc;
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
 

@@ -134,7 +134,7 @@ def hist_edges(b):
     return edges, bincrease
 
 
-def weighted_histogram(x, edges, weights=None, right_edge='xhistogram', deterministic=False):
+def weighted_histogram(x, edges, weights=None, right_edge='xhistogram', deterministic=False, det_top=None, det_limbs=4):
     """N-bin histogram of `x` over ascending `edges` (xhistogram semantics).
 
     bin k = [edges[k], edges[k+1]); NaN and out-of-range values dropped;
@@ -160,42 +160,106 @@ def weighted_histogram(x, edges, weights=None, right_edge='xhistogram', determin
         return counts.astype(np.float64), counts
     w = np.asarray(weights, dtype=np.float64).ravel()
     if deterministic:
-        return deterministic_bin_sums(idx, w, nb), counts
+        return deterministic_bin_sums(idx, w, nb, det_top, det_limbs), counts
     sums = np.bincount(idx, weights=w, minlength=nb + 2)[1:nb + 1]
     return sums, counts
 
 
-def deterministic_bin_sums(idx, w, nb):
+# ---- the order-free summation rule of the `deterministic` mode (round 5: ONE pass, a fixed-point superaccumulator)
+DET_LIMB_BITS = 48        # S: the accumulator of a (bin, channel) is a row of limbs, limb i counting units of 2^(top - S (i + 1))
+DET_PREC_BITS = 49        # P = S + 1: a weight rounded to P significant bits spans exactly two adjacent limbs
+DET_TOP_SLACK = 12        # the window starts 12 bits above the bound of the weights: the top limb never overflows
+DET_TOP_FLOOR = -800      # ... and never below 2^-800: zeros and denormals lie under every window
+
+
+def det_window_top(bound):
+    """exponent e with |w| < 2^e for every weight |w| <= bound (the exponent field of the bound, as frexp gives it for a normal
+    number), + DET_TOP_SLACK, not below DET_TOP_FLOOR"""
+    E = (int(np.float64(bound).view(np.uint64)) >> 52) & 0x7ff
+    return max(E - 1022 + DET_TOP_SLACK, DET_TOP_FLOOR)
+
+
+def det_chunks(w, top, nlimb):
+    """The integer a weight contributes to its accumulator, in units of 2^(top - S nlimb) (the window's last bit).
+    w = (-1)^sg m 2^x with m a 53-bit integer; n = m cut to its leading DET_PREC_BITS bits (ONE truncation per cell, a
+    function of the cell alone); n 2^x is cut at the limb boundaries into a high and a low chunk; a chunk that lies below
+    the window's last limb is dropped whole.  Zero, denormal and non-finite weights contribute nothing here."""
+    S, P = DET_LIMB_BITS, DET_PREC_BITS
+    b = int(np.float64(w).view(np.uint64))
+    E = (b >> 52) & 0x7ff
+    if E == 0 or E == 0x7ff:
+        return 0
+    m = (b & ((1 << 52) - 1)) | (1 << 52)
+    n = m >> (53 - P)                           # the low 4 bits of the significand are dropped
+    d = top + 1023 + 52 - (53 - P) - E          # bits from the rounded value's last bit up to the window top (>= P)
+    j = (d - 1) // S                            # limb that holds the last bit (limb 0 is the most significant)
+    sh = S * (j + 1) - d
+    hi, lo = n >> (S - sh), (n << sh) & ((1 << S) - 1)
+    t = 0
+    if j - 1 < nlimb:
+        t += hi << (S * (nlimb - j))
+    if j < nlimb:
+        t += lo << (S * (nlimb - 1 - j))
+    return -t if (b >> 63) else t
+
+
+def deterministic_bin_sums(idx, w, nb, top=None, nlimb=4):
     """Order-free per-bin sums (BUILD-DEFINED: the `deterministic` mode of the HIP histogram pass, include/xcontour_hip.h
-    "Deterministic sums"; the reference itself sums with np.bincount).  For every bin: M = max |w|, c = count,
-    k = 62 - ceil(log2 c) - (ilogb(M) + 1); every weight becomes the integer rint(w * 2^k) (round half to even, one
-    rounding per cell), the integers are added exactly (int64) and the total is converted once: float(n) * 2^-k.
-    Because integer addition is associative the result does not depend on the order of the cells -- the GPU must
-    reproduce it BIT FOR BIT.  A bin that holds an infinite weight yields NaN.  idx: bin of every cell in 1..nb
-    (np.digitize convention; everything else is dropped)."""
+    "Deterministic sums"; the reference itself sums with np.bincount, core.py:1284, 1307: the same input, the same bits).
+    Every weight is cut ONCE to its leading 49 significant bits and becomes an exact integer multiple of the accumulator's last bit
+    (`det_chunks`); the integers of a bin are added exactly and the total is converted ONCE to float64 (round half to even).
+    Integer addition is associative: the result does not depend on the order of the cells, the block geometry, the launch
+    partition or the number of ranks -- the GPU must reproduce it BIT FOR BIT.
+    `top`: the window's first bit, det_window_top(bound) for a rigorous bound of |w| known BEFORE the pass (the GPU: max dA; for
+    the in-kernel squared gradient 2 ((max - min) max(rdx, rdy))^2 max dA; max |integrand| max dA) -- default: from max |w|
+    itself.  The window holds 48 `nlimb` bits (the GPU: 4 limbs, 192 bits): weights more than 2^-119 below the bound start
+    losing their last bits, like in any finite accumulator -- the pole row of a lat-lon grid carries squared gradients 2^100
+    times the typical ones and both kinds keep all their 49 bits.
+    A bin that holds an infinite weight yields NaN.  idx: bin of every cell in 1..nb (np.digitize convention; everything
+    else is dropped)."""
+    import math
     idx = np.asarray(idx); w = np.asarray(w, dtype=np.float64)
     ok = (idx >= 1) & (idx <= nb)
     b, v = idx[ok] - 1, w[ok]
     out = np.zeros(nb, dtype=np.float64)
-    cnt = np.bincount(b, minlength=nb)
-    mx = np.zeros(nb, dtype=np.float64)
-    np.maximum.at(mx, b, np.abs(v))
-    for j in range(nb):
-        if cnt[j] == 0 or mx[j] == 0.0:
-            continue
-        if not np.isfinite(mx[j]):
-            out[j] = np.nan
-            continue
-        e = int(np.frexp(mx[j])[1])                  # mx < 2^e  (frexp: mx = m * 2^e with 0.5 <= m < 1), = ilogb + 1
-        L = int(cnt[j] - 1).bit_length() if cnt[j] > 1 else 0
-        k = 62 - L - e
-        t = np.ldexp(v[b == j], k)                   # exact scaling (|t| < 2^62 / c)
-        n = int(np.rint(t).astype(np.int64).sum(dtype=np.int64))      # np.rint: half to even; |sum| < 2^63
-        out[j] = np.ldexp(np.float64(n), -k)         # float(n): one rounding to 53 bits
+    fin = np.isfinite(v)
+    if top is None:
+        mx = float(np.max(np.abs(v[fin]))) if fin.any() else 0.0
+        top = det_window_top(mx if mx > 0 else 1.0)
+    S, P = DET_LIMB_BITS, DET_PREC_BITS
+    ebot = top - S * nlimb
+    bad = np.bincount(b[~fin], minlength=nb) > 0                  # a bin that saw an infinite weight reports NaN
+    # det_chunks for every cell at once (uint64 arithmetic; the per-bin sums of the 48-bit chunks are taken in two 24-bit
+    # halves with np.bincount, whose float64 accumulators hold integers below 2^53 exactly)
+    u = v.view(np.uint64)
+    E = ((u >> np.uint64(52)) & np.uint64(0x7ff)).astype(np.int64)
+    live = (E != 0) & (E != 0x7ff)
+    m = (u & np.uint64((1 << 52) - 1)) | np.uint64(1 << 52)
+    n = m >> np.uint64(53 - P)
+    d = top + 1023 + 52 - (53 - P) - E
+    j = (d - 1) // S
+    sh = (S * (j + 1) - d).astype(np.uint64)
+    hi = n >> (np.uint64(S) - sh)
+    lo = (n & ((np.uint64(1) << (np.uint64(S) - sh)) - np.uint64(1))) << sh
+    neg = (u >> np.uint64(63)) == 1
+    tot = [0] * nb
+    m24 = np.uint64((1 << 24) - 1)
+    for L in range(nlimb):
+        c = np.where(live & (j - 1 == L), hi, np.uint64(0)) + np.where(live & (j == L), lo, np.uint64(0))     # a cell feeds a limb at most once
+        for sgn, sel in ((1, ~neg), (-1, neg)):
+            if not sel.any():
+                continue
+            cl = np.bincount(b[sel], weights=(c[sel] & m24).astype(np.float64), minlength=nb)
+            ch = np.bincount(b[sel], weights=(c[sel] >> np.uint64(24)).astype(np.float64), minlength=nb)
+            for k in range(nb):
+                if cl[k] or ch[k]:
+                    tot[k] += sgn * ((int(ch[k]) << 24) + int(cl[k])) << (S * (nlimb - 1 - L))
+    for k in range(nb):
+        out[k] = np.nan if bad[k] else (math.ldexp(float(tot[k]), ebot) if tot[k] else 0.0)     # float(int): correctly rounded, half to even
     return out
 
 
-def histogram_cdf(q, b, weights, lt, right_edge='xhistogram', deterministic=False):
+def histogram_cdf(q, b, weights, lt, right_edge='xhistogram', deterministic=False, det_top=None, det_limbs=4):
     """`_histogram(var, bins, dim, weights, lt)` for one slab (core.py:1296-1325).
 
     Result is in ASCENDING-VALUE order (position i <-> i-th smallest level),
@@ -205,7 +269,7 @@ def histogram_cdf(q, b, weights, lt, right_edge='xhistogram', deterministic=Fals
     edges, bincrease = hist_edges(b)
     q = np.asarray(q)
     w = np.broadcast_to(np.asarray(weights), q.shape)
-    pdf, counts = weighted_histogram(q, edges, w, right_edge, deterministic)
+    pdf, counts = weighted_histogram(q, edges, w, right_edge, deterministic, det_top, det_limbs)
     cdf = np.cumsum(pdf)                                     # core.py:1320
     if not lt:
         cdf = cdf[-1] - cdf                                  # core.py:1322-1323
@@ -227,11 +291,11 @@ def _weights(dA, integrand, shape):
 
 
 def cal_integral_within_contours_hist(q, ctr, dA, integrand=None, lt=False,
-                                      right_edge='xhistogram', return_counts=False, deterministic=False):
+                                      right_edge='xhistogram', return_counts=False, deterministic=False, det_top=None, det_limbs=4):
     """core.py:412-460 for one slab: out[k] <-> ctr[k] whatever the direction."""
     q = np.asarray(q)
     wei = _weights(dA, integrand, q.shape)
-    cdf, pdf, counts, binc = histogram_cdf(q, ctr, wei, lt, right_edge, deterministic)
+    cdf, pdf, counts, binc = histogram_cdf(q, ctr, wei, lt, right_edge, deterministic, det_top, det_limbs)
     if not binc:                                             # core.py:454-455
         cdf, pdf, counts = cdf[::-1], pdf[::-1], counts[::-1]
     if return_counts:
@@ -741,13 +805,33 @@ def keff_pipeline(q, dA, lat, N, grdS=None, lon=None, mask=None, increase=True,
     q = np.asarray(q)
     if mask is None:
         mask = np.ones(q.shape, dtype=q.dtype)
+    supplied = grdS is not None
     if grdS is None:
         grdS = grad2_sphere(q, lat, lon)
     tbl, cs = cal_area_eqCoord_table_hist(mask, dA, lat, increase, lt, right_edge)
     ctr = cal_contours(q, N, increase, dtype)
-    area, counts = cal_integral_within_contours_hist(q, ctr, dA, None, lt,
-                                                     right_edge, return_counts=True, deterministic=deterministic)
-    intgrdS = cal_integral_within_contours_hist(q, ctr, dA, grdS, lt, right_edge, deterministic=deterministic)
+    top0 = top1 = None
+    if deterministic:
+        # the accumulator windows of the deterministic mode come from bounds known BEFORE the pass (deterministic_bin_sums):
+        # max |dA|; for the in-kernel squared gradient 2 ((max - min) max(rdx, rdy))^2 max dA; for a supplied one max |grdS| max dA
+        dA64 = np.asarray(dA, dtype=np.float64)
+        fin = np.abs(dA64[np.isfinite(dA64)])
+        dmax = np.float64(fin.max()) if fin.size else np.float64(0.0)
+        top0 = det_window_top(dmax)
+        if supplied:
+            g64 = np.asarray(grdS, dtype=np.float64)
+            gmax = max(abs(np.float64(np.nanmin(g64))), abs(np.float64(np.nanmax(g64))))
+            top1 = det_window_top(gmax * dmax)
+        else:
+            mn, mx = np.nanmin(q), np.nanmax(q)                      # in the tracer dtype, like cal_contours (core.py:224-225)
+            rng = np.float64(abs(mx - mn))
+            rdx, rdy = grad_metrics(lat, lon)
+            rdm = np.float64(max(np.max(np.abs(rdx)), np.max(np.abs(rdy))))
+            B = rng * rdm
+            top1 = det_window_top(((B * B) * np.float64(2.0)) * dmax)
+    area, counts = cal_integral_within_contours_hist(q, ctr, dA, None, lt, right_edge, return_counts=True,
+                                                     deterministic=deterministic, det_top=top0)
+    intgrdS = cal_integral_within_contours_hist(q, ctr, dA, grdS, lt, right_edge, deterministic=deterministic, det_top=top1)
     latEq = lookup_coordinates(area, tbl, cs)
     Lmin = latitude_lengths_at(latEq)
     dintSdA = cal_gradient_wrt_area(intgrdS, area)

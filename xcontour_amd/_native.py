@@ -62,6 +62,7 @@ class KeffDesc(C.Structure):
         ('counts', _vp), ('interp', _vp), ('status', _vp), ('q_next', _vp),
         ('dA_pos_finite', _i32), ('q_gen', _i32),
         ('deterministic', _i32), ('out_stride', _i32),
+        ('dA_max', _f64),
     ]
 
 

@@ -71,7 +71,7 @@ class Contour2D(object):
         self.increase = increase
         self.right_edge = right_edge
         self.device = device
-        self.deterministic = bool(deterministic)     # order-free fixed-point sums (bit-reproducible; ~2x the histogram pass)
+        self.deterministic = bool(deterministic)     # order-free fixed-point sums (bit-reproducible; ~1.3x the histogram pass)
         # resident=True: the tracer and the weights of THIS object are uploaded once and stay on the device between calls (the
         # reference's Keff sequence passes them to four calls in a row; every call used to cross PCIe again).  Do not modify
         # them in place afterwards without calling touch().
@@ -840,6 +840,8 @@ class Contour2D(object):
                             counts=False)                      # (Keff never looks at the cell counts: a third of K3's LDS atomics saved)
         if slab_dA:
             plan.desc.dA_pos_finite = int(bool(np.isfinite(dA).all() and (dA >= 0).all()))
+            fin = np.abs(dA[np.isfinite(dA)])
+            plan.desc.dA_max = float(fin.max()) if fin.size else 0.0      # over EVERY slab: a valid bound for each batch uploaded below
         ctx = self.ctx
         qb, gb, db = ny * nx * q.dtype.itemsize, 0 if g is None else ny * nx * g.dtype.itemsize, ny * nx * 8
 

@@ -148,22 +148,51 @@ __device__ __forceinline__ void lds_add(unsigned long long* p, unsigned long lon
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// rint(w * 2^k) (half to even) as a two's-complement 64-bit integer, |w * 2^k| < 2^62 (the deterministic sums,
-// xc_hist_det.hip; the oracle's deterministic_bin_sums is np.rint(np.ldexp(w, k)).astype(int64)).  gfx950 has no f64 -> i64
-// conversion: split t = hi * 2^32 + lo with hi = floor(t / 2^32) (exact: a power-of-two scaling, a floor and an FMA that
-// cancels), 0 <= lo < 2^32, round lo -- the fraction and the parity of t are those of lo, so rint(lo) completes rint(t) --
-// and convert the halves; rint(lo) == 2^32 saturates the 32-bit conversion and is carried into the high half.
-__device__ __forceinline__ unsigned long long fixed_point(double w, int k)
+// ---- deterministic sums in ONE pass (round 5): a fixed-point superaccumulator per (bin, channel).
+// The accumulator is a row of kDetLimbs limbs on a FIXED grid: limb i counts units of 2^(top - S (i + 1)), top = the window's first
+// bit, chosen from a rigorous bound of the channel's weights that is known BEFORE the pass (max dA; for the in-kernel squared gradient
+// 2 ((max - min) max(rdx, rdy))^2 max dA from K1's extrema and the metrics; max |integrand| max dA) plus kDetTopSlack bits, so that
+// the top limb cannot overflow.  A weight's 53-bit significand is cut ONCE to P = S + 1 = 49 bits (its low 4 bits dropped: a function of
+// the cell alone) and the resulting integer is split at the limb boundary into a high and a low chunk (each < 2^48), added with two
+// ds_add_u64 to the ADJACENT limbs its bits fall into -- whatever its magnitude: the pole row of a lat-lon grid carries squared
+// gradients 2^100 times the typical ones and both kinds keep their 49 bits.  Integer addition is associative: the sums do not depend
+// on the order of arrival, the block geometry, the launch partition or the number of ranks.  Capacity: a limb of one LDS copy takes at
+// most 32767 chunks before a signed 64-bit word could wrap (negative weights are two's complement) -- hist_geometry sizes the blocks
+// for it.  LDS layout per (bin, copy): kDetWords words per channel -- the limbs and ONE trash word behind them for a low chunk that
+// falls under the window -- then the count / flag word.  The oracle's deterministic_bin_sums / det_chunks restate this rule; the GPU
+// reproduces it bit for bit.
+constexpr int kDetLimbBits = 48;     // S
+constexpr int kDetPrecBits = 49;     // P = S + 1: a P-bit integer at any offset spans exactly two limbs
+constexpr int kDetTopSlack = 12;     // the window starts this many bits above the bound (2^23 cells x 2^(48 - 12) < 2^63 in the top limb)
+constexpr int kDetTopFloor = -800;   // ... and never below 2^-800: zero and denormal weights then lie under every window by construction
+constexpr int kDetLimbsX   = 4;      // limbs per channel: a 192-bit window, 180 bits of it below the bound
+constexpr int kDetWords    = kDetLimbsX + 1;
+__host__ __device__ constexpr int det_total_limbs(int nch) { return nch * kDetLimbsX; }
+// c0 = top + 1023 + 52 - (53 - P): d = c0 - E is the number of bits from the cut weight's last bit up to the window top (E: the
+// weight's biased exponent).  Returns jc in [1, kDetLimbsX]: `hi` goes to limb jc - 1, `lo` to word jc (a limb, or the trash word).
+// Weights wholly under the window, zeros and denormals (E == 0: d = c0 > S (kDetLimbsX + 1) by the floor on the top) give two zero
+// chunks.  A non-finite weight (E == 2047) gives garbage chunks in valid words: the caller flags the bin.
+__device__ __forceinline__ int det_split(double w, int c0, unsigned long long& hi, unsigned long long& lo, int& E)
 {
-    const double t = ldexp(w, k);
-    const double th = floor(t * 0x1p-32);
-    const double tl = rint(__builtin_fma(th, -0x1p32, t));
-    const unsigned long long lo = (unsigned long long)(unsigned)tl + (tl >= 0x1p32 ? 1ull : 0ull);
-    return ((unsigned long long)(long long)(int)th << 32) + lo;
+    const unsigned bh = (unsigned)__double2hiint(w), bl = (unsigned)__double2loint(w);
+    E = (int)((bh >> 20) & 0x7ffu);
+    unsigned long long n = (((unsigned long long)((bh & 0xfffffu) | 0x100000u) << 32) | bl) >> (53 - kDetPrecBits);
+    const int d = c0 - E;
+    if (d > kDetLimbBits * (kDetLimbsX + 1)) n = 0ull;
+    int j = (int)((((unsigned)(d - 1) >> 4) * 43691u) >> 17);             // (d - 1) / 48
+    asm("v_med3_i32 %0, %1, 1, %2" : "=v"(j) : "v"(j), "v"(kDetLimbsX));  // a weight above its bound (or an infinite one) must not leave the cell
+    const int s = kDetLimbBits * (j + 1) - d;                             // 0 .. 47 for a weight inside the window
+    hi = n >> (kDetLimbBits - s);
+    lo = (n << s) & 0xffffffffffffull;
+    return j;
 }
-__device__ __forceinline__ void lds_max(unsigned long long* p, unsigned long long v)      // ds_max_u64
+__host__ __device__ inline int det_c0_from_bound(double bound)           // bound >= 0: every |w| <= bound
 {
-    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned long long b; __builtin_memcpy(&b, &bound, 8);
+    const int E = (int)((b >> 52) & 0x7ffu);
+    int top = (E - 1022) + kDetTopSlack;                                  // frexp exponent of the bound + slack
+    if (top < kDetTopFloor) top = kDetTopFloor;
+    return top + 1023 + 52 - (53 - kDetPrecBits);
 }
 
 // copy slot of a lane.  (Rotating the slot by the bin index to spread LDS banks was measured

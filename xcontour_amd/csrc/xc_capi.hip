@@ -560,20 +560,50 @@ static int check_hist_desc(xc_ctx* ctx, const xc_hist_desc* d)
     return XC_OK;
 }
 
-// Deterministic sums: max pass, scales, fixed-point pass, exact integer reduction into f.red_h / f.red_c
-// (xc_hist_det.hip); launch_finalize then runs its second stage only.
-static int det_passes(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, HistArgs& a,
-                      int* scale, FinalArgs& f)
+// Deterministic sums in ONE histogram pass (xc_binning.h, xc_hist_det.hip): the bounds that fix every channel's accumulator window
+// come first -- max |dA| from the caller or from a min / max pass over the dA array, the extrema of every supplied integrand
+// (and of the tracer, for the in-kernel gradient with explicit edges) from K1 passes of their own -- then the pass, then the exact
+// reduction of the blocks' limbs into f.red_h / f.red_c; launch_finalize runs its second stage only.
+// `work`: det_bounds_bytes(nslab) of scratch for those extrema.
+static size_t det_bounds_bytes(int64_t nslab)
 {
-    const void* q_next = a.q_next; double* mm_next = a.mm_next;          // the NEXT batch's min / max ride in the second pass
-    a.q_next = nullptr; a.mm_next = nullptr; a.det_scale = nullptr;
-    XC_TRY(launch_hist_det(ctx, q_dtype, nint, grad, g, nslab, a, 1));
-    XC_TRY(launch_det_scales(ctx, nslab, g.bps, f.nch, f.nbin, a.part_h, a.part_c, scale, f.red_c));
-    a.det_scale = scale;
-    a.ctr_out = nullptr; a.edges_out = nullptr; a.status = nullptr;      // written by the first pass
-    a.q_next = q_next; a.mm_next = mm_next;
-    XC_TRY(launch_hist_det(ctx, q_dtype, nint, grad, g, nslab, a, 2));
-    XC_TRY(launch_det_reduce(ctx, nslab, g.bps, f.nch, f.nbin, a.part_h, scale, f.red_h));
+    // K1 partials of one array at a time + (min, max) pairs: dA, the tracer, XC_MAX_INTEGRANDS integrands
+    return al((size_t)nslab * kMinmaxBlocks * 2 * sizeof(double)) + (3 + XC_MAX_INTEGRANDS) * al((size_t)nslab * 2 * sizeof(double));
+}
+
+static int det_one_pass(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, int64_t ny, int64_t nx,
+                        HistArgs& a, int* c0, char* work, double dA_max_host, const void* const* integ, const int* integ_dtype, FinalArgs& f)
+{
+    double* part = (double*)work;
+    char* pairs = work + al((size_t)nslab * kMinmaxBlocks * 2 * sizeof(double));
+    const size_t pb = al((size_t)nslab * 2 * sizeof(double));
+    auto extrema = [&](const void* p, int dtype, int64_t ns, int64_t ncell, double* out) -> int {
+        XC_TRY(launch_minmax_partial(ctx, p, dtype, ns, ncell, part));
+        return launch_minmax_final(ctx, part, ns, minmax_blocks(ncell, ns), out);
+    };
+    a.det_dA_max = -1.0; a.det_dA_max_dev = nullptr; a.det_dA_stride = 0;
+    if (dA_max_host > 0.0 && dA_max_host < __builtin_inf()) a.det_dA_max = dA_max_host;
+    else if (a.dA == ctx->ones) a.det_dA_max = 1.0;
+    else {
+        double* out = (double*)pairs;
+        const int64_t ns = a.dA_rank == XC_DA_SLAB ? nslab : 1, ncell = a.dA_rank == XC_DA_ROW ? ny : ny * nx;
+        XC_TRY(extrema(a.dA, XC_F64, ns, ncell, out));
+        a.det_dA_max_dev = out; a.det_dA_stride = a.dA_rank == XC_DA_SLAB ? 1 : 0;
+    }
+    a.det_q_mm = nullptr;
+    if (grad && !a.levels_mode) {
+        double* out = (double*)(pairs + pb);
+        XC_TRY(extrema(a.q, q_dtype, nslab, ny * nx, out));
+        a.det_q_mm = out;
+    }
+    for (int i = 0; i < nint; ++i) {
+        double* out = (double*)(pairs + (2 + i) * pb);
+        XC_TRY(extrema(integ[i], integ_dtype[i], nslab, ny * nx, out));
+        a.det_int_mm[i] = out;
+    }
+    a.det_c0_out = c0;
+    XC_TRY(launch_hist_det3(ctx, q_dtype, nint, grad, g, nslab, a));
+    XC_TRY(launch_det3_reduce(ctx, nslab, g.bps, f.nch, f.nbin, a.part_h, a.part_c, c0, f.red_h, f.red_c));
     f.skip_reduce = 1;
     return XC_OK;
 }
@@ -587,11 +617,12 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     const int det = d->deterministic ? 1 : 0;
     XC_TRY(hist_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, nbin, nch,
                          vec_align_bits(d->q, d->q_dtype, nullptr, d->dA, d->dA_rank, d->integrand, d->integrand_dtype, d->nint), &g, 0, det));
-    const size_t ph = al((size_t)d->nslab * g.bps * nch * nbin * sizeof(double));
+    const size_t ph = al((size_t)d->nslab * g.bps * (det ? det_limbs_total(nch) : nch) * nbin * sizeof(double));
     const size_t pc = al((size_t)d->nslab * g.bps * nbin * sizeof(unsigned));
     const size_t rh = al((size_t)d->nslab * nch * nbin * sizeof(double));
     const size_t rc = al((size_t)d->nslab * nbin * sizeof(unsigned long long));
-    XC_TRY(ensure_scratch(ctx, ph + pc + rh + rc + (det ? rh : 0)));
+    XC_TRY(ensure_scratch(ctx, ph + pc + rh + rc + (det ? al((size_t)d->nslab * nch * sizeof(int)) + det_bounds_bytes(d->nslab) : 0)));
+    ctx->mm_valid = 0;                          // (the scratch may have moved)
     HistArgs a; memset(&a, 0, sizeof(a));
     a.q = d->q; a.dA = d->dA; a.dA_rank = d->dA_rank;
     if (d->dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); a.dA = ctx->ones; a.dA_rank = XC_DA_ROW; }
@@ -609,8 +640,9 @@ int xc_hist_dev(xc_ctx* ctx, const xc_hist_desc* d)
     f.lt = d->lt; f.reverse = d->reverse; f.pdf = d->pdf; f.counts = d->counts; f.cdf = d->cdf;
     XC_TRY(hist_ev_begin(ctx));
     if (det) {
-        int* scale = (int*)((char*)ctx->scratch + ph + pc + rh + rc);
-        XC_TRY(det_passes(ctx, d->q_dtype, d->nint, d->grad, g, d->nslab, a, scale, f));
+        char* xb = (char*)ctx->scratch + ph + pc + rh + rc;
+        XC_TRY(det_one_pass(ctx, d->q_dtype, d->nint, d->grad, g, d->nslab, d->ny, d->nx, a, (int*)xb,
+                            xb + al((size_t)d->nslab * nch * sizeof(int)), 0.0, d->integrand, d->integrand_dtype, f));
     } else {
         XC_TRY(launch_hist(ctx, d->q_dtype, d->nint, d->grad, g, d->nslab, a));
     }
@@ -996,11 +1028,13 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
                              fast_layout ? 1 : (supplied_f32 ? 2 : 0), det));
     }
     const size_t mb = al((size_t)d->nslab * kMinmaxBlocks * 2 * sizeof(double));
-    const size_t ph = al((size_t)d->nslab * g.bps * nch * N * sizeof(double));
+    // (deterministic sums: a block's partial is the limbs of its superaccumulators instead of one double per channel)
+    const size_t ph = al((size_t)d->nslab * g.bps * (det ? det_limbs_total(nch) : nch) * N * sizeof(double));
     const size_t pc = al((size_t)d->nslab * g.bps * N * sizeof(unsigned));
     const size_t rh = al((size_t)d->nslab * nch * N * sizeof(double));
     const size_t rc = al((size_t)d->nslab * N * sizeof(unsigned long long));
-    XC_TRY(ensure_scratch(ctx, mb + ph + pc + rh + rc + (det ? rh : 0)));
+    const size_t dx = det ? al((size_t)d->nslab * nch * sizeof(int)) + det_bounds_bytes(d->nslab) : 0;
+    XC_TRY(ensure_scratch(ctx, mb + ph + pc + rh + rc + dx));
     double* mmpart = (double*)ctx->scratch;
     double* part_h = (double*)((char*)ctx->scratch + mb);
     unsigned* part_c = (unsigned*)((char*)ctx->scratch + mb + ph);
@@ -1041,8 +1075,10 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     f.red_h = (double*)((char*)ctx->scratch + mb + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + mb + ph + pc + rh);
     XC_TRY(hist_ev_begin(ctx));
     if (det) {
-        int* scale = (int*)((char*)ctx->scratch + mb + ph + pc + rh + rc);
-        XC_TRY(det_passes(ctx, d->q_dtype, d->grad ? 0 : 1, d->grad, g, d->nslab, a, scale, f));
+        char* xb = (char*)ctx->scratch + mb + ph + pc + rh + rc;
+        const void* gi[1] = {d->grdS}; const int gt[1] = {d->grdS_dtype};
+        XC_TRY(det_one_pass(ctx, d->q_dtype, d->grad ? 0 : 1, d->grad, g, d->nslab, d->ny, d->nx, a, (int*)xb,
+                            xb + al((size_t)d->nslab * nch * sizeof(int)), d->dA_max, gi, gt, f));
     } else {
         XC_TRY(launch_hist(ctx, d->q_dtype, d->grad ? 0 : 1, d->grad, g, d->nslab, a));
     }

@@ -118,9 +118,11 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     int ncopy = (env_ncopy >= 1 && env_ncopy <= kMaxCopies && (env_ncopy & (env_ncopy - 1)) == 0) ? env_ncopy : kMaxCopies;
     // (the fixed-point pass keeps its (nbin + 1) x nch binary exponents behind the cells)
     // (and the float32 Keff layout a float32 copy of its nbin + 1 edges, same place)
-    const size_t behind = det ? ((size_t)(nbin + 1) * nch + 1) / 2 : ((keff_fast_layout == 1 && q_dtype == XC_F32 && nbin <= kE32MaxBins) ? ((size_t)nbin + 2) / 2 : 0);
+    const size_t behind = det ? 0 : ((keff_fast_layout == 1 && q_dtype == XC_F32 && nbin <= kE32MaxBins) ? ((size_t)nbin + 2) / 2 : 0);
     const size_t fixed = (64 + ((nbin + 2) & ~1) + behind) * sizeof(double);
-    const size_t cell = (size_t)(nch + 1) * 8;             // nch sums + the count, side by side; nbin + 1 bins (the last is the trash bin)
+    // nch sums + the count, side by side; nbin + 1 bins (the last is the trash bin).  Deterministic sums: the limbs of every channel's
+    // superaccumulator + a trash word + the count / flag word (xc_binning.h)
+    const size_t cell = det ? (size_t)(kDetWords * nch + 1) * 8 : (size_t)(nch + 1) * 8;
     while (ncopy > 1 && fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget) ncopy >>= 1;
     if (fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget)
         return fail(ctx, XC_EBADARG, "xc_hist: too many bins x channels for the LDS histogram");
@@ -134,7 +136,12 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     // (strip,row) pairs per wave when slabs are plentiful: long sweeps amortise the block prologue (min/max partials,
     // levels, LDS clear) and epilogue (copy reduction); scanned on MI355X: 64 -> 192 rows is +7 % on the chained cfg2
     // schedule and +9 % on cfg4-sized slabs, 256 and more lose to the tail of the last round
-    const int rows = env_rows > 0 ? env_rows : 192;
+    int rows = env_rows > 0 ? env_rows : 192;
+    // deterministic sums: a limb of one LDS copy holds at most 32767 chunks of 2^48 before a signed 64-bit word could wrap; a copy
+    // serves 64 / ncopy lanes of every wave, vec cells per lane and row (margin: the row chunks of the strip-fastest order are
+    // cut a little unevenly)
+    const int det_cap = det ? 28000 / (waves * (64 / ncopy) * g->vec) : 0;
+    if (det) { if (det_cap < 1) return fail(ctx, XC_EBADARG, "xc_hist: deterministic sums: too many bins for the LDS"); if (rows > det_cap) rows = det_cap; }
     int64_t bps = (total + waves * rows - 1) / (waves * rows);
     if (bps * nslab < cus) bps = (cus + nslab - 1) / nslab;
     // one block per CU is resident (LDS): make the grid a whole number of CU-wide rounds so that
@@ -148,6 +155,8 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     const int64_t maxb = (total + waves - 1) / waves;      // at least one pair per wave
     if (bps > maxb) bps = maxb;
     if (bps < 1) bps = 1;
+    if (det && (total + bps * waves - 1) / (bps * waves) > det_cap + det_cap / 16)
+        return fail(ctx, XC_EBADARG, "xc_hist: deterministic sums: this block geometry could overflow an accumulator limb (XC_HIST_BPS / XC_HIST_THREADS too small)");
     g->bps = (int)bps;
     g->part_h_doubles = (size_t)nch * nbin;
     return XC_OK;

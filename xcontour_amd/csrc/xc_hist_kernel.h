@@ -1,5 +1,5 @@
 // K3 kernel body + its launcher template, shared by xc_hist.hip (the float64-atomics variants) and xc_hist_det.hip (the
-// order-free fixed-point variants, DET = 1 / 2).  Included INSIDE `namespace xc { namespace {` of each translation unit.
+// order-free fixed-point variant, DET = 3).  Included INSIDE `namespace xc { namespace {` of each translation unit.
 #pragma once
 
 #ifndef XC_U
@@ -43,11 +43,10 @@ struct RowBuf {
 // FAST (Keff layout only): periodic X and dA verified finite and >= 0 are COMPILE-time facts -- the wall selects and
 // the fillna selects vanish from the row body.
 // DET (deterministic sums, xc_hist_det.hip): 0 = float64 LDS atomics (sums depend on the order in which waves reach the
-// LDS: last bits vary from run to run); 1 = per-bin max |w| with ds_max_u64 on the bit patterns (exact, order-free);
-// 2 = fixed-point accumulation: every weight becomes the 64-bit integer rint(w * 2^k), k chosen per (bin, channel) from
-// pass 1's maximum and count so that the bin's sum stays below 2^62, and the integers are added with ds_add_u64 -- integer
+// LDS: last bits vary from run to run); 3 = ONE pass into a fixed-point superaccumulator per (bin, channel): every weight is
+// rounded once to 49 bits and added as two integer chunks with ds_add_u64 to limbs on a fixed grid (xc_binning.h) -- integer
 // addition is associative, so the per-bin sums do not depend on the order of arrival, the block geometry or the number of
-// slabs per launch.
+// slabs per launch.  (Rounds 3-4: two passes, DET = 1 / 2 -- a per-bin scale needed the bin's maximum first.)
 // E32 (float32 tracer AND float32 contour levels, the Keff FAST layout; round 4): everything that is exact in float32 stays in
 // float32 -- the bin search (float32 values against float32 edges: the comparison np.digitize makes, so the counts are the same
 // bits; the nearest-edge guess in float32 is good to ~1e-4 of a bin, the decision is the exact compare), the min / max of the
@@ -86,10 +85,11 @@ void k_hist(const HistArgs a)
     // one CELL per (bin, copy): the NCH sums and the count side by side (count = low word of the last slot), so a cell's
     // three adds share ONE address computation; bin N is a trash bin -- NaN, out-of-range and inactive cells add there
     // unconditionally instead of branching around the adds (round 2: 86 -> 7x VALU instructions per 128-cell wave-row)
-    constexpr int CW = NCH + 1;
+    // DET == 3: a cell is, per channel, the limbs of its superaccumulator and a trash word (a chunk that falls below the window), then
+    // the count word (low half: count, high half: one bit per channel that saw a non-finite weight)
+    constexpr int CW = DET == 3 ? kDetWords * NCH + 1 : NCH + 1;
     double*   s_cell  = s_edges + epad;                         // [(N + 1) * ncopy][CW]
     const int hsz = (N + 1) * ncopy;
-    int*      s_scale = reinterpret_cast<int*>(s_cell + (size_t)CW * hsz);   // DET == 2: [(N + 1)][NCH] binary exponents k (w -> w * 2^k)
 
     // ------------------------------------------------------------------ this wave's share of (strip,row) pairs
     const int ny = (int)a.ny, nx = (int)a.nx;                    // host guarantees < 2^31
@@ -236,6 +236,19 @@ void k_hist(const HistArgs a)
     for (int i = tid; i < CW * hsz; i += blockDim.x) s_cell[i] = 0.0;
 
     // ------------------------------------------------------------------ edges -> LDS
+    int* s_c0 = reinterpret_cast<int*>(s_red + 56);             // DET == 3: the window constant of every channel (s_red[0 .. 47] hold the reductions)
+    double det_rng = 0.0, det_rdm = 0.0;                          // DET == 3: tracer range and largest gradient metric of this slab
+    if (DET == 3 && GRAD) {
+        // the largest factor a tracer difference can meet in the stencil: max over the rows of |rdx| (x 2 at the walls of a
+        // non-periodic domain) and |rdy|; fixed order of evaluation does not matter for a maximum
+        double m = 0.0;
+        for (int y = tid; y < ny; y += blockDim.x) {
+            const double rx = fabs(rdxp[y]) * (periodic_x ? 1.0 : 2.0);
+            m = fmax(m, fmax(rx, fabs(rdyp[y])));
+        }
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+        if (lane == 0) s_red[32 + wave] = m;
+    }
     if (a.levels_mode) {
         // reduce the per-block partial min/max of K1 (fixed order: deterministic)
         const double* mp = a.mmpart + (size_t)slab * a.P * 2;
@@ -247,6 +260,7 @@ void k_hist(const HistArgs a)
         mn = s_red[0]; mx = s_red[1];
         for (int w = 1; w < nwave; ++w) { mn = fmin(mn, s_red[2 * w]); mx = fmax(mx, s_red[2 * w + 1]); }
         if (mn == dinf() && mx == -dinf()) { mn = dnan(); mx = dnan(); }     // all-NaN slab
+        if (DET == 3 && GRAD) det_rng = a.q_f32 ? fabs((double)__fsub_rn((float)mx, (float)mn)) : fabs(__dsub_rn(mx, mn));
         for (int k = tid; k < N; k += blockDim.x) {
             const double c = level_value(mn, mx, k, a.increase, a.q_f32, a.ctr_f32, a.inv_nm1);
             s_edges[a.increase ? k + 1 : N - k] = c;
@@ -272,7 +286,41 @@ void k_hist(const HistArgs a)
         const double* e = a.edges + (a.edges_per_slab ? (size_t)slab * (N + 1) : 0);
         for (int k = tid; k <= N; k += blockDim.x) s_edges[k] = e[k];
         __syncthreads();
+        if (DET == 3 && GRAD) {                                   // explicit edges: the tracer's extrema come from a K1 pass of their own
+            const double mn = a.det_q_mm[2 * (size_t)slab], mx = a.det_q_mm[2 * (size_t)slab + 1];
+            det_rng = a.q_f32 ? fabs((double)__fsub_rn((float)mx, (float)mn)) : fabs(__dsub_rn(mx, mn));
+        }
     }
+    if (DET == 3) {
+        // the window of every channel's accumulator, from bounds known before the pass (see xc_binning.h); every block of the slab
+        // derives the same constants from the same inputs
+        if (GRAD) { det_rdm = s_red[32]; for (int w = 1; w < nwave; ++w) det_rdm = fmax(det_rdm, s_red[32 + w]); }
+        if (tid == 0) {
+            double dmax = a.det_dA_max;
+            if (!(dmax >= 0.0)) {
+                const double* mm = a.det_dA_max_dev + 2 * (size_t)slab * a.det_dA_stride;
+                dmax = fmax(fabs(mm[0]), fabs(mm[1]));
+            }
+            s_c0[0] = det_c0_from_bound(dmax);
+#pragma unroll
+            for (int i = 0; i < NINT; ++i) {
+                const double* mm = a.det_int_mm[i] + 2 * (size_t)slab;
+                double bnd = __dmul_rn(fmax(fabs(mm[0]), fabs(mm[1])), dmax);
+                if (a.prod_f32) bnd = __dmul_rn(bnd, 1.0000002384185791);        // (the float32 product may round up past the float64 one)
+                s_c0[1 + i] = det_c0_from_bound(bnd);
+            }
+            if (GRAD) {
+                const double B = __dmul_rn(det_rng, det_rdm);
+                s_c0[NCH - 1] = det_c0_from_bound(__dmul_rn(__dmul_rn(__dmul_rn(B, B), 2.0), dmax));
+            }
+            if (bx == 0 && a.det_c0_out)
+                for (int ch = 0; ch < NCH; ++ch) a.det_c0_out[(size_t)slab * NCH + ch] = s_c0[ch];
+        }
+        __syncthreads();
+    }
+    int c0r[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) c0r[ch] = DET == 3 ? __builtin_amdgcn_readfirstlane(s_c0[ch]) : 0;
     const double e0 = s_edges[0], eN = s_edges[N];
     const double inv = (double)N / (eN - e0);
     // E32: a float32 copy of the edges (they ARE float32 values: ctr_f32) behind the cells, for 4-byte reads
@@ -293,15 +341,6 @@ void k_hist(const HistArgs a)
     const int negate = a.negate;
     const bool want_cnt = DET != 0 || a.part_c != nullptr;         // counts are an OUTPUT only: the float64-atomics pass skips their adds when none is wanted
     const bool wpos = FAST ? true : (a.dA_pos_finite != 0);
-    if (DET == 2) {
-        const int* sc = a.det_scale + (size_t)slab * NCH * N;                     // [NCH][N], written by k_det_scales
-        for (int i = tid; i < NCH * (N + 1); i += blockDim.x) {
-            const int b = i / NCH, ch = i - b * NCH;
-            s_scale[i] = b < N ? sc[(size_t)ch * N + b] : 0;                       // the trash bin takes any exponent
-        }
-        __syncthreads();
-    }
-
     double   acc[NCH];
     unsigned cnt = 0;
     int      cur = -1;                   // wave-uniform: bin of the register accumulators
@@ -423,16 +462,24 @@ void k_hist(const HistArgs a)
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) lds_add(cp + ch, w[ch][c]);
                     if (want_cnt) lds_add(reinterpret_cast<unsigned*>(cp + NCH), 1u);       // (wave-uniform: a third of the LDS atomics when nobody asked for counts)
-                } else if (DET == 1) {
-#pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch)
-                        lds_max(reinterpret_cast<unsigned long long*>(cp + ch), (unsigned long long)__double_as_longlong(fabs(w[ch][c])));
-                    lds_add(reinterpret_cast<unsigned*>(cp + NCH), 1u);
                 } else {
-                    const int* sp = s_scale + k[c] * (unsigned)NCH;
+                    unsigned long long* cw = reinterpret_cast<unsigned long long*>(cp);
 #pragma unroll
-                    for (int ch = 0; ch < NCH; ++ch)
-                        lds_add(reinterpret_cast<unsigned long long*>(cp + ch), fixed_point(w[ch][c], sp[ch]));
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        const double wv = w[ch][c];                             // (NaN went to 0 above)
+                        unsigned long long hi, lo; int E;
+                        const int jc = det_split(wv, c0r[ch], hi, lo, E);
+                        if (__any(E == 0x7ff)) {                                // an infinite weight (wave-uniform, rare): the bin reports NaN
+                            if (E == 0x7ff) atomicOr(reinterpret_cast<unsigned*>(cw + (CW - 1)) + 1, 1u << ch);
+                        }
+                        if (!wpos || (ch >= 1 && ch <= NINT)) {                 // weights that may be negative (a supplied integrand; dA not vouched for): two's complement chunks
+                            const unsigned long long sm = (unsigned long long)(__double_as_longlong(wv) >> 63);
+                            hi = (hi ^ sm) - sm; lo = (lo ^ sm) - sm;
+                        }
+                        unsigned long long* p = cw + (kDetWords * ch - 1) + jc;  // limb jc - 1, and the word behind it
+                        lds_add(p, hi); lds_add(p + 1, lo);
+                    }
+                    lds_add(reinterpret_cast<unsigned*>(cw + (CW - 1)), 1u);
                 }
             }
         }
@@ -498,27 +545,51 @@ void k_hist(const HistArgs a)
 
     // ------------------------------------------------------------------ per-block partials (plain stores)
     const size_t pb = (size_t)slab * nbx + bx;
+    if (DET == 3) {
+        // one thread per (channel, bin): the limbs of the LDS copies added in copy order with carries, so that what leaves the block is
+        // canonical -- every limb below the first in [0, 2^48), the first one signed -- and a few thousand blocks can be added in 64 bits
+        constexpr int NL = det_total_limbs(NCH);
+        unsigned long long* pl = reinterpret_cast<unsigned long long*>(a.part_h) + pb * NL * N;
+        for (int i = tid; i < NCH * N; i += blockDim.x) {
+            const int ch = i / N, b = i - ch * N;
+            long long acc[kDetLimbsX] = {0, 0, 0, 0};
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(s_cell) + (size_t)b * ncopy * CW + kDetWords * ch;
+            for (int c = 0; c < ncopy; ++c) {
+                long long carry = 0;
+#pragma unroll
+                for (int l = kDetLimbsX - 1; l >= 0; --l) {
+                    long long v = acc[l] + (long long)src[(size_t)c * CW + l] + carry;
+                    carry = 0;
+                    if (l > 0) { carry = v >> kDetLimbBits; v -= carry << kDetLimbBits; }
+                    acc[l] = v;
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < kDetLimbsX; ++l) pl[(size_t)(kDetLimbsX * ch + l) * N + b] = (unsigned long long)acc[l];
+        }
+        unsigned* pc3 = a.part_c + pb * N;
+        for (int b = tid; b < N; b += blockDim.x) {
+            unsigned sum = 0u, fl = 0u;
+            for (int c = 0; c < ncopy; ++c) {
+                const unsigned* p = reinterpret_cast<const unsigned*>(s_cell + (size_t)(b * ncopy + c) * CW + (CW - 1));
+                sum += p[0]; fl |= p[1];
+            }
+            pc3[b] = sum | (fl << 28);                            // a block holds fewer than 2^28 cells: the flags ride in the top bits
+        }
+        return;
+    }
     double* ph = a.part_h + pb * NCH * N;
     // sum the lane-privatised copies; every thread starts at a rotated copy index so that the
     // 64 lanes of a wave hit distinct LDS banks (a fixed, thread-determined order)
     for (int i = tid; i < NCH * N; i += blockDim.x) {
         const int ch = i / N, b = i - ch * N;
         const double* src = s_cell + (size_t)b * ncopy * CW + ch;
-        if (DET == 0) {
-            double sum = 0.0;
-            for (int c = 0; c < ncopy; ++c) sum += src[(size_t)((c + tid) & (ncopy - 1)) * CW];
-            ph[i] = sum;
-        } else {                                      // bit patterns: the maximum (DET 1) or the wrapping sum (DET 2) of the copies
-            unsigned long long r = 0ull;
-            for (int c = 0; c < ncopy; ++c) {
-                const unsigned long long v = *reinterpret_cast<const unsigned long long*>(src + (size_t)c * CW);
-                r = DET == 1 ? (v > r ? v : r) : r + v;
-            }
-            reinterpret_cast<unsigned long long*>(ph)[i] = r;
-        }
+        double sum = 0.0;
+        for (int c = 0; c < ncopy; ++c) sum += src[(size_t)((c + tid) & (ncopy - 1)) * CW];
+        ph[i] = sum;
     }
     unsigned* pc = a.part_c + pb * N;
-    if (DET != 2 && a.part_c)                                     // the fixed-point pass takes the counts of the max pass
+    if (a.part_c)
     for (int b = tid; b < N; b += blockDim.x) {
         unsigned sum = 0u;
         for (int c = 0; c < ncopy; ++c)

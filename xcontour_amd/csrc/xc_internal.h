@@ -149,7 +149,13 @@ struct HistArgs {
     int           ctr_stride;   // doubles between consecutive slabs in ctr_out (nbin: dense)
     double*       edges_out;    // [nslab][nbin+1] (levels mode, may be null)
     int32_t*      status;       // [nslab]         (levels mode, may be null)
-    const int*    det_scale;    // [nslab][nch][nbin] binary exponents of the fixed-point pass (DET == 2), else null
+    // DET == 3 (one-pass superaccumulator): the bounds that fix every channel's window BEFORE the pass
+    double        det_dA_max;   // max finite |dA| (host value), or < 0: read det_dA_max_dev
+    const double* det_dA_max_dev;   // [nslab or 1][2] (min, max) pairs of the dA array, as K1 leaves them (stride det_dA_stride pairs per slab)
+    int           det_dA_stride;
+    const double* det_q_mm;     // [nslab][2] min / max of the tracer (explicit-edges mode with the in-kernel gradient), else null (levels mode: the prologue's own)
+    const double* det_int_mm[XC_MAX_INTEGRANDS];   // [nslab][2] min / max of every supplied integrand
+    int*          det_c0_out;   // [nslab][nch]: the window constants the blocks derived (the reduction needs them)
 };
 
 struct FinalArgs {
@@ -184,13 +190,11 @@ int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab,
 int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int nbin, int nch,
                   const void* q, HistGeom* g, int keff_fast_layout = 0, int det = 0);
 int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a);
-// deterministic sums (xc_hist_det.hip): pass 1 (det = 1, per-bin max |w| + counts), the scales, pass 2 (det = 2, fixed point),
-// and the exact integer reduction that fills FinalArgs.red_h / red_c (launch_finalize is then called with skip_reduce)
-int launch_hist_det(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a, int det);
-int launch_det_scales(xc_ctx* ctx, int64_t nslab, int bps, int nch, int nbin, const double* part_h, const unsigned* part_c,
-                      int* scale, unsigned long long* red_c);
-int launch_det_reduce(xc_ctx* ctx, int64_t nslab, int bps, int nch, int nbin, const double* part_h, const int* scale,
-                      double* red_h);
+// the one-pass deterministic sums (DET == 3, xc_binning.h): the histogram pass itself and the exact reduction of its limbs
+int launch_hist_det3(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a);
+int launch_det3_reduce(xc_ctx* ctx, int64_t nslab, int bps, int nch, int nbin, const double* part_l, const unsigned* part_c,
+                       const int* c0, double* red_h, unsigned long long* red_c);
+int det_limbs_total(int nch);
 int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a);
 int launch_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, int dA_rank,
                   int64_t ny, int64_t nx, int multiply, double* out_rows);

@@ -101,6 +101,10 @@ class KeffPlan(object):
             self._dA_ptr = self.dA_buf.ptr
             d.dA = self._dA_ptr
             d.dA_pos_finite = int(bool(np.isfinite(dA).all() and (dA >= 0).all()))   # static metric: checked once
+            fin = np.abs(dA[np.isfinite(dA)])
+            d.dA_max = float(fin.max()) if fin.size else 0.0          # (deterministic sums: the window of the dA channel's accumulator)
+            if d.dA_rank == nat.XC_DA_SLAB and dA.ndim == 3 and dA.shape[0] < self.nslab:
+                d.dA_max = 0.0                                        # planes uploaded later: the library looks at the device array itself
         if grdS_dtype is None:
             if rdx is None:
                 rdx, rdy = grad_metrics(lat, lon, Rearth)
@@ -210,6 +214,7 @@ class KeffPlan(object):
         """Use an existing device pointer as dA (same rank and shape as the dA given to the constructor)."""
         self._dA_ptr = int(ptr)
         self.desc.dA = self._dA_ptr
+        self.desc.dA_max = 0.0                       # unknown contents: deterministic sums take the bound from the device array
 
     def set_grdS(self, g):
         g = np.ascontiguousarray(g, dtype=self.grdS_dtype).reshape(self.nslab, self.ny, self.nx)
