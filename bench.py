@@ -744,7 +744,7 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=64, help='slabs per step per GPU')
     ap.add_argument('--group', type=int, default=0, help='slabs per launch set (0: whole batch)')
-    ap.add_argument('--variant', type=int, default=0, help='0 PV-like, 1 noise, 2 sin(lat)')
+    ap.add_argument('--variant', type=int, default=0, choices=[0, 1, 2, 3], help='0 PV-like (grid-scale noise), 1 noise, 2 sin(lat), 3 the reference\'s barotropic vorticity field interpolated to the cfg2 grid (smooth at grid scale)')
     ap.add_argument('--chain', dest='chain', action='store_true', default=True,
                     help="(default) software-pipelined stack processing: this step's histogram pass also streams the "
                          "NEXT step's batch and leaves its min/max partials (xc_keff_desc.q_next), so the stand-alone "
@@ -868,7 +868,10 @@ def main():
     plan = KeffPlan(ctx, NB * B, NY, NX, NCONT, qdt, qdt, dA=dA, lat=lat, lon=lon, tbl=tbl,
                     tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.ptr, detect_row_dA=a.row_dA,
                     out_slabs=B, replicate_dA=a.slab_dA, right_edge='xhistogram', deterministic=a.deterministic)
-    plan.synth(lat, lon, SEED + rank * NB * B, a.variant)         # slab s of rank r: seed + r*2B + s
+    if a.variant == 3:
+        plan.set_q(baro_slabs(NB * B, qdt, rank * NB * B))        # the reference's barotropic field on the cfg2 grid (smooth at grid scale)
+    else:
+        plan.synth(lat, lon, SEED + rank * NB * B, a.variant)     # slab s of rank r: seed + r*2B + s
     grp = a.group or B
     chain = bool(a.chain)
 
@@ -985,7 +988,8 @@ def main():
         # (float32 contours: the last level is the float32 rounding of the maximum and `+ 1e-8` is below its resolution, so the
         #  maximum cell itself may fall outside the last edge -- reference behaviour; the oracle check below is exact)
         csum = out['counts'].sum(axis=1).astype(np.int64)
-        if not ((csum == NY * NX).all() if a.dtype == 'f64' else ((csum <= NY * NX) & (csum >= NY * NX - 4)).all()) or out['status'].any():
+        lost = NX if a.variant == 2 else 4                           # (sin(lat): the whole pole row holds the maximum)
+        if not ((csum == NY * NX).all() if a.dtype == 'f64' else ((csum <= NY * NX) & (csum >= NY * NX - lost)).all()) or out['status'].any():
             raise RuntimeError('bench self-check failed: counts %r status %r' % (out['counts'].sum(axis=1), out['status']))
         extras = world == 1 and grp == B and not a.no_extras
         if extras and chain:
@@ -1091,7 +1095,14 @@ def main():
     if rank == 0 and world == 1 and a.dtype == 'f64' and grp == B and not a.no_extras and not (a.slab_dA or a.row_dA or a.deterministic):
         # float32 tracers and contours -- the reference's default `dtype` and the dtype of the files it ships -- through the same
         # chained schedule, so that the driver's line carries them; two slabs of its last step against the oracle
-        line.setdefault('variants', {})['f32'] = variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain)
+        v32 = variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain)
+        if a.variant == 0 and 'skipped' not in v32:
+            # the same float32 schedule on fields that look like the reference's data: sin(lat) (whole rows in one bin) and the
+            # reference's own barotropic vorticity field interpolated to this grid (smooth at grid scale: adjacent cells share bins)
+            v32['fields'] = {'pv_like_with_grid_scale_noise': {k: v32[k] for k in ('us_per_slab', 'launch_ms', 'frac', 'hbm_unique_frac')},
+                             'sin_lat': variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain, variant=2, ncheck=0, brief=True),
+                             'barotropic_vorticity_interpolated': variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain, variant=3, ncheck=1, brief=True)}
+        line.setdefault('variants', {})['f32'] = v32
     # ---- cfg4 strong scaling: every rank takes part (its own timed region, after the cfg2 buffers are gone)
     if not a.no_cfg4 and a.dtype == 'f64':
         stage('cfg4')
@@ -1111,6 +1122,28 @@ def main():
     group.close()
 
 
+def baro_slabs(nslab, dtype, seed=0):
+    """`--variant 3`: the reference's own barotropic vorticity field (tests/golden/baro_q.npy, 256 x 512 float32 on a Gaussian
+    grid) interpolated bilinearly to the cfg2 grid -- smooth at grid scale, as real data is (a 256-cell row spans two to four of the
+    201 bins; the PV-like default carries grid-scale noise that puts every cell in a bin of its own) -- as `nslab` distinct slabs
+    (a slow drift in amplitude and offset per slab)."""
+    q = np.load(os.path.join(ROOT, 'tests', 'golden', 'baro_q.npy')).astype(np.float64)
+    lat0 = np.load(os.path.join(ROOT, 'tests', 'golden', 'baro_lat.npy')).astype(np.float64)
+    ny0, nx0 = q.shape
+    lat = np.linspace(-90, 90, NY)
+    fy = np.interp(lat, lat0, np.arange(ny0))                          # fractional row index (clamped at the poles)
+    y0 = np.minimum(fy.astype(np.int64), ny0 - 2); wy = (fy - y0)[:, None]
+    fx = np.arange(NX) * (nx0 / float(NX))
+    x0 = fx.astype(np.int64) % nx0; x1 = (x0 + 1) % nx0; wx = (fx - np.floor(fx))[None, :]
+    rows = q[:, x0] * (1 - wx) + q[:, x1] * wx                          # (ny0, NX), periodic in X
+    base = rows[y0] * (1 - wy) + rows[y0 + 1] * wy                      # (NY, NX)
+    out = np.empty((nslab, NY, NX), dtype=dtype)
+    for s_ in range(nslab):
+        k = seed + s_
+        out[s_] = (base * (1.0 + 0.002 * (k % 97)) + 1e-6 * (k % 13)).astype(dtype)
+    return out
+
+
 def device_count(nat):
     import ctypes as C
     n = C.c_int(0)
@@ -1118,7 +1151,7 @@ def device_count(nat):
     return n.value
 
 
-def variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain):
+def variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain, variant=None, ncheck=2, brief=False):
     """`variants.f32` of the default line: the headline schedule on float32 tracers with float32 contours (12 B/cell algorithmic:
     tracer 4 + dA 8), HIP events around every histogram launch, two slabs of the last step compared with the oracle."""
     from xcontour_amd.pipeline import KeffPlan
@@ -1128,7 +1161,11 @@ def variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain):
     try:
         p = KeffPlan(ctx, NB * B, NY, NX, NCONT, qdt, qdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
                      increase=True, lt=True, nslots=1, out_slabs=B, right_edge='xhistogram')
-        p.synth(lat, lon, SEED, a.variant)
+        variant = a.variant if variant is None else variant
+        if variant == 3:
+            p.set_q(baro_slabs(NB * B, qdt))
+        else:
+            p.synth(lat, lon, SEED, variant)
 
         def step(k):
             s0, nxt = (k % NB) * B, ((k + 1) % NB) * B
@@ -1155,14 +1192,17 @@ def variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain):
             s0 = ((KV - 1) % NB) * B
             qh = np.empty((2, NY, NX), dtype=qdt)
             ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, qh.ctypes.data, p._q_ptr + s0 * NY * NX * 4, qh.nbytes))
-            for s_ in range(2):
+            for s_ in range(ncheck):
                 r = O.keff_pipeline(qh[s_], dA, lat, NCONT, lon=lon, increase=True, lt=True, dtype=np.float32)
                 _compare_with_oracle(out, {k: np.asarray(r[k], np.float64) for k in CHECK_NAMES + ('counts',)}, s_)
                 checked += 1
         cells = B * NY * NX
         alg, ub = cells * 12, cells * 4 + NY * NX * 8
-        vt, vsrc = stored_traffic('f32_chain' if chain else 'f32_nochain', B) if a.variant == 0 else (None, 'not measured')
+        vt, vsrc = stored_traffic('f32_chain' if chain else 'f32_nochain', B) if variant == 0 else (None, 'not measured')
         work = B * NY * NX * NCONT
+        if brief:
+            return {'us_per_slab': el / KV / B * 1e6, 'launch_ms': float(vms.mean()), 'frac': alg / (vms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'hbm_unique_frac': ub / (vms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS, 'oracle_checked_slabs': checked}
         return {'steps': KV, 'ms_per_step': el / KV * 1e3, 'value': work * KV / el, 'us_per_slab': el / KV / B * 1e6,
                 'kernel': 'k_hist<float,DA_PLANE,%s>' % ('NEXT' if chain else 'plain'), 'dtype': 'f32',
                 'launch_ms': float(vms.mean()), 'launch_ms_std': float(vms.std()),
