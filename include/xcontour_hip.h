@@ -79,6 +79,10 @@ int         xc_device_name(xc_ctx* ctx, char* buf, size_t buflen);
 int         xc_device_cus(xc_ctx* ctx, int* out_cus);
 int         xc_sync(xc_ctx* ctx);
 void*       xc_stream(xc_ctx* ctx);              /* the hipStream_t, for interop */
+/* Where the host-form entry points of this context spent their time since the last reset, in seconds: out3[0] staging inputs
+ * (memcpy into the pinned bounce buffer + enqueue, or the runtime's staged copy of a large block), out3[1] handing results over
+ * (enqueue + memcpy out of the pinned buffer), out3[2] waiting for the stream.  Diagnostic (tools/facade_time.py --breakdown). */
+int         xc_trace(xc_ctx* ctx, int reset, double* out3);
 
 /* device memory + HIP-event timing on the context's stream */
 int xc_malloc(xc_ctx* ctx, size_t bytes, void** out_dptr);
@@ -135,6 +139,12 @@ int xc_levels_dev(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab,
 int xc_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab,
               int N, int increase, int ctr_dtype, int right_edge,
               double* ctr, double* edges, int32_t* status);
+
+/* cal_contours(int levels) (core.py:205-249) as ONE host-form call: xc_minmax + xc_levels without the round trip between them --
+ * one upload of the tracer (or none: a resident one), one result hand-over, one synchronisation.  out_ctr double[nslab][N]; out_minmax
+ * (double[nslab][2]), out_edges (double[nslab][N+1]) and out_status (int32[nslab]) may be NULL. */
+int xc_contours(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, int N, int increase, int ctr_dtype,
+                int right_edge, double* out_minmax, double* out_ctr, double* out_edges, int32_t* out_status);
 
 /* ------------------------------------------------------------------ K3+K5  weighted multi-channel histogram + CDF
  * Replaces histogram(var, bins=[edges], dim=dims, weights=w) + cumsum + lt flip

@@ -87,16 +87,59 @@ if S:
                                             'bare_h2d_pageable_s': t_page, 'bare_h2d_pinned_s': t_pin,
                                             'keff_over_pinned_copy': None if not t_pin else t_keff / t_pin}}))
 
-# ---- the reference's own problem size (cfg1: 15 levels of 241 x 480 float32): per-call latency, where fixed costs rule
-if os.environ.get('XC_FACADE_SMALL'):
+# ---- the reference's own problem size (cfg1: 15 levels of 241 x 480 float32): per-call latency, where fixed costs rule.
+# `--breakdown`: every call's wall time split into (a) time inside the C library, call by call (ctypes wrappers around every xc_*
+# function), itself split by the library's own stopwatch (xc_trace) into staging inputs / handing results over / waiting for the stream
+# / everything else (argument checks, launches), and (b) the Python around it (labelled-array unwrap / wrap, numpy glue, ctypes marshalling).
+class _LibTimer(object):
+    """wraps every function of the ctypes library object in a stopwatch (per-name seconds and call counts)"""
+
+    def __init__(self, lib):
+        self.lib, self.t, self.n = lib, {}, {}
+
+    def install(self, names):
+        for name in names:
+            fn = getattr(self.lib, name)
+
+            def wrapped(*a, __fn=fn, __name=name):
+                t0 = time.perf_counter()
+                r = __fn(*a)
+                self.t[__name] = self.t.get(__name, 0.0) + time.perf_counter() - t0
+                self.n[__name] = self.n.get(__name, 0) + 1
+                return r
+            setattr(self.lib, name, wrapped)
+
+    def reset(self):
+        self.t, self.n = {}, {}
+
+
+if os.environ.get('XC_FACADE_SMALL') or '--breakdown' in sys.argv:
     def small():
         rec = {}
+        from xcontour_amd import _native as nat
+        lt = None
+        if '--breakdown' in sys.argv:
+            lt = _LibTimer(nat.load())
+            lt.install([n for n in nat.PROTOTYPES if n not in ('xc_last_error', 'xc_version', 'xc_trace')])
+
         def timed(name, fn, reps=20):
             fn(); fn()
+            ctx = nat.default_context(0)
+            if lt:
+                lt.reset(); ctx.trace(True)
             t = time.perf_counter()
             for _ in range(reps):
                 out = fn()
-            rec[name] = (time.perf_counter() - t) / reps * 1e6
+            wall = (time.perf_counter() - t) / reps * 1e6
+            rec[name] = wall
+            if lt:
+                tr = ctx.trace(True)
+                inlib = sum(lt.t.values()) / reps * 1e6
+                rec[name] = {'us': wall, 'python_us': wall - inlib, 'library_us': inlib,
+                             'library_calls': {k: round(lt.t[k] / reps * 1e6, 1) for k in sorted(lt.t, key=lambda k: -lt.t[k])},
+                             'library_split_us': {'stage_inputs': tr['stage_in_s'] / reps * 1e6, 'hand_over_results': tr['hand_over_s'] / reps * 1e6,
+                                                  'wait_for_stream': tr['sync_wait_s'] / reps * 1e6,
+                                                  'checks_and_launches': inlib - (tr['stage_in_s'] + tr['hand_over_s'] + tr['sync_wait_s']) / reps * 1e6}}
             return out
         NL1, NY1, NX1, N1 = 15, 241, 480, 201
         lat = np.linspace(-90, 90, NY1).astype(np.float32); lon = (np.arange(NX1) * 0.75).astype(np.float32); lev = np.arange(NL1, dtype=np.float32)

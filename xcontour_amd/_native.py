@@ -77,6 +77,7 @@ PROTOTYPES = {
     'xc_device_cus': (C.c_int, [_vp, C.POINTER(C.c_int)]),
     'xc_sync': (C.c_int, [_vp]),
     'xc_stream': (_vp, [_vp]),
+    'xc_trace': (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     'xc_malloc': (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     'xc_free': (C.c_int, [_vp, _vp]),
     'xc_memcpy_h2d': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -97,6 +98,7 @@ PROTOTYPES = {
     'xc_minmax': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _vp]),
     'xc_levels_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     'xc_levels': (C.c_int, [_vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'xc_contours': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     'xc_hist_dev': (C.c_int, [_vp, C.POINTER(HistDesc)]),
     'xc_hist': (C.c_int, [_vp, C.POINTER(HistDesc)]),
     'xc_rowsum_dev': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _i64, _i64, C.c_int, _vp]),
@@ -472,6 +474,27 @@ class Context(object):
         self._check(self.lib.xc_minmax(self.handle, _ptr(q), dtype_code(q.dtype), nslab,
                                        int(q.size // nslab), _ptr(out)))
         return out
+
+    def contours(self, q, N, increase, ctr_dtype, right_edge=XC_EDGE_XHISTOGRAM, want_minmax=False):
+        """cal_contours(int) in one call (xc_contours): q (nslab, ny, nx) -> levels (nslab, N) float64 [, minmax (nslab, 2)]"""
+        q = _stack_in(q)
+        nslab = q.shape[0]
+        bt = self._batches(nslab, q.nbytes // max(1, nslab))
+        if len(bt) > 1 or _is_lazy(q):
+            mm = self.minmax(q)
+            ctr = self.levels(mm, q.dtype, N, increase, ctr_dtype, right_edge)[0]
+            return (ctr, mm) if want_minmax else ctr
+        ctr = np.empty((nslab, N), dtype=np.float64)
+        mm = np.empty((nslab, 2), dtype=np.float64) if want_minmax else None
+        self._check(self.lib.xc_contours(self.handle, _ptr(q), dtype_code(q.dtype), nslab, int(q.size // nslab), int(N),
+                                         int(bool(increase)), dtype_code(ctr_dtype), int(right_edge), _ptr(mm), _ptr(ctr), None, None))
+        return (ctr, mm) if want_minmax else ctr
+
+    def trace(self, reset=True):
+        """seconds the host-form calls spent staging inputs / handing results over / waiting for the stream since the last reset"""
+        out = (C.c_double * 3)()
+        self._check(self.lib.xc_trace(self.handle, 1 if reset else 0, out))
+        return {'stage_in_s': out[0], 'hand_over_s': out[1], 'sync_wait_s': out[2]}
 
     def levels(self, minmax, q_dtype, N, increase, ctr_dtype, right_edge=XC_EDGE_XHISTOGRAM):
         minmax = np.ascontiguousarray(minmax, dtype=np.float64)

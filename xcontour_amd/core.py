@@ -72,9 +72,9 @@ class Contour2D(object):
         self.right_edge = right_edge
         self.device = device
         self.deterministic = bool(deterministic)     # order-free fixed-point sums (bit-reproducible; ~1.3x the histogram pass)
-        # resident=True: the tracer and the weights of THIS object are uploaded once and stay on the device between calls (the
-        # reference's Keff sequence passes them to four calls in a row; every call used to cross PCIe again).  Do not modify
-        # them in place afterwards without calling touch().
+        # resident=True: the tracer, the weights, the table mask and the LAST integrand handed to THIS object are uploaded once and
+        # stay on the device between calls (the reference's Keff sequence passes them to four calls in a row; every call used to
+        # cross PCIe again).  Do not modify them in place afterwards without calling touch().
         self.resident = bool(resident)
         self._memo = {}
         if self.dimEqV not in self.dimVs:
@@ -291,14 +291,12 @@ class Contour2D(object):
         """
         q, lead, lshape, coords = self._plane(self.tracer)
         q = self._float(q)
-        mm = self.ctx.minmax(q)
         if type(levels) is int or isinstance(levels, np.integer):
-            ctr, _, _ = self.ctx.levels(mm, q.dtype, int(levels), self.increase, self.dtype)
-            ctr = ctr.astype(self.dtype)
+            ctr = self.ctx.contours(q, int(levels), self.increase, self.dtype).astype(self.dtype)      # K1 + levels, one call, one sync
             ccoord = np.linspace(0.0, levels - 1.0, levels, dtype=self.dtype)
         else:
             levs = np.asarray(levels)
-            mmin = mm[:, 0].astype(q.dtype)
+            mmin = self.ctx.minmax(q)[:, 0].astype(q.dtype)
             ctr = ((mmin - mmin)[:, None] + levs[None, :]).astype(self.dtype)   # core.py:254
             ccoord = levs
         return self._wrap_contour(ctr, lead, lshape, coords, lb.unwrap(self.tracer, lazy=True)[3], self.tracer, ccoord)
@@ -362,13 +360,21 @@ class Contour2D(object):
         dA, dA_f32 = self._dA_array(ny, nx, nslab)
         integ, prod_f32 = [], False
         if integrand is not None:
-            g, _, _, _ = self._plane(integrand)
-            g = self._float(g)
+            g = self._integrand_plane(integrand)
             if g.shape != q.shape:
                 g = np.ascontiguousarray(np.broadcast_to(np.asarray(g), q.shape))
             integ = [g]
             prod_f32 = bool(g.dtype == np.float32 and dA_f32)         # f32*f32 stays f32 (core.py:444)
         return tracer, q, lead, lshape, coords, dA, integ, prod_f32
+
+    def _integrand_plane(self, integrand):
+        """(S, ny, nx) values of an integrand.  resident=True: the LAST integrand handed to this object keeps a device mirror too, keyed
+        on the identity of the labelled array like tracer and weights -- the squared gradient goes to cal_integral_within_contours_hist,
+        to cal_contour_mean_hist and to keff() in one analysis and used to cross PCIe each time (140 us per 7 MB at the reference's
+        demo size, more than everything else in the call together).  Same contract: do not modify it in place without touch()."""
+        if self.resident and lb.is_labeled(integrand) and not lb.is_lazy_data(lb.unwrap(integrand, lazy=True)[0]):
+            return self._keep(('integrand',), integrand, lambda: (np.ascontiguousarray(self._float(self._plane_of(integrand)[0])),))[0]
+        return self._float(self._plane(integrand)[0])
 
     def cal_integral_within_contours_hist(self, contour, tracer=None, integrand=None):
         """
@@ -802,7 +808,7 @@ class Contour2D(object):
             raise Exception('the A(Yeq) table has %d entries but the tracer has %d rows along %s' % (len(tv), ny, self.dimEqV))
         g = None
         if grdS is not None:
-            g = self._float(self._plane(grdS)[0])
+            g = self._integrand_plane(grdS)
         elif rdx is None:
             rdx, rdy = grad_metrics(lat if lat is not None else coords[self.dimEqV],
                                     lon if lon is not None else coords[self._xdim])
@@ -974,18 +980,20 @@ def _edges_from_levels(b, right_edge):
     if n1 < 1:
         raise Exception('need at least two contour levels')
     with np.errstate(invalid='ignore'):
-        binc = bool(b[0, 0] < b[0, -1])
+        # every slab at once (a Python loop with np.insert per slab was 110 us of a 160 us call at the reference's demo size); the
+        # arithmetic stays in the levels' own dtype, as np.insert's cast of the new edge does (core.py:1300-1304)
+        first, last = b[:, 0], b[:, -1]
+        binc = bool(first[0] < last[0])
+        other = (first < last) != binc
+        if other.any() and not np.isnan(b[other]).any(axis=1).all():
+            raise Exception('not every time or level is increasing/decreasing')
         edges = np.empty((b.shape[0], b.shape[1] + 1), dtype=b.dtype)
-        for s in range(b.shape[0]):
-            bs = b[s]
-            if bool(bs[0] < bs[-1]) != binc and not np.isnan(bs).any():
-                raise Exception('not every time or level is increasing/decreasing')
-            if binc:
-                step = (bs[-1] - bs[0]) / n1
-                edges[s] = np.insert(bs, 0, bs[0] - step)
-            else:
-                step = (bs[0] - bs[-1]) / n1
-                edges[s] = np.insert(bs[::-1], 0, bs[-1] - step)
+        if binc:
+            edges[:, 1:] = b
+            edges[:, 0] = first - (last - first) / n1
+        else:
+            edges[:, 1:] = b[:, ::-1]
+            edges[:, 0] = last - (first - last) / n1
     last_closed = True
     if right_edge == 'xhistogram':
         edges = np.concatenate((edges[:, :-1], edges[:, -1:] + 1e-8), axis=1)

@@ -4,6 +4,7 @@
 #include "xc_internal.h"
 #include <string.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <new>
 #include <mutex>
@@ -16,7 +17,12 @@ static thread_local std::string g_err;   // errors without a context (xc_create)
 
 int fail(xc_ctx* ctx, int code, const std::string& msg)
 {
-    if (ctx) ctx->err = msg; else g_err = msg;
+    if (ctx) {
+        ctx->err = msg;
+        // a call that fails delivers nothing: results still parked in the pinned output buffer must not reach arrays the caller may
+        // free once it has seen the error
+        ctx->pending_out.clear(); ctx->pin_in_off = 0; ctx->pin_out_off = 0;
+    } else g_err = msg;
     return code;
 }
 
@@ -102,17 +108,50 @@ static const void* resident_lookup(const xc_ctx* ctx, const void* h, size_t n)
     return nullptr;
 }
 
+constexpr size_t kPinBytes = (size_t)4 << 20;        // each bounce buffer
+constexpr size_t kPinSmall = (size_t)1 << 20;        // transfers up to this size take the bounce buffers
+
+static inline double now_s()
+{
+    struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+static int ensure_pins(xc_ctx* ctx)
+{
+    if (ctx->pin_in) return XC_OK;
+    XC_HIP(ctx, hipHostMalloc((void**)&ctx->pin_in, kPinBytes, hipHostMallocDefault));
+    hipError_t e = hipHostMalloc((void**)&ctx->pin_out, kPinBytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; return hipfail(ctx, e, "hipHostMalloc"); }
+    return XC_OK;
+}
+
+// host bytes -> device on the compute stream.  Small blocks: memcpy into the pinned input buffer + an asynchronous copy (the slot is
+// free again after the call's xc_sync); larger ones: the runtime's own staged copy straight from the caller's memory.
+static int h2d_raw(xc_ctx* ctx, void* d, const void* h, size_t n)
+{
+    if (n <= kPinSmall && ensure_pins(ctx) == XC_OK && ctx->pin_in_off + n <= kPinBytes) {
+        char* p = ctx->pin_in + ctx->pin_in_off;
+        ctx->pin_in_off += (n + 63) & ~(size_t)63;
+        memcpy(p, h, n);
+        XC_HIP(ctx, hipMemcpyAsync(d, p, n, hipMemcpyHostToDevice, ctx->stream));
+        return XC_OK;
+    }
+    XC_HIP(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream));
+    return XC_OK;
+}
+
 // every host-form entry point stages its inputs through here: bytes that have a device mirror are copied from the mirror
 // (device to device, ~50 us for a cfg2 slab) instead of crossing PCIe again (~1 ms)
 static int h2d(xc_ctx* ctx, void* d, const void* h, size_t n)
 {
-    if (!ctx->resident.empty())
-        if (const void* m = resident_lookup(ctx, h, n)) {
-            XC_HIP(ctx, hipMemcpyAsync(d, m, n, hipMemcpyDeviceToDevice, ctx->stream));
-            return XC_OK;
-        }
-    XC_HIP(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream));
-    return XC_OK;
+    const double t0 = now_s();
+    int rc = XC_OK;
+    const void* m = ctx->resident.empty() ? nullptr : resident_lookup(ctx, h, n);
+    if (m) { hipError_t e = hipMemcpyAsync(d, m, n, hipMemcpyDeviceToDevice, ctx->stream); if (e != hipSuccess) rc = hipfail(ctx, e, "hipMemcpyAsync(d2d)"); }
+    else rc = h2d_raw(ctx, d, h, n);
+    ctx->tr_h2d += now_s() - t0;
+    return rc;
 }
 // the big read-only inputs of the Keff sequence skip even that copy: the kernel reads the mirror itself (`slot`: the arena bytes
 // reserved for the upload, unused then)
@@ -121,13 +160,29 @@ static int stage_in(xc_ctx* ctx, void* slot, const void* h, size_t n, const void
     if (!ctx->resident.empty())
         if (const void* m = resident_lookup(ctx, h, n)) { *dev = m; return XC_OK; }
     *dev = slot;
-    XC_HIP(ctx, hipMemcpyAsync(slot, h, n, hipMemcpyHostToDevice, ctx->stream));
-    return XC_OK;
+    const double t0 = now_s();
+    const int rc = h2d_raw(ctx, slot, h, n);
+    ctx->tr_h2d += now_s() - t0;
+    return rc;
 }
+// device -> the caller's host array.  Small results wait in the pinned output buffer and are handed over by xc_sync (EVERY host-form
+// entry point ends in xc_sync): the copies of a call are asynchronous and its stream is waited for once.
 static int d2h(xc_ctx* ctx, void* h, const void* d, size_t n)
 {
-    XC_HIP(ctx, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->stream));
-    return XC_OK;
+    const double t0 = now_s();
+    int rc = XC_OK;
+    if (n <= kPinSmall && ensure_pins(ctx) == XC_OK && ctx->pin_out_off + n <= kPinBytes) {
+        char* p = ctx->pin_out + ctx->pin_out_off;
+        ctx->pin_out_off += (n + 63) & ~(size_t)63;
+        hipError_t e = hipMemcpyAsync(p, d, n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = hipfail(ctx, e, "hipMemcpyAsync(d2h)");
+        else ctx->pending_out.push_back({h, p, n});
+    } else {
+        hipError_t e = hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = hipfail(ctx, e, "hipMemcpyAsync(d2h)");
+    }
+    ctx->tr_d2h += now_s() - t0;
+    return rc;
 }
 
 }  // namespace xc
@@ -214,6 +269,8 @@ int xc_destroy(xc_ctx* ctx)
     if (ctx->ev_comm_in) (void)hipEventDestroy(ctx->ev_comm_in);
     if (ctx->ev_comm_out) (void)hipEventDestroy(ctx->ev_comm_out);
     if (ctx->pinned_flag) (void)hipHostFree(ctx->pinned_flag);
+    if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
+    if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
     if (ctx->lwa_flag) (void)hipFree(ctx->lwa_flag);
     for (auto& e : ctx->resident) (void)hipFree(e.dev);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
@@ -245,7 +302,29 @@ int xc_device_cus(xc_ctx* ctx, int* out_cus)
     return XC_OK;
 }
 
-int xc_sync(xc_ctx* ctx) { XC_CTX(ctx); XC_HIP(ctx, hipStreamSynchronize(ctx->stream)); return XC_OK; }
+int xc_sync(xc_ctx* ctx)
+{
+    XC_CTX(ctx);
+    const double t0 = now_s();
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    const double t1 = now_s();
+    ctx->tr_sync += t1 - t0;
+    // results parked in the pinned output buffer go to the caller's arrays now; both bounce buffers are free again
+    if (e == hipSuccess) for (const auto& po : ctx->pending_out) memcpy(po.host, po.pinned, po.bytes);
+    ctx->pending_out.clear();
+    ctx->pin_in_off = 0; ctx->pin_out_off = 0;
+    ctx->tr_d2h += now_s() - t1;
+    if (e != hipSuccess) return hipfail(ctx, e, "hipStreamSynchronize");
+    return XC_OK;
+}
+
+int xc_trace(xc_ctx* ctx, int reset, double* out3)
+{
+    if (!ctx) return fail(nullptr, XC_EBADARG, "null context");
+    if (out3) { out3[0] = ctx->tr_h2d; out3[1] = ctx->tr_d2h; out3[2] = ctx->tr_sync; }
+    if (reset) ctx->tr_h2d = ctx->tr_d2h = ctx->tr_sync = 0.0;
+    return XC_OK;
+}
 
 void* xc_stream(xc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
@@ -358,9 +437,8 @@ int xc_memcpy_d2h(xc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes
 {
     XC_CTX(ctx);
     if (bytes && (!dst_host || !src_dev)) return fail(ctx, XC_EBADARG, "xc_memcpy_d2h: NULL pointer");
-    XC_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    XC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return XC_OK;
+    XC_TRY(d2h(ctx, dst_host, src_dev, bytes));
+    return xc_sync(ctx);
 }
 
 int xc_memset(xc_ctx* ctx, void* dptr, int value, size_t bytes)
@@ -515,6 +593,32 @@ int xc_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int
     XC_TRY(h2d(ctx, dm, minmax, mb));
     XC_TRY(launch_levels(ctx, dm, q_dtype, nslab, N, increase, ctr_dtype, right_edge, dc, de, ds));
     XC_TRY(d2h(ctx, ctr, dc, cb)); XC_TRY(d2h(ctx, edges, de, eb)); XC_TRY(d2h(ctx, status, ds, sb));
+    return xc_sync(ctx);
+}
+
+// cal_contours(int levels) (core.py:205-249) in ONE call: min / max of every slab (K1), the levels (and edges) from them, ONE result
+// hand-over and ONE stream synchronisation -- the facade used to make two host-form calls (xc_minmax, then xc_levels with the extrema
+// sent back up) with a blocking transfer for each of their five small arrays.  Any output may be NULL except out_ctr.
+int xc_contours(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, int N, int increase, int ctr_dtype, int right_edge,
+                double* out_minmax, double* out_ctr, double* out_edges, int32_t* out_status)
+{
+    XC_CTX(ctx);
+    if (!q || !out_ctr || nslab < 1 || ncell < 1 || N < 2) return fail(ctx, XC_EBADARG, "xc_contours: bad arguments (need N >= 2)");
+    if (q_dtype != XC_F32 && q_dtype != XC_F64) return fail(ctx, XC_EBADARG, "xc_contours: q_dtype must be XC_F32 or XC_F64");
+    const size_t qb = (size_t)nslab * ncell * esize(q_dtype);
+    const size_t mb = (size_t)nslab * 2 * 8, cb = (size_t)nslab * N * 8, eb = (size_t)nslab * (N + 1) * 8, sb = (size_t)nslab * 4;
+    XC_TRY(ensure_arena(ctx, al(qb) + al(mb) + al(cb) + al(eb) + al(sb)));
+    Stage st(ctx);
+    const void* dq;
+    XC_TRY(stage_in(ctx, st.take(qb), q, qb, &dq));
+    double* dm = (double*)st.take(mb); double* dc = (double*)st.take(cb);
+    double* de = (double*)st.take(eb); int32_t* ds = (int32_t*)st.take(sb);
+    XC_TRY(xc_minmax_dev(ctx, dq, q_dtype, nslab, ncell, dm));
+    XC_TRY(launch_levels(ctx, dm, q_dtype, nslab, N, increase, ctr_dtype, right_edge, dc, de, ds));
+    if (out_minmax) XC_TRY(d2h(ctx, out_minmax, dm, mb));
+    XC_TRY(d2h(ctx, out_ctr, dc, cb));
+    if (out_edges) XC_TRY(d2h(ctx, out_edges, de, eb));
+    if (out_status) XC_TRY(d2h(ctx, out_status, ds, sb));
     return xc_sync(ctx);
 }
 

@@ -36,6 +36,18 @@ struct xc_ctx {
     hipEvent_t ev_comm_in = nullptr, ev_comm_out = nullptr;
     hipEvent_t ev_copy = nullptr, ev_compute = nullptr;
     unsigned* pinned_flag = nullptr;   // 64 bytes of pinned host memory: the sort's one read-back
+    // Small transfers of the host-form entry points go through pinned bounce buffers (round 5): a copy between PAGEABLE memory and the
+    // device is staged and waited for inside hipMemcpyAsync itself -- every small input and every result vector of a call cost a blocking
+    // round trip of its own (three D2H copies in xc_levels, five in the Keff epilogue).  Inputs are memcpy'd into `pin_in` and leave
+    // with a truly asynchronous copy; results land in `pin_out` and are handed to the caller's arrays after the call's ONE stream
+    // synchronisation (xc_sync).  Both are bump-allocated per call and reset by xc_sync; what does not fit takes the direct path.
+    char* pin_in = nullptr;  size_t pin_in_off = 0;
+    char* pin_out = nullptr; size_t pin_out_off = 0;
+    struct PendingOut { void* host; const void* pinned; size_t bytes; };
+    std::vector<PendingOut> pending_out;
+    // where a host-form call spends its time, accumulated between two xc_trace calls (seconds): input staging (memcpy + enqueue),
+    // result hand-over (enqueue + memcpy), waiting for the stream
+    double tr_h2d = 0.0, tr_d2h = 0.0, tr_sync = 0.0;
     struct Resident { const char* host; size_t bytes; void* dev; };
     std::vector<Resident> resident;    // host arrays with a device mirror (xc_keep_resident): the host-form entry points copy from the mirror
     int cus = 0;
