@@ -1103,6 +1103,12 @@ def main():
                              'sin_lat': variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain, variant=2, ncheck=0, brief=True),
                              'barotropic_vorticity_interpolated': variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain, variant=3, ncheck=1, brief=True)}
         line.setdefault('variants', {})['f32'] = v32
+    if rank == 0 and world == 1 and a.dtype == 'f64' and not a.no_extras and not (a.slab_dA or a.row_dA):
+        # ONE cfg2 slab through the pipeline, a sync before every call: north_star's literal unit and what a caller with one (time, level)
+        # field gets (the reference's callers hand planes over one at a time, tests/LWA.py:40-43) -- four dependent launches
+        # (K1, K3, reduce, finalize), nothing to overlap them with
+        stage('single_slab')
+        line['single_slab'] = single_slab(ctx, nat, a, lat, lon, dA, tbl)
     # ---- cfg4 strong scaling: every rank takes part (its own timed region, after the cfg2 buffers are gone)
     if not a.no_cfg4 and a.dtype == 'f64':
         stage('cfg4')
@@ -1149,6 +1155,50 @@ def device_count(nat):
     n = C.c_int(0)
     nat.load().xc_device_count(C.byref(n))
     return n.value
+
+
+def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
+    """`single_slab` of the default line: one 3600 x 1801 float64 slab, 201 contours, K1 -> K3 -> reduce -> finalize with a stream
+    synchronisation before every call; `warm`: back to back (slab and weights stay in the 256 MiB Infinity Cache), `cold`: a 600 MB
+    memset between calls.  frac = 16 B x cells / time / 8 TB/s, the same numerator as the headline."""
+    from xcontour_amd.pipeline import KeffPlan
+    p = big = None
+    try:
+        p = KeffPlan(ctx, 1, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
+                     increase=True, lt=True, right_edge='xhistogram', deterministic=a.deterministic)
+        p.synth(lat, lon, SEED + 7, a.variant if a.variant != 3 else 0)
+        big = ctx.alloc(600 << 20)
+        e0, e1 = ctx.event(), ctx.event()
+
+        def timed(evict):
+            ts = []
+            for r in range(reps + 3):
+                if evict:
+                    ctx._check(ctx.lib.xc_memset(ctx.handle, big.ptr, r & 255, big.nbytes))
+                ctx.sync()
+                ctx.record(e0); p.run(); ctx.record(e1)
+                ms = ctx.elapsed_ms(e0, e1)
+                if r >= 3:
+                    ts.append(ms * 1e3)
+            return np.array(ts)
+        cold, warm = timed(True), timed(False)
+        out = p.fetch()
+        ok = bool((out['counts'].sum(axis=1) == NY * NX).all() and not out['status'].any())
+        for e in (e0, e1):
+            ctx.lib.xc_event_destroy(ctx.handle, e)
+        alg = NY * NX * BYTES_PER_CELL
+        return {'us': float(np.median(warm)), 'us_cold': float(np.median(cold)), 'us_min': float(warm.min()), 'reps': reps,
+                'frac': alg / (np.median(warm) * 1e-6) / 1e9 / HBM_PEAK_GBS, 'frac_cold': alg / (np.median(cold) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                'launches': 'k_minmax_partial, k_hist, k_reduce_partials, k_finalize', 'self_check': ok,
+                'note': 'one 3600x1801 f64 slab per call, a stream sync before every call (HIP events around the call); warm = back to back '
+                        '(Infinity-Cache resident), cold = a 600 MB memset between calls; 16 B/cell numerator as the headline'}
+    except nat.XContourHipError as e:
+        return {'skipped': str(e)}
+    finally:
+        if p is not None:
+            p.free()
+        if big is not None:
+            big.free()
 
 
 def variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain, variant=None, ncheck=2, brief=False):

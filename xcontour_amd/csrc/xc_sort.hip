@@ -205,10 +205,14 @@ __device__ __forceinline__ unsigned digit_of(K key, int shift, const RangeMap& m
 // the extremes cluster in one wave's share.  (Exact selection by rank counting over all groups: 11-24 us per call; this: ~3.)
 // out: [nslab][4] = min, max, rlo, rhi (all-NaN plane: NaN).
 __global__ __launch_bounds__(512)
-void k_range_bounds(const double* __restrict__ part, int P, double* __restrict__ out)
+void k_range_bounds(const double* __restrict__ part, int P, double* __restrict__ out, unsigned* __restrict__ rhist, unsigned* __restrict__ tick)
 {
     __shared__ double s_c[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (round 5) this kernel runs before the sampled population is counted: it clears the slab's coarse histogram and the arrival
+    // tickets of the later kernels itself -- one hipMemsetAsync less in a chain of ~20 dependent launches
+    if (tid < RANGE_NB) rhist[(size_t)blockIdx.x * RANGE_NB + tid] = 0u;
+    if (tid < 4) tick[(size_t)blockIdx.x * 4 + tid] = 0u;
     const double* mp = part + (size_t)blockIdx.x * P * 2;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     const int per = (P + 511) / 512, ng = (P + per - 1) / per;           // groups of `per` consecutive blocks
@@ -670,7 +674,7 @@ void k_fix_runs(K* __restrict__ keys, double* __restrict__ vals, int64_t n, unsi
         if (s_d[il] != RANGE_INVALID) nvalid[blockIdx.y] = (unsigned)n;
     }
     if (__syncthreads_or(bad)) {                                               // the stack goes to the eight-pass path: nothing else to do here
-        if (tid == 0) atomicOr(flag, 1u);
+        if (tid == 0) __hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (pinned host memory)
         return;
     }
     // ---- 3. stable rank inside the run; a cell whose place changes writes itself there
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(256)
 void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
            const double* __restrict__ acum, const unsigned* __restrict__ nvalid,
            const double* __restrict__ tbl, const double* __restrict__ coord, int ntbl, double* __restrict__ part,
-           int64_t ncell)
+           int64_t ncell, unsigned* __restrict__ tick, double* __restrict__ out)
 {
     { const size_t so = (size_t)blockIdx.y * ncell; keys += so; vals += so; acum += so; }
     part += (size_t)blockIdx.y * gridDim.x;
@@ -838,20 +842,25 @@ void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
     __shared__ double s[4];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
-}
-
-// one wave per plane: lane l sums its contiguous share of the block partials, then a fixed xor tree (deterministic; the loop of
-// one thread over 256 dependent loads it replaces took 17 us)
-__global__ __launch_bounds__(64)
-void k_sum_parts(const double* __restrict__ part, int n, double* __restrict__ out)
-{
-    part += (size_t)blockIdx.x * n;
-    const int per = (n + 63) / 64, i0 = threadIdx.x * per;
-    double s = 0.0;
-    for (int i = i0; i < i0 + per && i < n; ++i) s += part[i];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (threadIdx.x == 0) out[blockIdx.x] = s;
+    // (round 5) the block that arrives last sums the plane's partials in block order -- one launch less at the end of the chain.  Every
+    // hand-off word is an agent-scope 8-byte atomic on both sides (a partial is ONE store of one lane, the ticket returns the order of
+    // arrival): MI355X_MICROARCH.md, valid forms; the sum is taken in a fixed order, whoever arrives last.
+    __shared__ unsigned s_last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(part + blockIdx.x, s[0] + s[1] + s[2] + s[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(tick + (size_t)blockIdx.y * 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    const int np = (int)gridDim.x, per = (np + 63) / 64, i0 = (int)threadIdx.x * per;     // one wave: lane l sums its contiguous share, then a fixed xor tree
+    double t = 0.0;
+    for (int i = i0; i < i0 + per && i < np; ++i) t += __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (threadIdx.x == 0) {
+        out[blockIdx.y] = t;
+        __hip_atomic_store(tick + (size_t)blockIdx.y * 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch (a stack that is sorted again runs this kernel twice)
+    }
 }
 
 }  // namespace
@@ -866,7 +875,7 @@ size_t sort_workspace_bytes(int64_t n, int64_t nslab)
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t S = (size_t)nslab;
     return 4 * al(S * n * 8) + al(S * 256 * ntiles * 4) + al(S * 256 * 4) + al(S * 4) + al(S * nb * 8) + al(S * BPE_BLOCKS * 8) +
-           al(S * kMinmaxBlocks * 2 * 8) + al(S * 4 * 8) + 256 + al(S * RANGE_NB * 4) + al(S * RANGE_NB * 8);
+           al(S * kMinmaxBlocks * 2 * 8) + al(S * 4 * 8) + al(S * 4 * 4) + al(S * RANGE_NB * 4) + al(S * RANGE_NB * 8);
 }
 
 template <typename TQ, typename K>
@@ -893,9 +902,10 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
     double* parts = (double*)w; w += al(S * BPE_BLOCKS * 8);
     double* mmpart = (double*)w; w += al(S * kMinmaxBlocks * 2 * 8);
     double* mm = (double*)w; w += al(S * 4 * 8);
-    unsigned* flag = (unsigned*)w; w += 256;
+    unsigned* tick = (unsigned*)w; w += al(S * 4 * 4);      // arrival tickets of the kernels that finish in their last block (zeroed by k_range_bounds / a memset)
     unsigned* rhist = (unsigned*)w; w += al(S * RANGE_NB * 4);
     unsigned* rtab = (unsigned*)w;
+    if (out_nvalid) nvalid = out_nvalid;                     // the caller's own buffer: no copy at the end
     const unsigned ns = (unsigned)nslab;
 
     const unsigned gb = (unsigned)((n + 255) / 256);
@@ -954,12 +964,10 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
         }
         if (out_bpe) {
             if (!tbl || !coord || ntbl < 2) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
-            hipLaunchKernelGGL(k_bpe<K>, dim3(BPE_BLOCKS, ns), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts, n);
-            hipLaunchKernelGGL(k_sum_parts, dim3(ns), dim3(64), 0, ctx->stream, parts, BPE_BLOCKS, out_bpe);
+            hipLaunchKernelGGL(k_bpe<K>, dim3(BPE_BLOCKS, ns), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts, n, tick, out_bpe);
         }
         if (out_qsorted) hipLaunchKernelGGL(k_unkey<K>, dim3(gb, ns), dim3(256), 0, ctx->stream, kin, n, out_qsorted);
         if (out_acum) XC_HIP(ctx, hipMemcpyAsync(out_acum, acum, S * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        if (out_nvalid) XC_HIP(ctx, hipMemcpyAsync(out_nvalid, nvalid, S * sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream));
         XC_HIP(ctx, hipGetLastError());
         return XC_OK;
     };
@@ -968,8 +976,13 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
         if (ctx->knobs.sort_range) {
             // ---- three passes over the 24-bit range key, then the short runs (see the head of this file)
             XC_TRY_(launch_minmax_partial(ctx, q, q_dtype, nslab, n, mmpart));
-            XC_HIP(ctx, hipMemsetAsync(flag, 0, 256 + S * RANGE_NB * 4, ctx->stream));      // the flag and the coarse histogram behind it
-            hipLaunchKernelGGL(k_range_bounds, dim3(ns), dim3(512), 0, ctx->stream, mmpart, minmax_blocks(n, nslab), mm);
+            // the "not sorted" word lives in pinned host memory and the repair kernel writes it THERE (a system-scope atomic, only when a
+            // run fails): no device word to clear before and to copy back after (two of the chain's ~20 dependent launches)
+            if (!ctx->pinned_flag) XC_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_flag, 64, hipHostMallocDefault));
+            volatile unsigned& h_flag = *ctx->pinned_flag;
+            h_flag = 0;
+            unsigned* flag = ctx->pinned_flag;
+            hipLaunchKernelGGL(k_range_bounds, dim3(ns), dim3(512), 0, ctx->stream, mmpart, minmax_blocks(n, nslab), mm, rhist, tick);
             {
                 const int64_t samp = n > (int64_t)256 * RANGE_SAMPLE * 64 ? RANGE_SAMPLE : 1;
                 int64_t hb = ((n + 256 * samp - 1) / (256 * samp) + 7) / 8;                  // eight 256-cell segments per block and round
@@ -983,11 +996,6 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
             for (int p = 0; p < 3; ++p) XC_TRY_(pass(std::integral_constant<int, 1>(), p == 0, 8 * p));
             hipLaunchKernelGGL(k_fix_runs<K>, dim3((unsigned)((n + FIX_C - 1) / FIX_C), ns), dim3(256), 0, ctx->stream, kin, vin, n, flag, nvalid, src);
             XC_HIP(ctx, hipGetLastError());
-            // (read back into pinned memory: a copy to pageable memory holds the stream -- the kernels behind it waited 18 us)
-            if (!ctx->pinned_flag) XC_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_flag, 64, hipHostMallocDefault));
-            volatile unsigned& h_flag = *ctx->pinned_flag;
-            h_flag = 1;
-            XC_HIP(ctx, hipMemcpyAsync(ctx->pinned_flag, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
             // the rest is enqueued as if the repair had sufficed -- it nearly always has -- so that the GPU does not idle through
             // the one host round trip of the sort; a stack that failed the check is sorted again below and the rest redone
             XC_TRY_(tail(false));
@@ -997,6 +1005,7 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
             kin = kA; kout = kB; vin = vA; vout = vB;
         } else ctx->last_sort_path = 0;
     } else ctx->last_sort_path = 0;
+    if (ctx->last_sort_path == 0) XC_HIP(ctx, hipMemsetAsync(tick, 0, S * 4 * 4, ctx->stream));       // (the range path's first kernel clears the tickets itself)
     for (int p = 0; p < KeyTraits<K>::passes; ++p) XC_TRY_(pass(std::integral_constant<int, 0>(), p == 0, 8 * p));
     return tail(true);
 }
