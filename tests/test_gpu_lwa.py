@@ -1,0 +1,145 @@
+"""-m gpu: K7 local wave activity (band walk, interval kernel and its premises, leading dims of Q) and K9 box-counting crossing.
+(Regrouped in round 5 from the per-round files of rounds 2-4; nothing dropped.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import xcontour_oracle as O
+from test_gpu_parity import rel, RTOL, TIGHT, LMIN_FLOOR, _baro_da
+from gpu_common import GOLD, NINE, ROOT, bits, check_nine, check_nine_det, _clean_env
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lwa_Q_leading_dims_in_any_order(ctx):
+    """q is (time, level, lat, lon); Q given as (level, time, lat), as (level, lat) and as (lat,): slab s of q must meet
+    ITS row of Q (the reference relies on xarray's by-name broadcasting, core.py:754)"""
+    import xcontour_amd as xa
+    rng = np.random.default_rng(8)
+    nt, nl, ny, nx = 2, 3, 21, 30
+    lat = np.linspace(-70, 70, ny); lon = np.arange(nx) * 12.0
+    q = rng.standard_normal((nt, nl, ny, nx)) + np.linspace(-2, 2, ny)[None, None, :, None]
+    Q = np.sort(rng.standard_normal((nt, nl, ny)), axis=-1) + np.arange(nl)[None, :, None] * 0.3 + np.arange(nt)[:, None, None] * 0.7
+    dAv = O.cell_area(lat, lon)
+    c = {'time': np.arange(float(nt)), 'level': np.arange(float(nl)), 'lat': lat, 'lon': lon}
+    tr = xa.DataArray(q, ('time', 'level', 'lat', 'lon'), c, 'pv')
+    cm = xa.Contour2D(tr, xa.DataArray(dAv, ('lat', 'lon'), {'lat': lat, 'lon': lon}, 'dA'),
+                      dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'}, increase=True, lt=True)
+    Qa = xa.DataArray(np.transpose(Q, (1, 0, 2)).copy(), ('level', 'time', 'lat'), c, 'pv')      # swapped leading dims
+    Qb = xa.DataArray(Q, ('time', 'level', 'lat'), c, 'pv')
+    la, lb_ = cm.cal_local_wave_activity(tr, Qa), cm.cal_local_wave_activity(tr, Qb)
+    assert la.dims == tr.dims and np.array_equal(la.values, lb_.values)
+    for t in range(nt):
+        for l in range(nl):
+            assert np.array_equal(la.values[t, l], O.cal_local_wave_activity(q[t, l], Q[t, l], lat, dAv, True, 'all'))
+    Qc = xa.DataArray(Q[0], ('level', 'lat'), {'level': c['level'], 'lat': lat}, 'pv')          # a subset of the dims: broadcast over time
+    lc = cm.cal_local_wave_activity(tr, Qc)
+    for t in range(nt):
+        for l in range(nl):
+            assert np.array_equal(lc.values[t, l], O.cal_local_wave_activity(q[t, l], Q[0, l], lat, dAv, True, 'all'))
+    Qd = xa.DataArray(Q[0, 0], ('lat',), {'lat': lat}, 'pv')
+    ld = cm.cal_local_wave_activity(tr, Qd, mask_idx=[3, 9])
+    assert np.array_equal(ld[0].values[1, 2], O.cal_local_wave_activity(q[1, 2], Q[0, 0], lat, dAv, True, 'all'))
+    with pytest.raises(Exception, match='does not have'):
+        cm.cal_local_wave_activity(tr, xa.DataArray(Q[:, 0], ('member', 'lat'), {'lat': lat}, 'pv'))
+
+
+def _lwa_case(rng, ny, nx, dt, increase, coord_up, with_nan):
+    lat = np.linspace(-80, 80, ny) if coord_up else np.linspace(80, -80, ny)
+    prof = np.sin(np.deg2rad(np.linspace(-80, 80, ny)))
+    if not increase:
+        prof = -prof
+    q = (prof[:, None] + 0.3 * np.sin(np.linspace(0, 12, nx))[None, :] * np.cos(np.deg2rad(lat))[:, None]
+         + 0.05 * rng.standard_normal((ny, nx))).astype(dt)
+    Q = np.sort(q.astype(np.float64).mean(axis=1))
+    if not increase:
+        Q = Q[::-1].copy()
+    # ties: some cells exactly ON reference levels
+    idx = rng.integers(0, ny * nx, 500)
+    q.ravel()[idx] = Q[rng.integers(0, ny, 500)].astype(dt)
+    if with_nan:
+        q[rng.integers(0, ny, 40), rng.integers(0, nx, 40)] = np.nan
+        q[5:9, 10:30] = np.nan
+    dA = np.abs(np.cos(np.deg2rad(lat)))[:, None] * np.ones((1, nx)) * 1e9 + 1e7 * rng.random((ny, nx))
+    return lat, q, Q, dA
+
+
+@pytest.mark.parametrize('dt,increase,coord_up,part,mkind', [
+    (np.float64, True, True, 'all', 'row'), (np.float32, True, False, 'upper', 'plane'), (np.float64, False, True, 'lower', None),
+    (np.float32, False, False, 'all', 'row'), (np.float64, True, True, 'upper', None), (np.float64, False, False, 'upper', 'plane')])
+def test_lwa_interval_kernel_matches_the_oracle(ctx, dt, increase, coord_up, part, mkind):
+    """planes of more than 512 rows: one binary search in the (monotone) reference state per cell + difference arrays + prefix
+    sums instead of the band walk -- against the oracle's literal python loop (core.py:752-791) for both directions of the
+    tracer and of the coordinate, every `part`, the three metric forms, float32 / float64 tracers, NaN cells, ties with
+    levels: <= 1e-11 of the plane's largest value (summation order; the bit-exact band walk is `exact=True`)"""
+    rng = np.random.default_rng(int(increase) * 4 + int(coord_up) * 2 + (mkind is not None))
+    ny, nx = 600, 334                                       # 334: a ragged last column group
+    lat, q, Q, dA = _lwa_case(rng, ny, nx, dt, increase, coord_up, True)
+    M = None if mkind is None else (np.abs(np.gradient(np.deg2rad(lat))) * 6.371e6 if mkind == 'row' else 1.0 + rng.random((ny, nx)))
+    pcode = {'all': 0, 'upper': 1, 'lower': 2}[part]
+    got, _ = ctx.lwa(q[None], Q[None], lat, dA, float(dA.max()), M=M, increase=increase, part=pcode)
+    assert ctx.last_lwa_path() == 1
+    ref = O.cal_local_wave_activity(q, Q, lat, dA, increase, part, metric=M)
+    scale = np.abs(ref).max()
+    assert scale > 0 and np.abs(got[0] - ref).max() <= 1e-11 * scale
+    ex, _ = ctx.lwa(q[None], Q[None], lat, dA, float(dA.max()), M=M, increase=increase, part=pcode, exact=True)
+    assert ctx.last_lwa_path() == 0 and np.array_equal(ex[0], ref)              # the band walk: numpy's own summation order
+
+
+def test_lwa_interval_kernel_premises_and_stacks(ctx):
+    """a reference state that is NOT monotone (or holds a NaN), or a coordinate with a repeated value, sends the call to the
+    bit-exact band walk (path 2); a stack of slabs with per-slab Q; masks for mask_idx stay exact on the fast path; planes of
+    up to 512 rows never take it"""
+    rng = np.random.default_rng(9)
+    ny, nx = 520, 128
+    lat, q, Q, dA = _lwa_case(rng, ny, nx, np.float64, True, True, False)
+    Qbad = Q.copy(); Qbad[100], Qbad[101] = Q[101], Q[100]
+    for Qx, c in ((Qbad, lat), (np.where(np.arange(ny) == 7, np.nan, Q), lat), (Q, np.where(np.arange(ny) == 300, lat[299], lat))):
+        got, _ = ctx.lwa(q[None], Qx[None], c, dA, float(dA.max()))
+        assert ctx.last_lwa_path() == 2
+        assert np.array_equal(got[0], O.cal_local_wave_activity(q, Qx, c, dA, True, 'all'), equal_nan=True)
+    S = 3
+    qs = np.stack([q * (1 + 0.1 * s) for s in range(S)])
+    Qs = np.stack([Q * (1 + 0.1 * s) for s in range(S)])
+    got, masks = ctx.lwa(qs, Qs, lat, dA, float(dA.max()), mask_idx=[3, 400])
+    assert ctx.last_lwa_path() == 1
+    for s in range(S):
+        ref, _, mref = O.cal_local_wave_activity(qs[s], Qs[s], lat, dA, True, 'all', mask_idx=[3, 400])
+        assert np.abs(got[s] - ref).max() <= 1e-11 * np.abs(ref).max()
+        assert np.array_equal(masks[s, 0], mref[0]) and np.array_equal(masks[s, 1], mref[1])
+    small = _lwa_case(rng, 256, 128, np.float64, True, True, False)
+    sref = O.cal_local_wave_activity(small[1], small[2], small[0], small[3], True, 'all')
+    g2, _ = ctx.lwa(small[1][None], small[2][None], small[0], small[3], float(small[3].max()))
+    assert ctx.last_lwa_path() == 0 and np.array_equal(g2[0], sref)
+    # exact=False: the premises are checked on the host and vouched for -- ONE launch of the interval kernel, any plane size
+    g3, _ = ctx.lwa(small[1][None], small[2][None], small[0], small[3], float(small[3].max()), exact=False)
+    assert ctx.last_lwa_path() == 1 and np.abs(g3[0] - sref).max() <= 1e-11 * np.abs(sref).max() and not np.array_equal(g3[0], sref)
+    g4, _ = ctx.lwa(q[None], Qbad[None], lat, dA, float(dA.max()), exact=False)            # not monotone: the host check sends it to the band walk
+    assert ctx.last_lwa_path() == 0 and np.array_equal(g4[0], O.cal_local_wave_activity(q, Qbad, lat, dA, True, 'all'))
+
+
+def test_crossing_uncrossed_interior_levels_are_exact_zeros(ctx):
+    """two regions of the plane separated by NaN columns hold values in [0, 0.3] and [0.7, 1]; no box has corners in
+    both, so the levels in between are crossed by nothing and must come out as the exact 0 of the reference's per-contour
+    loop (the difference-array accumulation used to leave ~1e-16-of-the-mass residues there), and nothing is negative"""
+    rng = np.random.default_rng(8)
+    ny, nx = 96, 260
+    q = np.empty((2, ny, nx))
+    q[:, :, :128] = 0.3 * rng.random((2, ny, 128))
+    q[:, :, 128:132] = np.nan
+    q[:, :, 132:] = 0.7 + 0.3 * rng.random((2, ny, nx - 132))
+    area = 1e9 * (1 + rng.random((ny, nx)))
+    ctr = np.linspace(0.0, 1.0, 101)
+    lens, cnts = ctx.crossing(q, ctr, area, stride=1, full_width=True)
+    mid = (ctr > 0.305) & (ctr < 0.695)
+    assert (cnts[:, mid] == 0).all() and (cnts[:, (ctr > 0.05) & (ctr < 0.25)] > 0).all() and (cnts[:, (ctr > 0.75) & (ctr < 0.95)] > 0).all()
+    assert (lens[:, mid] == 0.0).all()
+    assert (lens >= 0).all()
+    for s in range(2):
+        ol, oc = O.contour_crossing(q[s], ctr, area, 1, True)
+        assert np.array_equal(cnts[s].astype(np.int64), oc) and rel(lens[s], ol) < 1e-13

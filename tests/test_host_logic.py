@@ -180,7 +180,7 @@ def test_cfg4_launch_sets_tile_the_blocks_of_every_rank_count():
 def test_xarray_branch_of_labeled_runs_with_a_test_double():
     """xarray is the reference's in/out type (core.py:8-13) and is absent from both boxes: tests/fake_xarray/xarray.py is a
     60-line double that makes `labeled.is_xarray` true, so unwrap (coords filter included) / wrap / merge run for real
-    (CPU part here; the facade's call sequences through it: tests/test_gpu_round4.py)"""
+    (CPU part here; the facade's call sequences through it: tests/test_gpu_facade.py)"""
     import subprocess
     import sys
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'tests', 'fake_xarray'))
