@@ -912,9 +912,10 @@ def main():
         if grp == B:
             ctx.set_hist_events(ev[k][0], ev[k][1])               # events around the K3 launch only
         step(k, k)
+        if world > 1:
+            gather.push(rb, res.ptr + k * slot, slot, k * slot)   # this step's vectors leave for rank 0 on the comm stream while the next step computes
     if world > 1:
-        gather.push(rb, res.ptr, nres)                            # the one collective: every step's vectors to rank 0, behind the last step
-        gather.finish(rb)
+        gather.finish(rb)                                         # the one collective of the job ends here: only the last step's piece is exposed
     ctx.sync()                                                    # the library's own HIP streams (every kernel and the gather run on them)
     group.barrier()
     t1 = time.perf_counter()

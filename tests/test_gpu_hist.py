@@ -601,3 +601,56 @@ def test_keff_without_counts_gives_the_same_vectors(ctx):
     assert np.array_equal(bits(full['pdf']), bits(part['pdf'])) and np.array_equal(bits(full['cdf']), bits(part['cdf']))
     plain = ctx.hist(qh, ed, dA=w, want=('cdf',))
     assert rel(plain['cdf'], full['cdf']) < 1e-13
+
+
+def test_deterministic_sums_keep_49_bits_over_a_wide_dynamic_range(ctx):
+    """round 5, the one-pass rule: a bin holds weights 2^120 apart (the pole row of a lat-lon grid does that to |grad q|^2) and BOTH ends
+    keep their 49 bits -- the GPU's sums are the oracle's superaccumulator bit for bit, with the window the oracle is told (the
+    bound the library derives: max |integrand| x max dA); a signed integrand, float32 and float64; and the sum of the
+    cut weights is exact where float64 summation in cell order loses the small ones"""
+    rng = np.random.default_rng(77)
+    S, ny, nx, nb = 2, 96, 256, 37
+    q = rng.random((S, ny, nx))
+    edges = np.linspace(0.0, 1.0, nb + 1)
+    mag = 10.0 ** rng.integers(-18, 18, (S, ny, nx))
+    g = rng.standard_normal((S, ny, nx)) * mag
+    g[0, 5, 7] = 3.0e30; g[0, 5, 8] = -3.0e30                               # cancel exactly: what is left are the small ones
+    q[0, 5, 8] = q[0, 5, 7]
+    dA = 0.5 + rng.random((ny, nx))
+    dA[5, 8] = dA[5, 7]
+    out = ctx.hist(q, edges, dA=dA, integrands=[g], last_closed=True, want=('pdf', 'counts'), deterministic=True)
+    again = ctx.hist(q[:, :, ::1].copy(), edges, dA=dA, integrands=[g], last_closed=True, want=('pdf',), deterministic=True)
+    assert np.array_equal(bits(out['pdf']), bits(again['pdf']))
+    for s_ in range(S):
+        w = g[s_] * dA
+        top = O.det_window_top(max(abs(g[s_].min()), abs(g[s_].max())) * dA.max())
+        od, cnt = O.weighted_histogram(q[s_], edges, w, 'numpy', deterministic=True, det_top=top)
+        assert np.array_equal(out['counts'][s_].astype(np.int64), cnt)
+        assert np.array_equal(bits(out['pdf'][s_, 1]), bits(od))
+        oa, _ = O.weighted_histogram(q[s_], edges, np.broadcast_to(dA, q[s_].shape), 'numpy', deterministic=True, det_top=O.det_window_top(dA.max()))
+        assert np.array_equal(bits(out['pdf'][s_, 0]), bits(oa))
+    k = int(np.digitize(q[0, 5, 7], edges)) - 1
+    plain = ctx.hist(q[:1], edges, dA=dA, integrands=[g[:1]], last_closed=True, want=('pdf',))['pdf'][0, 1, k]
+    from fractions import Fraction
+    sel = (np.digitize(q[0], edges) - 1) == k
+    exact = float(sum(Fraction(float(v)) for v in (g[0] * dA)[sel]))
+    assert abs(out['pdf'][0, 1, k] - exact) <= 1e-13 * np.abs((g[0] * dA)[sel & (np.abs(g[0]) < 1e30)]).sum()
+    assert abs(plain - exact) > abs(out['pdf'][0, 1, k] - exact)             # float64 atomics lost what 3e30 - 3e30 swallowed
+
+
+def test_contours_in_one_call_equals_minmax_then_levels(ctx, baro):
+    """round 5: xc_contours (K1 + levels, one upload, one hand-over, one sync) gives the bits of xc_minmax followed by xc_levels -- float32
+    and float64 tracers, both directions, both contour dtypes; cal_contours goes through it"""
+    q0, lat, lon = baro
+    rng = np.random.default_rng(1)
+    for dt in (np.float32, np.float64):
+        q = np.stack([q0.astype(dt) * (1 + 0.1 * s_) + dt(1e-5) * rng.standard_normal(q0.shape).astype(dt) for s_ in range(3)])
+        q[1, 4, 5] = np.nan
+        mm = ctx.minmax(q)
+        for inc in (True, False):
+            for cd in (np.float32, np.float64):
+                ctr, mm2 = ctx.contours(q, 61, inc, cd, want_minmax=True)
+                ref = ctx.levels(mm, q.dtype, 61, inc, cd)[0]
+                assert np.array_equal(bits(ctr), bits(ref)) and np.array_equal(bits(mm2), bits(mm))
+                for s_ in range(3):
+                    assert np.array_equal(ctr[s_], O.cal_contours(q[s_], 61, inc, cd).astype(np.float64))

@@ -123,6 +123,49 @@ def test_lwa_interval_kernel_premises_and_stacks(ctx):
     assert ctx.last_lwa_path() == 0 and np.array_equal(g4[0], O.cal_local_wave_activity(q, Qbad, lat, dA, True, 'all'))
 
 
+def test_lwa_interval_kernel_refuses_infinities(ctx):
+    """round-4 advisor: an INFINITE reference level passed the premise check (only NaN failed it) and the interval kernel then
+    computed inf * 0 = NaN where the reference sums to 0; an infinite tracer CELL turned every row behind it into inf - inf.  Now the
+    device check wants Q finite, and a cell the interval kernel finds infinite stamps the flag: the gated band walk behind it runs
+    and the call returns the reference's own answer (path 2).  exact=False checks the same on the host."""
+    rng = np.random.default_rng(21)
+    ny, nx = 600, 96
+    lat, q, Q, dA = _lwa_case(rng, ny, nx, np.float64, True, True, False)
+    Qinf = Q.copy(); Qinf[-1] = np.inf                                     # still monotone, no NaN
+    with np.errstate(invalid='ignore'):
+        ref = O.cal_local_wave_activity(q, Qinf, lat, dA, True, 'all')
+    got, _ = ctx.lwa(q[None], Qinf[None], lat, dA, float(dA.max()))
+    assert ctx.last_lwa_path() == 2 and np.array_equal(got[0], ref, equal_nan=True)
+    qinf = q.copy(); qinf[300, 17] = -np.inf; qinf[10, 60] = np.inf         # two infinite cells, far from each other
+    with np.errstate(invalid='ignore'):
+        ref = O.cal_local_wave_activity(qinf, Q, lat, dA, True, 'all')
+    got, _ = ctx.lwa(qinf[None], Q[None], lat, dA, float(dA.max()))
+    assert ctx.last_lwa_path() == 2 and np.array_equal(got[0], ref, equal_nan=True)
+    assert np.isfinite(got[0][:, :17]).all()                               # columns without an infinite cell are untouched by it
+    g2, _ = ctx.lwa(qinf[None], Q[None], lat, dA, float(dA.max()), exact=False)       # vouching needs a look at the tracer too
+    assert ctx.last_lwa_path() == 0 and np.array_equal(g2[0], ref, equal_nan=True)
+    g3, _ = ctx.lwa(q[None], Qinf[None], lat, dA, float(dA.max()), exact=False)
+    assert ctx.last_lwa_path() == 0
+
+
+def test_deterministic_facade_keeps_lwa_on_the_band_walk(ctx):
+    """round-4 advisor: Contour2D(deterministic=True) promises run-to-run identical bits; planes of more than 512 rows used to take the
+    interval kernel (LDS atomics in arrival order) all the same.  Now `exact` defaults to True there: the oracle's own bits."""
+    import xcontour_amd as xa
+    rng = np.random.default_rng(5)
+    ny, nx = 560, 64
+    lat, q, Q, dA = _lwa_case(rng, ny, nx, np.float64, True, True, False)
+    lon = np.arange(nx) * 1.0
+    c = {'lat': lat, 'lon': lon}
+    tr = xa.DataArray(q, ('lat', 'lon'), c, 'pv')
+    cm = xa.Contour2D(tr, xa.DataArray(dA, ('lat', 'lon'), c, 'dA'), dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'}, increase=True, lt=True,
+                      deterministic=True)
+    lwa = cm.cal_local_wave_activity(tr, xa.DataArray(Q, ('lat',), {'lat': lat}, 'Q'))
+    assert cm.ctx.last_lwa_path() == 0
+    assert np.array_equal(lwa.values, O.cal_local_wave_activity(q, Q, lat, dA, True, 'all'))
+    cm.close()
+
+
 def test_crossing_uncrossed_interior_levels_are_exact_zeros(ctx):
     """two regions of the plane separated by NaN columns hold values in [0, 0.3] and [0.7, 1]; no box has corners in
     both, so the levels in between are crossed by nothing and must come out as the exact 0 of the reference's per-contour

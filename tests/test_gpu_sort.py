@@ -91,6 +91,30 @@ def test_sort_range_path_spike_falls_back(ctx):
     assert _sort_equals_oracle(ctx, b3) == 2
 
 
+def test_bpe_through_both_paths_and_twice_on_the_fallback(ctx):
+    """round 5: the last-arriving k_bpe block sums the partials (no k_sum_parts launch) behind an arrival ticket that the chain's first
+    kernel clears -- and that the last arriver clears again, because a stack that fails the range-key check runs the tail TWICE in one
+    call.  BPE of a plane that takes path 1, of one that falls back (path 2), and again: the oracle's value every time"""
+    rng = np.random.default_rng(3)
+    nz, nxx = 64, 512
+    Z = -(np.arange(nz) + 0.5) * 2.0
+    yA = np.full((nz, nxx), 40.0)
+    tbl, cs = O.cal_area_eqCoord_table_hist(np.ones((nz, nxx)), yA, Z, False, False)
+    ok = rng.standard_normal((nz, nxx))
+    spike = 1.0 + 1e-12 * rng.standard_normal((nz, nxx)); spike[::7, 3] = -5.0; spike[::9, 5] = 7.0
+    for _ in range(2):
+        for q, want in ((ok, 1), (spike, 2), (ok, 1)):
+            r = ctx.sort_profile(q, dA=yA, tbl=tbl, coord=cs)
+            assert ctx.last_sort_path() == want
+            ref = O.bpe_integral(q, yA, tbl, cs)
+            assert abs(r['bpe'] / ref - 1) < 1e-10 and r['nvalid'] == q.size
+    st = np.stack([ok, spike, ok * 2])
+    r = ctx.sort_profile(st, dA=yA, tbl=tbl, coord=cs)                      # the batch falls back as a whole
+    assert ctx.last_sort_path() == 2
+    for s_ in range(3):
+        assert abs(r['bpe'][s_] / O.bpe_integral(st[s_], yA, tbl, cs) - 1) < 1e-10
+
+
 def test_sort_profile_of_planes_without_valid_cells(ctx):
     """an all-NaN plane inside a stack: nvalid 0 and NaN for every target on that plane (the oracle's rule), the other planes
     unaffected; both sort paths"""
