@@ -966,8 +966,9 @@ def main():
             ms = np.array([ctx.elapsed_ms(e0, e1) for e0, e1 in ev])
             ach = alg / (ms.mean() * 1e-3) / 1e9
             uniq = uniq_bytes(a.slab_dA)
-            traffic, tsrc = (None, 'not measured for this variant') if (a.row_dA or a.variant != 0 or a.deterministic or (a.dtype != 'f64' and a.slab_dA)) else \
-                stored_traffic(('f32_' if a.dtype == 'f32' else '') + ('slab_' if a.slab_dA else '') + ('chain' if chain else 'nochain'), B)
+            det_key = a.deterministic and a.dtype == 'f64' and not a.slab_dA and chain
+            traffic, tsrc = (None, 'not measured for this variant') if (a.row_dA or a.variant != 0 or (a.deterministic and not det_key) or (a.dtype != 'f64' and a.slab_dA)) else \
+                stored_traffic('det_chain' if det_key else (('f32_' if a.dtype == 'f32' else '') + ('slab_' if a.slab_dA else '') + ('chain' if chain else 'nochain')), B)
             line['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': ach / HBM_PEAK_GBS,
                                 'hbm_unique_frac': uniq / (ms.mean() * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -7,11 +7,12 @@
 # Writes gpurun_out/hist_traffic.json (copy to profiles/) and gpurun_out/kt_<mode>/.
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && cd $R
 COMMIT=${1:-unknown}
-for mode in chain nochain slab_chain slab_nochain f32_chain f32_nochain; do
+for mode in chain nochain slab_chain slab_nochain f32_chain f32_nochain det_chain; do
   arg=""
   case $mode in *nochain) arg="--no-chain";; esac
   case $mode in slab_*) arg="$arg --slab-dA";; esac
   case $mode in f32_*) arg="$arg --dtype f32";; esac
+  case $mode in det_*) arg="$arg --deterministic";; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb_${mode}_$c -- python3 bench.py --steps 12 --warmup 3 --no-cpu --no-extras --no-cfg4 $arg > /dev/null 2>&1
   done

@@ -210,11 +210,14 @@ class Contour2D(object):
             raise Exception('no coordinate values for %s' % self.dimEqV)
         return np.asarray(coords[self.dimEqV])
 
-    def _wrap_contour(self, values, lead, lshape, coords, name, like, ccoord):
+    def _wrap_contour(self, values, lead, lshape, coords, name, like, ccoord, shared=None):
+        """`shared`: a coords dict built by an earlier call for the same (lead, contour) layout -- the nine outputs of keff() share one"""
         out = values.reshape(tuple(lshape) + (values.shape[-1],))
-        c = {d: coords[d] for d in lead if d in coords}
-        c['contour'] = ccoord
-        return lb.wrap(out, tuple(lead) + ('contour',), c, name, like)
+        c = shared
+        if c is None:
+            c = {d: np.asarray(coords[d]) for d in lead if d in coords}
+            c['contour'] = np.asarray(ccoord)
+        return lb.wrap(out, tuple(lead) + ('contour',), c, name, like, trusted=True)
 
     # ------------------------------------------------------------------ A(Yeq) table
     def _table_rows(self, mask, multiply):
@@ -888,8 +891,10 @@ class Contour2D(object):
             plans.pop(next(iter(plans))).free()
         ccoord = np.linspace(0.0, N - 1.0, N, dtype=self.dtype)
         out = []
+        shared = {d: np.asarray(coords[d]) for d in lead if d in coords}
+        shared['contour'] = ccoord
         for name in OUT_NAMES:
-            out.append(self._wrap_contour(res[name], lead, lshape, coords, name, self.tracer, ccoord))
+            out.append(self._wrap_contour(res[name], lead, lshape, coords, name, self.tracer, ccoord, shared=shared))
         if preY is not None:
             c = {d: coords[d] for d in lead if d in coords}
             c['new'] = np.asarray(preY)
