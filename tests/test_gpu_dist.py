@@ -318,3 +318,41 @@ def test_contexts_on_every_visible_device():
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_comm_stream_fences_and_root_gather_with_one_rank(ctx):
+    """the comm stream on its own (all one GPU and one rank can show of it): a device-to-device push waits for the compute stream's
+    producer (xc_comm_wait_compute), the compute stream's consumer waits for the push (xc_compute_wait_comm), xc_streams_idle polls
+    without blocking, sync_within gives up or returns True; and xc_comm_gather_dev of a one-rank communicator is its own block copied
+    into place on that stream (the root's share of every real gather)"""
+    n = 1 << 20
+    x = np.arange(n, dtype=np.float64)
+    src, mid, dst = ctx.to_device(x), ctx.alloc(n * 8), ctx.alloc(3 * n * 8)
+    ctx._check(ctx.lib.xc_memset(ctx.handle, dst.ptr, 0, 3 * n * 8))
+    ctx.comm_memcpy_d2d(mid.ptr, src.ptr, n * 8)                          # (producer stand-in on the comm stream itself)
+    ctx.comm_wait_compute()
+    ctx.comm_memcpy_d2d(dst.ptr + n * 8, mid.ptr, n * 8)
+    ctx.compute_wait_comm()
+    assert ctx.sync_within(30.0) and ctx.streams_idle()
+    got = dst.download((3, n), np.float64)
+    assert np.array_equal(got[1], x) and not got[0].any() and not got[2].any()
+    uid = ctx.comm_unique_id()
+    ctx.comm_init(1, 0, uid)
+    ctx.comm_wait_compute()
+    ctx.comm_gather(src.ptr, n * 8, dst.ptr + 2 * n * 8, n * 8, 0)       # rank 0's block lands at recv + 0 * stride
+    ctx.compute_wait_comm(); ctx.sync()
+    assert np.array_equal(dst.download((3, n), np.float64)[2], x)
+    ctx.comm_finalize()
+    for b in (src, mid, dst):
+        b.free()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_ipc_pushes_between_rank_processes_on_one_gpu(world):
+    """xc_ipc_export / xc_ipc_open / xc_comm_memcpy_d2d below bench.py: rank processes that share this box's GPU push patterned blocks into a
+    buffer the root exported, the root compares every word (tools/probe/ipc_probe.py, the probe that answered "does HIP IPC work here?")"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'probe', 'ipc_probe.py'), str(world), '8'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, env=_clean_env(), timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['ipc_push_ok'] is True and d['world'] == world
