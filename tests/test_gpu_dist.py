@@ -356,3 +356,23 @@ def test_ipc_pushes_between_rank_processes_on_one_gpu(world):
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert d['ipc_push_ok'] is True and d['world'] == world
+
+
+def test_a_rank_that_never_joins_rccl_does_not_hang_the_job():
+    """the failure the deadline on communicator creation exists for, with the REAL RCCL: rank 1 never calls ncclCommInitRank (fault injection), so
+    rank 0 sits in RCCL's bootstrap waiting for it.  After XC_COMM_TIMEOUT_S its helper thread is given up, every rank learns the verdict, the
+    ladder moves on to HIP IPC, the job completes with its JSON line, and rank 0 -- which still owns a thread stuck inside librccl -- leaves
+    through os._exit instead of waiting for it"""
+    import time
+    env = _clean_env()
+    env.update({'XC_TEST_SKIP_COMM_INIT_RANK': '1', 'XC_COMM_TIMEOUT_S': '5'})
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--no-cpu',
+                        '--cfg4-slabs', '32', '--cfg4-reps', '1', '--deadline-s', '240'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=400, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert time.time() - t0 < 200
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    tr = d['config']['carrier_trials']
+    assert 'rank 0: ncclCommInitRank did not return within 5 s' in tr['rccl']['error'] and 'rank 1: comm_init skipped' in tr['rccl']['error']
+    assert 'carrier ipc' in d['config']['parallelism'] and d['n_gpus'] == 2 and d['cfg4_strong']['checks']['rank0_block_bit_identical']

@@ -257,6 +257,10 @@ class SocketGroup(object):
 
             def call():
                 try:
+                    if os.environ.get('XC_TEST_SKIP_COMM_INIT_RANK') == str(self.rank):
+                        # fault injection (tests only): this rank never joins the bootstrap -- the others then sit in the REAL
+                        # ncclCommInitRank until their deadline, which is the failure the deadline exists for
+                        raise Exception('comm_init skipped on this rank (XC_TEST_SKIP_COMM_INIT_RANK)')
                     ctx.comm_init(self.world, self.rank, uid)
                     box['ok'] = True
                 except Exception as e:                             # noqa: BLE001 -- the verdict travels to every rank
