@@ -195,7 +195,9 @@ int xc_hist(xc_ctx* ctx, const xc_hist_desc* d);
  * default pass.  Precision: 2^-49 relative per weight anywhere in the 180 bits below the bound (the pole row of
  * a lat-lon grid carries squared gradients 2^100 times the typical ones: both keep their 49 bits); weights further down
  * lose their last bits, zeros and denormals contribute nothing; a bin that received an infinite weight reports NaN.
- * Levels, edges and counts are the same bits in both modes.  oracle/xcontour_oracle.py: deterministic_bin_sums. */
+ * Levels, edges and counts are the same bits in both modes.  oracle/xcontour_oracle.py: deterministic_bin_sums.
+ * Limit: the LDS histogram of this mode holds 5 words per channel and bin -- up to ~1700 contours with two weight channels (the Keff
+ * layout), ~850 with four; beyond that the call fails with XC_EBADARG (the default sums take about three times as many). */
 
 /* ------------------------------------------------------------------ K2  row sums for the A(Yeq) table
  * Replaces the degenerate histogram of cal_area_eqCoord_table_hist   core.py:176-193
