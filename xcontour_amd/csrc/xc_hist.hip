@@ -125,9 +125,7 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     const size_t cell = det ? (size_t)(kDetWords * nch + 1) * 8 : (size_t)(nch + 1) * 8;
     while (ncopy > 1 && fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget) ncopy >>= 1;
     if (fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget)
-        return fail(ctx, XC_EBADARG, det ? "xc_hist: too many bins x channels for the LDS histogram of the deterministic sums (a cell holds 5 words per channel: "
-                                           "about 1700 contours with two weight channels, 850 with four; the default sums take about three times as many)"
-                                         : "xc_hist: too many bins x channels for the LDS histogram");
+        return fail(ctx, XC_EBADARG, "xc_hist: too many bins x channels for the LDS histogram");
     g->ncopy = ncopy;
     g->lds = fixed + (size_t)(nbin + 1) * ncopy * cell;
     g->lds = (g->lds + 15) & ~(size_t)15;
