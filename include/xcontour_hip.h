@@ -101,6 +101,9 @@ int xc_memset(xc_ctx* ctx, void* dptr, int value, size_t bytes);
  * Python: Contour2D(..., resident=True). */
 int xc_keep_resident(xc_ctx* ctx, const void* host_ptr, size_t bytes);
 int xc_release_resident(xc_ctx* ctx, const void* host_ptr);
+/* the device address of the mirror of [host_ptr, host_ptr + bytes), or NULL if those bytes are not inside a registered array: a
+ * caller that drives the _dev entry points itself (the fused pipeline) points its descriptor at the mirror instead of copying it */
+int xc_resident_lookup(xc_ctx* ctx, const void* host_ptr, size_t bytes, void** out_dev);
 
 /* Uploads that overlap compute: xc_memcpy_h2d_async copies on the context's second (copy) stream and returns when the
  * host buffer may be reused (pageable memory: when the copy is done; kernels enqueued earlier on the compute stream run

@@ -87,6 +87,7 @@ PROTOTYPES = {
     'xc_stream_wait_copies': (C.c_int, [_vp]),
     'xc_keep_resident': (C.c_int, [_vp, _vp, C.c_size_t]),
     'xc_release_resident': (C.c_int, [_vp, _vp]),
+    'xc_resident_lookup': (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(_vp)]),
     'xc_copies_wait_stream': (C.c_int, [_vp]),
     'xc_event_create': (C.c_int, [_vp, C.POINTER(_vp)]),
     'xc_event_destroy': (C.c_int, [_vp, _vp]),
@@ -336,6 +337,14 @@ class Context(object):
         elif arr.ctypes.data in self._resident:
             self._check(self.lib.xc_release_resident(self.handle, _ptr(arr)))
             del self._resident[arr.ctypes.data]
+
+    def resident_ptr(self, arr):
+        """device address of the mirror of `arr` (a C-contiguous ndarray, or a leading-index slice of a registered one), or None"""
+        if not self._resident:
+            return None
+        p = _vp()
+        self._check(self.lib.xc_resident_lookup(self.handle, _ptr(arr), arr.nbytes, C.byref(p)))
+        return p.value
 
     def copies_wait_stream(self):
         self._check(self.lib.xc_copies_wait_stream(self.handle))

@@ -813,8 +813,13 @@ class Contour2D(object):
         if grdS is not None:
             g = self._integrand_plane(grdS)
         elif rdx is None:
-            rdx, rdy = grad_metrics(lat if lat is not None else coords[self.dimEqV],
-                                    lon if lon is not None else coords[self._xdim])
+            la = np.ascontiguousarray(lat if lat is not None else coords[self.dimEqV])
+            lo = np.ascontiguousarray(lon if lon is not None else coords[self._xdim])
+            mk = (la.tobytes(), lo.tobytes(), la.dtype.str, lo.dtype.str)
+            memo = self.__dict__.get('_metrics_memo')
+            if memo is None or memo[0] != mk:                    # the metrics of a grid are computed once per object and grid
+                memo = self.__dict__['_metrics_memo'] = (mk, grad_metrics(la, lo))
+            rdx, rdy = memo[1]
         # The plan owns the device copies of everything static (dA, metrics, table, preY) and the work buffers:
         # it is kept between calls, so a second keff() on the same grid only uploads the tracer.  Key = the
         # configuration + the bytes of the small arrays + a fingerprint of dA (shape, ends and a strided sample:
@@ -854,11 +859,21 @@ class Contour2D(object):
         ctx = self.ctx
         qb, gb, db = ny * nx * q.dtype.itemsize, 0 if g is None else ny * nx * g.dtype.itemsize, ny * nx * 8
 
+        direct = {}                                          # batch -> (tracer mirror, grdS mirror): resident inputs are read where they are
+
         def upload(k):
-            """batch k -> half k % nbuf of the device buffers, on the copy stream"""
+            """batch k -> half k % nbuf of the device buffers, on the copy stream.  A batch whose tracer (and supplied gradient) lie inside
+            resident mirrors is not copied at all: the descriptor points at the mirrors (a 52 MB cfg2 slab: ~50 us of device-to-device
+            copy per array and call saved)"""
             s0 = k * batch
             m = min(batch, nslab - s0)
             off = (k % nbuf) * batch
+            if self.resident and not slab_dA:
+                qp = ctx.resident_ptr(q[s0:s0 + m])
+                gp = None if g is None else ctx.resident_ptr(g[s0:s0 + m])
+                if qp and (g is None or gp):
+                    direct[k] = (qp, gp)
+                    return
             plan.q_buf.upload_async(q[s0:s0 + m], off * qb)
             if slab_dA:
                 plan.dA_buf.upload_async(dA[s0:s0 + m], off * db)
@@ -874,7 +889,18 @@ class Contour2D(object):
                 m = min(batch, nslab - k * batch)
                 ctx.stream_wait_copies()                              # the kernels of batch k wait for its upload
                 plan.touch()
-                plan.run_range(h, h * batch, m, None, out_s0=0)
+                if k in direct:
+                    qp, gp = direct.pop(k)
+                    own = plan._q_ptr
+                    plan.set_q_device(qp)
+                    plan.set_grdS_device(gp)
+                    try:
+                        plan.run_range(h, 0, m, None, out_s0=0)
+                    finally:
+                        plan.set_q_device(own)
+                        plan.set_grdS_device(0)
+                else:
+                    plan.run_range(h, h * batch, m, None, out_s0=0)
                 if k + 1 < nb:
                     upload(k + 1)                                     # overlaps the kernels just enqueued (the other half is free:
                                                                       # batch k - 1 was fetched, i.e. synchronised, last turn)

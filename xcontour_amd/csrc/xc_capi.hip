@@ -371,6 +371,13 @@ int xc_keep_resident(xc_ctx* ctx, const void* host_ptr, size_t bytes)
     return XC_OK;
 }
 
+int xc_resident_lookup(xc_ctx* ctx, const void* host_ptr, size_t bytes, void** out_dev)
+{
+    if (!ctx || !out_dev) return fail(ctx, XC_EBADARG, "xc_resident_lookup: bad arguments");
+    *out_dev = (host_ptr && bytes && !ctx->resident.empty()) ? const_cast<void*>(resident_lookup(ctx, host_ptr, bytes)) : nullptr;
+    return XC_OK;
+}
+
 int xc_release_resident(xc_ctx* ctx, const void* host_ptr)
 {
     XC_CTX(ctx);

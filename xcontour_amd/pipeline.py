@@ -112,9 +112,11 @@ class KeffPlan(object):
             self.rdy_buf = ctx.to_device(np.asarray(rdy, dtype=np.float64))
             d.grad, d.rdx, d.rdy = 1, self.rdx_buf.ptr, self.rdy_buf.ptr
             self.grdS_buf = None
+            self._g_ptr = 0
         else:
             self.grdS_dtype = np.dtype(grdS_dtype)
             self.grdS_buf = ctx.alloc(cells * self.grdS_dtype.itemsize)
+            self._g_ptr = 0
             d.grad, d.grdS, d.grdS_dtype = 0, self.grdS_buf.ptr, nat.dtype_code(self.grdS_dtype)
         d.prod_f32 = int(bool(prod_f32))
         d.periodic_x = int(bool(periodic_x))
@@ -190,7 +192,7 @@ class KeffPlan(object):
         if d.dA_rank == nat.XC_DA_SLAB:
             d.dA = self._dA_ptr + s0 * self.ny * self.nx * 8
         if self.grdS_buf is not None:
-            d.grdS = self.grdS_buf.ptr + s0 * self.ny * self.nx * self.grdS_dtype.itemsize
+            d.grdS = (self._g_ptr or self.grdS_buf.ptr) + s0 * self.ny * self.nx * self.grdS_dtype.itemsize
 
     # -- inputs
     def touch(self):
@@ -209,6 +211,10 @@ class KeffPlan(object):
         pointer, written by someone else than this library, do.)"""
         self._q_ptr = int(ptr)
         self.desc.q = self._q_ptr
+
+    def set_grdS_device(self, ptr):
+        """Use an existing device pointer ([nslab][ny][nx], grdS_dtype) as the supplied squared gradient; 0 / None: the plan's own buffer again."""
+        self._g_ptr = int(ptr or 0)
 
     def set_dA_device(self, ptr):
         """Use an existing device pointer as dA (same rank and shape as the dA given to the constructor)."""
