@@ -836,7 +836,7 @@ class Contour2D(object):
             batch = int(min(nslab, max(1, int(max_batch_bytes) // (2 * per_slab)), 65535))
         flat = dA.reshape(-1)
         # a per-slab dA travels with every batch (like the tracer): only its shape enters the key
-        dkey = ('slab',) if slab_dA else (flat[::max(1, flat.size // 4096)].tobytes(), float(flat[0]), float(flat[-1]))
+        dkey = ('slab',) if slab_dA else (flat[::max(1, flat.size // 512)].tobytes(), float(flat[0]), float(flat[-1]))       # (hashing a 32 KB sample was 20 us per call)
         key = (batch, nbuf, ny, nx, int(N), q.dtype.str, np.dtype(self.dtype).str, None if g is None else g.dtype.str,
                bool(periodic_x), float(nkeff_mask), bool(self.increase), bool(self.lt), self.right_edge, self.device, self.deterministic,
                dA.shape[-2:] if slab_dA else dA.shape, dkey,
