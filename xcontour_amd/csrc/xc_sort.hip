@@ -32,7 +32,10 @@
 namespace xc {
 namespace {
 
-constexpr int TILE_ROUNDS = 16;
+#ifndef XC_TILE_ROUNDS
+#define XC_TILE_ROUNDS 16
+#endif
+constexpr int TILE_ROUNDS = XC_TILE_ROUNDS;
 constexpr int TILE = 64 * TILE_ROUNDS;      // elements per wave
 constexpr int BTILE = 4 * TILE;             // elements per block tile
 typedef unsigned long long u64;
@@ -822,18 +825,33 @@ void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
     }
     const bool tinc = tbl[ntbl - 1] > tbl[0];
     double sum = 0.0;
+    // BU cells per thread and round: their three loads each are issued before the first bracket search starts (one cell at a time --
+    // load, ~log2(ntbl) dependent LDS reads, a division, next load -- was a chain of seven memory round trips per thread on the cfg5
+    // planes: 19 us for a kernel that moves 32 MB); the terms are still added in cell order
+    constexpr int BU = 4;
     auto walk = [&](auto X, auto F) {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-            const double a = acum[i] - 0.5 * vals[i];
-            double z;
-            if (a >= X(ntbl - 1)) z = F(ntbl - 1);
-            else if (a <= X(0)) z = F(0);
-            else {
-                int lo = 0, hi = ntbl - 1;
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a >= X(mid)) lo = mid; else hi = mid; }
-                z = F(lo) + (F(lo + 1) - F(lo)) * (a - X(lo)) / (X(lo + 1) - X(lo));
+        const int64_t step = (int64_t)gridDim.x * 256;
+        for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += BU * step) {
+            double ac[BU], va[BU]; K ke[BU];
+#pragma unroll
+            for (int u = 0; u < BU; ++u) {
+                const int64_t i = i0 + u * step, ic = i < n ? i : n - 1;
+                ac[u] = acum[ic]; va[u] = vals[ic]; ke[u] = keys[ic];
             }
-            sum += KeyTraits<K>::decode(keys[i]) * z * vals[i];
+#pragma unroll
+            for (int u = 0; u < BU; ++u) {
+                if (i0 + u * step >= n) break;
+                const double a = ac[u] - 0.5 * va[u];
+                double z;
+                if (a >= X(ntbl - 1)) z = F(ntbl - 1);
+                else if (a <= X(0)) z = F(0);
+                else {
+                    int lo = 0, hi = ntbl - 1;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a >= X(mid)) lo = mid; else hi = mid; }
+                    z = F(lo) + (F(lo + 1) - F(lo)) * (a - X(lo)) / (X(lo + 1) - X(lo));
+                }
+                sum += KeyTraits<K>::decode(ke[u]) * z * va[u];
+            }
         }
     };
     if (in_lds) walk([&](int k) { return s_tbl[tinc ? k : ntbl - 1 - k]; }, [&](int k) { return s_tbl[BPE_TBL + (tinc ? k : ntbl - 1 - k)]; });
@@ -867,7 +885,10 @@ void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
 
 // Workspace layout (device), every array with a leading slab dim: keys A/B, vals A/B, hist, totals, nvalid, bsums, bpe parts,
 // K1 partials + min/max + the "not sorted" flag of the range-key path
-constexpr int BPE_BLOCKS = 256;
+#ifndef XC_BPE_BLOCKS
+#define XC_BPE_BLOCKS 256
+#endif
+constexpr int BPE_BLOCKS = XC_BPE_BLOCKS;
 size_t sort_workspace_bytes(int64_t n, int64_t nslab)
 {
     const int64_t ntiles = (n + BTILE - 1) / BTILE;
