@@ -132,3 +132,25 @@ def test_sort_profile_of_planes_without_valid_cells(ctx):
             assert np.array_equal(r['Q'][s], Q.astype(np.float64), equal_nan=True)
             n = int(r['nvalid'][s])
             assert np.array_equal(r['q_sorted'][s][:n], xs.astype(np.float64))
+
+
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+def test_sort_tile_choice_both_sides_of_the_switch(ctx, dt):
+    """xc_sort.hip small_tiles(): stacks with at most 400 full-size tiles run the radix passes on half tiles (2048 pairs per
+    block), larger ones on 4096-pair tiles.  One plane shape with a ragged last tile in BOTH tilings, 44 planes (396 tiles:
+    half tiles) and 45 planes (405: full tiles): every plane's order, payloads and count against the oracle's stable argsort."""
+    rng = np.random.default_rng(77)
+    ny, nx = 193, 170                                           # 32810 cells = 8 full tiles + 42 cells; 16 half tiles + 42
+    for S in (44, 45):
+        q = rng.standard_normal((S, ny, nx)).astype(dt)
+        q[rng.random(q.shape) < 0.01] = np.nan
+        q[2, 5:9] = 0.25                                         # ties: the payload order is the stable one
+        dA = rng.random((ny, nx)) + 0.5
+        r = ctx.sort_profile(q, dA=dA, want_sorted=True, want_acum=True)
+        assert ctx.last_sort_path() == (1 if dt == np.float64 else 0)
+        for s in range(S):
+            _, xs, ac = O.sorted_profile(q[s], dA, [0.0], None)
+            n = len(xs)
+            assert int(r['nvalid'][s]) == n
+            assert np.array_equal(r['q_sorted'][s][:n], xs.astype(np.float64)), (S, s)
+            assert rel(r['acum'][s][:n], ac) < 1e-12, (S, s)

@@ -353,10 +353,11 @@ __device__ __forceinline__ unsigned long long digit_peers(unsigned d, unsigned l
 // Counting needs no ranks: one returnless ds_add_u32 per key on per-wave counters (the ballot ranking
 // of the scatter costs ~60 VALU instructions per 64 keys and made this kernel ALU-bound); a round
 // whose 64 digits are all equal -- sorted or constant data -- is added once by one lane.
-template <typename K, bool FIRST = false, typename TQ = double, typename TM = double, int MODE = 0>
+template <typename K, bool FIRST = false, typename TQ = double, typename TM = double, int MODE = 0, int TR = XC_TILE_ROUNDS>
 __global__ __launch_bounds__(256)
 void k_radix_hist(const K* __restrict__ keys, int64_t n, int shift, int ntiles, unsigned* __restrict__ hist, const PairSrc src)
 {
+    constexpr int TILE_ROUNDS = TR, TILE = 64 * TR, BTILE = 4 * TILE;      // (the tile of THIS instance: small_tiles() below)
     __shared__ unsigned s_cnt[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = blockIdx.x;
@@ -456,13 +457,14 @@ void k_radix_scan_rows(unsigned* __restrict__ hist, int ntiles, unsigned* __rest
 // (stable: wave-major, then round, then lane = element order), then written out position by position:
 // consecutive LDS positions with the same digit go to consecutive global addresses, so the stores
 // of a wave cover runs of ~BTILE/256 elements instead of 64 unrelated 8-byte targets.
-template <typename K, bool FIRST = false, typename TQ = double, typename TM = double, int MODE = 0>
+template <typename K, bool FIRST = false, typename TQ = double, typename TM = double, int MODE = 0, int TR = XC_TILE_ROUNDS>
 __global__ __launch_bounds__(256)
 void k_radix_scatter(const K* __restrict__ kin, const double* __restrict__ vin,
                      K* __restrict__ kout, double* __restrict__ vout, int64_t n, int shift,
                      int ntiles, const unsigned* __restrict__ hist, const unsigned* __restrict__ totals, int inline_scan,
                      const PairSrc src)
 {
+    constexpr int TILE_ROUNDS = TR, TILE = 64 * TR, BTILE = 4 * TILE;
     extern __shared__ unsigned long long s_dyn[];
     K* s_k = (K*)s_dyn;                                        // [BTILE] staging: keys first, then the payload
     double* s_v = (double*)s_dyn;
@@ -889,9 +891,19 @@ void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
 #define XC_BPE_BLOCKS 256
 #endif
 constexpr int BPE_BLOCKS = XC_BPE_BLOCKS;
+// Tile of the radix passes: 4 waves x 64 lanes x TILE_ROUNDS pairs.  Sixteen rounds per lane keep a large sort's per-tile costs
+// (digit scans, the histogram row per tile) small; a stack with few tiles -- the cfg5 stand-in: 3 planes x 110 tiles on 256 CUs --
+// fills the chip only with the half tile (measured, r05: cfg5 0.192 -> 0.171 ms, one such plane 0.131 -> 0.108 ms with 8 rounds; 16 planes of
+// 256 x 512 -- 512 tiles -- 0.178 -> 0.198 ms, 64 planes 25 % slower: the choice is by the number of tiles, not a constant).
+constexpr int TILE_ROUNDS_SMALL = 8, BTILE_SMALL = 4 * 64 * TILE_ROUNDS_SMALL;
+#ifndef XC_SMALL_TILES_MAX
+#define XC_SMALL_TILES_MAX 400
+#endif
+static inline bool small_tiles(int64_t n, int64_t nslab) { return nslab * ((n + BTILE - 1) / BTILE) <= XC_SMALL_TILES_MAX; }
+
 size_t sort_workspace_bytes(int64_t n, int64_t nslab)
 {
-    const int64_t ntiles = (n + BTILE - 1) / BTILE;
+    const int64_t ntiles = (n + BTILE_SMALL - 1) / BTILE_SMALL;        // (the larger of the two tilings)
     const int64_t nb = (n + 2047) / 2048;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t S = (size_t)nslab;
@@ -907,7 +919,9 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
                               unsigned* out_nvalid, double* out_bpe)
 {
     const int64_t n = ny * nx;
-    const int64_t ntiles = (n + BTILE - 1) / BTILE;
+    const bool tsmall = small_tiles(n, nslab);
+    const int64_t btile = tsmall ? BTILE_SMALL : BTILE;
+    const int64_t ntiles = (n + btile - 1) / btile, ntiles_ws = (n + BTILE_SMALL - 1) / BTILE_SMALL;
     const int nb = (int)((n + 2047) / 2048);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t S = (size_t)nslab;
@@ -916,7 +930,7 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
     K* kB = (K*)w; w += al(S * n * 8);
     double* vA = (double*)w; w += al(S * n * 8);
     double* vB = (double*)w; w += al(S * n * 8);
-    unsigned* hist = (unsigned*)w; w += al(S * 256 * ntiles * 4);
+    unsigned* hist = (unsigned*)w; w += al(S * 256 * ntiles_ws * 4);
     unsigned* totals = (unsigned*)w; w += al(S * 256 * 4);
     unsigned* nvalid = (unsigned*)w; w += al(S * 4);
     double* bsum = (double*)w; w += al(S * nb * 8);
@@ -935,7 +949,7 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
     const int64_t dstride = dA_rank == XC_DA_SLAB ? n : 0, mstride = (mask && mask_per_slab) ? n : 0;
     const PairSrc src = {q, mask, dA, krank, negate, nx, mstride, dstride, mm, rtab};
     const unsigned gt = (unsigned)ntiles;
-    const size_t sc_lds = (size_t)BTILE * 8 + (4 * 256 + 256 + 8) * sizeof(unsigned) + BTILE;
+    const size_t sc_lds = (size_t)btile * 8 + (4 * 256 + 256 + 8) * sizeof(unsigned) + btile;
     const int inline_scan = ntiles <= 32 ? 1 : 0;       // measured: the O(ntiles) walk per block costs ~0.14 us per tile, the scan launch ~5 us
     K *kin = kA, *kout = kB;
     double *vin = vA, *vout = vB;
@@ -943,32 +957,36 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
 
     // one LSD pass (histogram, row scan, scatter); MODE 0: byte `shift / 8` of the key, MODE 1: of the 24-bit range key
     auto big_lds = [&](const void* f) { return ensure_big_lds(ctx, f, (int)sc_lds); };
-    auto pass = [&](auto mode_tag, bool first, int shift) -> int {
-        constexpr int MODE = decltype(mode_tag)::value;
+    auto pass_tr = [&](auto mode_tag, auto tr_tag, bool first, int shift) -> int {
+        constexpr int MODE = decltype(mode_tag)::value, TR = decltype(tr_tag)::value;
         if (first) {            // reads the tracer itself (the unsorted pairs never touch memory)
             if (mf32) {
-                XC_TRY_(big_lds((const void*)k_radix_scatter<K, true, TQ, float, MODE>));
-                hipLaunchKernelGGL((k_radix_hist<K, true, TQ, float, MODE>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
+                XC_TRY_(big_lds((const void*)k_radix_scatter<K, true, TQ, float, MODE, TR>));
+                hipLaunchKernelGGL((k_radix_hist<K, true, TQ, float, MODE, TR>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
             } else {
-                XC_TRY_(big_lds((const void*)k_radix_scatter<K, true, TQ, double, MODE>));
-                hipLaunchKernelGGL((k_radix_hist<K, true, TQ, double, MODE>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
+                XC_TRY_(big_lds((const void*)k_radix_scatter<K, true, TQ, double, MODE, TR>));
+                hipLaunchKernelGGL((k_radix_hist<K, true, TQ, double, MODE, TR>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
             }
         } else {
-            XC_TRY_(big_lds((const void*)k_radix_scatter<K, false, double, double, MODE>));
-            hipLaunchKernelGGL((k_radix_hist<K, false, double, double, MODE>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
+            XC_TRY_(big_lds((const void*)k_radix_scatter<K, false, double, double, MODE, TR>));
+            hipLaunchKernelGGL((k_radix_hist<K, false, double, double, MODE, TR>), dim3(gt, ns), dim3(256), 0, ctx->stream, kin, n, shift, (int)ntiles, hist, src);
         }
         if (!inline_scan) hipLaunchKernelGGL(k_radix_scan_rows, dim3(256, ns), dim3(1024), 0, ctx->stream, hist, (int)ntiles, totals);
         if (first) {
-            if (mf32) hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, float, MODE>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+            if (mf32) hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, float, MODE, TR>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
                                          (int)ntiles, hist, totals, inline_scan, src);
-            else hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, double, MODE>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+            else hipLaunchKernelGGL((k_radix_scatter<K, true, TQ, double, MODE, TR>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
                                     (int)ntiles, hist, totals, inline_scan, src);
-        } else hipLaunchKernelGGL((k_radix_scatter<K, false, double, double, MODE>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
+        } else hipLaunchKernelGGL((k_radix_scatter<K, false, double, double, MODE, TR>), dim3(gt, ns), dim3(256), sc_lds, ctx->stream, kin, vin, kout, vout, n, shift,
                                   (int)ntiles, hist, totals, inline_scan, src);
         XC_HIP(ctx, hipGetLastError());
         K* tk = kin; kin = kout; kout = tk;
         double* tv = vin; vin = vout; vout = tv;
         return XC_OK;
+    };
+    auto pass = [&](auto mode_tag, bool first, int shift) -> int {
+        return tsmall ? pass_tr(mode_tag, std::integral_constant<int, TILE_ROUNDS_SMALL>(), first, shift)
+                      : pass_tr(mode_tag, std::integral_constant<int, TILE_ROUNDS>(), first, shift);
     };
 
     // everything after the sort: cumulative area, profile, BPE, copies of the requested arrays
