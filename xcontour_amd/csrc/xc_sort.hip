@@ -788,12 +788,11 @@ void k_unkey(const K* __restrict__ keys, int64_t n, double* __restrict__ out)
 
 // Q_exact(A_j) = q_sorted[min(searchsorted(acum[:nvalid], A_j, 'right'), nvalid-1)]
 template <typename K>
-__global__ __launch_bounds__(256)
-void k_profile(const K* __restrict__ keys, const double* __restrict__ acum,
-               const unsigned* __restrict__ nvalid, const double* __restrict__ targets, int J,
-               double* __restrict__ Q, int64_t ncell)
+__device__ __forceinline__ void profile_body(const K* __restrict__ keys, const double* __restrict__ acum,
+                                             const unsigned* __restrict__ nvalid, const double* __restrict__ targets, int J,
+                                             double* __restrict__ Q, int64_t ncell, int bx)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = bx * 256 + threadIdx.x;
     if (j >= J) return;
     keys += (size_t)blockIdx.y * ncell; acum += (size_t)blockIdx.y * ncell; Q += (size_t)blockIdx.y * J;
     const int64_t n = nvalid[blockIdx.y];
@@ -804,6 +803,14 @@ void k_profile(const K* __restrict__ keys, const double* __restrict__ acum,
     if (lo > n - 1) lo = n - 1;
     Q[j] = KeyTraits<K>::decode(keys[lo]);
 }
+template <typename K>
+__global__ __launch_bounds__(256)
+void k_profile(const K* __restrict__ keys, const double* __restrict__ acum,
+               const unsigned* __restrict__ nvalid, const double* __restrict__ targets, int J,
+               double* __restrict__ Q, int64_t ncell)
+{
+    profile_body<K>(keys, acum, nvalid, targets, J, Q, ncell, (int)blockIdx.x);
+}
 
 // BPE-like integral: sum_i q_i * z*(A_i - dA_i/2) * dA_i with z* = np.interp(A, tbl, coord)
 template <typename K>
@@ -811,10 +818,18 @@ __global__ __launch_bounds__(256)
 void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
            const double* __restrict__ acum, const unsigned* __restrict__ nvalid,
            const double* __restrict__ tbl, const double* __restrict__ coord, int ntbl, double* __restrict__ part,
-           int64_t ncell, unsigned* __restrict__ tick, double* __restrict__ out)
+           int64_t ncell, unsigned* __restrict__ tick, double* __restrict__ out,
+           const double* __restrict__ targets, int J, double* __restrict__ Q, int nprof)
 {
+    // (round 5) the first `nprof` workgroups are the profile Q(A_j) of this plane (k_profile's body): both only read the sorted
+    // state, so the J binary searches -- ~19 dependent reads, 7 us as a launch of their own -- run beside the integral (cfg5:
+    // -6 us, same-box A/B).  Folding a seam into the LAST-ARRIVING workgroup of the kernel before it does NOT pay: tried on the
+    // range table (into k_range_hist) and the block-sum scan (into the first scan pass) -- ticket round trip + agent-scope
+    // re-reads cost the 3-4 us the launch boundary costs; 3 / 16 / 64-plane stacks +1..3 us, reverted (profiles/r05_notes.md).
+    if ((int)blockIdx.x < nprof) { profile_body<K>(keys, acum, nvalid, targets, J, Q, ncell, (int)blockIdx.x); return; }
+    const int bx = (int)blockIdx.x - nprof, nbx = (int)gridDim.x - nprof;
     { const size_t so = (size_t)blockIdx.y * ncell; keys += so; vals += so; acum += so; }
-    part += (size_t)blockIdx.y * gridDim.x;
+    part += (size_t)blockIdx.y * nbx;
     const int64_t n = nvalid[blockIdx.y];
     // the table goes into LDS when it fits (nz or ny entries): the bracket search is a chain of ~log2(ntbl) dependent reads per
     // cell, ~1 us each from global memory (20 us per launch on the cfg5 stand-in), ~0.1 us from LDS
@@ -832,8 +847,8 @@ void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
     // planes: 19 us for a kernel that moves 32 MB); the terms are still added in cell order
     constexpr int BU = 4;
     auto walk = [&](auto X, auto F) {
-        const int64_t step = (int64_t)gridDim.x * 256;
-        for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += BU * step) {
+        const int64_t step = (int64_t)nbx * 256;
+        for (int64_t i0 = (int64_t)bx * 256 + threadIdx.x; i0 < n; i0 += BU * step) {
             double ac[BU], va[BU]; K ke[BU];
 #pragma unroll
             for (int u = 0; u < BU; ++u) {
@@ -867,13 +882,13 @@ void k_bpe(const K* __restrict__ keys, const double* __restrict__ vals,
     // arrival): MI355X_MICROARCH.md, valid forms; the sum is taken in a fixed order, whoever arrives last.
     __shared__ unsigned s_last;
     if (threadIdx.x == 0) {
-        __hip_atomic_store(part + blockIdx.x, s[0] + s[1] + s[2] + s[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part + bx, s[0] + s[1] + s[2] + s[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(tick + (size_t)blockIdx.y * 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+        s_last = __hip_atomic_fetch_add(tick + (size_t)blockIdx.y * 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nbx - 1u ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last || threadIdx.x >= 64) return;
-    const int np = (int)gridDim.x, per = (np + 63) / 64, i0 = (int)threadIdx.x * per;     // one wave: lane l sums its contiguous share, then a fixed xor tree
+    const int np = nbx, per = (np + 63) / 64, i0 = (int)threadIdx.x * per;     // one wave: lane l sums its contiguous share, then a fixed xor tree
     double t = 0.0;
     for (int i = i0; i < i0 + per && i < np; ++i) t += __hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
@@ -997,14 +1012,14 @@ static int sort_profile_typed(xc_ctx* ctx, const TQ* q, int q_dtype, const void*
         hipLaunchKernelGGL(k_scan_bsums, dim3(ns), dim3(1024), 0, ctx->stream, bsum, nb);
         hipLaunchKernelGGL(k_scan_local<true>, dim3(nb, ns), dim3(256), 0, ctx->stream, vin, acum, n, bsum);
         XC_HIP(ctx, hipGetLastError());
-        if (out_Q && J > 0) {
-            if (!targets) return fail(ctx, XC_EBADARG, "xc_sort_profile: targets is NULL");
-            hipLaunchKernelGGL(k_profile<K>, dim3((J + 255) / 256, ns), dim3(256), 0, ctx->stream, kin, acum, nvalid, targets, J, out_Q, n);
-        }
-        if (out_bpe) {
-            if (!tbl || !coord || ntbl < 2) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
-            hipLaunchKernelGGL(k_bpe<K>, dim3(BPE_BLOCKS, ns), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts, n, tick, out_bpe);
-        }
+        const bool prof = out_Q && J > 0;
+        if (prof && !targets) return fail(ctx, XC_EBADARG, "xc_sort_profile: targets is NULL");
+        if (out_bpe && (!tbl || !coord || ntbl < 2)) return fail(ctx, XC_EBADARG, "xc_sort_profile: BPE needs tbl/coord");
+        const int nprof = prof ? (J + 255) / 256 : 0;
+        if (out_bpe)            // (the profile rides in the same launch: see k_bpe)
+            hipLaunchKernelGGL(k_bpe<K>, dim3(BPE_BLOCKS + nprof, ns), dim3(256), 0, ctx->stream, kin, vin, acum, nvalid, tbl, coord, ntbl, parts, n, tick, out_bpe,
+                               targets, J, out_Q, nprof);
+        else if (prof) hipLaunchKernelGGL(k_profile<K>, dim3(nprof, ns), dim3(256), 0, ctx->stream, kin, acum, nvalid, targets, J, out_Q, n);
         if (out_qsorted) hipLaunchKernelGGL(k_unkey<K>, dim3(gb, ns), dim3(256), 0, ctx->stream, kin, n, out_qsorted);
         if (out_acum) XC_HIP(ctx, hipMemcpyAsync(out_acum, acum, S * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
         XC_HIP(ctx, hipGetLastError());
