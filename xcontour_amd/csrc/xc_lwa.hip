@@ -414,126 +414,185 @@ void k_lwa_check(const double* __restrict__ Q, const double* __restrict__ coord,
     if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(flag, epoch);      // the word holds the epoch of the last call whose check failed
 }
 
+// (round 5) The kernel is PERSISTENT over column groups -- `gridDim.x` workgroups (one per CU: the difference arrays fill the LDS)
+// walk the groups b, b + gridDim.x, ... -- so that
+//   * Q' and the bucket table below are staged once per workgroup, not once per group;
+//   * the cells of the NEXT group are requested before this group's prefix sums, transform and stores (a group used to pay its
+//     ~5 us of load latency with nothing else in flight: one workgroup per CU);
+//   * bracket search: a table G of LWA_NB + 1 row indices over equal-width value buckets of [Q'_0, Q'_last] -- G[k] = number of levels
+//     whose bucket is below k, the bucket being the SAME monotone function of the value for levels and cells -- confines the lower
+//     bound of a cell of bucket k to [G[k], G[k + 1]] exactly (no float consistency needed between an edge and a cell), so the 11
+//     dependent LDS reads of a full binary search over 1801 levels become ~1 (measured by ablation: the search was 32 of the 108 us);
+//   * the prefix sums use all sixteen waves (two waves per array: 128 pieces) instead of eight.
+constexpr int LWA_NB = 4096;
 template <typename T>
 __global__ __launch_bounds__(1024)
 void k_lwa_fast(const T* __restrict__ q, const double* __restrict__ Q, const double* __restrict__ dA, int dA_rank, double dA_max,
-                const double* __restrict__ M, int M_rank, int ny, int64_t nx, int increase, int side, int CG,
+                const double* __restrict__ M, int M_rank, int ny, int64_t nx, int increase, int side, int CG, int64_t nvb,
                 double* __restrict__ out, unsigned* __restrict__ gate, unsigned epoch)
 {
     if (gate && *gate == epoch) return;          // k_lwa_check found a premise broken: the band walk enqueued behind this kernel runs instead (gate NULL: the caller vouches)
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x, nthr = blockDim.x, slab = blockIdx.y;
-    // Column groups that share 128-byte lines (16 float64 columns = 16 / CG groups) go to ONE XCD: workgroups are dealt round-robin
-    // over the eight XCDs (b and b + 8 share one), each XCD has its own L2, and a group touches only CG * 8 bytes of every line of
-    // its rows -- with the plain order the four groups of a line ran on four XCDs and every line of the tracer, the weights and the
-    // output crossed the fabric four times (measured: 0.176 -> 0.148 ms per cfg2-sized slab; two / one columns per workgroup: 0.217 / 0.362).  b = 8 k + xcd  ->  group ((k / GQ) * 8 + xcd) * GQ + k % GQ,
-    // GQ = 16 / CG groups per line; the grid is padded to a multiple of 8 GQ and the surplus workgroups leave at once.
-    const int GQ = 16 / CG;
-    const int64_t bq = blockIdx.x, kq = bq >> 3, xcd = bq & 7;
-    const int64_t grp = ((kq / GQ) * 8 + xcd) * GQ + (kq % GQ);
-    const int64_t x0 = grp * CG;
-    if (x0 >= nx) return;
-    const int ncol = (int)((nx - x0 < CG) ? nx - x0 : CG);
     const int L = ny + 1;
     double* Qs = sm;                         // [ny]  Q' = s Q
     double* D0 = sm + L;                     // [CG][ny + 1]
     double* D1 = D0 + (size_t)CG * L;        // [CG][ny + 1]
+    int* G = (int*)(D1 + (size_t)CG * L);    // [LWA_NB + 1]
+    __shared__ double s_half[16];
     const double s = increase ? 1.0 : -1.0;
     const double* Qg = Q + (size_t)slab * ny;
     for (int j = tid; j < ny; j += nthr) Qs[j] = s * Qg[j];
-    for (int i = tid; i < 2 * CG * L; i += nthr) D0[i] = 0.0;
     __syncthreads();
     const double cref = Qs[ny / 2];
+    const double q0 = Qs[0], qw_ = Qs[ny - 1] - q0;
+    const double bscale = (qw_ > 0.0) ? (double)LWA_NB / qw_ : 0.0;
+    auto bucket = [&](double v) { return (int)fmin(fmax((v - q0) * bscale, 0.0), (double)(LWA_NB - 1)); };      // monotone in v; NaN -> 0
+    for (int j = tid; j <= ny; j += nthr) {                            // Q' is sorted: level j opens the buckets (k_{j-1}, k_j]
+        const int kp = j == 0 ? -1 : bucket(Qs[j - 1]), kj = j < ny ? bucket(Qs[j]) : LWA_NB;
+        for (int k = kp + 1; k <= kj; ++k) G[k] = j;
+    }
     const T* qs = q + (size_t)slab * ny * nx;
+    double* os = out + (size_t)slab * ny * nx;
+    // Column groups that share 128-byte lines (16 float64 columns = 16 / CG groups) go to ONE XCD: workgroups are dealt round-robin
+    // over the eight XCDs (b and b + 8 share one), each XCD has its own L2, and a group touches only CG * 8 bytes of every line of
+    // its rows -- with the plain order the four groups of a line ran on four XCDs and every line of the tracer, the weights and the
+    // output crossed the fabric four times (measured: 0.176 -> 0.148 ms per cfg2-sized slab; two / one columns per workgroup: 0.217 / 0.362).
+    // virtual block vb = 8 k + xcd  ->  group ((k / GQ) * 8 + xcd) * GQ + k % GQ, GQ = 16 / CG groups per line; vb runs over nvb
+    // (a multiple of 8 GQ) in steps of gridDim.x (a multiple of 8: vb keeps its XCD) and the surplus groups are skipped.
+    const int GQ = 16 / CG;
+    auto group_x0 = [&](int64_t vb) { const int64_t kq = vb >> 3, xcd = vb & 7; return (((kq / GQ) * 8 + xcd) * GQ + (kq % GQ)) * CG; };
     // cells: row-major over (y, column of the group); CPT cells per thread and round: all their loads are issued first (a workgroup
-    // of 1024 threads x 8 covers the 7204 cells of four cfg2 columns in ONE round of loads), then the CPT binary searches advance
-    // together, one LDS read each per step
+    // of 1024 threads x 8 covers the 7204 cells of four cfg2 columns in ONE round of loads), then the CPT searches advance together
     constexpr int CPT = 8;
-    const int ncell = ny * ncol;
-    for (int i0 = tid; i0 < ncell; i0 += CPT * nthr) {
-        int yy[CPT], cc[CPT];
-        double qv[CPT], wv[CPT];
-        bool ok[CPT];
-        T qraw[CPT];
-        double da[CPT], mm_[CPT];
+    T qraw[CPT];
+    double da[CPT], mm_[CPT];
+    const double inv_max = 1.0 / dA_max;
+    const bool da_row = dA_rank == XC_DA_ROW, m_row = M_rank == XC_DA_NONE ? da_row : (M_rank == XC_DA_ROW);
+    const double* Mp = M_rank == XC_DA_NONE ? dA : M;
+    // cell i of a group: row i >> cshift, column i & (CG - 1) (CG is 4, 2 or 1: no integer division -- with a runtime `ncol` the four
+    // index computations per cell were ~1300 instructions per thread and group, ~9 of a group's ~28 us); columns >= ncol of a ragged
+    // last group are simply not there
+    const int cshift = CG == 4 ? 2 : (CG == 2 ? 1 : 0), cmask = CG - 1;
+    const int ncell = ny << cshift;
+    // Addresses: a uniform base (the group's first column: scalar registers) + a 32-bit byte offset per cell; a plane-rank weight
+    // shares the tracer's element offset, a row-rank one uses the row.  (Per-cell 64-bit addresses of three arrays, kept alive over the
+    // group loop as loop invariants, cost 71 spilled VGPRs in the first persistent version.)  The launcher admits planes of < 2^29 cells.
+    auto request = [&](int64_t x0, int ncol, int i0) {                 // the loads of one round of one group (clamped: never out of bounds)
+        asm volatile("" : "+v"(i0));                                   // (not a loop invariant: the few index operations per cell are recomputed, not kept in 24 registers)
+        const char* qb = (const char*)(qs + x0);
+        const char* db = (const char*)(da_row ? dA : dA + x0);
+        const char* mb = (const char*)(m_row ? Mp : Mp + x0);
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
             const int i = i0 + u * nthr;
-            ok[u] = i < ncell;
-            const int ii = ok[u] ? i : 0;
-            yy[u] = ii / ncol; cc[u] = ii - yy[u] * ncol;
-            const size_t cell = (size_t)yy[u] * nx + x0 + cc[u];
-            qraw[u] = qs[cell];
-            da[u] = dA_rank == XC_DA_ROW ? dA[yy[u]] : dA[cell];
-            mm_[u] = M_rank == XC_DA_NONE ? 0.0 : (M_rank == XC_DA_ROW ? M[yy[u]] : M[cell]);
+            const unsigned y = (unsigned)((i < ncell ? i : 0) >> cshift), c = (unsigned)((i & cmask) < ncol ? (i & cmask) : 0);
+            const unsigned e = y * (unsigned)nx + c;                       // element offset from the group's first column
+            qraw[u] = *(const T*)(qb + (size_t)(e * (unsigned)sizeof(T)));
+            da[u] = *(const double*)(db + (size_t)((da_row ? y : e) * 8u));    // branch-free: the rank picks the INDEX (three loads per cell, no control flow)
+            mm_[u] = *(const double*)(mb + (size_t)((m_row ? y : e) * 8u));    // (no M: the weight itself, from the same line -- core.py:789 with M = dA)
         }
-        int lo[CPT], hi[CPT];
+    };
+    int64_t vb = blockIdx.x;
+    while (vb < nvb && group_x0(vb) >= nx) vb += gridDim.x;
+    if (vb < nvb) { const int64_t x0 = group_x0(vb); request(x0, (int)((nx - x0 < CG) ? nx - x0 : CG), tid); }
+    while (vb < nvb) {
+        const int64_t x0 = group_x0(vb);
+        const int ncol = (int)((nx - x0 < CG) ? nx - x0 : CG);
+        int64_t vnext = vb + gridDim.x;
+        while (vnext < nvb && group_x0(vnext) >= nx) vnext += gridDim.x;
+        for (int i = tid; i < 2 * CG * L; i += nthr) D0[i] = 0.0;
+        __syncthreads();                                               // (also: Qs, G of the prologue; the stores of the group before)
+        for (int i0 = tid; i0 < ncell; i0 += CPT * nthr) {
+            if (i0 != tid) request(x0, ncol, i0);                      // (planes of more than 2048 rows: further rounds, not prefetched)
+            int lo[CPT], hi[CPT];
+            double qv[CPT], wv[CPT];
+            bool ok[CPT];
 #pragma unroll
-        for (int u = 0; u < CPT; ++u) {
-            qv[u] = s * (double)qraw[u];
-            const double m = M_rank == XC_DA_NONE ? da[u] : mm_[u];
-            wv[u] = (da[u] / dA_max) * m;                                 // (u * wei) * M of core.py:789, weights first
-            // an INFINITE tracer cell is a premise this kernel cannot check ahead of time: +-inf into the difference arrays turns every
-            // row behind the cell into inf - inf = NaN, where the reference's per-row sums stay finite.  Stamp the flag: the gated band
-            // walk enqueued behind this kernel then runs and overwrites the plane (mode 3 has no gate: the caller vouched for finite cells)
-            if (gate && ok[u] && fabs(qv[u]) == __longlong_as_double(0x7ff0000000000000LL)) atomicMax(gate, epoch);
-            ok[u] = ok[u] && (qv[u] == qv[u]) && (wv[u] == wv[u]);        // NaN tracer / weight: the term is NaN and nansum skips it
-            lo[u] = 0; hi[u] = ok[u] ? ny : 0;                            // lower bound: first j with Q'_j >= q'
-        }
-        for (int step = 0; step < 32; ++step) {                           // ceil(log2(ny + 1)) steps at most
-            bool any = false;
+            for (int u = 0; u < CPT; ++u) {
+                const int i = i0 + u * nthr;
+                ok[u] = i < ncell && (i & cmask) < ncol;
+                qv[u] = s * (double)qraw[u];
+                wv[u] = (da[u] * inv_max) * mm_[u];                       // (u * wei) * M of core.py:789, weights first (wei = dA / max: here times the reciprocal -- eight float64 divisions per thread and group were ~7 % of the kernel; this path is not the bit-exact one)
+                // an INFINITE tracer cell is a premise this kernel cannot check ahead of time: +-inf into the difference arrays turns every
+                // row behind the cell into inf - inf = NaN, where the reference's per-row sums stay finite.  Stamp the flag: the gated band
+                // walk enqueued behind this kernel then runs and overwrites the plane (mode 3 has no gate: the caller vouched for finite cells)
+                if (gate && ok[u] && fabs(qv[u]) == __longlong_as_double(0x7ff0000000000000LL)) atomicMax(gate, epoch);
+                ok[u] = ok[u] && (qv[u] == qv[u]) && (wv[u] == wv[u]);    // NaN tracer / weight: the term is NaN and nansum skips it
+                const int k = bucket(qv[u]);
+                lo[u] = ok[u] ? G[k] : 0; hi[u] = ok[u] ? G[k + 1] : 0;   // lower bound: first j with Q'_j >= q'
+            }
+            for (int step = 0; step < 32; ++step) {                       // ceil(log2(ny + 1)) steps at most; ~1 behind the bucket table
+                bool any = false;
 #pragma unroll
-            for (int u = 0; u < CPT; ++u)
-                if (lo[u] < hi[u]) { const int mid = (lo[u] + hi[u]) >> 1; if (Qs[mid] < qv[u]) lo[u] = mid + 1; else hi[u] = mid; any = true; }
-            if (!any) break;
-        }
+                for (int u = 0; u < CPT; ++u)
+                    if (lo[u] < hi[u]) { const int mid = (lo[u] + hi[u]) >> 1; if (Qs[mid] < qv[u]) lo[u] = mid + 1; else hi[u] = mid; any = true; }
+                if (!any) break;
+            }
 #pragma unroll
-        for (int u = 0; u < CPT; ++u) {
-            if (!ok[u]) continue;
-            const int b = lo[u];
-            int a = b;
-            while (a < ny && Qs[a] == qv[u]) ++a;                          // upper bound: ties with a level are rare
-            int p = -1;
-            if (a <= yy[u]) { if (side != 2) p = a; }                      // near-side term of targets [a, y]
-            else if (b >= yy[u] + 2) { if (side != 1) p = b; }             // far-side term of targets [y + 1, b - 1]
-            if (p >= 0) {
-                double* d0 = D0 + (size_t)cc[u] * L;
-                double* d1 = D1 + (size_t)cc[u] * L;
-                const double w = wv[u], qw = (qv[u] - cref) * w;
-                atomicAdd(d0 + p, w);  atomicAdd(d0 + yy[u] + 1, -w);
-                atomicAdd(d1 + p, qw); atomicAdd(d1 + yy[u] + 1, -qw);
+            for (int u = 0; u < CPT; ++u) {
+                if (!ok[u]) continue;
+                const int i = i0 + u * nthr, y = i >> cshift, c = i & cmask;
+                const int b = lo[u];
+                int a = b;
+                while (a < ny && Qs[a] == qv[u]) ++a;                      // upper bound: ties with a level are rare
+                int p = -1;
+                if (a <= y) { if (side != 2) p = a; }                      // near-side term of targets [a, y]
+                else if (b >= y + 2) { if (side != 1) p = b; }             // far-side term of targets [y + 1, b - 1]
+                if (p >= 0) {
+                    double* d0 = D0 + (size_t)c * L;
+                    double* d1 = D1 + (size_t)c * L;
+                    const double w = wv[u], qw = (qv[u] - cref) * w;
+                    atomicAdd(d0 + p, w);  atomicAdd(d0 + y + 1, -w);
+                    atomicAdd(d1 + p, qw); atomicAdd(d1 + y + 1, -qw);
+                }
             }
         }
-    }
-    __syncthreads();
-    // prefix sums over j: one wave per (column, array), in place: every lane sums a contiguous piece of ceil(ny / 64) elements
-    // (independent LDS reads, one dependent add each), ONE wave scan of the 64 piece totals, then the piece is written back with
-    // its offset.  (First version: 64 elements per step, six shuffles deep, 29 dependent steps for ny = 1801: ~10 us of a 35 us
-    // workgroup.)  Then lwa[j] = s ((Q'_j - c) S0_j - S1_j) overwrites D0.
-    {
-        const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
-        const int per = (ny + 63) >> 6;
-        for (int t = wave; t < 2 * ncol; t += nw) {
-            double* d = (t & 1 ? D1 : D0) + (size_t)(t >> 1) * L;
-            const int j0 = lane * per, j1 = (j0 + per < ny) ? j0 + per : ny;
-            double tot = 0.0;
-            for (int j = j0; j < j1; ++j) tot += d[j];
-            double v = tot;                                                // inclusive scan of the piece totals over the lanes
-            for (int o = 1; o < 64; o <<= 1) { const double tt = __shfl_up(v, o); if (lane >= o) v += tt; }
-            double run = v - tot;                                          // sum of the pieces before this lane's
-            for (int j = j0; j < j1; ++j) { run += d[j]; d[j] = run; }
+        // the next group's first round of loads is requested HERE: its latency runs under this group's prefix sums and stores (while the
+        // searches run the registers are needed: requested before them, 60 VGPRs spilled and the kernel was slower than without)
+        __builtin_amdgcn_sched_barrier(0);                             // (the scheduler must not lift these loads above the searches)
+        if (vnext < nvb) { const int64_t xn = group_x0(vnext); request(xn, (int)((nx - xn < CG) ? nx - xn : CG), tid); }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // prefix sums over j, in place: an array is cut into 64 * split contiguous pieces, every lane sums its piece (independent LDS
+        // reads, one dependent add each), ONE wave scan of the piece totals (the second wave of an array adds the first one's
+        // total), then the piece is written back with its offset.  Then lwa[j] = s ((Q'_j - c) S0_j - S1_j) overwrites D0.
+        {
+            const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+            const int split = (4 * ncol <= nw) ? 2 : 1;
+            const int per = (ny + 64 * split - 1) / (64 * split);
+            for (int t0 = 0; t0 < 2 * ncol * split; t0 += nw) {
+                const int task = t0 + wave;
+                const bool on = task < 2 * ncol * split;
+                const int arr = on ? task / split : 0, h = task % split;
+                double* d = (arr & 1 ? D1 : D0) + (size_t)(arr >> 1) * L;
+                int j0 = (h * 64 + lane) * per, j1 = j0 + per;
+                if (j1 > ny) j1 = ny;
+                if (!on) j1 = j0;
+                double tot = 0.0;
+                for (int j = j0; j < j1; ++j) tot += d[j];
+                double v = tot;                                            // inclusive scan of the piece totals over the lanes
+                for (int o = 1; o < 64; o <<= 1) { const double tt = __shfl_up(v, o); if (lane >= o) v += tt; }
+                double base = 0.0;
+                if (split == 2) {                                          // (uniform over the workgroup: ncol is)
+                    if (on && h == 0 && lane == 63) s_half[arr] = v;
+                    __syncthreads();
+                    if (on && h == 1) base = s_half[arr];
+                    __syncthreads();
+                }
+                double run = base + (v - tot);                             // sum of the pieces before this lane's
+                for (int j = j0; j < j1; ++j) { run += d[j]; d[j] = run; }
+            }
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < ncell; i += nthr) {
-        const int y = i / ncol, c = i - y * ncol;
-        D0[(size_t)c * L + y] = s * ((Qs[y] - cref) * D0[(size_t)c * L + y] - D1[(size_t)c * L + y]);
-    }
-    __syncthreads();
-    double* os = out + (size_t)slab * ny * nx;
-    for (int i = tid; i < ncell; i += nthr) {
-        const int y = i / ncol, c = i - y * ncol;
-        os[(size_t)y * nx + x0 + c] = D0[(size_t)c * L + y];
+        __syncthreads();
+        // lwa and its store in one sweep (a thread reads only the two sums of its own cell: nothing to wait for in between)
+#pragma unroll 2
+        for (int i = tid; i < ncell; i += nthr) {
+            const int y = i >> cshift, c = i & cmask;
+            if (c < ncol) os[(size_t)y * nx + x0 + c] = s * ((Qs[y] - cref) * D0[(size_t)c * L + y] - D1[(size_t)c * L + y]);
+        }
+        __syncthreads();                                               // D0 is cleared at the top of the next group
+        vb = vnext;
     }
 }
 
@@ -580,10 +639,10 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
     // vouched for by the caller (it looked at Q and the coordinate on the host): ONE launch, no check, no gated band walk behind it
     const int mode = ctx->lwa_exact;
     const bool want_fast = mode >= 2 || (mode == 0 && ctx->knobs.lwa_fast && (ny > kLwaFastMinRows || ctx->knobs.lwa_fast > 1));
-    if (variant == 0 && want_fast && nx <= 0x7fffffff) {
+    if (variant == 0 && want_fast && ny * nx < ((int64_t)1 << 29)) {           // (32-bit byte offsets inside a plane: k_lwa_fast)
         int CG = 0;
         for (int c : {4, 2, 1})
-            if (!CG && (size_t)(1 + 2 * c) * (ny + 1) * 8 <= kLdsBudget) CG = c;
+            if (!CG && (size_t)(1 + 2 * c) * (ny + 1) * 8 + (size_t)(LWA_NB + 1) * 4 <= kLdsBudget) CG = c;
         if (CG) {
             unsigned* flag = nullptr;
             if (mode != 3) {
@@ -593,15 +652,20 @@ int launch_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const d
                 hipLaunchKernelGGL(k_lwa_check, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, Q, coord, (int)ny, increase, flag, epoch);
                 XC_HIP(ctx, hipGetLastError());
             }
-            const size_t lds = (size_t)(1 + 2 * CG) * (ny + 1) * 8;
+            const size_t lds = (size_t)(1 + 2 * CG) * (ny + 1) * 8 + (size_t)(LWA_NB + 1) * 4;
             // part (core.py:773-784): 'upper' keeps mask3 > 0 (the near side) if increase else mask3 < 0 (the far side)
             const int side = part == 0 ? 0 : (((part == 1) == (increase != 0)) ? 1 : 2);
             const int64_t ngrp = (nx + CG - 1) / CG, gq = 8 * (16 / CG);                 // (XCD-aware group order: k_lwa_fast)
-            const dim3 grid((unsigned)(((ngrp + gq - 1) / gq) * gq), (unsigned)nslab);
+            const int64_t nvb = ((ngrp + gq - 1) / gq) * gq;                                // virtual blocks: the groups, padded to whole lines per XCD
+            // persistent: one workgroup per CU and slab at most (the LDS holds one), a multiple of 8 so that a workgroup keeps its XCD; a stack
+            // of slabs fills the chip with its first slabs and the rest queue behind them
+            int64_t pw = ((ctx->cus > 0 ? ctx->cus : 256) / 8) * 8;
+            if (pw < 8) pw = 8;
+            const dim3 grid((unsigned)(nvb < pw ? nvb : pw), (unsigned)nslab);
 #define XC_LWAF(T) do { \
                 const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(k_lwa_fast<T>), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; \
                 hipLaunchKernelGGL((k_lwa_fast<T>), grid, dim3(1024), lds, ctx->stream, (const T*)q, Q, dA, dA_rank, dA_max, \
-                                   M, M_rank, (int)ny, nx, increase, side, CG, out_lwa, flag, epoch); } while (0)
+                                   M, M_rank, (int)ny, nx, increase, side, CG, nvb, out_lwa, flag, epoch); } while (0)
             if (q_dtype == XC_F64) XC_LWAF(double); else XC_LWAF(float);
 #undef XC_LWAF
             XC_HIP(ctx, hipGetLastError());
