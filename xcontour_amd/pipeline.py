@@ -286,7 +286,8 @@ class KeffPlan(object):
         return out
 
     def fetch(self, check=True, slot=0):
-        self.ctx.sync()
+        # (xc_memcpy_d2h enqueues the copy on the compute stream behind the kernels and waits for it: ONE host wait per fetch;
+        # a ctx.sync() in front of it was a second one, ~20 us per call at the reference's demo sizes)
         raw = np.empty(self.slot_bytes, dtype=np.uint8)
         self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, raw.ctypes.data,
                                                    self.out_ptr + slot * self.slot_bytes, self.slot_bytes))
