@@ -186,3 +186,25 @@ def test_crossing_uncrossed_interior_levels_are_exact_zeros(ctx):
     for s in range(2):
         ol, oc = O.contour_crossing(q[s], ctr, area, 1, True)
         assert np.array_equal(cnts[s].astype(np.int64), oc) and rel(lens[s], ol) < 1e-13
+
+
+@pytest.mark.parametrize('ny,nx,dt,da_row', [(2100, 23, np.float64, False), (4500, 9, np.float32, True), (530, 3, np.float64, False)])
+def test_lwa_interval_kernel_tall_planes_and_odd_reference_states(ctx, ny, nx, dt, da_row):
+    """k_lwa_fast (round 5: persistent over column groups, a bucket table in front of the bracket search): planes so tall that a
+    workgroup holds TWO columns (2100 rows) or ONE (4500) instead of four, a plane narrower than one group (3 columns), a
+    row-rank weight, a stack of two slabs (one reference state each) -- and reference states that stress the table: levels crowded
+    into the last bucket, one constant level (no bucket width: the full binary search), a range of 1e150."""
+    rng = np.random.default_rng(ny)
+    lat, q, Q, dA = _lwa_case(rng, ny, nx, dt, True, True, True)
+    dAu = dA[:, 0].copy() if da_row else dA
+    Qc = Q.copy(); Qc[ny // 2:] = Q[ny // 2] + (Q[-1] - Q[ny // 2]) * (1 - 1e-9 * (ny - 1 - np.arange(ny // 2, ny)))     # half of the levels within 1e-6 of the maximum
+    cases = [Q, np.sort(Qc), np.full(ny, float(np.nanmean(q))), Q * 1e150 / np.abs(Q).max()]
+    for k, Qx in enumerate(cases):
+        qx = q if k < 3 else (q.astype(np.float64) * 1e150 / np.abs(Q).max()).astype(np.float64)
+        qs = np.stack([qx, qx[:, ::-1] * 0.5]); Qs = np.stack([Qx, Qx * 0.5])
+        got, _ = ctx.lwa(qs, Qs, lat, dAu, float(dAu.max()), exact=False)
+        assert ctx.last_lwa_path() == 1, k
+        for s in range(2):
+            ref = O.cal_local_wave_activity(qs[s], Qs[s], lat, dA if not da_row else dAu[:, None] * np.ones((1, nx)), True, 'all')
+            scale = np.abs(ref).max()
+            assert np.isfinite(scale) and np.abs(got[s] - ref).max() <= 1e-11 * max(scale, 1e-300), (k, s)
