@@ -654,3 +654,37 @@ def test_contours_in_one_call_equals_minmax_then_levels(ctx, baro):
                 assert np.array_equal(bits(ctr), bits(ref)) and np.array_equal(bits(mm2), bits(mm))
                 for s_ in range(3):
                     assert np.array_equal(ctr[s_], O.cal_contours(q[s_], 61, inc, cd).astype(np.float64))
+
+
+@pytest.mark.parametrize('dt,counts', [(np.float64, True), (np.float32, True), (np.float64, False)])
+def test_one_slab_alone_equals_the_same_slab_in_a_stack(ctx, dt, counts):
+    """a launch of ONE slab spreads it over ~256 blocks: they add their sums into the slab's accumulators (cleared by the K1 launch;
+    no k_reduce_partials: three dependent launches instead of four), a stack of 8 keeps per-block partials -- levels and counts
+    are identical, the sums agree to 1e-13, all nine vectors against the oracle; run twice (the accumulators must be cleared again)"""
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
+    ny, nx, N, S = 721, 1440, 201, 8
+    lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 0.25
+    dA = cell_area(lat, lon)
+    tbl = table_from_rowsums(ctx.rowsum(None, dA, ny, nx), True, last_row_included(lat))
+    kw = dict(dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=True, lt=True, counts=counts)
+    stack = KeffPlan(ctx, S, ny, nx, N, dt, dt, **kw)
+    stack.synth(lat, lon, 777, 0)
+    stack.run()
+    ref = stack.fetch()
+    q = stack.download_q()
+    one = KeffPlan(ctx, 1, ny, nx, N, dt, dt, **kw)
+    for s in (0, 5):
+        one.q_buf.upload(q[s])
+        for _ in range(2):
+            one.run()
+            got = one.fetch()
+            assert np.array_equal(got['ctr'][0], ref['ctr'][s])
+            if counts:
+                assert np.array_equal(got['counts'][0], ref['counts'][s])
+            assert rel(got['area'][0], ref['area'][s]) < 1e-13 and rel(got['intgrdS'][0], ref['intgrdS'][s]) < 1e-13
+        r = O.keff_pipeline(q[s], dA, lat, N, lon=lon, increase=True, lt=True, dtype=dt)
+        if not counts:
+            got['counts'] = r['counts'][None]                  # (not produced: nothing to compare)
+        check_nine(got, 0, r)
+    one.free(); stack.free()

@@ -1150,13 +1150,18 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     double* part_h = (double*)((char*)ctx->scratch + mb);
     unsigned* part_c = (unsigned*)((char*)ctx->scratch + mb + ph);
     int mmP = minmax_blocks(d->ny * d->nx, d->nslab);
+    bool accum = false;
 
     // min/max partials: either produced by the previous call's histogram pass (q_next) or by K1 now
     if (ctx->mm_valid && ctx->mm_q == d->q && ctx->mm_nslab == d->nslab && ctx->mm_ny == d->ny &&
         ctx->mm_nx == d->nx && ctx->mm_dtype == d->q_dtype && ctx->mm_gen == d->q_gen) {
         mmpart = ctx->mmnext[ctx->mm_cur]; mmP = ctx->mm_P;
     } else {
-        XC_TRY(launch_minmax_partial(ctx, d->q, d->q_dtype, d->nslab, d->ny * d->nx, mmpart));
+        // FEW slabs (more than 64 blocks per slab: a single cfg2 slab has ~200): the blocks add into per-slab accumulators, cleared by
+        // this K1 launch, and the finalize kernel reads them directly -- three dependent launches instead of four
+        accum = !det && g.bps > 64;
+        XC_TRY(launch_minmax_partial(ctx, d->q, d->q_dtype, d->nslab, d->ny * d->nx, mmpart,
+                                     accum ? (double*)((char*)ctx->scratch + mb + ph + pc) : nullptr, accum ? (int64_t)((rh + rc) / 8) : 0));
     }
     ctx->mm_valid = 0;
     double* mm_next = nullptr;
@@ -1184,6 +1189,7 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     FinalArgs f; memset(&f, 0, sizeof(f));
     f.part_h = part_h; f.part_c = part_c; f.bps = g.bps; f.nch = nch; f.nbin = N;
     f.red_h = (double*)((char*)ctx->scratch + mb + ph + pc); f.red_c = (unsigned long long*)((char*)ctx->scratch + mb + ph + pc + rh);
+    if (accum) { a.acc_h = f.red_h; a.acc_c = d->counts ? f.red_c : nullptr; f.skip_reduce = 1; }
     XC_TRY(hist_ev_begin(ctx));
     if (det) {
         char* xb = (char*)ctx->scratch + mb + ph + pc + rh + rc;

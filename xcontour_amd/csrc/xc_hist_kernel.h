@@ -579,6 +579,10 @@ void k_hist(const HistArgs a)
         return;
     }
     double* ph = a.part_h + pb * NCH * N;
+    // few slabs in the launch (a.acc_h): hundreds of blocks share a slab, and summing their partials is a launch of its own in a chain
+    // of four dependent ones -- the block adds what it has to the slab's accumulators instead (global float64 atomics, ~1 us for the
+    // ~200 k adds of a cfg2 slab; a block meets a fraction of the bins, zeros are not sent)
+    double* ah = a.acc_h ? a.acc_h + (size_t)slab * NCH * N : nullptr;
     // sum the lane-privatised copies; every thread starts at a rotated copy index so that the
     // 64 lanes of a wave hit distinct LDS banks (a fixed, thread-determined order)
     for (int i = tid; i < NCH * N; i += blockDim.x) {
@@ -586,7 +590,8 @@ void k_hist(const HistArgs a)
         const double* src = s_cell + (size_t)b * ncopy * CW + ch;
         double sum = 0.0;
         for (int c = 0; c < ncopy; ++c) sum += src[(size_t)((c + tid) & (ncopy - 1)) * CW];
-        ph[i] = sum;
+        if (ah) { if (sum != 0.0) atomicAdd(ah + i, sum); }
+        else ph[i] = sum;
     }
     unsigned* pc = a.part_c + pb * N;
     if (a.part_c)
@@ -594,7 +599,8 @@ void k_hist(const HistArgs a)
         unsigned sum = 0u;
         for (int c = 0; c < ncopy; ++c)
             sum += *reinterpret_cast<const unsigned*>(s_cell + (size_t)(b * ncopy + ((c + tid) & (ncopy - 1))) * CW + NCH);
-        pc[b] = sum;
+        if (ah) { if (sum && a.acc_c) atomicAdd(a.acc_c + (size_t)slab * N + b, (unsigned long long)sum); }
+        else pc[b] = sum;
     }
 }
 

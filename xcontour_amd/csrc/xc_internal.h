@@ -157,6 +157,8 @@ struct HistArgs {
     int           nchunk;       // > 0: wave -> (row chunk, strip) with the strip fastest (see k_hist); 0: even split of the strip-major pairs
     double*       part_h;       // [nslab][bps][nch][nbin]
     unsigned*     part_c;       // [nslab][bps][nbin]
+    double*       acc_h;        // non-null: a launch of FEW slabs (hundreds of blocks per slab): the block ADDS its sums to [nslab][nch][nbin] here (zeroed
+    unsigned long long* acc_c;  //           by the caller; global float64 / 64-bit atomics) instead of storing a partial, and k_reduce_partials is not launched
     double*       ctr_out;      // levels of slab s at ctr_out + s * ctr_stride (levels mode, may be null)
     int           ctr_stride;   // doubles between consecutive slabs in ctr_out (nbin: dense)
     double*       edges_out;    // [nslab][nbin+1] (levels mode, may be null)
@@ -195,7 +197,8 @@ struct FinalArgs {
 };
 
 // ---------------------------------------------------------------- launchers (defined in the .hip files)
-int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part);
+int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part,
+                          double* zero = nullptr, int64_t nzero = 0);      // zero: `nzero` 8-byte words cleared by the same launch (the accumulators of HistArgs::acc_h)
 int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, int P, double* out);
 int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
                   int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status);

@@ -44,11 +44,15 @@ __device__ __forceinline__ void mmv(double& mn, double& mx, const float4& v)
 // evicted anyway).  Without it -- a launch of a few slabs -- the tracer stays in the Infinity Cache for the histogram pass that follows.
 template <typename T, bool NT>
 __global__ __launch_bounds__(256)
-void k_minmax_partial(const T* __restrict__ q, int64_t ncell, double* __restrict__ part)
+void k_minmax_partial(const T* __restrict__ q, int64_t ncell, double* __restrict__ part, double* __restrict__ zero, int64_t nzero)
 {
     using V = typename V16<T>::type;
     constexpr int VN = V16<T>::n;
     const int P = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
+    // (round 5) a few words some LATER kernel of the chain wants cleared (the accumulators a few-slab histogram pass adds into): done
+    // here, by the first threads of the grid, instead of by a memset launch of its own between two dependent kernels
+    if (zero)
+        for (int64_t w = ((int64_t)blockIdx.y * P + b) * 256 + tid; w < nzero; w += (int64_t)gridDim.y * P * 256) zero[w] = 0.0;
     const T* qs = q + (size_t)blockIdx.y * ncell;
     double mn = dinf(), mx = -dinf();
 
@@ -516,18 +520,18 @@ void k_synth(T* __restrict__ out, int64_t ny, int64_t nx, const double* __restri
 }  // namespace
 
 // ------------------------------------------------------------------------------------ launchers
-int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part)
+int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part, double* zero, int64_t nzero)
 {
     if (!q || !part || nslab < 1 || ncell < 1) return fail(ctx, XC_EBADARG, "xc_minmax: bad arguments");
     if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_minmax: at most 65535 slabs per launch");
     dim3 grid((unsigned)minmax_blocks(ncell, nslab), (unsigned)nslab);      // partials: [nslab][minmax_blocks(ncell, nslab)][2]
     const bool nt = (double)nslab * (double)ncell * (q_dtype == XC_F64 ? 8.0 : 4.0) > 128.0 * 1048576.0 || ctx->knobs.k1_nt > 0;
     if (q_dtype == XC_F64) {
-        if (nt) hipLaunchKernelGGL((k_minmax_partial<double, true>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part);
-        else hipLaunchKernelGGL((k_minmax_partial<double, false>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part);
+        if (nt) hipLaunchKernelGGL((k_minmax_partial<double, true>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part, zero, nzero);
+        else hipLaunchKernelGGL((k_minmax_partial<double, false>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part, zero, nzero);
     } else if (q_dtype == XC_F32) {
-        if (nt) hipLaunchKernelGGL((k_minmax_partial<float, true>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part);
-        else hipLaunchKernelGGL((k_minmax_partial<float, false>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part);
+        if (nt) hipLaunchKernelGGL((k_minmax_partial<float, true>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part, zero, nzero);
+        else hipLaunchKernelGGL((k_minmax_partial<float, false>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part, zero, nzero);
     }
     else return fail(ctx, XC_EBADARG, "xc_minmax: q_dtype must be XC_F32 or XC_F64");
     XC_HIP(ctx, hipGetLastError());
