@@ -1191,7 +1191,7 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
         alg = NY * NX * BYTES_PER_CELL
         return {'us': float(np.median(warm)), 'us_cold': float(np.median(cold)), 'us_min': float(warm.min()), 'reps': reps,
                 'frac': alg / (np.median(warm) * 1e-6) / 1e9 / HBM_PEAK_GBS, 'frac_cold': alg / (np.median(cold) * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                'launches': 'k_minmax_partial, k_hist, k_reduce_partials, k_finalize', 'self_check': ok,
+                'launches': 'k_minmax_partial (also clears the accumulators), k_hist (blocks add into them), k_finalize', 'self_check': ok,
                 'note': 'one 3600x1801 f64 slab per call, a stream sync before every call (HIP events around the call); warm = back to back '
                         '(Infinity-Cache resident), cold = a 600 MB memset between calls; 16 B/cell numerator as the headline'}
     except nat.XContourHipError as e:
