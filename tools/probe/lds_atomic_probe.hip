@@ -63,6 +63,23 @@ int main()
     unsigned* sink; CK(hipMalloc(&sink, 4096 * 4));
     hipStream_t st; CK(hipStreamCreate(&st));
     const int cus = p.multiProcessorCount;
+    // several workgroups per CU (the radix histogram has eight 256-thread workgroups per CU): 4 x 256 threads against 1 x 1024
+    {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int bpc : {1, 2, 4}) for (int n : {4096, 16}) {
+            const int reps = n == 16 ? 200 : 5, blocks = cus * bpc * (n == 16 ? 8 : 1);      // n = 16: many short workgroups, like one tile each
+            hipLaunchKernelGGL((k_probe<0, 2>), dim3(blocks), dim3(256), 0, st, n, sink);
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_probe<0, 2>), dim3(blocks), dim3(256), 0, st, n, sink);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / reps, instr = (double)n * 4 * blocks / cus;
+            printf("{\"op\": \"ds_add_u32 random, 256-thread workgroups\", \"workgroups_per_cu_resident\": %d, \"adds_per_wave\": %d, \"workgroups\": %d, \"us\": %.1f, \"ns_per_wave_instr_per_cu\": %.2f}\n",
+                   bpc, n, blocks, us, us * 1e3 / instr);
+        }
+    }
     for (int threads : {256, 1024}) {
         if (run<0, 0>("ds_add_u32 lane-private", threads, st, sink, cus)) return 1;
         if (run<0, 2>("ds_add_u32 random over 256 words", threads, st, sink, cus)) return 1;
