@@ -186,8 +186,9 @@ int xc_hist(xc_ctx* ctx, const xc_hist_desc* d);
 
 /* Deterministic sums (`deterministic != 0` in xc_hist_desc / xc_keff_desc).  The reference's per-bin sums come out of
  * np.bincount inside xhistogram (core.py:1284, 1307): the same input gives the same bits.  The default histogram pass
- * adds float64 weights with LDS atomics, so the last bits of pdf / cdf (area, intgrdS) depend on the order in which
- * waves reach the LDS and differ from run to run (~1e-13 relative).  With `deterministic` every (bin, channel) owns a
+ * adds float64 weights with LDS atomics (and, in xc_keff_dev launches of FEW slabs -- more than 64 blocks per slab -- the
+ * blocks' sums with global float64 atomics into per-slab accumulators), so the last bits of pdf / cdf (area, intgrdS) depend
+ * on the order of arrival and differ from run to run (~1e-13 relative).  With `deterministic` every (bin, channel) owns a
  * fixed-point SUPERACCUMULATOR instead: four 48-bit limbs on a fixed grid below a window top that follows from bounds known
  * before the pass (max |dA|; for the in-kernel squared gradient 2 ((max - min) max(rdx, rdy))^2 max |dA| from K1's extrema; for a
  * supplied integrand max |integrand| max |dA|, from one extra min / max pass over it).  A weight is cut once to its leading 49
