@@ -427,9 +427,15 @@ void k_hist(const HistArgs a)
         // wave-uniform fast path: every valid cell of the row in one bin -> per-lane registers, no LDS traffic.  A field with
         // grid-scale noise never takes it, and the test itself (readfirstlane, compares, ballot) is a tenth of the row: after 8
         // consecutive failures the wave stops testing for 48 rows, then looks again (smooth fields never stop)
+        // (round 5) ... and only in the chained (NEXT) kernels at all.  Ablation builds (profiles/r05_notes.md): no variant waits for its LDS adds
+        // (removing every one of them changes nothing), so the register path saves nothing that matters, and carrying the test costs the
+        // unchained float64 kernel 6 % on smooth and noisy fields alike (0.784 -> 0.734 / 0.797 -> 0.750 ms per 64 slabs); rows of land cells
+        // piling onto the trash bin cost nothing measurable either (30 % land, unchained: 24.9 with the test, 24.1 us per slab without).  The
+        // chained kernel keeps it: there it measured 1.4 % FASTER with the test (1.147 against 1.163 ms).
+        constexpr bool ROWTEST = NEXT;
         bool one_bin = false, all_dropped = false;
         int rb = 0;
-        if (DET == 0 && fp_skip == 0) {                  // (the order-free variants always go through the LDS)
+        if (ROWTEST && DET == 0 && fp_skip == 0) {       // (the order-free variants always go through the LDS)
             rb = __builtin_amdgcn_readfirstlane((int)k[0]);
             bool match = true;
 #pragma unroll
