@@ -1164,41 +1164,54 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
     synchronisation before every call; `warm`: back to back (slab and weights stay in the 256 MiB Infinity Cache), `cold`: a 600 MB
     memset between calls.  frac = 16 B x cells / time / 8 TB/s, the same numerator as the headline."""
     from xcontour_amd.pipeline import KeffPlan
-    p = big = None
+    p = pc = big = None
     try:
-        p = KeffPlan(ctx, 1, NY, NX, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
-                     increase=True, lt=True, right_edge='xhistogram', deterministic=a.deterministic)
+        kw = dict(dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, increase=True, lt=True, right_edge='xhistogram', deterministic=a.deterministic)
+        p = KeffPlan(ctx, 1, NY, NX, NCONT, np.float64, np.float64, **kw)
         p.synth(lat, lon, SEED + 7, a.variant if a.variant != 3 else 0)
+        pc = KeffPlan(ctx, 1, NY, NX, NCONT, np.float64, np.float64, alloc_q=False, single_read=False, **kw)   # the same slab through the chain
+        pc.set_q_device(p._q_ptr)
         big = ctx.alloc(600 << 20)
         e0, e1 = ctx.event(), ctx.event()
 
-        def timed(evict):
+        def timed(plan, evict):
             ts = []
             for r in range(reps + 3):
                 if evict:
                     ctx._check(ctx.lib.xc_memset(ctx.handle, big.ptr, r & 255, big.nbytes))
                 ctx.sync()
-                ctx.record(e0); p.run(); ctx.record(e1)
+                ctx.record(e0); plan.run(); ctx.record(e1)
                 ms = ctx.elapsed_ms(e0, e1)
                 if r >= 3:
                     ts.append(ms * 1e3)
             return np.array(ts)
-        cold, warm = timed(True), timed(False)
+        cold, warm = timed(p, True), timed(p, False)
+        path = ctx.last_keff_path()
         out = p.fetch()
-        ok = bool((out['counts'].sum(axis=1) == NY * NX).all() and not out['status'].any())
+        ok = bool((out['counts'].sum(axis=1) == NY * NX).all() and not out['status'].any() and p.replays == 0)
+        ccold, cwarm = timed(pc, True), timed(pc, False)
+        outc = pc.fetch()
+        ok = ok and bool(np.array_equal(out['counts'], outc['counts']) and np.array_equal(out['ctr'], outc['ctr']) and
+                         np.allclose(out['area'], outc['area'], rtol=1e-12, atol=0) and np.allclose(out['intgrdS'], outc['intgrdS'], rtol=1e-12, atol=0))
         for e in (e0, e1):
             ctx.lib.xc_event_destroy(ctx.handle, e)
         alg = NY * NX * BYTES_PER_CELL
         return {'us': float(np.median(warm)), 'us_cold': float(np.median(cold)), 'us_min': float(warm.min()), 'reps': reps,
                 'frac': alg / (np.median(warm) * 1e-6) / 1e9 / HBM_PEAK_GBS, 'frac_cold': alg / (np.median(cold) * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                'launches': 'k_minmax_partial (also clears the accumulators), k_hist (blocks add into them), k_finalize', 'self_check': ok,
+                'path': 'single-read kernel (one launch: min/max -> levels -> histogram -> epilogue, the slab held in registers)' if path == 1
+                        else 'chain: k_minmax_partial (also clears the accumulators), k_hist (blocks add into them), k_finalize',
+                'chain': {'us': float(np.median(cwarm)), 'us_cold': float(np.median(ccold)),
+                          'launches': 'k_minmax_partial, k_hist, k_finalize (xc_keff_desc.single_read = XC_SINGLE_NEVER)'},
+                'self_check': ok,
                 'note': 'one 3600x1801 f64 slab per call, a stream sync before every call (HIP events around the call); warm = back to back '
-                        '(Infinity-Cache resident), cold = a 600 MB memset between calls; 16 B/cell numerator as the headline'}
+                        '(Infinity-Cache resident), cold = a 600 MB memset between calls; 16 B/cell numerator as the headline; `chain`: the same '
+                        'slab through the three-launch path this kernel replaces, results compared'}
     except nat.XContourHipError as e:
         return {'skipped': str(e)}
     finally:
-        if p is not None:
-            p.free()
+        for x in (pc, p):
+            if x is not None:
+                x.free()
         if big is not None:
             big.free()
 

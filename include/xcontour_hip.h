@@ -347,7 +347,8 @@ typedef struct xc_keff_desc {
     double*       dqdA;         double* dintSdA; double* Leq2;   double* Lmin;  double* nkeff;
     uint64_t*     counts;       /* uint64[nslab][N]; NULL: not wanted -- the histogram pass then skips the count adds (a third of its LDS atomics) */
     double*       interp;       /* double[nslab][9][npre]: ctr, area, intgrdS, latEq, dintSdA, dqdA, Leq2, Lmin, nkeff on preY */
-    int32_t*      status;       /* int32[nslab] 0 ok, 1 degenerate levels ('non monotonic bins', core.py:1233) */
+    int32_t*      status;       /* int32[nslab] 0 ok, 1 degenerate levels ('non monotonic bins', core.py:1233), 2 the single-read kernel gave up
+                                   waiting for its workgroups (see single_read): nothing was computed for the slab */
     const void*   q_next;       /* optional: the batch the NEXT xc_keff_dev call will process (same dtype and
                                    shape, may equal q).  Its per-slab min/max partials are accumulated inside this
                                    call's histogram pass (+8 B/cell of loads, no extra kernel) and the next call on
@@ -365,8 +366,24 @@ typedef struct xc_keff_desc {
                                    with no repacking pass.  counts / interp / status keep their dense layout. */
     double        dA_max;       /* deterministic sums only: the largest finite |dA| value, if the caller knows it (a static metric: computed once
                                    on the host); <= 0 or NaN: the library takes it from the device array with one extra min / max pass over dA per call */
+    int32_t       single_read;  /* calls of ONE or TWO slabs (the reference's own pattern: one (time, level) plane per call, tests/LWA.py:40-43;
+                                   core.py:224-225 then 1307 per object): XC_SINGLE_AUTO (0) takes the single-read kernel -- min / max, levels,
+                                   histogram and epilogue in ONE launch with the slab held in registers between them, the tracer read once --
+                                   when grad = 1, the sums are not `deterministic` and the slab fits the chip's register tiles (3600 x 1801 does);
+                                   XC_SINGLE_NEVER (1) keeps the min/max pass + histogram pass + finalize chain.  That kernel waits for ALL its
+                                   workgroups to be resident at once; every wait is bounded (XC_KEFF_SINGLE_TIMEOUT_US, default 50 ms): when
+                                   something else holds compute units for longer, status[slab] = 2 comes back, NOTHING is written to the
+                                   slab's result vectors, and the caller repeats the call with XC_SINGLE_NEVER (pipeline.KeffPlan.fetch does). */
+    int32_t       reserved0;
 } xc_keff_desc;
+#define XC_SINGLE_AUTO  0
+#define XC_SINGLE_NEVER 1
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
+/* which path the last xc_keff_dev call took: 0 the min/max + histogram + finalize chain (two reads of the tracer), 1 the single-read kernel */
+int xc_last_keff_path(xc_ctx* ctx, int* out_path);
+/* diagnostics of the single-read kernel: wall-clock stamps (100 MHz) of every workgroup at its phase boundaries, [2][CUs][slots] uint64 on
+ * the device (enable = 0 frees them) */
+int xc_dbg_single_stamps(xc_ctx* ctx, int enable, void** out_dev, int* out_slots);
 
 /* K5 / K6 alone -- the Keff epilogue without the cell-touching passes (SURVEY 8b `xc_keff_epilogue`): from the per-bin sums of
  * dA and |grad q|^2 dA (the PDFs xc_hist returns, ascending-VALUE bin order, bin 0 = the dummy bin) to the nine Keff vectors.

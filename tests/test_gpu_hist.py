@@ -656,10 +656,12 @@ def test_contours_in_one_call_equals_minmax_then_levels(ctx, baro):
                     assert np.array_equal(ctr[s_], O.cal_contours(q[s_], 61, inc, cd).astype(np.float64))
 
 
+@pytest.mark.parametrize('single', [True, False])
 @pytest.mark.parametrize('dt,counts', [(np.float64, True), (np.float32, True), (np.float64, False)])
-def test_one_slab_alone_equals_the_same_slab_in_a_stack(ctx, dt, counts):
-    """a launch of ONE slab spreads it over ~256 blocks: they add their sums into the slab's accumulators (cleared by the K1 launch;
-    no k_reduce_partials: three dependent launches instead of four), a stack of 8 keeps per-block partials -- levels and counts
+def test_one_slab_alone_equals_the_same_slab_in_a_stack(ctx, dt, counts, single):
+    """a launch of ONE slab against the same slab in a stack of 8 (per-block partials), on BOTH one-slab paths: `single` -- the
+    single-read kernel (xc_keff1.hip: min/max, levels, histogram, epilogue in ONE launch, the slab held in registers), else the chain
+    K1 -> K3 -> finalize, where ~256 blocks add their sums into the slab's accumulators (cleared by the K1 launch).  Levels and counts
     are identical, the sums agree to 1e-13, all nine vectors against the oracle; run twice (the accumulators must be cleared again)"""
     from xcontour_amd.pipeline import KeffPlan
     from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
@@ -673,12 +675,14 @@ def test_one_slab_alone_equals_the_same_slab_in_a_stack(ctx, dt, counts):
     stack.run()
     ref = stack.fetch()
     q = stack.download_q()
-    one = KeffPlan(ctx, 1, ny, nx, N, dt, dt, **kw)
+    one = KeffPlan(ctx, 1, ny, nx, N, dt, dt, single_read=single, **kw)
     for s in (0, 5):
         one.q_buf.upload(q[s])
         for _ in range(2):
             one.run()
+            assert ctx.last_keff_path() == (1 if single else 0)
             got = one.fetch()
+            assert one.replays == 0
             assert np.array_equal(got['ctr'][0], ref['ctr'][s])
             if counts:
                 assert np.array_equal(got['counts'][0], ref['counts'][s])

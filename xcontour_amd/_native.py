@@ -19,6 +19,7 @@ XC_OK, XC_EBADARG, XC_EEDGES, XC_EHIP, XC_ENOMEM, XC_ENODEV = 0, -1, -2, -3, -4,
 XC_F32, XC_F64 = 0, 1
 XC_DA_NONE, XC_DA_ROW, XC_DA_PLANE, XC_DA_SLAB = 0, 1, 2, 3
 XC_EDGE_NUMPY, XC_EDGE_XHISTOGRAM = 0, 1
+XC_SINGLE_AUTO, XC_SINGLE_NEVER = 0, 1
 XC_MAX_INTEGRANDS = 2
 MAX_SLABS_PER_LAUNCH = 65535
 XC_PAD_EDGE, XC_PAD_WRAP, XC_PAD_NAN, XC_PAD_REFLECT, XC_PAD_SYMMETRIC = 0, 1, 2, 3, 4
@@ -63,6 +64,7 @@ class KeffDesc(C.Structure):
         ('dA_pos_finite', _i32), ('q_gen', _i32),
         ('deterministic', _i32), ('out_stride', _i32),
         ('dA_max', _f64),
+        ('single_read', _i32), ('reserved0', _i32),
     ]
 
 
@@ -123,6 +125,8 @@ PROTOTYPES = {
     'xc_sort_profile_batch': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _i64, _i64, _i64, C.c_int,
                                         _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'xc_last_sort_path': (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    'xc_last_keff_path': (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    'xc_dbg_single_stamps': (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_int)]),
     'xc_set_lwa_exact': (C.c_int, [_vp, C.c_int]),
     'xc_last_lwa_path': (C.c_int, [_vp, C.POINTER(C.c_int)]),
     'xc_keff_dev': (C.c_int, [_vp, C.POINTER(KeffDesc)]),
@@ -384,6 +388,18 @@ class Context(object):
         p = C.c_int()
         self._check(self.lib.xc_last_sort_path(self.handle, C.byref(p)))
         return p.value
+
+    def last_keff_path(self):
+        """last xc_keff_dev call: 0 the min/max + histogram + finalize chain, 1 the single-read kernel (calls of one or two slabs)"""
+        p = C.c_int()
+        self._check(self.lib.xc_last_keff_path(self.handle, C.byref(p)))
+        return p.value
+
+    def single_stamps(self, enable=True):
+        """diagnostics: (device pointer, slots) of the single-read kernel's phase stamps; enable=False frees them"""
+        ptr, n = _vp(), C.c_int()
+        self._check(self.lib.xc_dbg_single_stamps(self.handle, 1 if enable else 0, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
 
     def last_lwa_path(self):
         """K7, last call: 0 band walk (bit-exact), 1 the O(ny log ny) interval kernel, 2 its premises failed the check"""

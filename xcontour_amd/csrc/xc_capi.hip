@@ -231,7 +231,9 @@ int xc_create(int device_id, xc_ctx** out)
         std::string m = std::string("xc_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
         delete ctx; return fail(nullptr, XC_ENODEV, m);
     }
-    snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    // (some boxes of the pool report an EMPTY marketing name: the field a reader checks first must still say what ran)
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs, %.0f GB)", prop.name[0] ? prop.name : "AMD Instinct [name not reported by the driver]",
+             prop.gcnArchName, prop.multiProcessorCount, (double)prop.totalGlobalMem / 1e9);
     {
         // the only place the library reads the environment: K3 geometry knobs for experiments (xc_internal.h, HistKnobs)
         auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
@@ -240,6 +242,7 @@ int xc_create(int device_id, xc_ctx** out)
         k.threads = env_int("XC_HIST_THREADS", 0); k.ncopy = env_int("XC_HIST_NCOPY", 0); k.rows = env_int("XC_HIST_ROWS", 0);
         k.bps = env_int("XC_HIST_BPS", 0);
         k.cross_ncopy = env_int("XC_CROSS_NCOPY", 0); k.cross_blocks = env_int("XC_CROSS_BLOCKS", 0);
+        k.single = env_int("XC_KEFF_SINGLE", 1); k.single_timeout_us = env_int("XC_KEFF_SINGLE_TIMEOUT_US", 50000);
         k.sort_range = env_int("XC_SORT_RANGE", 1); k.lwa_fast = env_int("XC_LWA_FAST", 1); k.k1_nt = env_int("XC_K1_NT", 0); k.lwa_strip = env_int("XC_LWA_STRIP", 1);
     }
     ctx->cus = prop.multiProcessorCount;
@@ -272,6 +275,8 @@ int xc_destroy(xc_ctx* ctx)
     if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
     if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
     if (ctx->lwa_flag) (void)hipFree(ctx->lwa_flag);
+    if (ctx->single_ws) (void)hipFree(ctx->single_ws);
+    if (ctx->single_stamps) (void)hipFree(ctx->single_stamps);
     for (auto& e : ctx->resident) (void)hipFree(e.dev);
     if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     if (ctx->ev_compute) (void)hipEventDestroy(ctx->ev_compute);
@@ -1110,6 +1115,82 @@ int xc_keff_epilogue(xc_ctx* ctx, const double* pdf, const double* ctr, int ctr_
 }
 
 // ------------------------------------------------------------------------------------ fused Keff pipeline
+constexpr int XC_EAGAIN = -1000;      // internal: "not this path" (never leaves the library)
+
+static int keff_single(xc_ctx* ctx, const xc_keff_desc* d)
+{
+    const int N = d->N;
+    const int vstride = d->out_stride ? d->out_stride : N;
+    const double* dA = d->dA; int dA_rank = d->dA_rank;
+    if (dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); dA = ctx->ones; dA_rank = XC_DA_ROW; }
+    SingleGeom g;
+    if (!single_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, d->q, dA, dA_rank, (int)d->ny, &g)) return XC_EAGAIN;
+    if (d->interp && d->npre > 0 && d->npre > 65536) return XC_EAGAIN;
+    if (!ctx->single_ws) {
+        XC_HIP(ctx, hipMalloc(&ctx->single_ws, 2 * sizeof(SingleSet)));
+        XC_HIP(ctx, hipMemsetAsync(ctx->single_ws, 0, 2 * sizeof(SingleSet), ctx->stream));
+        ctx->single_launches = 0; ctx->single_dirty_bins[0] = ctx->single_dirty_bins[1] = 0;
+    }
+    const unsigned cur = ctx->single_launches & 1u;
+    SingleSet* sets = (SingleSet*)ctx->single_ws;
+    SingleArgs a; memset(&a, 0, sizeof(a));
+    a.q = d->q; a.dA = dA; a.dA_rank = dA_rank;
+    a.dA_pos_finite = (d->dA_rank == XC_DA_NONE) ? 1 : d->dA_pos_finite;
+    a.rdx = d->rdx; a.rdy = d->rdy; a.periodic_x = d->periodic_x;
+    a.ny = d->ny; a.nx = d->nx; a.nslab = (int)d->nslab;
+    a.nbin = N; a.ncopy = g.ncopy; a.increase = d->increase; a.q_f32 = d->q_dtype == XC_F32; a.ctr_f32 = d->ctr_dtype == XC_F32;
+    a.right_edge = d->right_edge; a.last_closed = d->right_edge == XC_EDGE_NUMPY; a.want_counts = d->counts ? 1 : 0;
+    a.inv_nm1 = 1.0 / (double)(N - 1);
+    a.G = g.G; a.nstrip = g.nstrip; a.cps = g.cps; a.rpc = g.rpc;
+    a.cur = sets + cur; a.other = sets + (1u - cur); a.other_dirty_bins = ctx->single_dirty_bins[1u - cur];
+    a.ctr_out = d->ctr; a.ctr_stride = vstride; a.status = d->status;
+    a.timeout_ticks = (unsigned long long)(ctx->knobs.single_timeout_us > 0 ? ctx->knobs.single_timeout_us : 1) * 100ull;   // 100 MHz wall clock
+    a.stamps = ctx->single_stamps;
+    FinalArgs& f = a.fin;
+    f.bps = 1; f.nch = 2; f.nbin = N; f.skip_reduce = 1;
+    f.red_h = a.cur->acc_h; f.red_c = a.cur->acc_c;
+    f.lt = d->lt; f.reverse = !d->increase;
+    f.counts = d->counts;
+    f.keff = 1; f.ctr_f32 = a.ctr_f32; f.ctr = d->ctr; f.vstride = vstride;
+    f.tbl = d->tbl; f.tbl_coord = d->tbl_coord; f.ntbl = (int)d->ny; f.tbl_in_lds = g.fin_tbl_in_lds;
+    f.preY = d->preY; f.npre = d->interp ? d->npre : 0;
+    f.nkeff_mask = d->nkeff_mask; f.lmin_scale = d->lmin_scale;
+    f.o_area = d->area; f.o_intS = d->intgrdS; f.o_latEq = d->latEq; f.o_dqdA = d->dqdA; f.o_dSdA = d->dintSdA;
+    f.o_Leq2 = d->Leq2; f.o_Lmin = d->Lmin; f.o_nkeff = d->nkeff; f.o_interp = d->interp;
+    ctx->mm_valid = 0;                                        // (no chained min/max comes out of this path)
+    XC_TRY(hist_ev_begin(ctx));
+    XC_TRY(launch_keff_single(ctx, d->q_dtype, a, g));
+    XC_TRY(hist_ev_end(ctx));
+    ctx->single_dirty_bins[cur] = N;                          // what the NEXT launch clears in this set
+    ctx->single_dirty_bins[1u - cur] = 0;
+    ++ctx->single_launches;
+    ctx->last_keff_path = 1;
+    return XC_OK;
+}
+
+int xc_last_keff_path(xc_ctx* ctx, int* out_path)
+{
+    if (!ctx || !out_path) return fail(ctx, XC_EBADARG, "xc_last_keff_path: bad arguments");
+    *out_path = ctx->last_keff_path;
+    return XC_OK;
+}
+
+// diagnostics: wall-clock stamps (100 MHz) of thread 0 of every workgroup of the single-read kernel at its phase boundaries;
+// enable != 0 allocates [kSingleMaxSlabs][cus][12] uint64 and returns the device pointer, 0 frees it
+int xc_dbg_single_stamps(xc_ctx* ctx, int enable, void** out_dev, int* out_slots)
+{
+    XC_CTX(ctx);
+    if (ctx->single_stamps) { XC_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->single_stamps); ctx->single_stamps = nullptr; }
+    if (enable) {
+        const size_t bytes = (size_t)kSingleMaxSlabs * ctx->cus * kSingleStampSlots * sizeof(unsigned long long);
+        XC_HIP(ctx, hipMalloc((void**)&ctx->single_stamps, bytes));
+        XC_HIP(ctx, hipMemset(ctx->single_stamps, 0, bytes));
+    }
+    if (out_dev) *out_dev = ctx->single_stamps;
+    if (out_slots) *out_slots = kSingleStampSlots;
+    return XC_OK;
+}
+
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
 {
     XC_CTX(ctx);
@@ -1126,6 +1207,13 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     const int N = d->N, nch = 2;
     const int det = d->deterministic ? 1 : 0;
     const void* q_next = d->q_next;                          // (deterministic sums: carried by the fixed-point pass)
+    ctx->last_keff_path = 0;
+    // ONE or two slabs (the reference's callers hand planes over one at a time): the single-read kernel (xc_keff1.hip) where the slab
+    // fits the register tiles of the chip -- min/max, levels, histogram and the epilogue in ONE launch, the tracer read ONCE
+    if (d->single_read != XC_SINGLE_NEVER && ctx->knobs.single != 0 && !det && d->grad && d->nslab <= kSingleMaxSlabs) {
+        const int rc = keff_single(ctx, d);
+        if (rc != XC_EAGAIN) return rc;                      // (XC_EAGAIN: the shape does not suit it; nothing was enqueued)
+    }
     HistGeom g;
     {
         const void* gi[1] = {d->grdS}; const int32_t gt[1] = {d->grdS_dtype};

@@ -25,6 +25,9 @@ struct HistKnobs {
     int lwa_fast = 1;    // XC_LWA_FAST      K7: the O(ny log ny) interval kernel for planes of more than 512 rows (0: never, 2: for every plane)
     int lwa_strip = 1;   // XC_LWA_STRIP     K7: the one-launch kernel with the strip in LDS where it fits (0: always prep + streaming kernel)
     int sort_range = 1;  // XC_SORT_RANGE    K8: three range-key passes + short-run repair for float64 tracers (0: always eight passes)
+    int single = 1;      // XC_KEFF_SINGLE   xc_keff_dev calls of at most kSingleMaxSlabs slabs: 1 the single-read kernel where the slab fits the chip, 0 never
+    int single_timeout_us = 50000;   // XC_KEFF_SINGLE_TIMEOUT_US   bound of every wait on another workgroup inside that kernel (status 2 when it expires)
+    int single_dr = 0;   // XC_KEFF_SINGLE_DR (experiments; unused by the shipped build)
 };
 
 struct xc_ctx {
@@ -73,6 +76,11 @@ struct xc_ctx {
     unsigned lwa_epoch = 0;
     unsigned* lwa_flag = nullptr;   // device word written by k_lwa_check: the interval kernel and the band walk gate themselves on it
     int last_sort_path = 0;     // K8, last call: 0 eight / four key passes, 1 three range-key passes sufficed, 2 they did not (re-sorted)
+    // the single-read Keff kernel (xc_keff1.hip): two sets of synchronisation records + per-slab accumulators; launch n works in set n % 2
+    // and clears what launch n - 1 left in the other one (the kernel boundary orders the two), so no memset launch sits in the chain
+    void* single_ws = nullptr;  unsigned single_launches = 0;  int single_dirty_bins[2] = {0, 0};
+    int last_keff_path = 0;     // last xc_keff_dev call: 0 min/max pass + histogram pass (two reads of the tracer), 1 the single-read kernel
+    unsigned long long* single_stamps = nullptr;   // diagnostics (xc_dbg_single_stamps): wall-clock stamps of every workgroup at the phase boundaries
 };
 
 namespace xc {
@@ -195,6 +203,41 @@ struct FinalArgs {
     double          nkeff_mask, lmin_scale;
     double *o_area, *o_intS, *o_latEq, *o_dqdA, *o_dSdA, *o_Leq2, *o_Lmin, *o_nkeff, *o_interp;
 };
+
+// ---------------------------------------------------------------- the single-read Keff kernel (xc_keff1.hip)
+constexpr int kSingleThreads  = 768;    // 12 waves per workgroup = 3 per SIMD at 168 VGPRs: one workgroup per CU, the whole grid co-resident
+constexpr int kSingleRows     = 18;     // rows of a wave's chunk of the slab (its register tile: kSingleRows + 2 rows of 2 cells per lane)
+constexpr int kSingleCols     = 124;    // computed columns of a strip (lanes 1..62, two cells each; lanes 0 and 63 hold the halo columns)
+constexpr int kSingleMaxSlabs = 2;      // calls of more slabs stream (the two-read path overlaps slabs, this kernel cannot)
+constexpr int kSingleMaxBins  = 1024;
+constexpr int kSingleStampSlots = 16;
+constexpr int kSingleMaxGrid = 256;     // workgroups (= CUs used) at most
+struct SingleSlot { unsigned long long kmn, kmx; };     // a workgroup's extrema of the slab as order-preserving keys (~key(min), key(max)); zero = not there yet
+struct SingleShard { unsigned done; unsigned pad[15]; };                                            // 64 bytes: tickets of one XCD-sized share of the grid
+struct SingleSlabSync { SingleSlot slot[kSingleMaxGrid]; SingleShard shard[8]; unsigned top_done; unsigned pad[15]; };
+struct SingleSet {                       // everything a launch dirties: cleared by the NEXT launch (up to the bins it used)
+    SingleSlabSync sync[kSingleMaxSlabs];
+    unsigned abort; unsigned pad[15];
+    double acc_h[kSingleMaxSlabs * 2 * kSingleMaxBins];           // dense for the launch's own N: [slab][channel][N] (what the finalize stage reads)
+    unsigned long long acc_c[kSingleMaxSlabs * kSingleMaxBins];   // [slab][N]
+};
+struct SingleGeom { int G, nstrip, cps, rpc, ncopy; size_t lds; int fin_tbl_in_lds; };
+struct SingleArgs {
+    const void*   q;  const double* dA;  int dA_rank, dA_pos_finite;
+    const double* rdx; const double* rdy; int periodic_x;
+    int64_t       ny, nx;  int nslab;
+    int           nbin, ncopy, increase, q_f32, ctr_f32, right_edge, last_closed, want_counts;
+    double        inv_nm1;
+    int           G, nstrip, cps, rpc;
+    SingleSet*    cur;       SingleSet* other;  int other_dirty_bins;      // the set this launch works in; the one it clears for its successor
+    double*       ctr_out;   int ctr_stride;    int32_t* status;
+    unsigned long long timeout_ticks;          // of the 100 MHz wall clock
+    unsigned long long* stamps;                // diagnostics or null
+    FinalArgs     fin;       // red_h / red_c aimed at cur->acc_h / acc_c, skip_reduce = 1
+};
+bool single_geometry(const xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int N, const void* q, const double* dA,
+                     int dA_rank, int ntbl, SingleGeom* g);
+int launch_keff_single(xc_ctx* ctx, int q_dtype, const SingleArgs& a, const SingleGeom& g);
 
 // ---------------------------------------------------------------- launchers (defined in the .hip files)
 int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part,

@@ -38,7 +38,7 @@ class KeffPlan(object):
                  tbl=None, tbl_coord=None, preY=None, increase=True, lt=True,
                  right_edge='xhistogram', nkeff_mask=1e5, Rearth=Rearth, grdS_dtype=None,
                  prod_f32=False, alloc_q=True, nslots=1, out_ptr=None, detect_row_dA=False,
-                 out_slabs=None, replicate_dA=False, deterministic=False, slab_major=False, counts=True):
+                 out_slabs=None, replicate_dA=False, deterministic=False, slab_major=False, counts=True, single_read=True):
         """dA: None | (ny,) | (ny,nx) | (nslab,ny,nx) f64 (the last: weights that change with the leading
         (time, level) index, which the reference allows -- core.py:1271-1274).  Gradient metrics either `rdx, rdy`
         (per-row reciprocals) or derived from `lat, lon` (sphere).  If
@@ -57,7 +57,10 @@ class KeffPlan(object):
         `counts=False`: the per-bin cell counts are not wanted (the reference's Keff sequence never looks at them): the histogram
         pass then skips their LDS adds -- a third of its atomics; `fetch()['counts']` is meaningless.
         `deterministic`: order-free fixed-point sums (xc_keff_desc.deterministic): area / intgrdS and everything derived
-        from them are bit-identical between runs, launch-set sizes and ranks, chained (q_next) or not."""
+        from them are bit-identical between runs, launch-set sizes and ranks, chained (q_next) or not.
+        `single_read=False`: launch sets of one or two slabs keep the min/max + histogram + finalize chain instead of the
+        single-read kernel (xc_keff_desc.single_read; that kernel needs the whole GPU to itself -- `fetch` repeats a launch set
+        that came back with status 2 on the chain, so the switch is for measurements, not for safety)."""
         self.ctx = ctx
         self.nslab, self.ny, self.nx, self.N = int(nslab), int(ny), int(nx), int(N)
         self.q_dtype, self.ctr_dtype = np.dtype(q_dtype), np.dtype(ctr_dtype)
@@ -74,6 +77,9 @@ class KeffPlan(object):
         d.increase, d.lt = int(bool(increase)), int(bool(lt))
         d.right_edge = nat.XC_EDGE_XHISTOGRAM if right_edge == 'xhistogram' else nat.XC_EDGE_NUMPY
         d.deterministic = 1 if deterministic else 0
+        d.single_read = nat.XC_SINGLE_AUTO if single_read else nat.XC_SINGLE_NEVER
+        self._runs = {}                                  # slot -> the launch sets enqueued into it since its last fetch
+        self.replays = 0                                 # launch sets repeated on the chain after a status 2
         if dA is None:
             d.dA, d.dA_rank = None, nat.XC_DA_NONE
         else:
@@ -249,13 +255,14 @@ class KeffPlan(object):
         g = self.nslab if not group else int(group)
         starts = list(range(0, self.nslab, g))
         esz = self.ny * self.nx * self.q_dtype.itemsize
+        self._runs[slot] = []
         for i, s0 in enumerate(starts):
             n = min(g, self.nslab - s0)
             self._point(slot, s0, n)
             nxt = starts[(i + 1) % len(starts)]
             ok = chain and min(g, self.nslab - nxt) == n          # same shape only
             self.desc.q_next = (self._q_ptr + nxt * esz) if ok else None
-            self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
+            self._enqueue(slot, s0, n, None)
 
     def run_range(self, slot, s0, n, next_s0=None, out_s0=None):
         """One launch set over slabs [s0, s0+n) into result slot `slot`; `next_s0`: first slab of
@@ -264,7 +271,45 @@ class KeffPlan(object):
         self._point(slot, s0, n, out_s0)
         esz = self.ny * self.nx * self.q_dtype.itemsize
         self.desc.q_next = (self._q_ptr + next_s0 * esz) if next_s0 is not None else None
+        self._runs.setdefault(slot, [])
+        self._enqueue(slot, s0, n, out_s0)
+
+    def _enqueue(self, slot, s0, n, out_s0):
         self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
+        if n <= 2 and self.desc.single_read == nat.XC_SINGLE_AUTO:
+            # a launch set the single-read kernel may have taken: remember where it read and wrote, in case it comes back with status 2
+            runs = self._runs[slot]
+            runs.append((s0, n, out_s0, self._q_ptr, self._dA_ptr if self.desc.dA_rank != nat.XC_DA_NONE else 0, self._g_ptr))
+            del runs[:-64]
+
+    def _replay(self, slot, status):
+        """launch sets of `slot` whose slabs came back with status 2 (the single-read kernel gave up waiting for its workgroups:
+        something else held compute units): once more, on the min/max + histogram + finalize chain"""
+        keep = (self._q_ptr, getattr(self, '_dA_ptr', 0), self._g_ptr, self.desc.single_read)
+        done = False
+        try:
+            self.desc.single_read = nat.XC_SINGLE_NEVER
+            for s0, n, out_s0, qp, dp, gp in self._runs.get(slot, []):
+                o0 = s0 if out_s0 is None else out_s0
+                if not (status[o0:o0 + n] == 2).any():
+                    continue
+                self._q_ptr = qp
+                if dp:
+                    self._dA_ptr = dp
+                    self.desc.dA = dp                      # (per-slab weights: _point moves it to the launch set's first slab)
+                self._g_ptr = gp
+                self._point(slot, s0, n, out_s0)
+                self.desc.q_next = None
+                self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
+                self.replays += 1
+                done = True
+        finally:
+            self._q_ptr, dp, self._g_ptr, self.desc.single_read = keep
+            if dp:
+                self._dA_ptr = dp
+                self.desc.dA = dp
+            self.desc.q = self._q_ptr
+        return done
 
     def unpack(self, raw):
         """one result slot (bytes as a uint8 ndarray) -> dict of arrays"""
@@ -292,6 +337,13 @@ class KeffPlan(object):
         self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, raw.ctypes.data,
                                                    self.out_ptr + slot * self.slot_bytes, self.slot_bytes))
         out = self.unpack(raw)
+        if (out['status'] == 2).any() and self._replay(slot, out['status']):
+            self.ctx._check(self.ctx.lib.xc_memcpy_d2h(self.ctx.handle, raw.ctypes.data,
+                                                       self.out_ptr + slot * self.slot_bytes, self.slot_bytes))
+            out = self.unpack(raw)
+        self._runs[slot] = []
+        if check and (out['status'] == 2).any():
+            raise Exception('xc_keff: status 2 -- the single-read kernel gave up waiting for its workgroups and the launch set is not on record')
         if check and out['status'].any():
             raise Exception('non monotonic bins')          # reference core.py:1233-1251
         return out
