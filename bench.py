@@ -1198,7 +1198,7 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
         alg = NY * NX * BYTES_PER_CELL
         return {'us': float(np.median(warm)), 'us_cold': float(np.median(cold)), 'us_min': float(warm.min()), 'reps': reps,
                 'frac': alg / (np.median(warm) * 1e-6) / 1e9 / HBM_PEAK_GBS, 'frac_cold': alg / (np.median(cold) * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                'path': 'single-read kernel (one launch: min/max -> levels -> histogram -> epilogue, the slab held in registers)' if path == 1
+                'path': 'single-read kernel (k_keff_single: min/max -> levels -> histogram in one launch, the slab held in registers; then k_finalize)' if path == 1
                         else 'chain: k_minmax_partial (also clears the accumulators), k_hist (blocks add into them), k_finalize',
                 'chain': {'us': float(np.median(cwarm)), 'us_cold': float(np.median(ccold)),
                           'launches': 'k_minmax_partial, k_hist, k_finalize (xc_keff_desc.single_read = XC_SINGLE_NEVER)'},

@@ -15,7 +15,7 @@ from xcontour_amd import _native as nat
 from xcontour_amd.pipeline import KeffPlan
 from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
 
-NAMES = ['start', 'tile landed + min/max', 'arrive', 'wait for the grid', 'edges', 'bin', 'flush + ticket', 'finalize (last workgroup)']
+NAMES = ['start', 'tile landed + min/max', 'publish', 'wait for the grid', 'edges', 'bin', 'flush (adds issued)']
 
 
 def main():
@@ -39,6 +39,7 @@ def main():
     cus = ctx.device_cus()
     n = 2 * cus * slots
     acc = []
+    fst = []
     e0, e1 = ctx.event(), ctx.event()
     tms = []
     for r in range(a.reps + 3):
@@ -51,9 +52,10 @@ def main():
         st = np.empty(n, np.uint64)
         ctx._check(ctx.lib.xc_memcpy_d2h(ctx.handle, st.ctypes.data, ptr, n * 8))
         st = st.reshape(2, cus, slots)[0].astype(np.float64)
+        f8 = st[0, 8:13].copy()                   # the finalize kernel's stamps (slots 8.. of workgroup 0)
         st = st[st[:, 0] > 0]                      # workgroups of the grid
         if r >= 3:
-            acc.append(st)
+            acc.append(st); fst.append(f8)
     out = p.fetch()
     assert not out['status'].any()
     rows = []
@@ -65,18 +67,12 @@ def main():
         last = np.array([s[:, k].max() - t for s, t in zip(acc, t0)]) / 100.0
         rows.append({'phase': NAMES[k], 'median_us': round(float(np.median(d)), 2), 'ends_at_us_median_wg': round(float(np.median(end)), 2),
                      'ends_at_us_last_wg': round(float(np.median(last)), 2)})
-    fin = []
-    ftl = []                      # the finalizer's own time line: ticket -> start -> (acc loaded) -> (cumsum) -> (table staged) -> (look-ups) -> end
-    for s, t in zip(acc, t0):
-        f = s[:, 13]
-        if (f > 0).any():
-            w = int(np.argmax(f))
-            fin.append((f[w] - t) / 100.0)
-            ftl.append([(s[w, k] - s[w, 6]) / 100.0 for k in (7, 9, 10, 11, 12, 13)])
-    res = {'workgroups': int(G), 'start_spread_us': round(float(np.median([s[:, 0].max() - s[:, 0].min() for s in acc])) / 100.0, 2),
-           'phases': rows, 'finalizer_us_after_its_ticket': dict(zip(['start', 'sums loaded', 'cumsum', 'table staged', 'look-ups', 'end'],
-                                                                     [round(float(x), 2) for x in np.median(np.array(ftl), axis=0)])) if ftl else None,
-           'kernel_end_us_after_first_start': round(float(np.median(fin)), 2) if fin else None,
+    raw = [s_ for s_ in acc]
+    sk = float(np.median([np.median(s_[:, 7] - s_[:, 5]) for s_ in acc])) / 100.0
+    res = {'flush_barrier_wait_us': round(sk, 2), 'workgroups': int(G), 'start_spread_us': round(float(np.median([s[:, 0].max() - s[:, 0].min() for s in acc])) / 100.0, 2),
+           'phases': rows,
+           'finalize_kernel_us_after_the_last_flush': dict(zip(['first instruction', 'sums + levels + table in LDS', 'cumsum', 'look-ups | gradients', 'nkeff (end)'],
+                                                               [round(float(np.median([(f[k] - s_[:, 6].max()) / 100.0 for f, s_ in zip(fst, raw)])), 2) for k in range(5)])),
            'event_us_median': round(float(np.median(tms[3:])), 2), 'event_us_min': round(float(np.min(tms[3:])), 2),
            'dtype': a.dtype, 'shape': [a.ny, a.nx], 'N': a.N, 'cold': bool(a.cold)}
     print(json.dumps(res))

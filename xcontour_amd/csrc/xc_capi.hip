@@ -242,7 +242,7 @@ int xc_create(int device_id, xc_ctx** out)
         k.threads = env_int("XC_HIST_THREADS", 0); k.ncopy = env_int("XC_HIST_NCOPY", 0); k.rows = env_int("XC_HIST_ROWS", 0);
         k.bps = env_int("XC_HIST_BPS", 0);
         k.cross_ncopy = env_int("XC_CROSS_NCOPY", 0); k.cross_blocks = env_int("XC_CROSS_BLOCKS", 0);
-        k.single = env_int("XC_KEFF_SINGLE", 1); k.single_timeout_us = env_int("XC_KEFF_SINGLE_TIMEOUT_US", 50000);
+        k.single = env_int("XC_KEFF_SINGLE", 1); k.single_timeout_us = env_int("XC_KEFF_SINGLE_TIMEOUT_US", 50000); k.single_map = env_int("XC_KEFF_SINGLE_MAP", 0);
         k.sort_range = env_int("XC_SORT_RANGE", 1); k.lwa_fast = env_int("XC_LWA_FAST", 1); k.k1_nt = env_int("XC_K1_NT", 0); k.lwa_strip = env_int("XC_LWA_STRIP", 1);
     }
     ctx->cus = prop.multiProcessorCount;
@@ -1124,8 +1124,7 @@ static int keff_single(xc_ctx* ctx, const xc_keff_desc* d)
     const double* dA = d->dA; int dA_rank = d->dA_rank;
     if (dA_rank == XC_DA_NONE) { XC_TRY(ensure_ones(ctx, (size_t)d->ny)); dA = ctx->ones; dA_rank = XC_DA_ROW; }
     SingleGeom g;
-    if (!single_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, d->q, dA, dA_rank, (int)d->ny, &g)) return XC_EAGAIN;
-    if (d->interp && d->npre > 0 && d->npre > 65536) return XC_EAGAIN;
+    if (!single_geometry(ctx, d->q_dtype, d->nslab, d->ny, d->nx, N, d->q, dA, dA_rank, &g)) return XC_EAGAIN;
     if (!ctx->single_ws) {
         XC_HIP(ctx, hipMalloc(&ctx->single_ws, 2 * sizeof(SingleSet)));
         XC_HIP(ctx, hipMemsetAsync(ctx->single_ws, 0, 2 * sizeof(SingleSet), ctx->stream));
@@ -1140,27 +1139,30 @@ static int keff_single(xc_ctx* ctx, const xc_keff_desc* d)
     a.ny = d->ny; a.nx = d->nx; a.nslab = (int)d->nslab;
     a.nbin = N; a.ncopy = g.ncopy; a.increase = d->increase; a.q_f32 = d->q_dtype == XC_F32; a.ctr_f32 = d->ctr_dtype == XC_F32;
     a.right_edge = d->right_edge; a.last_closed = d->right_edge == XC_EDGE_NUMPY; a.want_counts = d->counts ? 1 : 0;
-    a.inv_nm1 = 1.0 / (double)(N - 1);
-    a.G = g.G; a.nstrip = g.nstrip; a.cps = g.cps; a.rpc = g.rpc;
+    a.inv_nm1 = 1.0 / (double)(N - 1); a.inv_n = 1.0 / (double)N;
+    a.G = g.G; a.nstrip = g.nstrip; a.cps = g.cps; a.rpc = g.rpc; a.strip_fast = ctx->knobs.single_map;
     a.cur = sets + cur; a.other = sets + (1u - cur); a.other_dirty_bins = ctx->single_dirty_bins[1u - cur];
     a.ctr_out = d->ctr; a.ctr_stride = vstride; a.status = d->status;
     a.timeout_ticks = (unsigned long long)(ctx->knobs.single_timeout_us > 0 ? ctx->knobs.single_timeout_us : 1) * 100ull;   // 100 MHz wall clock
     a.stamps = ctx->single_stamps;
-    FinalArgs& f = a.fin;
+    FinalArgs f; memset(&f, 0, sizeof(f));
     f.bps = 1; f.nch = 2; f.nbin = N; f.skip_reduce = 1;
     f.red_h = a.cur->acc_h; f.red_c = a.cur->acc_c;
     f.lt = d->lt; f.reverse = !d->increase;
     f.counts = d->counts;
     f.keff = 1; f.ctr_f32 = a.ctr_f32; f.ctr = d->ctr; f.vstride = vstride;
-    f.tbl = d->tbl; f.tbl_coord = d->tbl_coord; f.ntbl = (int)d->ny; f.tbl_in_lds = g.fin_tbl_in_lds;
+    f.tbl = d->tbl; f.tbl_coord = d->tbl_coord; f.ntbl = (int)d->ny;
     f.preY = d->preY; f.npre = d->interp ? d->npre : 0;
     f.nkeff_mask = d->nkeff_mask; f.lmin_scale = d->lmin_scale;
     f.o_area = d->area; f.o_intS = d->intgrdS; f.o_latEq = d->latEq; f.o_dqdA = d->dqdA; f.o_dSdA = d->dintSdA;
     f.o_Leq2 = d->Leq2; f.o_Lmin = d->Lmin; f.o_nkeff = d->nkeff; f.o_interp = d->interp;
+    f.abort_flag = &a.cur->abort; f.status_out = d->status;
+    f.dbg = ctx->single_stamps ? ctx->single_stamps + 8 : nullptr;            // (slots 8.. of workgroup 0, slab 0)
     ctx->mm_valid = 0;                                        // (no chained min/max comes out of this path)
     XC_TRY(hist_ev_begin(ctx));
     XC_TRY(launch_keff_single(ctx, d->q_dtype, a, g));
     XC_TRY(hist_ev_end(ctx));
+    XC_TRY(launch_finalize(ctx, d->nslab, f));
     ctx->single_dirty_bins[cur] = N;                          // what the NEXT launch clears in this set
     ctx->single_dirty_bins[1u - cur] = 0;
     ++ctx->single_launches;

@@ -77,28 +77,35 @@ __device__ __forceinline__ double lane_value(double v, int idx)
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-// Stage 2: one workgroup per slab.  A device function so that it can run as a kernel of its own (k_finalize, xc_misc.hip) or at the
-// tail of the single-read Keff kernel, in the workgroup that arrives last (k_keff_single, xc_keff1.hip).
-// COH (that second use): the reduced sums in a.red_h / a.red_c were ADDED by other workgroups of the SAME launch with agent-scope
-// atomics -- they are read with agent-scope loads (no kernel boundary has made them visible); `ctr_own` (LDS) then holds the slab's
-// levels in level order instead of a.ctr (written by another workgroup a moment ago).
-template <bool COH>
-__device__ __forceinline__ void finalize_body(const FinalArgs& a, const int slab, const int tid, const int nthr, double* sm_lds,
-                                              const double* ctr_own, unsigned long long* dbg = nullptr)
+// Stage 2: one workgroup per slab.  (A device function in a header: it ran for a while at the tail of the single-read Keff kernel too, in
+// the workgroup that arrived last -- measured 12 us there against 6 us + a 1.8 us launch boundary as a kernel of its own, see
+// profiles/r06_notes.md -- and may be wanted inside another kernel again.)
+__device__ __forceinline__ void finalize_body(const FinalArgs& a, const int slab, const int tid, const int nthr, double* sm_lds)
 {
-    auto dstamp = [&](int k) { if (COH && dbg && tid == 0) dbg[k] = wall_clock64(); };
     const int N = a.nbin, NCH = a.nch;
+    auto dstamp = [&](int k) { if (a.dbg && tid == 0 && slab == 0) a.dbg[k] = wall_clock64(); };
+    dstamp(0);
+    // the single-read Keff kernel gave up waiting for its workgroups (its abort flag, xc_keff1.hip): nothing of this launch is valid
+    if (a.abort_flag && *a.abort_flag != 0u) {
+        if (tid == 0 && a.status_out) a.status_out[slab] = 2;
+        return;
+    }
     // thousands of contours: the work arrays live in global memory (same code; __syncthreads orders them)
     double* sm = a.big ? a.big + (size_t)slab * a.big_stride : sm_lds;
     double* s_pdf = sm;                   // [NCH][N]
     double* s_cdf = sm + (size_t)NCH * N; // [NCH][N] in LEVEL order (after optional reversal)
     double* s_x   = s_cdf + (size_t)NCH * N;   // 7*N scratch for the epilogue
 
-    // the A(Yeq) table goes into LDS for the look-ups of the epilogue: its loads are issued FIRST, eight pairs per thread at a
-    // time, so that their latency runs under the reduction and the cumulative sums (they used to be a loop of dependent
-    // round trips in the middle of the kernel: 7 of its 20 us per launch)
+    // Everything the epilogue needs from global memory is REQUESTED first, so that its latency runs under the reduction: the A(Yeq)
+    // table (eight pairs per thread at a time; it goes into LDS for the look-ups -- these used to be a loop of dependent round trips in
+    // the middle of the kernel: 7 of its 20 us per launch) and the contour levels (round 6: another dependent round trip in there).
     constexpr int TB = 8;
     double tb_t[TB], tb_c[TB];
+    double* s_ctr = s_x;            double* s_lat = s_x + N;       double* s_lmin = s_x + 2 * N;
+    double* s_dS  = s_x + 3 * N;    double* s_dq  = s_x + 4 * N;   double* s_leq = s_x + 5 * N;
+    double* s_nk  = s_x + 6 * N;
+    double* s_tbl = s_x + 7 * (size_t)N;
+    const double ctr_mine = (a.keff && tid < N) ? a.ctr[(size_t)slab * a.vstride + tid] : 0.0;
     const bool tbl_regs = a.keff && a.tbl_in_lds && a.ntbl <= TB * nthr;
     if (tbl_regs) {
 #pragma unroll
@@ -141,11 +148,23 @@ __device__ __forceinline__ void finalize_body(const FinalArgs& a, const int slab
     } else {
         const double* ph = a.red_h + (size_t)slab * NCH * N;
         for (int i = tid; i < NCH * N; i += nthr)
-            s_pdf[i] = COH ? __hip_atomic_load(ph + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ph[i];
+            s_pdf[i] = ph[i];
         if (a.counts) {
             const unsigned long long* pc = a.red_c + (size_t)slab * N;
             for (int i = tid; i < N; i += nthr)
-                a.counts[(size_t)slab * N + (a.reverse ? N - 1 - i : i)] = COH ? __hip_atomic_load(pc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pc[i];
+                a.counts[(size_t)slab * N + (a.reverse ? N - 1 - i : i)] = pc[i];
+        }
+    }
+    if (a.keff) {
+        // the levels and the table into LDS now (their loads were the first of the kernel: landed), covered by the SAME barrier as the sums
+        for (int k = tid; k < N; k += nthr) s_ctr[k] = k == tid ? ctr_mine : a.ctr[(size_t)slab * a.vstride + k];
+        if (a.tbl_in_lds) {
+            if (tbl_regs) {
+#pragma unroll
+                for (int u = 0; u < TB; ++u) { const int i = tid + u * nthr; if (i < a.ntbl) { s_tbl[i] = tb_t[u]; s_tbl[a.ntbl + i] = tb_c[u]; } }
+            } else {
+                for (int i = tid; i < a.ntbl; i += nthr) { s_tbl[i] = a.tbl[i]; s_tbl[a.ntbl + i] = a.tbl_coord[i]; }
+            }
         }
     }
     __syncthreads();
@@ -167,14 +186,14 @@ __device__ __forceinline__ void finalize_body(const FinalArgs& a, const int slab
                 double x[4], r[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = k + e < N ? p[k + e] : 0.0;      // (past N: + 0.0, the running sum stays)
-#pragma unroll 4
-                for (int t = 0; t < 64; ++t) {
+                const int nstep = (N - k0 + 3) / 4 < 64 ? (N - k0 + 3) / 4 : 64;    // lanes past the last element only repeat its sum
+                for (int t = 0; t < nstep; ++t) {
                     r[0] = __dadd_rn(lane_shr1_keep(r[3], carry), x[0]);
                     r[1] = __dadd_rn(r[0], x[1]); r[2] = __dadd_rn(r[1], x[2]); r[3] = __dadd_rn(r[2], x[3]);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (k + e < N) c[a.reverse ? N - 1 - k - e : k + e] = r[e];   // level order (core.py:454-455)
-                carry = lane_value(r[3], 63);
+                carry = lane_value(r[3], nstep - 1);                  // (the last lane that is final after nstep steps; its r[3] is the running total)
             }
             if (!a.lt)                                                // core.py:1322-1323; every lane revisits its own elements
                 for (int k0 = 0; k0 < N; k0 += 256)
@@ -194,55 +213,51 @@ __device__ __forceinline__ void finalize_body(const FinalArgs& a, const int slab
     }
     if (!a.keff) return;
 
-    // ---------------- Keff epilogue, one thread per contour
+    // ---------------- Keff epilogue, one thread per contour.  Two chains per contour that do not depend on each
+    // other -- the look-up A -> Yeq -> Lmin (a bracket search, a division, a cosine) and the gradients dS/dA, dq/dA, Leq^2 (three divisions)
+    // -- run side by side in the two halves of the workgroup (one wave per SIMD has nothing else to hide their latencies behind); the
+    // quotient that needs both follows.  The arithmetic of every quantity is what it was.
     const double* area = s_cdf;           // channel 0
     const double* intS = s_cdf + N;       // channel 1
-    double* s_ctr = s_x;            double* s_lat = s_x + N;       double* s_lmin = s_x + 2 * N;
-    double* s_dS  = s_x + 3 * N;    double* s_dq  = s_x + 4 * N;   double* s_leq = s_x + 5 * N;
-    double* s_nk  = s_x + 6 * N;
-    // stage the A(Yeq) table in LDS when it fits (coalesced reads instead of 11 dependent
-    // global round trips per contour)
-    const double* tblp = a.tbl; const double* crdp = a.tbl_coord;
-    if (a.tbl_in_lds) {
-        double* s_tbl = s_x + 7 * (size_t)N;
-        if (tbl_regs) {
-#pragma unroll
-            for (int u = 0; u < TB; ++u) { const int i = tid + u * nthr; if (i < a.ntbl) { s_tbl[i] = tb_t[u]; s_tbl[a.ntbl + i] = tb_c[u]; } }
-        } else {
-            for (int i = tid; i < a.ntbl; i += nthr) { s_tbl[i] = a.tbl[i]; s_tbl[a.ntbl + i] = a.tbl_coord[i]; }
-        }
-        __syncthreads();
-    dstamp(3);
-        tblp = s_tbl; crdp = s_tbl + a.ntbl;
-    }
+    const double* tblp = a.tbl_in_lds ? s_tbl : a.tbl;
+    const double* crdp = a.tbl_in_lds ? s_tbl + a.ntbl : a.tbl_coord;
     const int tinc = tblp[a.ntbl - 1] > tblp[0];            // Table.__init__, core.py:1122-1128
-    for (int k = tid; k < N; k += nthr) {
-        s_ctr[k] = ctr_own ? ctr_own[k] : a.ctr[(size_t)slab * a.vstride + k];
-        const int jt = interp_locate(area[k], tblp, a.ntbl, !tinc);
-        const double le = interp_eval(area[k], jt, tblp, crdp, a.ntbl, !tinc);       // core.py:1136-1174
-        s_lat[k] = le;
-        s_lmin[k] = __dmul_rn(a.lmin_scale, cos(__dmul_rn(le, 0.017453292519943295)));   // utils.py:532
+    const int half = nthr >= 128 ? ((nthr / 2) & ~63) : 0;
+    if (half == 0 || tid < half) {
+        for (int k = tid; k < N; k += (half ? half : nthr)) {
+            const int jt = interp_locate(area[k], tblp, a.ntbl, !tinc);
+            const double le = interp_eval(area[k], jt, tblp, crdp, a.ntbl, !tinc);       // core.py:1136-1174
+            const double lm = __dmul_rn(a.lmin_scale, cos(__dmul_rn(le, 0.017453292519943295)));   // utils.py:532
+            s_lat[k] = le; s_lmin[k] = lm;
+            const size_t o = (size_t)slab * a.vstride + k;
+            if (a.o_latEq) a.o_latEq[o] = le;
+            if (a.o_Lmin)  a.o_Lmin[o]  = lm;
+        }
+    }
+    if (half == 0 || tid >= half) {
+        for (int k = tid - half; k < N; k += nthr - half) {
+            const double dA = grad_f64(area, k, N);
+            const double dS = __ddiv_rn(grad_f64(intS, k, N), dA);                    // core.py:480-483
+            const double dq = __ddiv_rn(a.ctr_f32 ? grad_f32(s_ctr, k, N) : grad_f64(s_ctr, k, N), dA);
+            const double leq = __ddiv_rn(dS, __dmul_rn(dq, dq));                      // core.py:635
+            s_dS[k] = dS; s_dq[k] = dq; s_leq[k] = leq;
+            const size_t o = (size_t)slab * a.vstride + k;
+            if (a.o_area)  a.o_area[o]  = area[k];
+            if (a.o_intS)  a.o_intS[o]  = intS[k];
+            if (a.o_dSdA)  a.o_dSdA[o]  = dS;
+            if (a.o_dqdA)  a.o_dqdA[o]  = dq;
+            if (a.o_Leq2)  a.o_Leq2[o]  = leq;
+        }
     }
     __syncthreads();
-    dstamp(4);
+    dstamp(3);
     for (int k = tid; k < N; k += nthr) {
-        const double dA = grad_f64(area, k, N);
-        const double dS = __ddiv_rn(grad_f64(intS, k, N), dA);                    // core.py:480-483
-        const double dq = __ddiv_rn(a.ctr_f32 ? grad_f32(s_ctr, k, N) : grad_f64(s_ctr, k, N), dA);
-        const double leq = __ddiv_rn(dS, __dmul_rn(dq, dq));                      // core.py:635
-        double nk = __ddiv_rn(__ddiv_rn(leq, s_lmin[k]), s_lmin[k]);              // core.py:963
+        double nk = __ddiv_rn(__ddiv_rn(s_leq[k], s_lmin[k]), s_lmin[k]);         // core.py:963
         if (!(nk < a.nkeff_mask)) nk = dnan();                                    // core.py:964
-        s_dS[k] = dS; s_dq[k] = dq; s_leq[k] = leq; s_nk[k] = nk;
-        const size_t o = (size_t)slab * a.vstride + k;
-        if (a.o_area)  a.o_area[o]  = area[k];
-        if (a.o_intS)  a.o_intS[o]  = intS[k];
-        if (a.o_latEq) a.o_latEq[o] = s_lat[k];
-        if (a.o_Lmin)  a.o_Lmin[o]  = s_lmin[k];
-        if (a.o_dSdA)  a.o_dSdA[o]  = dS;
-        if (a.o_dqdA)  a.o_dqdA[o]  = dq;
-        if (a.o_Leq2)  a.o_Leq2[o]  = leq;
-        if (a.o_nkeff) a.o_nkeff[o] = nk;
+        s_nk[k] = nk;
+        if (a.o_nkeff) a.o_nkeff[(size_t)slab * a.vstride + k] = nk;
     }
+    dstamp(4);
     if (a.o_interp && a.npre > 0) {
         __syncthreads();
         // interp_to_coords (core.py:1050-1100): direction from latEq[0] < latEq[-1]

@@ -27,7 +27,7 @@ struct HistKnobs {
     int sort_range = 1;  // XC_SORT_RANGE    K8: three range-key passes + short-run repair for float64 tracers (0: always eight passes)
     int single = 1;      // XC_KEFF_SINGLE   xc_keff_dev calls of at most kSingleMaxSlabs slabs: 1 the single-read kernel where the slab fits the chip, 0 never
     int single_timeout_us = 50000;   // XC_KEFF_SINGLE_TIMEOUT_US   bound of every wait on another workgroup inside that kernel (status 2 when it expires)
-    int single_dr = 0;   // XC_KEFF_SINGLE_DR (experiments; unused by the shipped build)
+    int single_map = 0;  // XC_KEFF_SINGLE_MAP  wave -> tile order of that kernel: 0 chunks of one strip per workgroup, 1 adjacent strips of the same rows
 };
 
 struct xc_ctx {
@@ -202,6 +202,9 @@ struct FinalArgs {
     const double*   preY;     int npre;
     double          nkeff_mask, lmin_scale;
     double *o_area, *o_intS, *o_latEq, *o_dqdA, *o_dSdA, *o_Leq2, *o_Lmin, *o_nkeff, *o_interp;
+    const unsigned* abort_flag;   // non-null (behind the single-read Keff kernel): a non-zero word means that launch gave up -- the slab gets
+    int32_t*        status_out;   //   status_out[slab] = 2 and nothing else is written
+    unsigned long long* dbg;      // diagnostics (xc_dbg_single_stamps): eight wall-clock stamps of the finalize stage of slab 0, or null
 };
 
 // ---------------------------------------------------------------- the single-read Keff kernel (xc_keff1.hip)
@@ -213,30 +216,27 @@ constexpr int kSingleMaxBins  = 1024;
 constexpr int kSingleStampSlots = 16;
 constexpr int kSingleMaxGrid = 256;     // workgroups (= CUs used) at most
 struct SingleSlot { unsigned long long kmn, kmx; };     // a workgroup's extrema of the slab as order-preserving keys (~key(min), key(max)); zero = not there yet
-struct SingleShard { unsigned done; unsigned pad[15]; };                                            // 64 bytes: tickets of one XCD-sized share of the grid
-struct SingleSlabSync { SingleSlot slot[kSingleMaxGrid]; SingleShard shard[8]; unsigned top_done; unsigned pad[15]; };
-struct SingleSet {                       // everything a launch dirties: cleared by the NEXT launch (up to the bins it used)
-    SingleSlabSync sync[kSingleMaxSlabs];
+struct SingleSet {                       // everything a launch dirties: cleared by the NEXT launch (the accumulators: up to the bins it used)
+    SingleSlot slot[kSingleMaxSlabs][kSingleMaxGrid];
     unsigned abort; unsigned pad[15];
     double acc_h[kSingleMaxSlabs * 2 * kSingleMaxBins];           // dense for the launch's own N: [slab][channel][N] (what the finalize stage reads)
     unsigned long long acc_c[kSingleMaxSlabs * kSingleMaxBins];   // [slab][N]
 };
-struct SingleGeom { int G, nstrip, cps, rpc, ncopy; size_t lds; int fin_tbl_in_lds; };
+struct SingleGeom { int G, nstrip, cps, rpc, ncopy; size_t lds; };
 struct SingleArgs {
     const void*   q;  const double* dA;  int dA_rank, dA_pos_finite;
     const double* rdx; const double* rdy; int periodic_x;
     int64_t       ny, nx;  int nslab;
     int           nbin, ncopy, increase, q_f32, ctr_f32, right_edge, last_closed, want_counts;
-    double        inv_nm1;
-    int           G, nstrip, cps, rpc;
+    double        inv_nm1, inv_n;
+    int           G, nstrip, cps, rpc, strip_fast;
     SingleSet*    cur;       SingleSet* other;  int other_dirty_bins;      // the set this launch works in; the one it clears for its successor
     double*       ctr_out;   int ctr_stride;    int32_t* status;
     unsigned long long timeout_ticks;          // of the 100 MHz wall clock
     unsigned long long* stamps;                // diagnostics or null
-    FinalArgs     fin;       // red_h / red_c aimed at cur->acc_h / acc_c, skip_reduce = 1
 };
 bool single_geometry(const xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int N, const void* q, const double* dA,
-                     int dA_rank, int ntbl, SingleGeom* g);
+                     int dA_rank, SingleGeom* g);
 int launch_keff_single(xc_ctx* ctx, int q_dtype, const SingleArgs& a, const SingleGeom& g);
 
 // ---------------------------------------------------------------- launchers (defined in the .hip files)

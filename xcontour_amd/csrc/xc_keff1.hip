@@ -17,14 +17,15 @@
 //   * step B: the wave walks its rows in registers: nearest-edge guess + ONE exact comparison against the f64 edge in LDS (levels
 //     equally spaced to a quarter of a bin, verified per slab; otherwise a rolled loop over the chunk with the general search of the
 //     two-pass kernel), centred differences, weights, LDS atomics on lane-privatised copies; the rest of dA streams in DR rows ahead;
-//   * step C: the workgroup ADDS its sums to the slab's accumulators (agent-scope float64 atomics, zeros not sent) and takes a ticket;
-//     the workgroup that draws the last ticket runs the finalize stage (xc_finalize.h: cumulative sums, A(Yeq) look-up, Keff
-//     epilogue) on the accumulators -- no launch boundary, no k_finalize launch.
+//   * step C: the workgroup ADDS its sums to the slab's accumulators (agent-scope float64 atomics, zeros not sent) and the kernel ends;
+//     k_finalize (xc_misc.hip) reads them in the next launch.  (Round 6 measured the alternative -- tickets, the last workgroup runs
+//     the finalize stage at the tail of this kernel -- at 2 us for the ticket + 12 us for the stage against 1.8 us of launch boundary +
+//     6 us as a kernel: every agent-scope round trip inside a running kernel costs ~2 us here.  profiles/r06_notes.md.)
 //
 // Every wait on another workgroup is bounded by the wall clock: on a timeout (a grid that is not co-resident because something else
-// holds CUs) the kernel raises an abort flag, every workgroup leaves, the unfinished slabs get status 2 and NOTHING is written to their
-// result vectors; the host side (pipeline.KeffPlan.fetch, core.Contour2D.keff) then repeats those calls on the two-pass path.
-// The synchronisation records and accumulators live in two sets: launch n works in set n % 2 and clears the other one.
+// holds CUs) the kernel raises an abort flag and every workgroup leaves; k_finalize sees the flag, writes status 2 for every slab of the
+// call and NOTHING to their result vectors; the host side (pipeline.KeffPlan.fetch) then repeats the call on the two-pass path.
+// The slots and accumulators live in two sets: launch n works in set n % 2 and clears the other one.
 #include "xc_internal.h"
 #include <stdlib.h>
 #include <string.h>
@@ -35,7 +36,6 @@ namespace xc {
 namespace {
 
 #include "xc_binning.h"
-#include "xc_finalize.h"
 
 #ifndef XC_S_WPE
 #define XC_S_WPE 3
@@ -94,7 +94,7 @@ void k_keff_single(const SingleArgs a)
     const int cshift = __builtin_ctz((unsigned)ncopy);
     const int epad = (N + 2) & ~1;
     double*   s_red   = smem;                                  // [0 .. 2 NW): wave pairs; [32], [33]: the slab's pair
-    int*      s_flag  = reinterpret_cast<int*>(smem + 48);     // [0] the wait succeeded, [1] this workgroup drew the last ticket
+    int*      s_flag  = reinterpret_cast<int*>(smem + 48);     // [0] the wait succeeded
     double*   s_edges = smem + 64;                             // N + 1
     double*   s_cell  = s_edges + epad;                        // [(N + 1) * ncopy][CW]; bin N is the trash bin
     const int hsz = (N + 1) * ncopy;
@@ -102,8 +102,11 @@ void k_keff_single(const SingleArgs a)
     const int ny = (int)a.ny, nx = (int)a.nx;
     const int rank = (int)blockIdx.x;
     const int gw = rank * NW + wave;                           // wave index inside the grid
-    const int strip = gw / a.cps, chunk = gw - strip * a.cps;
-    const bool work = strip < a.nstrip;
+    // wave -> (strip, chunk).  strip_fast: the waves of a workgroup take ADJACENT strips of the same rows (12 KB contiguous per row and
+    // workgroup); otherwise consecutive chunks of one strip (halo rows shared inside the workgroup)
+    const int strip = a.strip_fast ? gw % a.nstrip : gw / a.cps;
+    const int chunk = a.strip_fast ? gw / a.nstrip : gw - strip * a.cps;
+    const bool work = a.strip_fast ? chunk < a.cps : strip < a.nstrip;
     const int r0 = work ? chunk * a.rpc : 0;
     const int nrows = work ? ((a.rpc < ny - r0) ? a.rpc : ny - r0) : 0;       // host: cps = ceil(ny / rpc) -> >= 1
     const int x0 = (work ? strip : 0) * PCOLS;
@@ -118,6 +121,7 @@ void k_keff_single(const SingleArgs a)
 #pragma unroll
     for (int c = 0; c < 2; ++c) cv[c] = work && lane >= 1 && lane <= 62 && col0 + c < nx;
     const int copy = lane & (ncopy - 1);
+    const unsigned cstride = (unsigned)(CW * 8) << cshift, cbase = (unsigned)copy * (unsigned)(CW * 8);
     const size_t rowq = (size_t)nx * sizeof(TQ), rowd = (size_t)nx * 8;
     const size_t slabq = (size_t)ny * rowq, slabd = (size_t)ny * rowd;
     // slab-invariant per-row quantities, lane-distributed (lane i <-> chunk row i): gradient metrics, per-row weights
@@ -142,8 +146,15 @@ void k_keff_single(const SingleArgs a)
 #pragma unroll
         for (int t = 0; t < PT; ++t)                           // rows past the chunk: duplicates of its last halo row
             Ld2<TQ>::ld(q0 + (unsigned)srow(t < nrw + 1 ? t : nrw + 1) * (unsigned)rowq, voff_q, T[t]);
+    };
+    // the first DR rows of the weights: requested once the tile has LANDED (behind the min/max), not with it -- the tile is what the
+    // whole grid waits for, the weights are not needed before step B, and 20 MB of them in front of the slowest workgroup's tile rows
+    // moved the end of every workgroup's wait by ~3 us
+    auto load_weights = [&](int sl) {
         if (DA2D) {
             const char* d0 = reinterpret_cast<const char*>(a.dA) + (a.dA_rank == XC_DA_SLAB ? (size_t)sl * slabd : 0);
+            int nrw = nrows;
+            asm volatile("" : "+s"(nrw));
 #pragma unroll
             for (int j = 0; j < DR; ++j)                       // weights of chunk rows 1 .. DR
                 Ld2<double>::ld(d0 + (unsigned)srow(j + 1 < nrw ? j + 1 : nrw) * (unsigned)rowd, voff_d, dAb[j]);
@@ -155,21 +166,18 @@ void k_keff_single(const SingleArgs a)
     {
         const unsigned gt = (unsigned)blockIdx.x * NT + (unsigned)tid, gn = gridDim.x * NT;
         unsigned long long* o = reinterpret_cast<unsigned long long*>(a.other);
-        constexpr unsigned nsync = (unsigned)((sizeof(SingleSlabSync) * kSingleMaxSlabs + 64) / 8);      // (the slots, the tickets, the abort flag)
+        constexpr unsigned nsync = (unsigned)((sizeof(SingleSlot) * kSingleMaxSlabs * kSingleMaxGrid + 64) / 8);      // (the slots, the abort flag)
         for (unsigned w = gt; w < nsync; w += gn) o[w] = 0ull;
         const unsigned nd = (unsigned)a.other_dirty_bins * kSingleMaxSlabs;      // (the launch that dirtied it may have used another N)
         for (unsigned w = gt; w < 2 * nd; w += gn) a.other->acc_h[w] = 0.0;
         for (unsigned w = gt; w < nd; w += gn) a.other->acc_c[w] = 0ull;
     }
 
-    unsigned mine = 0u;                                        // bit s: this workgroup drew the last ticket of slab s (wave-uniform)
-    bool aborted = false;
-    int s = 0;
-    for (; s < a.nslab; ++s) {
+    for (int s = 0; s < a.nslab; ++s) {
         // opaque per slab: what the rows derive from these (18 pairs of metrics by v_readlane, ...) is NOT hoisted out of the slab
         // loop and kept alive across it (it was: 240 VGPRs wanted, 168 available)
         asm volatile("" : "+v"(rdxv), "+v"(rdyv), "+v"(dArv));
-        // the whole tile (and the first weights) requested at once.  (Loaded HERE, at the top of the slab's iteration, and not ahead of
+        // the whole tile requested at once.  (Loaded HERE, at the top of the slab's iteration, and not ahead of
         // the previous slab's flush: a tile that is alive across the loop's back edge costs a second set of 80 registers in copies.)
         load_tile(s);
         int tz = tid;
@@ -184,19 +192,21 @@ void k_keff_single(const SingleArgs a)
         }
         for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
         if (lane == 0) { s_red[2 * wave] = mn; s_red[2 * wave + 1] = mx; }
+        asm volatile("" : "+v"(mn), "+v"(mx) :: "memory");      // the weights are requested BEHIND the tile's last use above, not hoisted in front of it
+        load_weights(s);
         __syncthreads();
         stamp(s, 1);
         // ALL-GATHER of the workgroups' pairs: every workgroup writes its own 16-byte slot (two write-through stores, nothing to wait
         // for) and one wave polls ALL slots until none is empty (~key(min) and key(max) are never zero; zero = "not there yet") -- one
         // round trip after the last arrival, where counters (atomic max x 2, wait, count, poll the counts, then read the pair) took
-        // four.  G <= 320 slots = 5 KB; lane l watches slots l, l + 64, ...
-        SingleSlabSync* rec = &a.cur->sync[s];
+        // four.  G <= 256 slots = 4 KB; lane l watches slots l, l + 64, ...
+        SingleSlot* slots = a.cur->slot[s];
         if (wave == 0) {
             double bmn = (lane < NW) ? s_red[2 * lane] : dinf(), bmx = (lane < NW) ? s_red[2 * lane + 1] : -dinf();
             for (int o = 8; o > 0; o >>= 1) { bmn = fmin(bmn, __shfl_xor(bmn, o)); bmx = fmax(bmx, __shfl_xor(bmx, o)); }
             if (lane == 0) {
-                __hip_atomic_store(&rec->slot[rank].kmn, ~dkey(bmn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&rec->slot[rank].kmx, dkey(bmx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slots[rank].kmn, ~dkey(bmn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slots[rank].kmx, dkey(bmx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             stamp(s, 2);
             const unsigned long long t0 = wall_clock64();
@@ -208,8 +218,8 @@ void k_keff_single(const SingleArgs a)
 #pragma unroll
                 for (int j = 0; j < SPL; ++j) {                // every load of the sweep in flight together
                     const int i = lane + 64 * j, ic = i < a.G ? i : 0;
-                    vn[j] = __hip_atomic_load(&rec->slot[ic].kmn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vx[j] = __hip_atomic_load(&rec->slot[ic].kmx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vn[j] = __hip_atomic_load(&slots[ic].kmn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vx[j] = __hip_atomic_load(&slots[ic].kmx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const unsigned ab = __hip_atomic_load(&a.cur->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bool full = true;
@@ -230,7 +240,7 @@ void k_keff_single(const SingleArgs a)
                     const unsigned long long an = __shfl_xor(kmn, o), ax = __shfl_xor(kmx, o);
                     kmn = an > kmn ? an : kmn; kmx = ax > kmx ? ax : kmx;
                 }
-                if (lane == 0) { s_red[32] = dunkey(~kmn); s_red[33] = dunkey(kmx); s_red[34 + 2 * s] = s_red[32]; s_red[35 + 2 * s] = s_red[33]; }
+                if (lane == 0) { s_red[32] = dunkey(~kmn); s_red[33] = dunkey(kmx); }
             } else if (lane == 0) {
                 __hip_atomic_store(&a.cur->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -238,7 +248,7 @@ void k_keff_single(const SingleArgs a)
         }
         __syncthreads();
         stamp(s, 3);
-        if (!__builtin_amdgcn_readfirstlane(s_flag[0])) { aborted = true; break; }     // (readfirstlane: the loop exit is UNIFORM, and so stays `s`)
+        if (!__builtin_amdgcn_readfirstlane(s_flag[0])) return;       // gave up (the abort flag is up: k_finalize reports status 2); uniform
         double gmn = uniform_d(s_red[32]), gmx = uniform_d(s_red[33]);
         if (gmn == dinf() && gmx == -dinf()) { gmn = dnan(); gmx = dnan(); }      // all-NaN slab
         // ------------------------------------------------------------ levels / edges, exactly as the two-pass prologue;
@@ -248,19 +258,26 @@ void k_keff_single(const SingleArgs a)
         const double lo = a.increase ? c_first : c_last, hi = a.increase ? c_last : c_first;
         const double e0 = uniform_d(dummy_edge(lo, hi, N, a.ctr_f32));
         const double eN = uniform_d(a.right_edge == XC_EDGE_XHISTOGRAM ? bump_last_edge(hi, a.ctr_f32) : hi);
-        const double hstep = uniform_d((eN - e0) / (double)N);
+        // (the spacing test and the bin guess take approximate quotients: both are tolerances around decisions that are made exactly)
+        const double hstep = uniform_d((eN - e0) * a.inv_n);
         int bad = 0;
         for (int k = tid; k < N; k += NT) {
             const double c = level_value(gmn, gmx, k, a.increase, a.q_f32, a.ctr_f32, a.inv_nm1);
             const int idx = a.increase ? k + 1 : N - k;
             const double e = (idx == N) ? eN : c;
             s_edges[idx] = e;
+            if (rank == 0 && a.ctr_out) a.ctr_out[(size_t)s * a.ctr_stride + k] = c;
+            if (k >= 1) bad |= (c == level_value(gmn, gmx, k - 1, a.increase, a.q_f32, a.ctr_f32, a.inv_nm1)) << 1;   // 'non monotonic bins', core.py:1233
             // equally spaced to a quarter of a bin?  (then ONE comparison against the nearest edge is exact)
             bad |= !(fabs(e - (e0 + (double)idx * hstep)) <= 0.25 * hstep);
         }
         if (tid == 0) s_edges[0] = e0;
-        const bool uni = !__syncthreads_or(bad);
-        const double inv = uniform_d((double)N / (eN - e0));   // the guess only: exactness comes from the comparison
+        const bool uni = !__syncthreads_or(bad & 1);           // (__syncthreads_or returns a truth value, not the OR of the words)
+        if (rank == 0 && a.status) {                           // (a workgroup-uniform branch: the barrier inside is reached by all of rank 0)
+            const int degenerate = __syncthreads_or(bad & 2);
+            if (tid == 0) a.status[s] = degenerate ? 1 : 0;
+        }
+        const double inv = uniform_d((double)N * __builtin_amdgcn_rcp(eN - e0));   // the guess only: exactness comes from the comparison
         stamp(s, 4);
 
         const char* dcur = reinterpret_cast<const char*>(a.dA) + (a.dA_rank == XC_DA_SLAB ? (size_t)s * slabd : 0);
@@ -281,7 +298,8 @@ void k_keff_single(const SingleArgs a)
             const double p = __dmul_rn(g2, dv);
             const double w0 = wpos ? dv : ((dv != dv) ? 0.0 : dv);     // fillna(0), core.py:449
             const double w1 = wpos ? fmax(p, 0.0) : ((p != p) ? 0.0 : p);
-            double* cp = s_cell + ((ku << cshift) + (unsigned)copy) * (unsigned)CW;
+            // byte offset of the cell = ku * (24 ncopy) + copy * 24: ONE full-rate v_mad_u32_u24 (ku <= N, the stride < 2^24)
+            double* cp = reinterpret_cast<double*>(reinterpret_cast<char*>(s_cell) + (__umul24(ku, cstride) + cbase));
             lds_add(cp, w0);
             lds_add(cp + 1, w1);
             if (want_cnt) lds_add(reinterpret_cast<unsigned*>(cp + 2), 1u);
@@ -353,7 +371,8 @@ void k_keff_single(const SingleArgs a)
 #endif
         stamp(s, 5);
         __syncthreads();
-        // ------------------------------------------------------------ C: the workgroup's sums -> the slab's accumulators; a ticket
+        stamp(s, 7);
+        // ------------------------------------------------------------ C: the workgroup's sums -> the slab's accumulators (k_finalize reads them)
         {
             int tf = tid;
             asm volatile("" : "+v"(tf));
@@ -362,63 +381,21 @@ void k_keff_single(const SingleArgs a)
                 const int ch = i / N, bn = i - ch * N;
                 const double* src = s_cell + (size_t)bn * ncopy * CW + ch;
                 double sum = 0.0;
-#pragma nounroll
+#pragma unroll 8
                 for (int c = 0; c < ncopy; ++c) sum += src[(size_t)((c + tf) & (ncopy - 1)) * CW];
                 if (sum != 0.0) __hip_atomic_fetch_add(ah + i, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (want_cnt)
                 for (int bn = tf; bn < N; bn += NT) {
                     unsigned sum = 0u;
-#pragma nounroll
+#pragma unroll 8
                     for (int c = 0; c < ncopy; ++c)
                         sum += *reinterpret_cast<const unsigned*>(s_cell + (size_t)(bn * ncopy + ((c + tf) & (ncopy - 1))) * CW + 2);
                     if (sum) __hip_atomic_fetch_add(a.cur->acc_c + (size_t)s * N + bn, (unsigned long long)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's adds are performed ...
-        __syncthreads();                                       // ... and everybody's, before the workgroup is counted
-        if (tid == 0) {
-            int last = 0;
-            const unsigned o1 = __hip_atomic_fetch_add(&rec->shard[rank & 7].done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (o1 == (unsigned)(a.G >> 3) - 1u) {
-                const unsigned o2 = __hip_atomic_fetch_add(&rec->top_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = o2 == 7u;
-            }
-            s_flag[1] = last;
-        }
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(s_flag[1])) mine |= 1u << s;
         stamp(s, 6);
-    }
-    if (aborted) {
-        if (tid == 0 && a.status)
-            for (int t = 0; t < a.nslab; ++t) a.status[t] = 2;      // nothing is finalized before the end: the host repeats the call on the two-pass path
-        return;
-    }
-    // ---------------------------------------------------------------- the finalize stage, by whoever drew a slab's last ticket
-    mine = (unsigned)__builtin_amdgcn_readfirstlane((int)mine);
-    for (int t = 0; t < a.nslab; ++t) {
-        if (!((mine >> t) & 1u)) continue;
-        __syncthreads();
-        double gmn = uniform_d(s_red[34 + 2 * t]), gmx = uniform_d(s_red[35 + 2 * t]);     // the slab's pair, kept from step A
-        if (gmn == dinf() && gmx == -dinf()) { gmn = dnan(); gmx = dnan(); }
-        __syncthreads();                                       // (s_ctr below overlaps nothing of s_red, but the edges: everybody is past them)
-        stamp(t, 7);
-        double* s_ctr = smem + 64;                             // the levels in level order, for the epilogue and for the caller
-        int bad = 0;
-        for (int k = tid; k < N; k += NT) {
-            const double c = level_value(gmn, gmx, k, a.increase, a.q_f32, a.ctr_f32, a.inv_nm1);
-            s_ctr[k] = c;
-            if (a.ctr_out) a.ctr_out[(size_t)t * a.ctr_stride + k] = c;
-            if (k >= 1) bad |= (c == level_value(gmn, gmx, k - 1, a.increase, a.q_f32, a.ctr_f32, a.inv_nm1));   // 'non monotonic bins', core.py:1233
-        }
-        bad = __syncthreads_or(bad);
-        if (tid == 0 && a.status) a.status[t] = bad ? 1 : 0;
-#ifndef XC_S_NOFIN
-        finalize_body<true>(a.fin, t, tid, NT, smem + 64 + epad, s_ctr,
-                            a.stamps ? a.stamps + ((size_t)t * gridDim.x + blockIdx.x) * kSingleStampSlots + 8 : nullptr);
-#endif
-        stamp(t, 13);
+        if (s + 1 < a.nslab) __syncthreads();                  // (the next slab zeroes the LDS copies)
     }
 }
 
@@ -444,7 +421,7 @@ int launch_s2(xc_ctx* ctx, const SingleArgs& a, const SingleGeom& g, bool da2d, 
 // Decomposition of a (ny, nx) slab over the chip; false when the shape does not suit the single-read kernel (the caller then takes
 // the two-pass path).
 bool single_geometry(const xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int N, const void* q, const double* dA,
-                     int dA_rank, int ntbl, SingleGeom* g)
+                     int dA_rank, SingleGeom* g)
 {
     const int cus = ctx->cus;
     if (nslab < 1 || nslab > kSingleMaxSlabs || N > kSingleMaxBins || N < 2) return false;
@@ -472,12 +449,7 @@ bool single_geometry(const xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, 
     const size_t fixed = (64 + ((N + 2) & ~1)) * sizeof(double);
     while (ncopy > 2 && fixed + (size_t)(N + 1) * ncopy * CW * 8 > kLdsBudget) ncopy >>= 1;
     if (fixed + (size_t)(N + 1) * ncopy * CW * 8 > kLdsBudget) return false;
-    size_t lds = fixed + (size_t)(N + 1) * ncopy * CW * 8;
-    size_t fin = fixed + ((size_t)2 * 2 * N + 7 * (size_t)N) * sizeof(double);
-    g->fin_tbl_in_lds = 0;
-    if (fin + (size_t)2 * ntbl * sizeof(double) <= 64 * 1024) { g->fin_tbl_in_lds = 1; fin += (size_t)2 * ntbl * sizeof(double); }
-    if (fin > kLdsBudget) return false;
-    if (fin > lds) lds = fin;
+    const size_t lds = fixed + (size_t)(N + 1) * ncopy * CW * 8;
     g->G = G; g->nstrip = nstrip; g->cps = cps; g->rpc = rpc; g->ncopy = ncopy;
     g->lds = (lds + 15) & ~(size_t)15;
     return true;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(1024)
 void k_finalize(const FinalArgs a)
 {
     extern __shared__ __align__(16) double sm_lds[];
-    finalize_body<false>(a, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, sm_lds, nullptr);
+    finalize_body(a, (int)blockIdx.x, (int)threadIdx.x, (int)blockDim.x, sm_lds);
 }
 
 // =====================================================================================
@@ -351,7 +351,8 @@ int launch_finalize(xc_ctx* ctx, int64_t nslab, const FinalArgs& a_in)
                            a.red_h, a.red_c);
         XC_HIP(ctx, hipGetLastError());
     }
-    int nthr = (a.keff && a.o_interp && a.npre > 256) ? 1024 : 256;
+    // (the Keff epilogue runs its two chains per contour in the two halves of the workgroup: 512 threads for up to 256 contours)
+    int nthr = (a.keff && a.o_interp && a.npre > 256) ? 1024 : (a.keff ? 512 : 256);
     if (a.fuse_reduce) {                 // one thread per partial sum to reduce: all loads of the reduction in flight at once
         const int want = ((nvh + (a.counts ? a.nbin : 0) + 63) / 64) * 64;
         nthr = want > 1024 ? 1024 : (want > nthr ? want : nthr);
