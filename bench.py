@@ -495,11 +495,15 @@ class Gather(object):
         ctx.compute_wait_comm()
         if deadline is None:
             ctx.sync()
-        elif not ctx.sync_within(deadline):
-            return False
-        if self.carrier == 'ipc':
-            g.barrier()                                                # the root learns that every rank's pushes have landed
-        return True
+            if self.carrier == 'ipc':
+                g.barrier()                                            # the root learns that every rank's pushes have landed
+            return True
+        # a trial: this rank's verdict goes to EVERY rank in ONE exchange that every rank reaches whatever its own outcome (round-5
+        # advisor: a rank that timed out used to skip the barrier below and the collective free_block, and its next frame -- the
+        # 'why' string -- met the others' barrier frames: garbage verdicts or a hang until the socket timeout).  The exchange is also
+        # the IPC carrier's "every push has landed" barrier.  The same answer on all ranks: all go on, or all take the abort path.
+        mine = ctx.sync_within(deadline)
+        return all(p == b'1' for p in g.allgather_bytes(b'1' if mine else b'0'))
 
     def fetch(self, rb):
         """root: the gathered bytes on the host, (world, stride) uint8 (outside every timed region)"""
@@ -905,21 +909,29 @@ def main():
         ctx.sync()
 
     stage('timed')
+    es0, es1 = ctx.event(), ctx.event()                           # this rank's own sweep: HIP events around its K steps
     group.barrier()
     ctx.sync()
     t0 = time.perf_counter()
+    ctx.record(es0)
     for k in range(K):
         if grp == B:
             ctx.set_hist_events(ev[k][0], ev[k][1])               # events around the K3 launch only
         step(k, k)
         if world > 1:
             gather.push(rb, res.ptr + k * slot, slot, k * slot)   # this step's vectors leave for rank 0 on the comm stream while the next step computes
+    ctx.record(es1)
     if world > 1:
         gather.finish(rb)                                         # the one collective of the job ends here: only the last step's piece is exposed
     ctx.sync()                                                    # the library's own HIP streams (every kernel and the gather run on them)
+    t_mine = time.perf_counter() - t0
     group.barrier()
     t1 = time.perf_counter()
     el = group.allreduce_max(t1 - t0)
+    # what every rank saw, for the line: its sweep (events), its own wall clock up to the end of its part of the gather, and what RCCL
+    # ITSELF reports about the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) -- the proof of "N ranks on N devices"
+    mine_info = {'rank': rank, 'sweep_ms': ctx.elapsed_ms(es0, es1), 'wall_ms': t_mine * 1e3, 'device': ctx.device, 'comm': ctx.comm_info()}
+    per_rank = [json.loads(p.decode()) for p in group.allgather_bytes(json.dumps(mine_info).encode())]
     stage('checks')
     if world > 1 and rank == 0:
         # every rank's block arrived, in rank order, and rank r's slabs differ from rank 0's (seed + r*2B + s)
@@ -949,7 +961,12 @@ def main():
                        'carrier_trials': gather.trials if world > 1 else None, 'preflight': pre,
                        'launcher': ('bench.py itself (one child process per rank)' if os.environ.get('XC_BENCH_LAUNCHED') else 'external (RANK / WORLD_SIZE from the environment)') if world > 1 else 'none',
                        'collective_note': gather.note,
+                       'rccl': rccl_block(per_rank, gather.carrier if world > 1 else None),
                        'host_code': 'python + ctypes, no torch', 'device': ctx.device_name()},
+            'per_rank': {'sweep_ms': [float(x['sweep_ms']) for x in per_rank], 'wall_ms': [float(x['wall_ms']) for x in per_rank],
+                         'device': [int(x['device']) for x in per_rank],
+                         'note': 'sweep_ms: HIP events around the rank\'s own K steps; wall_ms: its host clock from the common barrier to the end '
+                                 'of its part of the gather; value uses the MAX over ranks of the barrier-to-barrier time'},
         }
         cells = B * NY * NX
         alg = cells * (qdt.itemsize if a.row_dA else bpc)              # tracer once + dA once per slab
@@ -1128,6 +1145,22 @@ def main():
         os._exit(0)
     ctx.close()
     group.close()
+
+
+def rccl_block(per_rank, carrier):
+    """`config.rccl` of the line: what RCCL itself reported on every rank (xc_comm_info: ncclCommCount, ncclCommUserRank,
+    ncclCommCuDevice, ncclGetVersion, the file librccl came from).  None when the job's gather did not run on RCCL (one rank, or
+    another carrier of the ladder: `config.parallelism` / `carrier_trials` say which and why)."""
+    infos = [x['comm'] for x in per_rank]
+    if carrier != 'rccl' or not any(i['comm_count'] for i in infos):
+        return None
+    return {'comm_count': [int(i['comm_count']) for i in infos],            # ncclCommCount as EVERY rank's communicator reports it
+            'comm_rank': [int(i['comm_rank']) for i in infos],              # ncclCommUserRank: must read 0 .. N-1
+            'rank_devices': [int(i['comm_device']) for i in infos],         # ncclCommCuDevice: the HIP device each rank's communicator drives
+            'ctx_devices': [int(i['ctx_device']) for i in infos],
+            'librccl': infos[0]['rccl_path'], 'version': int(infos[0]['rccl_version']),
+            'consistent': bool(all(int(i['comm_count']) == len(infos) for i in infos) and
+                               sorted(int(i['comm_rank']) for i in infos) == list(range(len(infos))))}
 
 
 def baro_slabs(nslab, dtype, seed=0):

@@ -426,6 +426,22 @@ int xc_set_hist_events(xc_ctx* ctx, void* start_event, void* stop_event);
  * bytes_per_rank bytes, `recv` nranks * bytes_per_rank (device pointers).                 */
 int xc_comm_unique_id(xc_ctx* ctx, void* out_id128);
 int xc_comm_init(xc_ctx* ctx, int nranks, int rank, const void* id128);
+/* The same in two steps, for callers that put a deadline on the first contact with RCCL: ncclCommInitRank blocks until every rank has
+ * joined, so it runs in a helper thread -- xc_comm_create touches NO context (device: the HIP device of the rank; err: the failure text),
+ * xc_comm_attach hands the finished communicator to a context from the thread that owns it, xc_comm_release disposes of one that was
+ * never attached (its creator stopped waiting). */
+int xc_comm_create(int device, int nranks, int rank, const void* id128, void** out_comm, char* err, size_t errlen);
+int xc_comm_attach(xc_ctx* ctx, void* comm, int nranks, int rank);
+int xc_comm_release(void* comm);
+/* What RCCL itself reports about the context's communicator (ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion, the
+ * file librccl was loaded from): the evidence that a multi-GPU job's collective really spanned N ranks on N devices.
+ * comm_count = 0: no RCCL communicator on this context (the gather runs on another carrier). */
+typedef struct xc_comm_info_t {
+    int32_t comm_count, comm_rank, comm_device, ctx_device;
+    int32_t rccl_version, reserved0;
+    char    rccl_path[256];
+} xc_comm_info_t;
+int xc_comm_info(xc_ctx* ctx, xc_comm_info_t* out);
 int xc_comm_allgather_dev(xc_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
 int xc_comm_finalize(xc_ctx* ctx);
 /* Gather to ONE root (north_star: "RCCL gather"; SURVEY 8e "or gather-to-root"): every rank's `bytes` at `send` arrive at

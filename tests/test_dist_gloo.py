@@ -349,21 +349,37 @@ class _FakeCtx(object):
     """stands in for a device context: the unique id is 128 bytes, comm_init fails on the ranks named in `bad`"""
 
     def __init__(self, rank, bad):
-        self.rank, self.bad, self.inited, self.finalized = rank, bad, None, False
+        self.rank, self.bad, self.inited, self.finalized, self.released = rank, bad, None, False, None
 
     def comm_unique_id(self):
         if 'id' in self.bad:
             raise RuntimeError('cannot load librccl')
         return bytes(range(128))
 
-    def comm_init(self, world, rank, uid):
+    def comm_create(self, world, rank, uid):
+        """the helper thread's half (xc_comm_create touches no context): must not write to this object"""
+        import threading
+        assert threading.current_thread().name == 'xc-comm-init'
         assert len(uid) == 128 and uid == bytes(range(128)) and rank == self.rank
         if ('hang', rank) in self.bad:
             import time
             time.sleep(600)                       # a bootstrap that waits for a rank that never comes
+        if ('late', rank) in self.bad:
+            import time
+            time.sleep(5.0)                       # returns AFTER the deadline: its communicator must be released, never attached
         if rank in self.bad:
             raise RuntimeError('ncclCommInitRank: invalid usage (duplicate GPU)')
+        return ('comm', world, rank)
+
+    def comm_attach(self, comm, world, rank):
+        """the main thread's half"""
+        import threading
+        assert threading.current_thread() is threading.main_thread()
+        assert comm == ('comm', world, rank)
         self.inited = (world, rank)
+
+    def comm_release(self, comm):
+        self.released = comm
 
     def comm_finalize(self):
         self.finalized = True
@@ -410,6 +426,43 @@ def test_init_device_reaches_a_consensus(bad):
         msgs = set(got[r][1] for r in range(world))
         assert len(msgs) == 1                                                            # the same verdict everywhere
         assert ('librccl' in got[0][1]) if 'id' in bad else all(('rank %d' % b) in got[0][1] for b in bad)
+
+
+def _late_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import time
+    from xcontour_amd.distributed import SocketGroup
+    g = SocketGroup(rank, world, '127.0.0.1', port, token='t')
+    ctx = _FakeCtx(rank, (('late', 1),))
+    try:
+        g.init_device(ctx, timeout=2.0)
+        out = 'ok'
+    except Exception as e:
+        out = str(e)
+    time.sleep(5.0)                               # the late call comes back meanwhile
+    q.put((rank, out, ctx.inited, ctx.released, len(g.stuck)))
+    g.barrier()
+    g.close()
+
+
+def test_a_communicator_that_arrives_after_the_deadline_is_released_not_attached():
+    """(round-5 advisor) ncclCommInitRank returning AFTER init_device gave up must not write into the context the main thread keeps
+    using: the helper thread only creates (xc_comm_create), the main thread attaches -- or, past the deadline, marks the call
+    abandoned, and the late communicator is released by the helper itself"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_late_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=60) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert 'did not return' in got[1][0] and got[0][0] == got[1][0]                 # the same verdict on both ranks
+    assert got[1][1] is None and got[1][2] == ('comm', 2, 1) and got[1][3] == 1     # never attached; released by the helper; thread on record
+    assert got[0][1] == (2, 0) and got[0][3] == 0                                     # rank 0's own call returned in time (attached; finalised by the failed consensus)
 
 
 def test_init_device_has_a_deadline():

@@ -353,13 +353,35 @@ def test_deterministic_hist_channels_and_odd_inputs(ctx):
 
 
 def test_deterministic_infinite_weight_reports_nan(ctx):
+    """an infinite weight makes ITS bin report NaN and leaves every other bin alone -- bit for bit the oracle's sums (round-5 advisor:
+    the bound that positions the accumulator window came from extrema that kept +-inf, the window then sat at 2^1037 and every finite
+    weight fell out of it: the other bins summed to 0.0, which `isfinite` did not notice).  The same for an infinite cell in a supplied
+    integrand, for -inf, and for a weight array with no finite value at all."""
+    rng = np.random.default_rng(3)
     q = np.linspace(0.05, 0.95, 64 * 128).reshape(1, 64, 128)
-    dA = np.ones((64, 128)); dA[10, 7] = np.inf
     edges = np.linspace(0, 1, 11)
-    a = ctx.hist(q, edges, dA=dA, deterministic=True, last_closed=False, want=('pdf', 'counts'))
-    k = int(np.digitize(q[0, 10, 7], edges) - 1)
-    assert np.isnan(a['pdf'][0, 0, k]) and np.isfinite(np.delete(a['pdf'][0, 0], k)).all()
-    assert a['counts'].sum() == 64 * 128
+    base = 0.5 + rng.random((64, 128))
+    for sign in (1.0, -1.0):
+        dA = base.copy(); dA[10, 7] = sign * np.inf
+        a = ctx.hist(q, edges, dA=dA, deterministic=True, last_closed=False, want=('pdf', 'counts'))
+        k = int(np.digitize(q[0, 10, 7], edges) - 1)
+        od, _ = O.weighted_histogram(q[0], edges, dA, 'xhistogram', deterministic=True)
+        assert np.isnan(a['pdf'][0, 0, k]) and np.isnan(od[k])
+        keep = np.arange(10) != k
+        assert (a['pdf'][0, 0][keep] > 0).all() and np.array_equal(bits(a['pdf'][0, 0][keep]), bits(od[keep]))
+        assert a['counts'].sum() == 64 * 128
+    # an infinite cell in a supplied integrand: its bin of THAT channel is NaN, the area channel and the other bins are the oracle's bits
+    g = rng.standard_normal((1, 64, 128)); g[0, 33, 100] = np.inf
+    a = ctx.hist(q, edges, dA=base, integrands=[g], deterministic=True, last_closed=False, want=('pdf',))
+    k = int(np.digitize(q[0, 33, 100], edges) - 1)
+    o0, _ = O.weighted_histogram(q[0], edges, base, 'xhistogram', deterministic=True)
+    o1, _ = O.weighted_histogram(q[0], edges, g[0] * base, 'xhistogram', deterministic=True)
+    assert np.array_equal(bits(a['pdf'][0, 0]), bits(o0))
+    keep = np.arange(10) != k
+    assert np.isnan(a['pdf'][0, 1, k]) and np.array_equal(bits(a['pdf'][0, 1][keep]), bits(o1[keep])) and (a['pdf'][0, 1][keep] != 0).all()
+    # no finite weight at all: every bin that holds a cell reports NaN, nothing crashes
+    a = ctx.hist(q, edges, dA=np.full((64, 128), np.inf), deterministic=True, last_closed=False, want=('pdf',))
+    assert np.isnan(a['pdf'][0, 0][1:10]).all()
 
 
 def test_cfg2_full_size_deterministic(ctx):

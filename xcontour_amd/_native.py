@@ -47,6 +47,12 @@ class HistDesc(C.Structure):
     ]
 
 
+class CommInfo(C.Structure):
+    """struct xc_comm_info_t (include/xcontour_hip.h)"""
+    _fields_ = [('comm_count', _i32), ('comm_rank', _i32), ('comm_device', _i32), ('ctx_device', _i32),
+                ('rccl_version', _i32), ('reserved0', _i32), ('rccl_path', C.c_char * 256)]
+
+
 class KeffDesc(C.Structure):
     """struct xc_keff_desc (include/xcontour_hip.h)"""
     _fields_ = [
@@ -139,6 +145,10 @@ PROTOTYPES = {
     'xc_set_hist_events': (C.c_int, [_vp, _vp, _vp]),
     'xc_comm_unique_id': (C.c_int, [_vp, _vp]),
     'xc_comm_init': (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    'xc_comm_create': (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp), C.c_char_p, C.c_size_t]),
+    'xc_comm_attach': (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    'xc_comm_release': (C.c_int, [_vp]),
+    'xc_comm_info': (C.c_int, [_vp, _vp]),
     'xc_comm_allgather_dev': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     'xc_comm_finalize': (C.c_int, [_vp]),
     'xc_comm_gather_dev': (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int]),
@@ -289,6 +299,15 @@ class Context(object):
 
     def close(self):
         if getattr(self, 'handle', None):
+            # the per-upload events (in flight and recycled): wait for the copy stream, then destroy them (round-5 advisor: they leaked)
+            try:
+                self.lib.xc_stream_wait_copies(self.handle)
+                self.lib.xc_sync(self.handle)
+            except Exception:
+                pass
+            for ev in [e for _, e in self._staged] + list(self._ev_pool):
+                self.lib.xc_event_destroy(self.handle, ev)
+            self._staged, self._ev_pool = [], []
             for b in list(self._buffers):
                 b.free()
             self.lib.xc_destroy(self.handle)
@@ -427,6 +446,30 @@ class Context(object):
     def comm_init(self, nranks, rank, uid):
         assert len(uid) == 128
         self._check(self.lib.xc_comm_init(self.handle, int(nranks), int(rank), C.create_string_buffer(uid, 128)))
+
+    def comm_create(self, nranks, rank, uid):
+        """ncclCommInitRank WITHOUT touching this context (safe in a helper thread under a deadline): returns the communicator handle
+        for `comm_attach`, raises with RCCL's text otherwise"""
+        assert len(uid) == 128
+        h, err = _vp(), C.create_string_buffer(512)
+        rc = self.lib.xc_comm_create(self.device, int(nranks), int(rank), C.create_string_buffer(uid, 128), C.byref(h), err, 512)
+        if rc != 0:
+            raise XContourHipError(err.value.decode('utf-8', 'replace') or 'xc_comm_create failed (%d)' % rc)
+        return h.value
+
+    def comm_attach(self, comm, nranks, rank):
+        self._check(self.lib.xc_comm_attach(self.handle, comm, int(nranks), int(rank)))
+
+    def comm_release(self, comm):
+        self.lib.xc_comm_release(comm)
+
+    def comm_info(self):
+        """what RCCL itself reports about this context's communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice /
+        ncclGetVersion + the file it was loaded from); comm_count 0: no RCCL communicator here"""
+        i = CommInfo()
+        self._check(self.lib.xc_comm_info(self.handle, C.byref(i)))
+        return {'comm_count': i.comm_count, 'comm_rank': i.comm_rank, 'comm_device': i.comm_device, 'ctx_device': i.ctx_device,
+                'rccl_version': i.rccl_version, 'rccl_path': i.rccl_path.decode('utf-8', 'replace')}
 
     def comm_allgather(self, send_ptr, recv_ptr, bytes_per_rank):
         self._check(self.lib.xc_comm_allgather_dev(self.handle, send_ptr, recv_ptr, int(bytes_per_rank)))

@@ -694,7 +694,9 @@ static int det_one_pass(xc_ctx* ctx, int q_dtype, int nint, int grad, const Hist
     char* pairs = work + al((size_t)nslab * kMinmaxBlocks * 2 * sizeof(double));
     const size_t pb = al((size_t)nslab * 2 * sizeof(double));
     auto extrema = [&](const void* p, int dtype, int64_t ns, int64_t ncell, double* out) -> int {
-        XC_TRY(launch_minmax_partial(ctx, p, dtype, ns, ncell, part));
+        // (the bounds of the accumulator windows: the largest FINITE magnitudes -- an infinite weight flags its own bin, it must not push
+        // every finite one out of the window; the oracle takes its bounds the same way)
+        XC_TRY(launch_minmax_partial(ctx, p, dtype, ns, ncell, part, nullptr, 0, true));
         return launch_minmax_final(ctx, part, ns, minmax_blocks(ncell, ns), out);
     };
     a.det_dA_max = -1.0; a.det_dA_max_dev = nullptr; a.det_dA_stride = 0;

@@ -27,12 +27,16 @@ typedef int (*fn_destroy)(Comm);
 typedef const char* (*fn_errstr)(int);
 typedef int (*fn_sendrecv)(void*, size_t, int /*ncclDataType_t*/, int /*peer*/, Comm, hipStream_t);
 typedef int (*fn_group)(void);
+typedef int (*fn_comm_int)(const Comm, int*);
+typedef int (*fn_version)(int*);
 
 struct Rccl {
     void* h = nullptr;
     fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_allgather allgather = nullptr;
     fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
     fn_sendrecv send = nullptr, recv = nullptr; fn_group group_start = nullptr, group_end = nullptr; fn_destroy abort = nullptr;
+    fn_comm_int count = nullptr, user_rank = nullptr, cu_device = nullptr; fn_version version = nullptr;
+    char path[512] = {0};          // the file the symbols came from (dladdr)
 };
 Rccl g_rccl;
 
@@ -50,6 +54,9 @@ int load_rccl(xc_ctx* ctx)
     g_rccl.send = (fn_sendrecv)dlsym(h, "ncclSend"); g_rccl.recv = (fn_sendrecv)dlsym(h, "ncclRecv");
     g_rccl.group_start = (fn_group)dlsym(h, "ncclGroupStart"); g_rccl.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
     g_rccl.abort = (fn_destroy)dlsym(h, "ncclCommAbort");
+    g_rccl.count = (fn_comm_int)dlsym(h, "ncclCommCount"); g_rccl.user_rank = (fn_comm_int)dlsym(h, "ncclCommUserRank");
+    g_rccl.cu_device = (fn_comm_int)dlsym(h, "ncclCommCuDevice"); g_rccl.version = (fn_version)dlsym(h, "ncclGetVersion");
+    { Dl_info di; if (g_rccl.get_id && dladdr((void*)g_rccl.get_id, &di) && di.dli_fname) snprintf(g_rccl.path, sizeof(g_rccl.path), "%s", di.dli_fname); }
     if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.allgather || !g_rccl.destroy)
         return fail(ctx, XC_EHIP, "xc_comm: librccl lacks a required symbol");
     g_rccl.h = h;
@@ -94,18 +101,73 @@ int xc_comm_unique_id(xc_ctx* ctx, void* out_id128)
     return XC_OK;
 }
 
+// The communicator is CREATED without touching any context (ncclCommInitRank blocks until every rank has joined -- forever, if one
+// never does -- so callers run it in a helper thread under a deadline: that thread must not write into a context the main thread
+// keeps using) and ATTACHED to a context by the thread that owns the context, once the call has returned.
+int xc_comm_create(int device, int nranks, int rank, const void* id128, void** out_comm, char* err, size_t errlen)
+{
+    auto say = [&](const std::string& m) { if (err && errlen) snprintf(err, errlen, "%s", m.c_str()); };
+    if (err && errlen) err[0] = 0;
+    if (!id128 || !out_comm || nranks < 1 || rank < 0 || rank >= nranks) { say("xc_comm_create: bad arguments"); return XC_EBADARG; }
+    *out_comm = nullptr;
+    if (!g_rccl.h) {
+        xc_ctx tmp;                                            // (load_rccl reports through a context: a throw-away one)
+        const int rc = load_rccl(&tmp);
+        if (rc != XC_OK) { say(tmp.err); return rc; }
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { say(std::string("hipSetDevice: ") + hipGetErrorString(e)); return XC_EHIP; }
+    UniqueId id; memcpy(&id, id128, sizeof(id));
+    Comm c = nullptr;
+    const int r = g_rccl.init_rank(&c, nranks, id, rank);
+    if (r != 0) { say(std::string("RCCL error in ncclCommInitRank: ") + (g_rccl.errstr ? g_rccl.errstr(r) : "?")); return XC_EHIP; }
+    *out_comm = c;
+    return XC_OK;
+}
+
+int xc_comm_attach(xc_ctx* ctx, void* comm, int nranks, int rank)
+{
+    if (!ctx || !comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, XC_EBADARG, "xc_comm_attach: bad arguments");
+    if (ctx->comm) return fail(ctx, XC_EBADARG, "xc_comm_attach: the context already has a communicator");
+    ctx->comm = comm; ctx->comm_nranks = nranks; ctx->comm_rank = rank;
+    return XC_OK;
+}
+
+int xc_comm_release(void* comm)                       // a communicator that was never attached (its creator gave up waiting for it)
+{
+    if (!comm) return XC_OK;
+    if (g_rccl.abort) return g_rccl.abort(comm) == 0 ? XC_OK : XC_EHIP;
+    return g_rccl.destroy && g_rccl.destroy(comm) == 0 ? XC_OK : XC_EHIP;
+}
+
 int xc_comm_init(xc_ctx* ctx, int nranks, int rank, const void* id128)
 {
     if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, XC_EBADARG, "xc_comm_init: bad arguments");
     if (ctx->comm) return fail(ctx, XC_EBADARG, "xc_comm_init: communicator already initialised");
-    int rc = load_rccl(ctx); if (rc != XC_OK) return rc;
-    hipError_t e = hipSetDevice(ctx->device);
-    if (e != hipSuccess) return hipfail(ctx, e, "hipSetDevice");
-    UniqueId id; memcpy(&id, id128, sizeof(id));
-    Comm c = nullptr;
-    const int r = g_rccl.init_rank(&c, nranks, id, rank);
-    if (r != 0) return rccl_fail(ctx, r, "ncclCommInitRank");
-    ctx->comm = c; ctx->comm_nranks = nranks; ctx->comm_rank = rank;
+    void* c = nullptr; char err[512];
+    const int rc = xc_comm_create(ctx->device, nranks, rank, id128, &c, err, sizeof(err));
+    if (rc != XC_OK) return fail(ctx, rc, err);
+    return xc_comm_attach(ctx, c, nranks, rank);
+}
+
+// What RCCL ITSELF says about the communicator of this context: how many ranks it spans, which of them this process is, which device
+// it drives, the library's version and file -- read back from the library (ncclCommCount / ncclCommUserRank / ncclCommCuDevice /
+// ncclGetVersion), not from what the caller passed in.  comm_count = 0: the context has no RCCL communicator (another carrier).
+int xc_comm_info(xc_ctx* ctx, xc_comm_info_t* out)
+{
+    if (!ctx || !out) return fail(ctx, XC_EBADARG, "xc_comm_info: bad arguments");
+    memset(out, 0, sizeof(*out));
+    out->comm_rank = -1; out->comm_device = -1;
+    out->ctx_device = ctx->device;
+    if (g_rccl.h) {
+        if (g_rccl.version) (void)g_rccl.version(&out->rccl_version);
+        snprintf(out->rccl_path, sizeof(out->rccl_path), "%s", g_rccl.path);
+    }
+    if (!ctx->comm) return XC_OK;
+    int v = 0;
+    if (g_rccl.count && g_rccl.count(ctx->comm, &v) == 0) out->comm_count = v;
+    if (g_rccl.user_rank && g_rccl.user_rank(ctx->comm, &v) == 0) out->comm_rank = v;
+    if (g_rccl.cu_device && g_rccl.cu_device(ctx->comm, &v) == 0) out->comm_device = v;
     return XC_OK;
 }
 

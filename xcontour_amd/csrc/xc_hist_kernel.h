@@ -289,6 +289,7 @@ void k_hist(const HistArgs a)
         if (DET == 3 && GRAD) {                                   // explicit edges: the tracer's extrema come from a K1 pass of their own
             const double mn = a.det_q_mm[2 * (size_t)slab], mx = a.det_q_mm[2 * (size_t)slab + 1];
             det_rng = a.q_f32 ? fabs((double)__fsub_rn((float)mx, (float)mn)) : fabs(__dsub_rn(mx, mn));
+            if (!(det_rng == det_rng)) det_rng = 0.0;
         }
     }
     if (DET == 3) {
@@ -300,12 +301,15 @@ void k_hist(const HistArgs a)
             if (!(dmax >= 0.0)) {
                 const double* mm = a.det_dA_max_dev + 2 * (size_t)slab * a.det_dA_stride;
                 dmax = fmax(fabs(mm[0]), fabs(mm[1]));
+                if (!(dmax == dmax)) dmax = 0.0;                // no finite weight at all (the extrema skip NaN and +-inf)
             }
             s_c0[0] = det_c0_from_bound(dmax);
 #pragma unroll
             for (int i = 0; i < NINT; ++i) {
                 const double* mm = a.det_int_mm[i] + 2 * (size_t)slab;
-                double bnd = __dmul_rn(fmax(fabs(mm[0]), fabs(mm[1])), dmax);
+                double imax = fmax(fabs(mm[0]), fabs(mm[1]));
+                if (!(imax == imax)) imax = 0.0;
+                double bnd = __dmul_rn(imax, dmax);
                 if (a.prod_f32) bnd = __dmul_rn(bnd, 1.0000002384185791);        // (the float32 product may round up past the float64 one)
                 s_c0[1 + i] = det_c0_from_bound(bnd);
             }

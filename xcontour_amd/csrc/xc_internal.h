@@ -241,7 +241,7 @@ int launch_keff_single(xc_ctx* ctx, int q_dtype, const SingleArgs& a, const Sing
 
 // ---------------------------------------------------------------- launchers (defined in the .hip files)
 int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part,
-                          double* zero = nullptr, int64_t nzero = 0);      // zero: `nzero` 8-byte words cleared by the same launch (the accumulators of HistArgs::acc_h)
+                          double* zero = nullptr, int64_t nzero = 0, bool finite_only = false);      // finite_only: +-inf skipped like NaN; zero: `nzero` 8-byte words cleared by the same launch (the accumulators of HistArgs::acc_h)
 int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, int P, double* out);
 int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
                   int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status);

@@ -40,9 +40,27 @@ __device__ __forceinline__ void mmv(double& mn, double& mx, const float4& v)
     mn = fmin(mn, (double)lo); mx = fmax(mx, (double)hi);
 }
 
+// FIN: +-infinity is skipped like NaN (the deterministic sums derive the windows of their accumulators from these extrema: the bound
+// must be the largest FINITE magnitude, as in the oracle -- an infinite one would push every finite weight out of the window)
 // NT: the streaming hint (a pass over more bytes than the 256 MiB Infinity Cache holds: nothing read here is read again before it would be
 // evicted anyway).  Without it -- a launch of a few slabs -- the tracer stays in the Infinity Cache for the histogram pass that follows.
-template <typename T, bool NT>
+template <bool FIN> __device__ __forceinline__ double2 fin_only(double2 v)
+{
+    if (FIN) { if (fabs(v.x) == dinf()) v.x = dnan(); if (fabs(v.y) == dinf()) v.y = dnan(); }
+    return v;
+}
+template <bool FIN> __device__ __forceinline__ float4 fin_only(float4 v)
+{
+    if (FIN) {
+        const float nanf_ = __int_as_float(0x7fc00000), inff = __int_as_float(0x7f800000);
+        if (fabsf(v.x) == inff) v.x = nanf_; if (fabsf(v.y) == inff) v.y = nanf_;
+        if (fabsf(v.z) == inff) v.z = nanf_; if (fabsf(v.w) == inff) v.w = nanf_;
+    }
+    return v;
+}
+template <bool FIN> __device__ __forceinline__ double fin_only(double v) { return (FIN && fabs(v) == dinf()) ? dnan() : v; }
+
+template <typename T, bool NT, bool FIN = false>
 __global__ __launch_bounds__(256)
 void k_minmax_partial(const T* __restrict__ q, int64_t ncell, double* __restrict__ part, double* __restrict__ zero, int64_t nzero)
 {
@@ -70,12 +88,12 @@ void k_minmax_partial(const T* __restrict__ q, int64_t ncell, double* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) a[u] = NT ? ld16_nt<T>(qv + i + u * 256) : qv[i + u * 256];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mmv(mn, mx, a[u]);
+        for (int u = 0; u < 8; ++u) mmv(mn, mx, fin_only<FIN>(a[u]));
     }
-    for (; i < v1; i += 256) { const V a0 = NT ? ld16_nt<T>(qv + i) : qv[i]; mmv(mn, mx, a0); }
+    for (; i < v1; i += 256) { const V a0 = NT ? ld16_nt<T>(qv + i) : qv[i]; mmv(mn, mx, fin_only<FIN>(a0)); }
     if (b == 0) {
-        for (int64_t j = tid; j < head; j += 256) mm(mn, mx, (double)qs[j]);
-        for (int64_t j = head + nvec * VN + tid; j < ncell; j += 256) mm(mn, mx, (double)qs[j]);
+        for (int64_t j = tid; j < head; j += 256) mm(mn, mx, fin_only<FIN>((double)qs[j]));
+        for (int64_t j = head + nvec * VN + tid; j < ncell; j += 256) mm(mn, mx, fin_only<FIN>((double)qs[j]));
     }
     for (int o = 32; o > 0; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
     __shared__ double s[8];
@@ -285,17 +303,20 @@ void k_synth(T* __restrict__ out, int64_t ny, int64_t nx, const double* __restri
 }  // namespace
 
 // ------------------------------------------------------------------------------------ launchers
-int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part, double* zero, int64_t nzero)
+int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part, double* zero, int64_t nzero,
+                          bool finite_only)
 {
     if (!q || !part || nslab < 1 || ncell < 1) return fail(ctx, XC_EBADARG, "xc_minmax: bad arguments");
     if (nslab > 65535) return fail(ctx, XC_EBADARG, "xc_minmax: at most 65535 slabs per launch");
     dim3 grid((unsigned)minmax_blocks(ncell, nslab), (unsigned)nslab);      // partials: [nslab][minmax_blocks(ncell, nslab)][2]
     const bool nt = (double)nslab * (double)ncell * (q_dtype == XC_F64 ? 8.0 : 4.0) > 128.0 * 1048576.0 || ctx->knobs.k1_nt > 0;
     if (q_dtype == XC_F64) {
-        if (nt) hipLaunchKernelGGL((k_minmax_partial<double, true>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part, zero, nzero);
+        if (finite_only) hipLaunchKernelGGL((k_minmax_partial<double, false, true>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part, zero, nzero);
+        else if (nt) hipLaunchKernelGGL((k_minmax_partial<double, true>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part, zero, nzero);
         else hipLaunchKernelGGL((k_minmax_partial<double, false>), grid, dim3(256), 0, ctx->stream, (const double*)q, ncell, part, zero, nzero);
     } else if (q_dtype == XC_F32) {
-        if (nt) hipLaunchKernelGGL((k_minmax_partial<float, true>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part, zero, nzero);
+        if (finite_only) hipLaunchKernelGGL((k_minmax_partial<float, false, true>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part, zero, nzero);
+        else if (nt) hipLaunchKernelGGL((k_minmax_partial<float, true>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part, zero, nzero);
         else hipLaunchKernelGGL((k_minmax_partial<float, false>), grid, dim3(256), 0, ctx->stream, (const float*)q, ncell, part, zero, nzero);
     }
     else return fail(ctx, XC_EBADARG, "xc_minmax: q_dtype must be XC_F32 or XC_F64");

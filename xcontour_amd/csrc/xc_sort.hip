@@ -679,7 +679,9 @@ void k_fix_runs(K* __restrict__ keys, double* __restrict__ vals, int64_t n, unsi
         if (s_d[il] != RANGE_INVALID) nvalid[blockIdx.y] = (unsigned)n;
     }
     if (__syncthreads_or(bad)) {                                               // the stack goes to the eight-pass path: nothing else to do here
-        if (tid == 0) __hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (pinned host memory)
+        // (pinned host memory.  A plain system-scope STORE, not a read-modify-write: every writer stores the same 1, and an atomic OR on
+        // host memory needs PCIe AtomicOps, which pass-through / virtualised hosts may not route -- round-5 advisor)
+        if (tid == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     // ---- 3. stable rank inside the run; a cell whose place changes writes itself there

@@ -254,26 +254,39 @@ class SocketGroup(object):
             uid, err = self.broadcast_bytes(b''), str(e)
         if len(uid) == 128 and not err:
             box = {}
+            lock = threading.Lock()
 
             def call():
+                # (round 6, advisor) the helper thread creates the communicator WITHOUT touching `ctx` (xc_comm_create): the main thread
+                # keeps using the context while this call blocks, and a call that returns after its deadline must not write into it --
+                # it finds `abandoned` under the lock and disposes of what it got
                 try:
                     if os.environ.get('XC_TEST_SKIP_COMM_INIT_RANK') == str(self.rank):
                         # fault injection (tests only): this rank never joins the bootstrap -- the others then sit in the REAL
                         # ncclCommInitRank until their deadline, which is the failure the deadline exists for
                         raise Exception('comm_init skipped on this rank (XC_TEST_SKIP_COMM_INIT_RANK)')
-                    ctx.comm_init(self.world, self.rank, uid)
-                    box['ok'] = True
+                    comm = ctx.comm_create(self.world, self.rank, uid)
+                    with lock:
+                        if box.get('abandoned'):
+                            ctx.comm_release(comm)
+                        else:
+                            box['comm'] = comm
                 except Exception as e:                             # noqa: BLE001 -- the verdict travels to every rank
-                    box['err'] = str(e)
+                    with lock:
+                        box['err'] = str(e)
 
             t = threading.Thread(target=call, name='xc-comm-init', daemon=True)
             t.start()
             t.join(timeout)
-            if t.is_alive():
-                self.stuck.append(t)
-                err = 'ncclCommInitRank did not return within %.0f s' % timeout
-            elif 'err' in box:
-                err = box['err']
+            with lock:
+                if 'comm' in box:
+                    ctx.comm_attach(box.pop('comm'), self.world, self.rank)          # by the thread that owns the context
+                elif 'err' in box:
+                    err = box['err']
+                else:
+                    box['abandoned'] = True
+                    self.stuck.append(t)
+                    err = 'ncclCommInitRank did not return within %.0f s' % timeout
         elif not err:
             err = 'rank 0 could not create the RCCL unique id'
         # the slowest rank may sit in its deadline while the others already wait here: give the consensus that long
