@@ -174,6 +174,10 @@ def test_bench_launches_two_ranks_by_itself_on_one_gpu():
     b = c4['budget']
     assert len(b['sweep_ms_by_rank']) == 2 and len(b['gather_ms_by_rank']) == 2 and b['pack_ms'] == 0.0
     assert all(x > 0 for x in b['sweep_ms_by_rank'])
+    # the weak-scaling line itself says what every rank did and what RCCL reported (here: the host carrier, so `rccl` is null)
+    pr = d['per_rank']
+    assert len(pr['sweep_ms']) == 2 and all(x > 0 for x in pr['sweep_ms']) and len(pr['wall_ms']) == 2 and pr['device'] == [0, 0]
+    assert d['config']['rccl'] is None and 'carrier host' in d['config']['parallelism']
 
 
 def test_bench_refuses_a_world_that_disagrees_with_gpus():
@@ -246,11 +250,16 @@ def test_rccl_unavailable_lands_on_the_ipc_carrier_loudly():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert d['n_gpus'] == 2 and '[preflight] rank 1 -> device' in r.stderr and '[preflight] carrier:' in r.stderr
     tr = d['config']['carrier_trials']
+    assert len(d['per_rank']['sweep_ms']) == 2 and all(x > 0 for x in d['per_rank']['sweep_ms'])
     if n.value < 2:
         assert 'rccl unavailable' in d['config']['collective_note'] and 'carrier ipc' in d['config']['parallelism']
         assert 'error' in tr['rccl'] and tr['ipc']['ms_1MB'] > 0 and tr['ipc']['ms_32MB'] > 0 and 'host' not in tr
+        assert d['config']['rccl'] is None and d['per_rank']['device'] == [0, 0]          # RCCL carried nothing: nothing of it is reported
     else:
         assert d['config']['collective_note'] is None and 'carrier rccl' in d['config']['parallelism'] and tr['rccl']['ms_32MB'] > 0
+        rc = d['config']['rccl']                                                           # read back from the library, not from the launcher
+        assert rc['consistent'] and rc['comm_count'] == [2, 2] and rc['comm_rank'] == [0, 1] and rc['rank_devices'] == [0, 1]
+        assert rc['version'] > 20000 and 'rccl' in rc['librccl']
 
 
 @pytest.mark.parametrize('world', [2, 4])
@@ -271,6 +280,8 @@ def test_bench_ipc_ranks_on_one_gpu_equal_the_one_rank_job(world, tmp_path):
         outs[w] = (json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0]), np.load(f))
     d, full = outs[world]
     assert d['n_gpus'] == world and 'carrier ipc' in d['config']['parallelism'] and d['config']['collective_note'] is None
+    assert d['config']['rccl'] is None and len(d['per_rank']['sweep_ms']) == world and d['per_rank']['device'] == [0] * world
+    assert outs[1][0]['config']['rccl'] is None and len(outs[1][0]['per_rank']['sweep_ms']) == 1      # the fields are there at N = 1 too
     assert d['roofline']['frac'] > 0 and d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['parity_checked_slabs'] >= 1
     c4 = d['cfg4_strong']
     per = -(-100 // world)
@@ -336,8 +347,13 @@ def test_comm_stream_fences_and_root_gather_with_one_rank(ctx):
     assert ctx.sync_within(30.0) and ctx.streams_idle()
     got = dst.download((3, n), np.float64)
     assert np.array_equal(got[1], x) and not got[0].any() and not got[2].any()
+    assert ctx.comm_info()['comm_count'] == 0                             # no communicator yet
     uid = ctx.comm_unique_id()
-    ctx.comm_init(1, 0, uid)
+    comm = ctx.comm_create(1, 0, uid)                                     # (the two-step form: created off-context, attached by the owner)
+    ctx.comm_attach(comm, 1, 0)
+    info = ctx.comm_info()                                                # what RCCL ITSELF says: ncclCommCount / UserRank / CuDevice / version
+    assert info['comm_count'] == 1 and info['comm_rank'] == 0 and info['comm_device'] == info['ctx_device'] == ctx.device
+    assert info['rccl_version'] > 20000 and 'rccl' in info['rccl_path']
     ctx.comm_wait_compute()
     ctx.comm_gather(src.ptr, n * 8, dst.ptr + 2 * n * 8, n * 8, 0)       # rank 0's block lands at recv + 0 * stride
     ctx.compute_wait_comm(); ctx.sync()

@@ -454,7 +454,7 @@ class Context(object):
         h, err = _vp(), C.create_string_buffer(512)
         rc = self.lib.xc_comm_create(self.device, int(nranks), int(rank), C.create_string_buffer(uid, 128), C.byref(h), err, 512)
         if rc != 0:
-            raise XContourHipError(err.value.decode('utf-8', 'replace') or 'xc_comm_create failed (%d)' % rc)
+            raise XContourHipError(rc, err.value.decode('utf-8', 'replace') or 'xc_comm_create failed (%d)' % rc)
         return h.value
 
     def comm_attach(self, comm, nranks, rank):

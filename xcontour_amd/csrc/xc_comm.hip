@@ -43,7 +43,24 @@ Rccl g_rccl;
 int load_rccl(xc_ctx* ctx)
 {
     if (g_rccl.h) return XC_OK;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // The librccl that belongs to the HIP runtime THIS library is bound to: a process may hold two ROCm stacks (PyTorch wheels bundle
+    // their own libamdhip64 / libhsa-runtime64 / librccl; whichever libamdhip64 was loaded first serves this library), and a librccl
+    // bound to the OTHER runtime sees no initialised device (round 6: ncclCommInitRank "no ROCm-capable device is detected" when torch
+    // was imported after the context was created).  So: the directory of the libamdhip64 our own HIP calls resolve to comes first.
+    void* h = nullptr;
+    {
+        Dl_info di;
+        if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t sl = dir.rfind('/');
+            if (sl != std::string::npos) {
+                dir.resize(sl + 1);
+                h = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+            }
+        }
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(ctx, XC_EHIP, std::string("xc_comm: cannot load librccl: ") + dlerror());
     g_rccl.get_id = (fn_get_id)dlsym(h, "ncclGetUniqueId");
@@ -119,8 +136,17 @@ int xc_comm_create(int device, int nranks, int rank, const void* id128, void** o
     if (e != hipSuccess) { say(std::string("hipSetDevice: ") + hipGetErrorString(e)); return XC_EHIP; }
     UniqueId id; memcpy(&id, id128, sizeof(id));
     Comm c = nullptr;
+    // RCCL checks the process-wide "last error" of the HIP runtime in places: an error that some EARLIER call of this process returned
+    // (and its caller handled) must not fail the communicator -- it is cleared here, and named if the call fails all the same
+    const hipError_t stale = hipGetLastError();
     const int r = g_rccl.init_rank(&c, nranks, id, rank);
-    if (r != 0) { say(std::string("RCCL error in ncclCommInitRank: ") + (g_rccl.errstr ? g_rccl.errstr(r) : "?")); return XC_EHIP; }
+    if (r != 0) {
+        std::string m = std::string("RCCL error in ncclCommInitRank: ") + (g_rccl.errstr ? g_rccl.errstr(r) : "?");
+        if (stale != hipSuccess) m += std::string(" (pending before the call: ") + hipGetErrorName(stale) + ")";
+        const hipError_t now = hipGetLastError();
+        if (now != hipSuccess) m += std::string(" (HIP last error after it: ") + hipGetErrorName(now) + ")";
+        say(m); return XC_EHIP;
+    }
     *out_comm = c;
     return XC_OK;
 }
