@@ -206,9 +206,18 @@ def stored_traffic(key, B):
         e = tj.get(key, {})
         if e.get('slabs_per_launch') != B or e.get('hbm_bytes_per_launch') is None:
             return None, 'no PMC entry for this schedule / batch size'
+        when, age = tj.get('measured_at_utc'), None
+        if when:
+            import datetime
+            try:
+                age = (datetime.datetime.utcnow() - datetime.datetime.strptime(when, '%Y-%m-%dT%H:%M:%SZ')).total_seconds() / 86400.0
+            except ValueError:
+                age = None
         return e['hbm_bytes_per_launch'], ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_bench_traffic.sh) at commit %s, '
-                                           'same kernel sources as this tree (sha256 %s); not re-measured in this run'
-                                           % (e.get('commit', tj.get('commit')), tj['source_sha256'][:16]))
+                                           'same kernel sources as this tree (sha256 %s); the record: taken %s (%s days before this run) on %s; '
+                                           'a PMC pass cannot run inside a timed bench (the counters serialise the kernels): not re-measured in this run'
+                                           % (e.get('commit', tj.get('commit')), tj['source_sha256'][:16], when or 'at an unrecorded time',
+                                              ('%.2f' % age) if age is not None else '?', tj.get('device', 'an unrecorded box')))
     except Exception as ex:            # noqa: BLE001 -- a missing / malformed file only nulls the optional figure
         return None, 'profiles/hist_traffic.json unreadable: %s' % ex
 

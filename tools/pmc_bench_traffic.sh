@@ -27,7 +27,15 @@ B, NY, NX = 64, 1801, 3600
 _h = hashlib.sha256()
 for _f in ('xc_hist.hip', 'xc_hist_kernel.h', 'xc_binning.h'):
     _h.update(open('$R/xcontour_amd/csrc/' + _f, 'rb').read())
+import datetime, subprocess, sys
+sys.path.insert(0, '$R')
+try:
+    from xcontour_amd import _native as _nat
+    _c = _nat.Context(0); _dev = _c.device_name(); _c.close()
+except Exception as _e:
+    _dev = 'unknown (%s)' % _e
 out = {'commit': '$COMMIT', 'source_sha256': _h.hexdigest(), 'slabs_per_launch': B,
+       'measured_at_utc': datetime.datetime.utcnow().strftime('%Y-%m-%dT%H:%M:%SZ'), 'device': _dev,
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over python3 bench.py --steps 12 --warmup 3 --no-cpu '
                  '[--no-chain] [--slab-dA]; median over the dispatches of the dominant kernel; FETCH_SIZE x 2 '
                  '(gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md; calibrated on k_minmax_partial: '

@@ -119,6 +119,7 @@ void k_hist(const HistArgs a)
     const double* __restrict__ rdyp = a.rdy;
     const int copy = lane & (ncopy - 1);
     const int cshift = __builtin_ctz((unsigned)ncopy);            // ncopy is a power of two
+    const unsigned cstride = (unsigned)(CW * 8) << cshift, cbase = (unsigned)copy * (unsigned)(CW * 8);
     const int periodic_x = FAST ? 1 : a.periodic_x;
 
     // segment state (wave-uniform scalars + per-lane 32-bit byte offsets inside a row)
@@ -354,7 +355,7 @@ void k_hist(const HistArgs a)
 
     auto flush = [&]() {
         if (cnt) {
-            double* cp = s_cell + (unsigned)(cur * ncopy + copy) * (unsigned)CW;
+            double* cp = reinterpret_cast<double*>(reinterpret_cast<char*>(s_cell) + (__umul24((unsigned)cur, cstride) + cbase));
 #pragma unroll
             for (int c = 0; c < NCH; ++c) lds_add(cp + c, acc[c]);
             if (want_cnt) lds_add(reinterpret_cast<unsigned*>(cp + NCH), cnt);
@@ -467,7 +468,10 @@ void k_hist(const HistArgs a)
         } else {
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
-                double* cp = s_cell + ((k[c] << cshift) + (unsigned)XC_ROT(copy, k[c], ncopy)) * (unsigned)CW;      // 32-bit LDS offset
+                // byte offset of the cell = k * (8 CW ncopy) + copy * 8 CW: ONE full-rate v_mad_u32_u24 (k <= N and the stride are far below
+                // 2^24).  (Round 6: it was shift-add, v_mul_lo_u32 by CW, add -- and a 32-bit v_mul_lo is a QUARTER-rate instruction on
+                // CDNA: four issue slots per cell of a kernel that waits for its VALU work.)
+                double* cp = reinterpret_cast<double*>(reinterpret_cast<char*>(s_cell) + (__umul24(k[c], cstride) + cbase));
                 if (DET == 0) {
 #pragma unroll
                     for (int ch = 0; ch < NCH; ++ch) lds_add(cp + ch, w[ch][c]);
