@@ -187,3 +187,39 @@ def test_xarray_branch_of_labeled_runs_with_a_test_double():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'xarray_branch_script.py'), 'cpu'], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, universal_newlines=True, env=env, cwd=ROOT)
     assert r.returncode == 0 and r.stdout.strip() == 'ok cpu', r.stderr[-2000:]
+
+
+def test_fast_uniform_gradient_is_np_gradient_bit_for_bit():
+    """core._gradient_edge1 (round 6: np.gradient spends 15 us per call on dispatching at the reference's sizes) must BE
+    np.gradient(f, x, axis, edge_order=1) on a coordinate with constant spacing -- values AND dtype, float32 / float64 in both places --
+    and hand anything else (uneven spacing, integer data) to np.gradient itself (reference core.py:463-488)"""
+    rng = np.random.default_rng(0)
+    for fd in (np.float32, np.float64):
+        for xd in (np.float32, np.float64):
+            for shape, axis in (((15, 121), 1), ((121,), 0), ((3, 5, 201), 2), ((201, 4), 0), ((2, 2), 1), ((4, 3), 1)):
+                f = (rng.standard_normal(shape) * 10.0 ** int(rng.integers(-8, 8))).astype(fd)
+                n = shape[axis]
+                x = np.linspace(0, n - 1, n, dtype=xd)
+                a, b = np.gradient(f, x, axis=axis, edge_order=1), core._gradient_edge1(f, x, axis)
+                assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), (fd, xd, shape)
+                if n > 2:
+                    x2 = x.copy(); x2[-1] += 0.5                                     # uneven: the general formula, numpy's own
+                    assert np.array_equal(np.gradient(f, x2, axis=axis, edge_order=1), core._gradient_edge1(f, x2, axis))
+    fi = np.arange(12).reshape(3, 4)
+    assert np.array_equal(np.gradient(fi, np.arange(4.0), axis=1, edge_order=1), core._gradient_edge1(fi, np.arange(4.0), 1))
+
+
+def test_lookup_coordinates_of_a_stack_equals_the_loop_over_slabs():
+    """Table.lookup_coordinates on (level, contour) values with ONE table (round 6: one np.interp call for the stack) against the
+    reference's per-slab np.interp (core.py:1136-1174, 1405-1434), increasing and decreasing tables"""
+    rng = np.random.default_rng(1)
+    lat = np.linspace(-90, 90, 181).astype(np.float32)
+    for inc in (True, False):
+        t = np.cumsum(rng.random(181)); t = t if inc else t[::-1].copy()
+        tbl = xa.Table(xa.DataArray(t, ('lat',), {'lat': lat}, 'area'), 'lat')
+        v = rng.random((5, 41)) * t.max() * 1.1 - 0.05
+        vals = xa.DataArray(v, ('lev', 'contour'), {'lev': np.arange(5.0), 'contour': np.arange(41.0)}, 'area')
+        got = tbl.lookup_coordinates(vals).values
+        for s in range(5):
+            ref = np.interp(v[s], t, lat) if inc else np.interp(v[s], t[::-1], lat[::-1])
+            assert np.array_equal(got[s], ref.astype(got.dtype))
