@@ -208,3 +208,41 @@ def test_lwa_interval_kernel_tall_planes_and_odd_reference_states(ctx, ny, nx, d
             ref = O.cal_local_wave_activity(qs[s], Qs[s], lat, dA if not da_row else dAu[:, None] * np.ones((1, nx)), True, 'all')
             scale = np.abs(ref).max()
             assert np.isfinite(scale) and np.abs(got[s] - ref).max() <= 1e-11 * max(scale, 1e-300), (k, s)
+
+
+def _lwa_rows(q, Q, coord, dA, rows, increase=True):
+    """core.py:752-791 for the target rows `rows` only (the oracle's own loop body, one j at a time: a full 1801-row plane has 1801
+    of them at ~0.2 s each)"""
+    q64 = q.astype(np.float64)
+    wei = dA / np.nanmax(dA)
+    cinc = not (coord[-1] < coord[0])
+    out = np.empty((len(rows), q.shape[1]))
+    for i, j in enumerate(rows):
+        qe = q64 - Q[j]                                                               # core.py:754
+        m = ((coord >= coord[j]) if cinc else (coord <= coord[j]))[:, None]
+        if increase:                                                                   # core.py:759-766
+            mask3 = np.where(np.logical_and(qe < 0, m), 1, np.where(m, 0, np.where(qe > 0, -1, 0)))
+        else:
+            mask3 = np.where(np.logical_and(qe > 0, m), 1, np.where(m, 0, np.where(qe < 0, -1, 0)))
+        out[i] = -np.nansum(qe * mask3.astype(np.float64) * wei * dA, axis=0)         # core.py:789 (M = dA)
+    return out
+
+
+def test_lwa_interval_kernel_at_the_full_cfg2_size(ctx):
+    """K7F on ONE 1801 x 3600 float64 plane with J = 1801 target rows -- the size its 0.08 ms are quoted on (the
+    tall-plane tests use nx = 3-23) -- against the reference's loop body (core.py:752-791, restated row by row) on 16 sampled target
+    rows x all 3600 columns, 1e-12 of the plane's largest value; NaN cells and cells exactly on reference levels included."""
+    ny, nx = 1801, 3600
+    rng = np.random.default_rng(2026)
+    lat, q, Q, dA = _lwa_case(rng, ny, nx, np.float64, True, True, True)
+    got, _ = ctx.lwa(q[None], Q[None], lat, dA, float(dA.max()), exact=False)
+    assert ctx.last_lwa_path() == 1
+    rows = sorted(set([0, 1, 5, ny // 7, ny // 3, ny // 2 - 1, ny // 2, ny // 2 + 1, 1000, 1234, 1500, ny - 300, ny - 17, ny - 3, ny - 2, ny - 1]))
+    assert len(rows) == 16
+    ref = _lwa_rows(q, Q, lat, dA, rows)
+    scale = np.abs(ref).max()
+    assert np.isfinite(scale) and scale > 0
+    err = np.abs(got[0][rows] - ref).max() / scale
+    assert err <= 1e-12, err
+    # and every row is finite and non-negative up to rounding where the plane is (LWA >= 0 for a sorted reference state)
+    assert np.isfinite(got[0]).all() and got[0].min() > -1e-9 * scale

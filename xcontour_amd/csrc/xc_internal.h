@@ -208,8 +208,10 @@ struct FinalArgs {
 };
 
 // ---------------------------------------------------------------- the single-read Keff kernel (xc_keff1.hip)
-constexpr int kSingleThreads  = 768;    // 12 waves per workgroup = 3 per SIMD at 168 VGPRs: one workgroup per CU, the whole grid co-resident
-constexpr int kSingleRows     = 18;     // rows of a wave's chunk of the slab (its register tile: kSingleRows + 2 rows of 2 cells per lane)
+constexpr int kSingleThreads  = 512;    // 8 waves per workgroup = 2 per SIMD at up to 256 VGPRs: one workgroup per CU, the whole grid co-resident.  (Round 6
+                                        // measured 768 threads x 18-row tiles too: the 3072 waves take 4.3 us to dispatch against 2.3 for 2048, carry 11 % of
+                                        // halo rows against 7 %, and the tile lands 3.7 us later; their faster binning -- 4.9 against 6.6 us -- gives back 1.7)
+constexpr int kSingleRows     = 27;     // rows of a wave's chunk of the slab (its register tile: kSingleRows + 2 rows of 2 cells per lane = 116 VGPRs)
 constexpr int kSingleCols     = 124;    // computed columns of a strip (lanes 1..62, two cells each; lanes 0 and 63 hold the halo columns)
 constexpr int kSingleMaxSlabs = 2;      // calls of more slabs stream (the two-read path overlaps slabs, this kernel cannot)
 constexpr int kSingleMaxBins  = 1024;

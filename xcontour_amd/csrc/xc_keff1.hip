@@ -6,11 +6,11 @@
 // pass -> k_finalize": three dependent launches that read the tracer twice because the levels need the exact extrema before the first
 // cell can be binned.  Here the slab stays ON CHIP between the two steps:
 //
-//   * the grid is one 768-thread workgroup per CU (12 waves = 3 per SIMD at 168 VGPRs), all co-resident;
-//   * a wave owns a chunk of <= 18 rows x 124 columns of the slab and holds it -- plus one halo row above and below and one halo
-//     lane left and right (strips overlap by 4 columns, so x-neighbours always come from the adjacent lane by DPP) -- in 80 VGPRs per
-//     lane: 256 CUs x 12 waves x 20 rows x 1 KiB = 60 MiB of register tile for a 51.9 MB slab.  Every load of the tile is issued at
-//     once, and behind them the first XC_SINGLE_DR rows of the weights dA;
+//   * the grid is one 512-thread workgroup per CU (8 waves = 2 per SIMD at 230 VGPRs), all co-resident;
+//   * a wave owns a chunk of <= 27 rows x 124 columns of the slab and holds it -- plus one halo row above and below and one halo
+//     lane left and right (strips overlap by 4 columns, so x-neighbours always come from the adjacent lane by DPP) -- in 116 VGPRs per
+//     lane: 256 CUs x 8 waves x 29 rows x 1 KiB = 58 MiB of register tile for a 51.9 MB slab.  Every load of the tile is issued at
+//     once; the first XC_SINGLE_DR rows of the weights dA follow when the tile has landed (they would compete with it otherwise);
 //   * step A: per-wave min/max of the tile -> workgroup -> ONE pair per slab by agent-scope 64-bit atomic max on order-preserving keys
 //     in 8 shards -> an arrival counter per shard; every workgroup polls the 8 counters (one wave, bounded), reads the pair and builds
 //     the N levels / N + 1 edges in LDS with exactly the arithmetic of the two-pass path (xc_binning.h);
@@ -37,11 +37,14 @@ namespace {
 
 #include "xc_binning.h"
 
+#ifndef XC_S_BAR
+#define XC_S_BAR 3                     // a scheduling barrier every third row of step B (the rows' weight loads stay near their slots)
+#endif
 #ifndef XC_S_WPE
-#define XC_S_WPE 3
+#define XC_S_WPE 2                     // waves per SIMD (= kSingleThreads / 256)
 #endif
 #ifndef XC_SINGLE_DR
-#define XC_SINGLE_DR 7
+#define XC_SINGLE_DR 10
 #endif
 constexpr int NT = kSingleThreads, NW = NT / 64;
 constexpr int PR = kSingleRows;        // rows of a chunk
@@ -83,8 +86,8 @@ __device__ __forceinline__ double uniform_d(double v)      // a wave-uniform dou
 
 // FAST: periodic X, dA verified finite and >= 0, half-open last bin (the xhistogram rule) -- the selects for walls, fillna and the
 // closed last edge are compiled out.  Otherwise they are runtime (wave-uniform) flags.
-template <typename TQ, bool DA2D, bool FAST>
-__global__ __attribute__((amdgpu_flat_work_group_size(NT, NT), amdgpu_waves_per_eu(XC_S_WPE, 3)))
+template <typename TQ, bool DA2D, bool FAST, bool WCNT>
+__global__ __attribute__((amdgpu_flat_work_group_size(NT, NT), amdgpu_waves_per_eu(XC_S_WPE, XC_S_WPE)))
 void k_keff_single(const SingleArgs a)
 {
     extern __shared__ __align__(16) double smem[];
@@ -130,7 +133,7 @@ void k_keff_single(const SingleArgs a)
     double dArv = DA2D ? 0.0 : a.dA[ym];
     const bool wpos = FAST ? true : (a.dA_pos_finite != 0);
     const bool closed = FAST ? false : (a.last_closed != 0);
-    const bool want_cnt = a.want_counts != 0;
+    constexpr bool want_cnt = WCNT;
 
     double T[PT][2];                                           // the register tile
     double dAb[DR][2];                                         // ring of weight rows
@@ -175,7 +178,7 @@ void k_keff_single(const SingleArgs a)
 
     for (int s = 0; s < a.nslab; ++s) {
         // opaque per slab: what the rows derive from these (18 pairs of metrics by v_readlane, ...) is NOT hoisted out of the slab
-        // loop and kept alive across it (it was: 240 VGPRs wanted, 168 available)
+        // loop and kept alive across it (it was: 240 VGPRs wanted)
         asm volatile("" : "+v"(rdxv), "+v"(rdyv), "+v"(dArv));
         // the whole tile requested at once.  (Loaded HERE, at the top of the slab's iteration, and not ahead of
         // the previous slab's flush: a tile that is alive across the loop's back edge costs a second set of 80 registers in copies.)
@@ -309,10 +312,23 @@ void k_keff_single(const SingleArgs a)
             // -------------------------------------------------------- B: bin + accumulate from registers
             int nr = nrows;
             asm volatile("" : "+s"(nr));                       // opaque: the row predicates are not hoisted out of the slab loop (SGPR pressure)
+            // the bin search of row i + 1 (guess + the LDS read of the edge) is issued BEFORE the LDS adds of row i: the LDS queue of a wave
+            // is in order, and a read behind six atomics waits for all of them (measured: 6.6 -> ... us for the 27 rows of a wave)
+            int jn[2]; double en[2];
+            auto guess = [&](int t) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    int j = (int)__builtin_fma(T[t][c] - e0, inv, 0.5);                        // NaN -> 0
+                    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(j) : "v"(j), "s"(N));                // clamp to [0, N]
+                    jn[c] = j; en[c] = s_edges[j];
+                }
+            };
+            guess(1);
 #pragma unroll
             for (int i = 1; i <= PR; ++i) {
-                asm volatile("" ::: "memory");                 // keep every row's loads in that row's slot
-                if (i <= nr) {
+                if (i % XC_S_BAR == 1 || XC_S_BAR == 1) asm volatile("" ::: "memory");   // keep the rows' loads near their slots
+                const bool rowok = i <= nr;                    // (a row past the chunk goes to the trash bin: no branch, ONE basic block for the scheduler)
+                {
                     const double rdx = lane_get(rdxv, i - 1), rdy = lane_get(rdyv, i - 1);
                     double dAv[2];
                     if (DA2D) { dAv[0] = dAb[(i - 1) % DR][0]; dAv[1] = dAb[(i - 1) % DR][1]; }
@@ -320,15 +336,14 @@ void k_keff_single(const SingleArgs a)
                     const double (&qc)[2] = T[i];
                     unsigned b[2];
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {              // both cells' edge reads in flight together
+                    for (int c = 0; c < 2; ++c) {
                         const double q = qc[c];
-                        int j = (int)__builtin_fma(q - e0, inv, 0.5);                      // NaN -> 0
-                        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(j) : "v"(j), "s"(N));        // clamp to [0, N]
-                        int kb = (q >= s_edges[j]) ? j : j - 1;                            // NaN -> -1 (dropped); at or beyond the last edge -> N
+                        int kb = (q >= en[c]) ? jn[c] : jn[c] - 1;                         // NaN -> -1 (dropped); at or beyond the last edge -> N
                         if (!FAST) { if (closed && q == eN) kb = N - 1; }
                         const unsigned ku = (unsigned)kb < (unsigned)N ? (unsigned)kb : (unsigned)N;
-                        b[c] = cv[c] ? ku : (unsigned)N;
+                        b[c] = (cv[c] && rowok) ? ku : (unsigned)N;
                     }
+                    if (i < PR) guess(i + 1);
                     // x-neighbours from the adjacent lanes (halo lanes are part of the wave: no special cases)
                     const double fromL = lane_shift_keep<DPP_WAVE_SHR1>(qc[1], qc[1]);
                     const double fromR = lane_shift_keep<DPP_WAVE_SHL1>(qc[0], qc[0]);
@@ -341,7 +356,6 @@ void k_keff_single(const SingleArgs a)
             }
             asm volatile("" ::: "memory");
         }
-#ifndef XC_S_NOGEN
         else {
             // -------------------------------------------------------- B': levels that are NOT equally spaced (float32 contours of a tiny
             // range, infinite extrema, an all-NaN slab): the general search of the two-pass kernel, rows re-read from the caches.  Rare.
@@ -368,7 +382,6 @@ void k_keff_single(const SingleArgs a)
                 cell(b[1], qc[1], qc[0], fromR, qS[1], qN[1], dAv[1], rdx, rdy, col0 + 1);
             }
         }
-#endif
         stamp(s, 5);
         __syncthreads();
         stamp(s, 7);
@@ -399,14 +412,20 @@ void k_keff_single(const SingleArgs a)
     }
 }
 
-template <typename TQ, bool DA2D, bool FAST>
-int launch_s3(xc_ctx* ctx, const SingleArgs& a, const SingleGeom& g)
+template <typename TQ, bool DA2D, bool FAST, bool WCNT>
+int launch_s4(xc_ctx* ctx, const SingleArgs& a, const SingleGeom& g)
 {
-    auto kern = k_keff_single<TQ, DA2D, FAST>;
+    auto kern = k_keff_single<TQ, DA2D, FAST, WCNT>;
     { const int rc = ensure_big_lds(ctx, reinterpret_cast<const void*>(kern), (int)kLdsBudget + 4096); if (rc != XC_OK) return rc; }
     hipLaunchKernelGGL(kern, dim3((unsigned)g.G), dim3(NT), g.lds, ctx->stream, a);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
+}
+
+template <typename TQ, bool DA2D, bool FAST>
+int launch_s3(xc_ctx* ctx, const SingleArgs& a, const SingleGeom& g)
+{
+    return a.want_counts ? launch_s4<TQ, DA2D, FAST, true>(ctx, a, g) : launch_s4<TQ, DA2D, FAST, false>(ctx, a, g);
 }
 
 template <typename TQ>
