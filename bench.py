@@ -621,7 +621,8 @@ def cfg4_strong(ctx, nat, a, group, gather):
     # ONE result slot of `per` slabs, slab-major: its head is the rank's (per, 9, N) block (short blocks: zero padding)
     plan = KeffPlan(ctx, Cn, NY4, NX4, NCONT, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
                     increase=True, lt=True, nslots=1, out_slabs=per, alloc_q=False, right_edge='xhistogram', slab_major=True,
-                    deterministic=a.deterministic)
+                    deterministic=a.deterministic, single_read=False)   # (a stack job: a ragged last launch set of ONE slab stays on the chain -- nothing
+                                                                      # here looks at status 2, and ranks that share a GPU in a rehearsal could not all hold it)
     block_bytes = plan.head_bytes                                # per * 9 * N * 8
     ctx._check(ctx.lib.xc_memset(ctx.handle, plan.out_ptr, 0, plan.slot_bytes))
     rb = gather.recv_block(block_bytes)
@@ -880,7 +881,7 @@ def main():
     wres = ctx.alloc(slot)                                        # warm-up slot
     plan = KeffPlan(ctx, NB * B, NY, NX, NCONT, qdt, qdt, dA=dA, lat=lat, lon=lon, tbl=tbl,
                     tbl_coord=lat, increase=True, lt=True, nslots=K, out_ptr=res.ptr, detect_row_dA=a.row_dA,
-                    out_slabs=B, replicate_dA=a.slab_dA, right_edge='xhistogram', deterministic=a.deterministic)
+                    out_slabs=B, replicate_dA=a.slab_dA, right_edge='xhistogram', deterministic=a.deterministic, single_read=False)
     if a.variant == 3:
         plan.set_q(baro_slabs(NB * B, qdt, rank * NB * B))        # the reference's barotropic field on the cfg2 grid (smooth at grid scale)
     else:

@@ -366,18 +366,21 @@ typedef struct xc_keff_desc {
                                    with no repacking pass.  counts / interp / status keep their dense layout. */
     double        dA_max;       /* deterministic sums only: the largest finite |dA| value, if the caller knows it (a static metric: computed once
                                    on the host); <= 0 or NaN: the library takes it from the device array with one extra min / max pass over dA per call */
-    int32_t       single_read;  /* calls of ONE or TWO slabs (the reference's own pattern: one (time, level) plane per call, tests/LWA.py:40-43;
-                                   core.py:224-225 then 1307 per object): XC_SINGLE_AUTO (0) takes the single-read kernel -- min / max, levels,
-                                   histogram and epilogue in ONE launch with the slab held in registers between them, the tracer read once --
+    int32_t       single_read;  /* calls of ONE slab (the reference's own pattern: one (time, level) plane per call, tests/LWA.py:40-43;
+                                   core.py:224-225 then 1307 per object): XC_SINGLE_AUTO (0) takes the single-read kernel -- min / max, levels and
+                                   histogram in ONE launch with the slab held in registers between them, the tracer read once, then k_finalize --
                                    when grad = 1, the sums are not `deterministic` and the slab fits the chip's register tiles (3600 x 1801 does);
-                                   XC_SINGLE_NEVER (1) keeps the min/max pass + histogram pass + finalize chain.  That kernel waits for ALL its
-                                   workgroups to be resident at once; every wait is bounded (XC_KEFF_SINGLE_TIMEOUT_US, default 50 ms): when
-                                   something else holds compute units for longer, status[slab] = 2 comes back, NOTHING is written to the
-                                   slab's result vectors, and the caller repeats the call with XC_SINGLE_NEVER (pipeline.KeffPlan.fetch does). */
+                                   XC_SINGLE_NEVER (1) keeps the min/max pass + histogram pass + finalize chain; XC_SINGLE_FORCE (2) takes the
+                                   kernel for calls of TWO slabs too (measured slower there than the chain, 64.7 against 59.3 us: the two slabs
+                                   run one after the other; kept for tests).  That kernel waits for ALL its workgroups to be resident at once;
+                                   every wait is bounded (XC_KEFF_SINGLE_TIMEOUT_US, default 50 ms): when something else holds compute units
+                                   for longer, status[slab] = 2 comes back, NOTHING is written to the slab's result vectors, and the caller
+                                   repeats the call with XC_SINGLE_NEVER (pipeline.KeffPlan.fetch does). */
     int32_t       reserved0;
 } xc_keff_desc;
 #define XC_SINGLE_AUTO  0
 #define XC_SINGLE_NEVER 1
+#define XC_SINGLE_FORCE 2
 int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d);
 /* which path the last xc_keff_dev call took: 0 the min/max + histogram + finalize chain (two reads of the tracer), 1 the single-read kernel */
 int xc_last_keff_path(xc_ctx* ctx, int* out_path);

@@ -42,7 +42,9 @@ def _cfg4_block(ctx, lo, hi, chunk, det):
         ctx._check(ctx.lib.xc_synth_dev(ctx.handle, qbuf.ptr + c0 * sb, nat.XC_F64, m, NY4, NX4, lat_b.ptr, lon_b.ptr, SEED4 + lo + c0, 0))
     ctx.sync()
     plan = KeffPlan(ctx, Cn, NY4, NX4, N4, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat,
-                    increase=True, lt=True, nslots=nchunk, alloc_q=False, deterministic=det)
+                    increase=True, lt=True, nslots=nchunk, alloc_q=False, deterministic=det, single_read=False)
+    # (single_read=False: this helper calls xc_keff_dev directly and never looks at status 2 -- ranks that share ONE GPU cannot all hold it
+    # for the single-read kernel at once; KeffPlan.fetch would repeat such a launch set on the chain, tests/test_gpu_single.py)
     for ci in range(nchunk):
         c0 = ci * Cn
         m = min(Cn, n - c0)

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def _plan_pair(ctx, nslab, ny, nx, N, dt, cdt=None, **kw):
     from xcontour_amd.pipeline import KeffPlan
     cdt = dt if cdt is None else cdt
-    return (KeffPlan(ctx, nslab, ny, nx, N, dt, cdt, single_read=True, **kw),
+    return (KeffPlan(ctx, nslab, ny, nx, N, dt, cdt, single_read='force' if nslab > 1 else True, **kw),
             KeffPlan(ctx, nslab, ny, nx, N, dt, cdt, single_read=False, **kw))
 
 
@@ -167,11 +167,12 @@ def test_levels_that_are_not_equally_spaced_take_the_general_search(ctx):
 
 
 def test_shapes_the_kernel_does_not_take_fall_to_the_chain(ctx):
-    """an odd nx (no 16-byte pairs), three slabs, a tiny plane, deterministic sums, a supplied gradient: the chain runs, as before"""
+    """an odd nx (no 16-byte pairs), three slabs, two slabs unless forced, a tiny plane, deterministic sums, a supplied gradient:
+    the chain runs, as before"""
     from xcontour_amd.pipeline import KeffPlan
     from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
-    for nslab, ny, nx, kw in ((1, 400, 511, {}), (3, 400, 512, {}), (1, 90, 180, {}), (1, 400, 512, dict(deterministic=True)),
-                              (1, 400, 512, dict(grdS_dtype=np.float64))):
+    for nslab, ny, nx, kw in ((1, 400, 511, {}), (3, 400, 512, {}), (2, 400, 512, {}), (1, 90, 180, {}), (1, 400, 512, dict(deterministic=True)),
+                              (1, 400, 512, dict(grdS_dtype=np.float64)), (3, 400, 512, dict(single_read='force'))):
         lat = np.linspace(-89, 89, ny); lon = np.arange(nx) * (360.0 / nx)
         dA = cell_area(lat, lon)
         tbl = table_from_rowsums(ctx.rowsum(None, dA, ny, nx), True, last_row_included(lat))
@@ -205,7 +206,7 @@ ny, nx, N = 721, 1440, 101
 lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 0.25
 dA = cell_area(lat, lon)
 tbl = table_from_rowsums(ctx.rowsum(None, dA, ny, nx), True, last_row_included(lat))
-p = KeffPlan(ctx, 2, ny, nx, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat)
+p = KeffPlan(ctx, 2, ny, nx, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, single_read='force')
 p.synth(lat, lon, 11, 0)
 q = p.download_q()
 ctx._check(ctx.lib.xc_memset(ctx.handle, p.out_ptr, 0xff, p.slot_bytes))      # poison: a skipped slab must stay untouched
@@ -227,7 +228,7 @@ for s in range(2):
 p.free(); ctx.close()
 os.environ['XC_KEFF_SINGLE_TIMEOUT_US'] = '200000'
 ctx = nat.Context(0)
-p = KeffPlan(ctx, 2, ny, nx, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat)
+p = KeffPlan(ctx, 2, ny, nx, N, np.float64, np.float64, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, single_read='force')
 p.set_q(q)
 for _ in range(3):
     p.run(); assert ctx.last_keff_path() == 1

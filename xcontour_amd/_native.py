@@ -19,7 +19,7 @@ XC_OK, XC_EBADARG, XC_EEDGES, XC_EHIP, XC_ENOMEM, XC_ENODEV = 0, -1, -2, -3, -4,
 XC_F32, XC_F64 = 0, 1
 XC_DA_NONE, XC_DA_ROW, XC_DA_PLANE, XC_DA_SLAB = 0, 1, 2, 3
 XC_EDGE_NUMPY, XC_EDGE_XHISTOGRAM = 0, 1
-XC_SINGLE_AUTO, XC_SINGLE_NEVER = 0, 1
+XC_SINGLE_AUTO, XC_SINGLE_NEVER, XC_SINGLE_FORCE = 0, 1, 2
 XC_MAX_INTEGRANDS = 2
 MAX_SLABS_PER_LAUNCH = 65535
 XC_PAD_EDGE, XC_PAD_WRAP, XC_PAD_NAN, XC_PAD_REFLECT, XC_PAD_SYMMETRIC = 0, 1, 2, 3, 4

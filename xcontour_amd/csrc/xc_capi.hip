@@ -1214,9 +1214,11 @@ int xc_keff_dev(xc_ctx* ctx, const xc_keff_desc* d)
     const int det = d->deterministic ? 1 : 0;
     const void* q_next = d->q_next;                          // (deterministic sums: carried by the fixed-point pass)
     ctx->last_keff_path = 0;
-    // ONE or two slabs (the reference's callers hand planes over one at a time): the single-read kernel (xc_keff1.hip) where the slab
-    // fits the register tiles of the chip -- min/max, levels, histogram and the epilogue in ONE launch, the tracer read ONCE
-    if (d->single_read != XC_SINGLE_NEVER && ctx->knobs.single != 0 && !det && d->grad && d->nslab <= kSingleMaxSlabs) {
+    // ONE slab (the reference's callers hand planes over one at a time): the single-read kernel (xc_keff1.hip) where the slab fits the
+    // register tiles of the chip -- min/max, levels and histogram in ONE launch, the tracer read ONCE.  (Two slabs: only when forced --
+    // the kernel runs them one after the other, 64.7 us against the chain's 59.3.)
+    if (d->single_read != XC_SINGLE_NEVER && ctx->knobs.single != 0 && !det && d->grad &&
+        d->nslab <= (d->single_read == XC_SINGLE_FORCE ? kSingleMaxSlabs : 1)) {
         const int rc = keff_single(ctx, d);
         if (rc != XC_EAGAIN) return rc;                      // (XC_EAGAIN: the shape does not suit it; nothing was enqueued)
     }

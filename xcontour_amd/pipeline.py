@@ -58,8 +58,8 @@ class KeffPlan(object):
         pass then skips their LDS adds -- a third of its atomics; `fetch()['counts']` is meaningless.
         `deterministic`: order-free fixed-point sums (xc_keff_desc.deterministic): area / intgrdS and everything derived
         from them are bit-identical between runs, launch-set sizes and ranks, chained (q_next) or not.
-        `single_read=False`: launch sets of one or two slabs keep the min/max + histogram + finalize chain instead of the
-        single-read kernel (xc_keff_desc.single_read; that kernel needs the whole GPU to itself -- `fetch` repeats a launch set
+        `single_read=False`: launch sets of ONE slab keep the min/max + histogram + finalize chain instead of the
+        single-read kernel ('force': launch sets of two slabs take that kernel too -- slower than the chain there, for tests) (xc_keff_desc.single_read; that kernel needs the whole GPU to itself -- `fetch` repeats a launch set
         that came back with status 2 on the chain, so the switch is for measurements, not for safety)."""
         self.ctx = ctx
         self.nslab, self.ny, self.nx, self.N = int(nslab), int(ny), int(nx), int(N)
@@ -77,7 +77,7 @@ class KeffPlan(object):
         d.increase, d.lt = int(bool(increase)), int(bool(lt))
         d.right_edge = nat.XC_EDGE_XHISTOGRAM if right_edge == 'xhistogram' else nat.XC_EDGE_NUMPY
         d.deterministic = 1 if deterministic else 0
-        d.single_read = nat.XC_SINGLE_AUTO if single_read else nat.XC_SINGLE_NEVER
+        d.single_read = nat.XC_SINGLE_FORCE if single_read == 'force' else (nat.XC_SINGLE_AUTO if single_read else nat.XC_SINGLE_NEVER)
         self._runs = {}                                  # slot -> the launch sets enqueued into it since its last fetch
         self.replays = 0                                 # launch sets repeated on the chain after a status 2
         if dA is None:
@@ -276,7 +276,7 @@ class KeffPlan(object):
 
     def _enqueue(self, slot, s0, n, out_s0):
         self.ctx._check(self.ctx.lib.xc_keff_dev(self.ctx.handle, C.byref(self.desc)))
-        if n <= 2 and self.desc.single_read == nat.XC_SINGLE_AUTO:
+        if n <= 2 and self.desc.single_read != nat.XC_SINGLE_NEVER:
             # a launch set the single-read kernel may have taken: remember where it read and wrote, in case it comes back with status 2
             runs = self._runs[slot]
             runs.append((s0, n, out_s0, self._q_ptr, self._dA_ptr if self.desc.dA_rank != nat.XC_DA_NONE else 0, self._g_ptr))
