@@ -1236,6 +1236,18 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
         outc = pc.fetch()
         ok = ok and bool(np.array_equal(out['counts'], outc['counts']) and np.array_equal(out['ctr'], outc['ctr']) and
                          np.allclose(out['area'], outc['area'], rtol=1e-12, atol=0) and np.allclose(out['intgrdS'], outc['intgrdS'], rtol=1e-12, atol=0))
+        # the reference's default dtype (core.py:21): the same call on a float32 slab with float32 contours (12 B/cell algorithmic)
+        f32 = None
+        if not a.deterministic:
+            p32 = KeffPlan(ctx, 1, NY, NX, NCONT, np.float32, np.float32, **kw)
+            try:
+                p32.synth(lat, lon, SEED + 7, a.variant if a.variant != 3 else 0)
+                c32, w32 = timed(p32, True), timed(p32, False)
+                o32 = p32.fetch()
+                f32 = {'us': float(np.median(w32)), 'us_cold': float(np.median(c32)), 'path': ctx.last_keff_path(),
+                       'self_check': bool(not o32['status'].any() and p32.replays == 0 and int(o32['counts'].sum()) in (NY * NX, NY * NX - 1))}
+            finally:
+                p32.free()
         for e in (e0, e1):
             ctx.lib.xc_event_destroy(ctx.handle, e)
         alg = NY * NX * BYTES_PER_CELL
@@ -1245,7 +1257,7 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
                         else 'chain: k_minmax_partial (also clears the accumulators), k_hist (blocks add into them), k_finalize',
                 'chain': {'us': float(np.median(cwarm)), 'us_cold': float(np.median(ccold)),
                           'launches': 'k_minmax_partial, k_hist, k_finalize (xc_keff_desc.single_read = XC_SINGLE_NEVER)'},
-                'self_check': ok,
+                'f32': f32, 'self_check': ok,
                 'note': 'one 3600x1801 f64 slab per call, a stream sync before every call (HIP events around the call); warm = back to back '
                         '(Infinity-Cache resident), cold = a 600 MB memset between calls; 16 B/cell numerator as the headline; `chain`: the same '
                         'slab through the three-launch path this kernel replaces, results compared'}

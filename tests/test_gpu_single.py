@@ -261,3 +261,61 @@ def test_facade_keff_takes_the_single_read_kernel(ctx, baro):
     assert np.array_equal(ds['ctr'].values, r['ctr'].astype(np.float64))
     for k in ('area', 'intgrdS', 'latEq'):
         assert np.allclose(ds[k].values, r[k], rtol=1e-6, atol=0, equal_nan=True), k
+
+
+def test_single_read_fuzz_against_the_chain(ctx):
+    """a seeded differential fuzz: 120 random (shape, N, dtype, direction, last-bin rule, periodicity, weights, NaN pattern) cases, one slab
+    each, through the single-read kernel and through the chain -- status, levels and counts bit for bit, the sums to 1e-13, the same NaN
+    pattern in every derived vector.  Shapes include strips that end one or two columns into the last strip, chunks of 4 rows (tall
+    narrow planes), planes just above the 65 536-cell threshold and ragged last chunks."""
+    from xcontour_amd.pipeline import KeffPlan
+    from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
+    rng = np.random.default_rng(20261004)
+    taken = 0
+    for case in range(120):
+        nx = int(rng.choice([126, 128, 250, 372, 374, 496, 500, 620, 746, 994, 1240, 1488, 2 * int(rng.integers(65, 900))]))
+        ny = int(rng.integers(max(2, 65536 // nx + 1), max(65536 // nx + 40, 900)))
+        if ny * nx < 65536:
+            ny = 65536 // nx + 1
+        N = int(rng.choice([2, 3, 17, 64, 121, 201, 333]))
+        dt = [np.float64, np.float32][int(rng.integers(2))]
+        cdt = dt if rng.random() < 0.7 else np.float64
+        kw = dict(increase=bool(rng.integers(2)), lt=bool(rng.integers(2)), periodic_x=bool(rng.random() < 0.7),
+                  right_edge='xhistogram' if rng.random() < 0.7 else 'numpy', counts=bool(rng.random() < 0.8))
+        lat = np.linspace(-88, 88, ny); lon = np.arange(nx) * (360.0 / nx)
+        dA = cell_area(lat, lon)
+        mode = int(rng.integers(4))
+        if mode == 1:
+            dA = np.ascontiguousarray(dA[:, 0])
+        elif mode == 2:
+            dA = dA.copy(); dA[rng.integers(0, ny, 20), rng.integers(0, nx, 20)] = np.nan
+        elif mode == 3:
+            dA = None
+        tbl = table_from_rowsums(ctx.rowsum(None, cell_area(lat, lon), ny, nx), True, last_row_included(lat))
+        a = KeffPlan(ctx, 1, ny, nx, N, dt, cdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, single_read=True, **kw)
+        b = KeffPlan(ctx, 1, ny, nx, N, dt, cdt, dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat, single_read=False, **kw)
+        a.synth(lat, lon, 1000 + case, int(rng.integers(3)))
+        q = a.download_q()
+        if rng.random() < 0.5:
+            q[0, rng.integers(0, ny, 50), rng.integers(0, nx, 50)] = np.nan
+        if rng.random() < 0.2:
+            q[0, int(rng.integers(ny))] = np.nan                      # a whole row of land
+        if rng.random() < 0.1:
+            q[0] = np.round(q[0] * 4) / 4                             # many cells exactly on levels and ties in the extrema
+        a.set_q(q); b.set_q(q)
+        a.run(); pa = ctx.last_keff_path(); ra = a.fetch(check=False)
+        b.run(); pb = ctx.last_keff_path(); rb = b.fetch(check=False)
+        assert pb == 0 and a.replays == 0
+        taken += pa
+        tag = (case, ny, nx, N, np.dtype(dt).name, kw, mode)
+        assert np.array_equal(ra['status'], rb['status']), tag
+        assert np.array_equal(ra['ctr'], rb['ctr'], equal_nan=True), tag
+        if kw['counts']:
+            assert np.array_equal(ra['counts'], rb['counts']), tag
+        for k in ('area', 'intgrdS'):
+            x, y = ra[k], rb[k]
+            assert np.array_equal(np.isnan(x), np.isnan(y)) and rel(np.nan_to_num(x), np.nan_to_num(y)) < 1e-13, (tag, k)
+        for k in NINE[3:]:
+            assert np.array_equal(np.isnan(ra[k]), np.isnan(rb[k])), (tag, k)
+        a.free(); b.free()
+    assert taken >= 110                                               # (nearly every case fits the register tiles)
