@@ -319,3 +319,48 @@ def test_single_read_fuzz_against_the_chain(ctx):
             assert np.array_equal(np.isnan(ra[k]), np.isnan(rb[k])), (tag, k)
         a.free(); b.free()
     assert taken >= 110                                               # (nearly every case fits the register tiles)
+
+
+def test_two_processes_on_one_gpu_never_hang_and_never_return_garbage():
+    """the failure the bounded waits exist for, for real: TWO processes launch the single-read kernel on the SAME GPU at the same time --
+    neither grid can be co-resident while the other holds compute units.  Whatever the hardware scheduler does with them (serialise
+    them, or interleave them until a wait expires), every call of both processes must come back (status 0, or status 2 and the replay on
+    the chain inside KeffPlan.fetch) with the chain's own levels and counts; the processes report how many launch sets they repeated."""
+    code = r'''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %r)
+os.environ['XC_KEFF_SINGLE_TIMEOUT_US'] = '20000'
+from xcontour_amd import _native as nat
+from xcontour_amd.pipeline import KeffPlan
+from xcontour_amd.utils import cell_area, table_from_rowsums, last_row_included
+ctx = nat.Context(0)
+ny, nx, N = 1801, 3600, 201
+lat = np.linspace(-90, 90, ny); lon = np.arange(nx) * 0.1
+dA = cell_area(lat, lon)
+tbl = table_from_rowsums(ctx.rowsum(None, dA, ny, nx), True, last_row_included(lat))
+kw = dict(dA=dA, lat=lat, lon=lon, tbl=tbl, tbl_coord=lat)
+ref = KeffPlan(ctx, 1, ny, nx, N, np.float64, np.float64, single_read=False, **kw)
+ref.synth(lat, lon, 77 + int(sys.argv[1]), 0)
+ref.run(); want = ref.fetch()
+p = KeffPlan(ctx, 1, ny, nx, N, np.float64, np.float64, alloc_q=False, **kw)
+p.set_q_device(ref._q_ptr)
+while time.time() < float(sys.argv[2]):          # both processes start their loops at the same wall-clock instant
+    pass
+took = 0
+for it in range(150):
+    p.run(); took += ctx.last_keff_path()
+    got = p.fetch()
+    assert not got['status'].any(), (it, got['status'])
+    assert np.array_equal(got['ctr'], want['ctr']) and np.array_equal(got['counts'], want['counts']), it
+    assert np.allclose(got['area'], want['area'], rtol=1e-12, atol=0), it
+print('OK single-read launches %%d replays %%d' %% (took, p.replays))
+''' % ROOT
+    import time
+    t0 = time.time() + 20.0
+    procs = [subprocess.Popen([sys.executable, '-c', code, str(r), repr(t0)], env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              universal_newlines=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and 'OK single-read launches 150' in o, o[-3000:]
+    print(' | '.join(o.strip().splitlines()[-1] for o in outs))
