@@ -240,7 +240,7 @@ int xc_create(int device_id, xc_ctx** out)
         HistKnobs& k = ctx->knobs;
         k.xcd_map = env_int("XC_HIST_XCDMAP", 1); k.tile_map = env_int("XC_HIST_TILEMAP", 1); k.vec4 = env_int("XC_HIST_VEC4", -1); k.e32 = env_int("XC_HIST_E32", 1);
         k.threads = env_int("XC_HIST_THREADS", 0); k.ncopy = env_int("XC_HIST_NCOPY", 0); k.rows = env_int("XC_HIST_ROWS", 0);
-        k.bps = env_int("XC_HIST_BPS", 0); k.pad = env_int("XC_HIST_PAD", -1);
+        k.bps = env_int("XC_HIST_BPS", 0);
         k.cross_ncopy = env_int("XC_CROSS_NCOPY", 0); k.cross_blocks = env_int("XC_CROSS_BLOCKS", 0);
         k.single = env_int("XC_KEFF_SINGLE", 1); k.single_timeout_us = env_int("XC_KEFF_SINGLE_TIMEOUT_US", 50000); k.single_map = env_int("XC_KEFF_SINGLE_MAP", 0);
         k.sort_range = env_int("XC_SORT_RANGE", 1); k.lwa_fast = env_int("XC_LWA_FAST", 1); k.k1_nt = env_int("XC_K1_NT", 0); k.lwa_strip = env_int("XC_LWA_STRIP", 1);

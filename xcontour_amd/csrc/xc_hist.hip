@@ -123,12 +123,11 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     // nch sums + the count, side by side; nbin + 1 bins (the last is the trash bin).  Deterministic sums: the limbs of every channel's
     // superaccumulator + a trash word + the count / flag word (xc_binning.h)
     const size_t cell = det ? (size_t)(kDetWords * nch + 1) * 8 : (size_t)(nch + 1) * 8;
-    const int cpad = ctx->knobs.pad >= 0 ? ctx->knobs.pad : 0;
-    while (ncopy > 1 && fixed + (size_t)(nbin + 1) * (ncopy * cell + 8 * (size_t)cpad) > kLdsBudget) ncopy >>= 1;
-    if (fixed + (size_t)(nbin + 1) * (ncopy * cell + 8 * (size_t)cpad) > kLdsBudget)
+    while (ncopy > 1 && fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget) ncopy >>= 1;
+    if (fixed + (size_t)(nbin + 1) * ncopy * cell > kLdsBudget)
         return fail(ctx, XC_EBADARG, "xc_hist: too many bins x channels for the LDS histogram");
-    g->ncopy = ncopy; g->cpad = cpad;
-    g->lds = fixed + (size_t)(nbin + 1) * (ncopy * cell + 8 * (size_t)cpad);
+    g->ncopy = ncopy;
+    g->lds = fixed + (size_t)(nbin + 1) * ncopy * cell;
     g->lds = (g->lds + 15) & ~(size_t)15;
     // blocks per slab
     const int64_t total = (int64_t)g->nstrip * ny;

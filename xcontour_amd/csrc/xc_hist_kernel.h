@@ -119,10 +119,7 @@ void k_hist(const HistArgs a)
     const double* __restrict__ rdyp = a.rdy;
     const int copy = lane & (ncopy - 1);
     const int cshift = __builtin_ctz((unsigned)ncopy);            // ncopy is a power of two
-    // one bin = ncopy cells (+ a.cpad padding words: the stride between bins then spreads over the LDS banks instead of being a multiple
-    // of half of them -- lanes that share a copy but sit in different bins no longer meet on one bank pair)
-    const int cws = CW * ncopy + a.cpad;                         // words per bin
-    const unsigned cstride = (unsigned)cws * 8u, cbase = (unsigned)copy * (unsigned)(CW * 8);
+    const unsigned cstride = (unsigned)(CW * 8) << cshift, cbase = (unsigned)copy * (unsigned)(CW * 8);
     const int periodic_x = FAST ? 1 : a.periodic_x;
 
     // segment state (wave-uniform scalars + per-lane 32-bit byte offsets inside a row)
@@ -237,7 +234,7 @@ void k_hist(const HistArgs a)
     bool have = g0 < g1;
     if (have) prime();
 
-    for (int i = tid; i < (N + 1) * cws; i += blockDim.x) s_cell[i] = 0.0;
+    for (int i = tid; i < CW * hsz; i += blockDim.x) s_cell[i] = 0.0;
 
     // ------------------------------------------------------------------ edges -> LDS
     int* s_c0 = reinterpret_cast<int*>(s_red + 56);             // DET == 3: the window constant of every channel (s_red[0 .. 47] hold the reductions)
@@ -332,7 +329,7 @@ void k_hist(const HistArgs a)
     const double e0 = s_edges[0], eN = s_edges[N];
     const double inv = (double)N / (eN - e0);
     // E32: a float32 copy of the edges (they ARE float32 values: ctr_f32) behind the cells, for 4-byte reads
-    float* s_e32 = reinterpret_cast<float*>(s_cell + (size_t)(N + 1) * cws);
+    float* s_e32 = reinterpret_cast<float*>(s_cell + (size_t)CW * hsz);
     const float e0f = (float)e0, invf = (float)inv;
     if (E32) { for (int k = tid; k <= N; k += blockDim.x) s_e32[k] = (float)s_edges[k]; }
     const int last_closed = FAST ? 0 : a.last_closed;           // FAST: the half-open (xhistogram) rule is a compile-time fact
@@ -570,7 +567,7 @@ void k_hist(const HistArgs a)
         for (int i = tid; i < NCH * N; i += blockDim.x) {
             const int ch = i / N, b = i - ch * N;
             long long acc[kDetLimbsX] = {0, 0, 0, 0};
-            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(s_cell) + (size_t)b * cws + kDetWords * ch;
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(s_cell) + (size_t)b * ncopy * CW + kDetWords * ch;
             for (int c = 0; c < ncopy; ++c) {
                 long long carry = 0;
 #pragma unroll
@@ -588,7 +585,7 @@ void k_hist(const HistArgs a)
         for (int b = tid; b < N; b += blockDim.x) {
             unsigned sum = 0u, fl = 0u;
             for (int c = 0; c < ncopy; ++c) {
-                const unsigned* p = reinterpret_cast<const unsigned*>(s_cell + (size_t)b * cws + (size_t)c * CW + (CW - 1));
+                const unsigned* p = reinterpret_cast<const unsigned*>(s_cell + (size_t)(b * ncopy + c) * CW + (CW - 1));
                 sum += p[0]; fl |= p[1];
             }
             pc3[b] = sum | (fl << 28);                            // a block holds fewer than 2^28 cells: the flags ride in the top bits
@@ -604,7 +601,7 @@ void k_hist(const HistArgs a)
     // 64 lanes of a wave hit distinct LDS banks (a fixed, thread-determined order)
     for (int i = tid; i < NCH * N; i += blockDim.x) {
         const int ch = i / N, b = i - ch * N;
-        const double* src = s_cell + (size_t)b * cws + ch;
+        const double* src = s_cell + (size_t)b * ncopy * CW + ch;
         double sum = 0.0;
         for (int c = 0; c < ncopy; ++c) sum += src[(size_t)((c + tid) & (ncopy - 1)) * CW];
         if (ah) { if (sum != 0.0) atomicAdd(ah + i, sum); }
@@ -615,7 +612,7 @@ void k_hist(const HistArgs a)
     for (int b = tid; b < N; b += blockDim.x) {
         unsigned sum = 0u;
         for (int c = 0; c < ncopy; ++c)
-            sum += *reinterpret_cast<const unsigned*>(s_cell + (size_t)b * cws + (size_t)((c + tid) & (ncopy - 1)) * CW + NCH);
+            sum += *reinterpret_cast<const unsigned*>(s_cell + (size_t)(b * ncopy + ((c + tid) & (ncopy - 1))) * CW + NCH);
         if (ah) { if (sum && a.acc_c) atomicAdd(a.acc_c + (size_t)slab * N + b, (unsigned long long)sum); }
         else pc[b] = sum;
     }
@@ -630,7 +627,7 @@ int launch_three(xc_ctx* ctx, const HistGeom& g, int64_t nslab, const HistArgs& 
     HistArgs b = a;
     // the XCD-aware order needs whole groups of 8 row groups, otherwise it would leave XCDs idle (bps = 1 with many
     // small slabs would put every block on XCD 0): plain slab-fastest order then
-    b.cpad = g.cpad; b.bps = g.bps; b.nslab_grid = (int)nslab; b.xcd_map = (ctx->knobs.xcd_map && g.bps % 8 == 0) ? 1 : 0;
+    b.bps = g.bps; b.nslab_grid = (int)nslab; b.xcd_map = (ctx->knobs.xcd_map && g.bps % 8 == 0) ? 1 : 0;
     {
         const int64_t nw = (int64_t)g.bps * (g.threads / 64);
         const int64_t nchunk = nw / g.nstrip;

@@ -20,7 +20,6 @@ struct HistKnobs {
     int ncopy = 0;       // XC_HIST_NCOPY    LDS histogram copies
     int rows = 0;        // XC_HIST_ROWS     (strip, row) pairs per wave
     int bps = 0;         // XC_HIST_BPS      blocks per slab
-    int pad = -1;        // XC_HIST_PAD      padding words per LDS bin (-1: the built-in choice)
     int cross_ncopy = 0, cross_blocks = 0;   // XC_CROSS_NCOPY, XC_CROSS_BLOCKS (K9)
     int k1_nt = 0;       // XC_K1_NT         K1: 1 forces the non-temporal loads also for launches that fit the Infinity Cache
     int lwa_fast = 1;    // XC_LWA_FAST      K7: the O(ny log ny) interval kernel for planes of more than 512 rows (0: never, 2: for every plane)
@@ -132,7 +131,6 @@ struct HistGeom {
     int nstrip;     // column strips of 64*vec cells
     int bps;        // blocks per slab
     int ncopy;      // LDS histogram copies (power of two)
-    int cpad;       // padding words behind the ncopy cells of a bin (LDS bank spread)
     int nch;        // weight channels
     size_t lds;     // dynamic LDS bytes
     size_t part_h_doubles;   // per-(slab,block) partial doubles = nch*nbin
@@ -162,7 +160,7 @@ struct HistArgs {
     const double* rdy;
     int           periodic_x;
     int64_t       ny, nx;
-    int           nstrip, ncopy, cpad;
+    int           nstrip, ncopy;
     int           bps, nslab_grid, xcd_map;   // launch geometry (set by launch_hist): blocks per slab, slabs, XCD-aware block order
     int           nchunk;       // > 0: wave -> (row chunk, strip) with the strip fastest (see k_hist); 0: even split of the strip-major pairs
     double*       part_h;       // [nslab][bps][nch][nbin]
