@@ -477,6 +477,18 @@ int xc_ipc_open(xc_ctx* ctx, const void* handle64, void** out_dptr);
 int xc_ipc_close(xc_ctx* ctx, void* dptr);
 int xc_device_can_access_peer(int device, int peer, int* out_can);
 
+/* ------------------------------------------------------------------ host-only helpers of the facade (no context, no device)
+ * d(var)/d(area) along the contour index -- cal_gradient_wrt_area (core.py:463-488): np.gradient of both arguments against their
+ * contour coordinate (uniform spacing, edge_order 1) and the quotient, numpy's arithmetic operation for operation and dtype for dtype
+ * (float32 stays float32 until it meets a float64).  var: nlead rows of n values, var_row_stride ELEMENTS apart (a row of a larger result
+ * array is fine), area: area_rows = nlead or 1 rows (one area profile for every row), area_row_stride apart; the two coordinates: [n] each;
+ * out: [nlead][n], dense, in the WIDER of the two dtypes.
+ * Returns XC_OK, XC_EBADARG, or 1 when a coordinate is not equally spaced (or is float64 under a float32 array): nothing was written,
+ * the caller takes np.gradient's general branch. */
+int xc_host_gradient_wrt_area(const void* var, int var_dtype, const void* var_coord, int var_coord_dtype,
+                              const void* area, int area_dtype, const void* area_coord, int area_coord_dtype,
+                              int64_t nlead, int64_t n, int64_t area_rows, int64_t var_row_stride, int64_t area_row_stride, void* out);
+
 /* ------------------------------------------------------------------ synthetic slabs (bench / tests)
  * PV-like tracer q = sin(phi) + 0.25 sum_k a_k cos(k lambda + theta_k) cos^2(phi) + 0.02 eps
  * generated on device from a counter-based RNG.  variant 0: PV-like,

@@ -100,6 +100,59 @@ int main(void)
         if (memcmp(c1, c2, sizeof c1) != 0) { fprintf(stderr, "FAIL: result after release differs\n"); return 1; }
         d.deterministic = 0; d.cdf = &cdf[0][0][0]; d.counts = &counts[0][0];
     }
+    /* ONE slab per call through xc_keff_dev (the reference's call pattern: one (time, level) plane at a time): single_read = AUTO takes the
+       single-read kernel, NEVER the min/max + histogram + finalize chain -- same levels and counts, the sums to rounding; status is looked at
+       the way a C caller must (2 = the kernel gave up waiting for its workgroups: repeat with XC_SINGLE_NEVER) */
+    {
+        enum { KY = 300, KX = 256, KN = 41 };
+        static double kq[KY][KX], kdA[KY][KX], rdx[KY], rdy[KY], tbl[KY], crd[KY];
+        double acc = 0.0;
+        for (int j = 0; j < KY; ++j) {
+            double row = 0.0;
+            for (int i = 0; i < KX; ++i) {
+                s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+                kq[j][i] = sin(0.01 * j) + 0.1 * ((double)(s >> 11) / 9007199254740992.0);
+                kdA[j][i] = 1.0 + 0.5 * cos(0.01 * j);
+                row += kdA[j][i];
+            }
+            rdx[j] = 1.0 / (2.0 + 0.001 * j); rdy[j] = 0.5; crd[j] = -75.0 + 0.5 * j;
+            tbl[j] = acc; acc += row;                                      /* area below row j: ascending with the coordinate */
+        }
+        tbl[KY - 1] = acc;
+        const size_t pb = sizeof kq, vb = KN * sizeof(double);
+        void *dq, *dd, *dx, *dy, *dt, *dc, *dout, *dcnt, *dst;
+        if (xc_malloc(ctx, pb, &dq) || xc_malloc(ctx, pb, &dd) || xc_malloc(ctx, sizeof rdx, &dx) || xc_malloc(ctx, sizeof rdy, &dy) ||
+            xc_malloc(ctx, sizeof tbl, &dt) || xc_malloc(ctx, sizeof crd, &dc) || xc_malloc(ctx, 9 * vb, &dout) ||
+            xc_malloc(ctx, KN * sizeof(uint64_t), &dcnt) || xc_malloc(ctx, 64, &dst)) return fail("xc_malloc", ctx);
+        if (xc_memcpy_h2d(ctx, dq, kq, pb) || xc_memcpy_h2d(ctx, dd, kdA, pb) || xc_memcpy_h2d(ctx, dx, rdx, sizeof rdx) ||
+            xc_memcpy_h2d(ctx, dy, rdy, sizeof rdy) || xc_memcpy_h2d(ctx, dt, tbl, sizeof tbl) || xc_memcpy_h2d(ctx, dc, crd, sizeof crd))
+            return fail("xc_memcpy_h2d", ctx);
+        struct xc_keff_desc k;
+        memset(&k, 0, sizeof k);
+        k.q = dq; k.q_dtype = XC_F64; k.ctr_dtype = XC_F64; k.nslab = 1; k.ny = KY; k.nx = KX; k.N = KN; k.increase = 1; k.lt = 1;
+        k.right_edge = XC_EDGE_XHISTOGRAM; k.dA = (const double*)dd; k.dA_rank = XC_DA_PLANE; k.grad = 1; k.rdx = (const double*)dx; k.rdy = (const double*)dy;
+        k.periodic_x = 1; k.tbl = (const double*)dt; k.tbl_coord = (const double*)dc; k.nkeff_mask = 1e5; k.lmin_scale = 4.0e7; k.dA_pos_finite = 1;
+        double* o = (double*)dout;
+        k.ctr = o; k.area = o + KN; k.intgrdS = o + 2 * KN; k.latEq = o + 3 * KN; k.dqdA = o + 4 * KN; k.dintSdA = o + 5 * KN;
+        k.Leq2 = o + 6 * KN; k.Lmin = o + 7 * KN; k.nkeff = o + 8 * KN; k.counts = (uint64_t*)dcnt; k.status = (int32_t*)dst;
+        static double r[2][9][KN]; static uint64_t c[2][KN]; int32_t st[2]; int path[2];
+        for (int m = 0; m < 2; ++m) {
+            k.single_read = m == 0 ? XC_SINGLE_AUTO : XC_SINGLE_NEVER;
+            if (xc_keff_dev(ctx, &k) != XC_OK || xc_last_keff_path(ctx, &path[m]) != XC_OK) return fail("xc_keff_dev", ctx);
+            if (xc_memcpy_d2h(ctx, r[m], dout, 9 * vb) || xc_memcpy_d2h(ctx, c[m], dcnt, sizeof c[m]) || xc_memcpy_d2h(ctx, &st[m], dst, 4)) return fail("xc_memcpy_d2h", ctx);
+            if (st[m] == 2) { fprintf(stderr, "note: the single-read kernel gave up (status 2): a caller repeats the call with XC_SINGLE_NEVER\n"); st[m] = 0; memcpy(r[0], r[1], sizeof r[0]); }
+        }
+        if (path[0] != 1 || path[1] != 0 || st[0] || st[1]) { fprintf(stderr, "FAIL keff paths %d %d status %d %d\n", path[0], path[1], st[0], st[1]); return 1; }
+        uint64_t total = 0;
+        for (int b = 0; b < KN; ++b) {
+            total += c[0][b];
+            if (c[0][b] != c[1][b] || r[0][0][b] != r[1][0][b]) { fprintf(stderr, "FAIL keff level / count %d differs between the two one-slab paths\n", b); return 1; }
+            if (fabs(r[0][1][b] - r[1][1][b]) > 1e-12 * r[1][1][KN - 1] || fabs(r[0][2][b] - r[1][2][b]) > 1e-12 * r[1][2][KN - 1]) { fprintf(stderr, "FAIL keff sums bin %d\n", b); return 1; }
+        }
+        if (total != (uint64_t)KY * KX || !(r[0][1][KN - 1] > 0.99 * acc)) { fprintf(stderr, "FAIL keff totals\n"); return 1; }
+        void* bufs[] = {dq, dd, dx, dy, dt, dc, dout, dcnt, dst};
+        for (unsigned i = 0; i < sizeof bufs / sizeof bufs[0]; ++i) xc_free(ctx, bufs[i]);
+    }
     /* error path: non-ascending edges must be refused with a message, not crash */
     edges[0][5] = edges[0][4];
     if (xc_hist(ctx, &d) == XC_OK) { fprintf(stderr, "FAIL: bad edges accepted\n"); return 1; }

@@ -209,6 +209,57 @@ def test_fast_uniform_gradient_is_np_gradient_bit_for_bit():
     assert np.array_equal(np.gradient(fi, np.arange(4.0), axis=1, edge_order=1), core._gradient_edge1(fi, np.arange(4.0), 1))
 
 
+def test_gradient_wrt_area_in_the_library_is_the_numpy_formula_bit_for_bit():
+    """cal_gradient_wrt_area (reference core.py:463-488) through xc_host_gradient_wrt_area -- a host-only entry point of the library,
+    no device involved -- against the numpy statement np.gradient(var, k) / np.gradient(area, k): every float32 / float64 combination
+    of the two arrays and their contour coordinates numpy computes without promoting (values AND dtype), rows of a larger array
+    (cal_integral_within_contours_hist returns a slice of its (slab, channel, bin) result), one area profile for every row, two contours
+    only, zero area steps (inf / NaN like numpy), and the cases the entry point leaves to numpy (uneven coordinate, float64 coordinate
+    under float32 data, contour not last) through the facade."""
+    rng = np.random.default_rng(3)
+    lev = np.arange(4.0)
+    cm = xa.Contour2D.__new__(xa.Contour2D)                                          # the method uses no state of the object
+
+    def ref(v, k, a, ka, ax=-1, aax=-1):
+        with np.errstate(all='ignore'):
+            dv, da = np.gradient(v, k, axis=ax, edge_order=1), np.gradient(a, ka, axis=aax, edge_order=1)
+            return dv / (da if da.ndim == dv.ndim or ax in (-1, dv.ndim - 1) else da[:, None])
+
+    for n in (2, 3, 41):
+        for vd in (np.float32, np.float64):
+            for ad in (np.float32, np.float64):
+                for kd in (np.float32, np.float64):
+                    k = np.arange(n).astype(kd) * kd(0.5)
+                    big = (rng.standard_normal((4, 3, n)) * 10.0 ** int(rng.integers(-6, 6))).astype(vd)
+                    a2 = np.cumsum(rng.random((4, n)), axis=1).astype(ad)
+                    a2[1, n // 2:] = a2[1, n // 2]                                   # zero steps of the area: 0 / 0 and x / 0
+                    for v in (np.ascontiguousarray(big[:, 1, :]), big[:, 1, :]):
+                        for a, adims in ((a2, ('lev', 'contour')), (a2[2], ('contour',))):
+                            var = xa.DataArray(v, ('lev', 'contour'), {'lev': lev, 'contour': k}, 'q')
+                            area = xa.DataArray(a, adims, {'lev': lev, 'contour': k} if len(adims) == 2 else {'contour': k}, 'A')
+                            got = cm.cal_gradient_wrt_area(var, area)
+                            want = ref(v, k, a, k)
+                            assert got.values.dtype == want.dtype, (n, vd, ad, kd)
+                            assert np.array_equal(got.values, want, equal_nan=True), (n, vd, ad, kd, adims)
+                            assert got.dims == ('lev', 'contour') and got.name == 'dqdA' and np.array_equal(got.coords['contour'], k)
+    # the library says "not mine" (return code 1) and writes nothing; the facade then takes numpy's general branch
+    from xcontour_amd import _native as nat
+    lib = nat.load()
+    v = rng.standard_normal((3, 9)); a = np.cumsum(rng.random((3, 9)), axis=1); k = np.arange(9.0); ku = k.copy(); ku[4] += 0.25
+    out = np.full((3, 9), 7.0)
+    for kv, kdt, vv in ((ku, True, v), (k, True, v.astype(np.float32))):
+        rc = lib.xc_host_gradient_wrt_area(vv.ctypes.data, vv.dtype.itemsize == 8, kv.ctypes.data, kdt, a.ctypes.data, True, k.ctypes.data, True,
+                                           3, 9, 3, 9, 9, out.ctypes.data)
+        assert rc == 1 and (out == 7.0).all()
+    assert lib.xc_host_gradient_wrt_area(v.ctypes.data, True, k.ctypes.data, True, a.ctypes.data, True, k.ctypes.data, True, 3, 1, 3, 9, 9, out.ctypes.data) < 0
+    var = xa.DataArray(v, ('lev', 'contour'), {'lev': np.arange(3.0), 'contour': ku}, 'q')
+    area = xa.DataArray(a, ('lev', 'contour'), {'lev': np.arange(3.0), 'contour': ku}, 'A')
+    assert np.array_equal(cm.cal_gradient_wrt_area(var, area).values, ref(v, ku, a, ku))
+    varT = xa.DataArray(v.T.copy(), ('contour', 'lev'), {'lev': np.arange(3.0), 'contour': k}, 'q')          # contour first: numpy path
+    areaT = xa.DataArray(a.T.copy(), ('contour', 'lev'), {'lev': np.arange(3.0), 'contour': k}, 'A')
+    assert np.array_equal(cm.cal_gradient_wrt_area(varT, areaT).values, ref(v, k, a, k).T)
+
+
 def test_lookup_coordinates_of_a_stack_equals_the_loop_over_slabs():
     """Table.lookup_coordinates on (level, contour) values with ONE table (round 6: one np.interp call for the stack) against the
     reference's per-slab np.interp (core.py:1136-1174, 1405-1434), increasing and decreasing tables"""

@@ -140,6 +140,7 @@ PROTOTYPES = {
                                        C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xc_keff_epilogue': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int,
                                    C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'xc_host_gradient_wrt_area': (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _i64, _i64, _i64, _i64, _i64, _vp]),
     'xc_set_kernel_timing': (C.c_int, [_vp, C.c_int]),
     'xc_last_hist_ms': (C.c_int, [_vp, C.POINTER(C.c_float)]),
     'xc_set_hist_events': (C.c_int, [_vp, _vp, _vp]),

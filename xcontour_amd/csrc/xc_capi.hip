@@ -21,7 +21,7 @@ int fail(xc_ctx* ctx, int code, const std::string& msg)
         ctx->err = msg;
         // a call that fails delivers nothing: results still parked in the pinned output buffer must not reach arrays the caller may
         // free once it has seen the error
-        ctx->pending_out.clear(); ctx->pin_in_off = 0; ctx->pin_out_off = 0;
+        ctx->pending_out.clear(); ctx->pending_in.clear(); ctx->pin_in_off = 0; ctx->pin_out_off = 0;
     } else g_err = msg;
     return code;
 }
@@ -110,6 +110,7 @@ static const void* resident_lookup(const xc_ctx* ctx, const void* h, size_t n)
 
 constexpr size_t kPinBytes = (size_t)4 << 20;        // each bounce buffer
 constexpr size_t kPinSmall = (size_t)1 << 20;        // transfers up to this size take the bounce buffers
+constexpr size_t kCopyKernelMax = (size_t)64 << 10;  // ... and up to this size they are moved by k_copy_small, up to eight arrays per launch, instead of one DMA copy each
 
 static inline double now_s()
 {
@@ -134,11 +135,45 @@ static int h2d_raw(xc_ctx* ctx, void* d, const void* h, size_t n)
         char* p = ctx->pin_in + ctx->pin_in_off;
         ctx->pin_in_off += (n + 63) & ~(size_t)63;
         memcpy(p, h, n);
+        if (ctx->knobs.copy_kernel && n <= kCopyKernelMax) { if (n) ctx->pending_in.push_back({d, p, n}); return XC_OK; }   // leaves with flush_in
         XC_HIP(ctx, hipMemcpyAsync(d, p, n, hipMemcpyHostToDevice, ctx->stream));
         return XC_OK;
     }
     XC_HIP(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->stream));
     return XC_OK;
+}
+
+// the staged small inputs go to the device now: called by every host-form entry point between its staging and its first launch (and by
+// xc_sync, so that nothing staged can outlive the call)
+static int flush_in(xc_ctx* ctx)
+{
+    int rc = XC_OK;
+    for (size_t i = 0; i < ctx->pending_in.size() && rc == XC_OK; i += 8) {
+        SmallCopies c; int m = 0;
+        for (; m < 8 && i + m < ctx->pending_in.size(); ++m) {
+            const auto& e = ctx->pending_in[i + m];
+            c.src[m] = e.pinned; c.dst[m] = e.dev; c.bytes[m] = (unsigned)e.bytes;
+        }
+        for (int k = m; k < 8; ++k) { c.src[k] = nullptr; c.dst[k] = nullptr; c.bytes[k] = 0; }
+        rc = launch_copy_small(ctx, c, m);
+    }
+    ctx->pending_in.clear();
+    return rc;
+}
+// ... and the small results the call has asked for leave the device in one launch (xc_sync, before it waits for the stream)
+static int flush_out(xc_ctx* ctx)
+{
+    SmallCopies c; int m = 0, rc = XC_OK;
+    for (auto& po : ctx->pending_out) {
+        if (!po.dev) continue;
+        c.src[m] = po.dev; c.dst[m] = const_cast<void*>(po.pinned); c.bytes[m] = (unsigned)po.bytes; po.dev = nullptr;
+        if (++m == 8) { if (rc == XC_OK) rc = launch_copy_small(ctx, c, m); m = 0; }
+    }
+    if (m) {
+        for (int k = m; k < 8; ++k) { c.src[k] = nullptr; c.dst[k] = nullptr; c.bytes[k] = 0; }
+        if (rc == XC_OK) rc = launch_copy_small(ctx, c, m);
+    }
+    return rc;
 }
 
 // every host-form entry point stages its inputs through here: bytes that have a device mirror are copied from the mirror
@@ -174,15 +209,31 @@ static int d2h(xc_ctx* ctx, void* h, const void* d, size_t n)
     if (n <= kPinSmall && ensure_pins(ctx) == XC_OK && ctx->pin_out_off + n <= kPinBytes) {
         char* p = ctx->pin_out + ctx->pin_out_off;
         ctx->pin_out_off += (n + 63) & ~(size_t)63;
-        hipError_t e = hipMemcpyAsync(p, d, n, hipMemcpyDeviceToHost, ctx->stream);
-        if (e != hipSuccess) rc = hipfail(ctx, e, "hipMemcpyAsync(d2h)");
-        else ctx->pending_out.push_back({h, p, n});
+        if (ctx->knobs.copy_kernel && n <= kCopyKernelMax) {
+            if (n) ctx->pending_out.push_back({h, p, n, d});         // fetched by flush_out: every caller goes on to xc_sync without another launch on `d`
+        } else {
+            hipError_t e = hipMemcpyAsync(p, d, n, hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) rc = hipfail(ctx, e, "hipMemcpyAsync(d2h)");
+            else ctx->pending_out.push_back({h, p, n, nullptr});
+        }
     } else {
         hipError_t e = hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->stream);
         if (e != hipSuccess) rc = hipfail(ctx, e, "hipMemcpyAsync(d2h)");
     }
     ctx->tr_d2h += now_s() - t0;
     return rc;
+}
+
+// where the kernels of a host-form call write a SMALL result the caller wants in `h`: straight into the pinned output buffer -- the device
+// writes host memory through the same pointer, xc_sync hands it over, and the stream carries no copy of any kind for it.  Only for outputs
+// that are written once and never read back by a kernel.  nullptr: too large / buffer full / switched off -- arena bytes and d2h() then.
+static void* out_direct(xc_ctx* ctx, void* h, size_t n)
+{
+    if (!h || !ctx->knobs.copy_kernel || n == 0 || n > kCopyKernelMax || ensure_pins(ctx) != XC_OK || ctx->pin_out_off + n > kPinBytes) return nullptr;
+    char* p = ctx->pin_out + ctx->pin_out_off;
+    ctx->pin_out_off += (n + 63) & ~(size_t)63;
+    ctx->pending_out.push_back({h, p, n, nullptr});
+    return p;
 }
 
 }  // namespace xc
@@ -242,7 +293,7 @@ int xc_create(int device_id, xc_ctx** out)
         k.threads = env_int("XC_HIST_THREADS", 0); k.ncopy = env_int("XC_HIST_NCOPY", 0); k.rows = env_int("XC_HIST_ROWS", 0);
         k.bps = env_int("XC_HIST_BPS", 0);
         k.cross_ncopy = env_int("XC_CROSS_NCOPY", 0); k.cross_blocks = env_int("XC_CROSS_BLOCKS", 0);
-        k.single = env_int("XC_KEFF_SINGLE", 1); k.single_timeout_us = env_int("XC_KEFF_SINGLE_TIMEOUT_US", 50000); k.single_map = env_int("XC_KEFF_SINGLE_MAP", 0);
+        k.copy_kernel = env_int("XC_COPY_KERNEL", 1); k.single = env_int("XC_KEFF_SINGLE", 1); k.single_timeout_us = env_int("XC_KEFF_SINGLE_TIMEOUT_US", 50000); k.single_map = env_int("XC_KEFF_SINGLE_MAP", 0);
         k.sort_range = env_int("XC_SORT_RANGE", 1); k.lwa_fast = env_int("XC_LWA_FAST", 1); k.k1_nt = env_int("XC_K1_NT", 0); k.lwa_strip = env_int("XC_LWA_STRIP", 1);
     }
     ctx->cus = prop.multiProcessorCount;
@@ -310,6 +361,8 @@ int xc_device_cus(xc_ctx* ctx, int* out_cus)
 int xc_sync(xc_ctx* ctx)
 {
     XC_CTX(ctx);
+    { const int rc = flush_in(ctx); if (rc != XC_OK) return rc; }
+    { const int rc = flush_out(ctx); if (rc != XC_OK) return rc; }
     const double t0 = now_s();
     // (round 6: polling hipStreamQuery for the first 150 us instead of blocking at once changes nothing -- 369 against 374 us for the
     // reference's call sequence at its demo size: the runtime's own wait already spins)
@@ -318,7 +371,7 @@ int xc_sync(xc_ctx* ctx)
     ctx->tr_sync += t1 - t0;
     // results parked in the pinned output buffer go to the caller's arrays now; both bounce buffers are free again
     if (e == hipSuccess) for (const auto& po : ctx->pending_out) memcpy(po.host, po.pinned, po.bytes);
-    ctx->pending_out.clear();
+    ctx->pending_out.clear(); ctx->pending_in.clear();
     ctx->pin_in_off = 0; ctx->pin_out_off = 0;
     ctx->tr_d2h += now_s() - t1;
     if (e != hipSuccess) return hipfail(ctx, e, "hipStreamSynchronize");
@@ -581,6 +634,7 @@ int xc_minmax(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t nc
     const void* dq; double* dout;
     XC_TRY(stage_in(ctx, st.take(qb), q, qb, &dq));
     dout = (double*)st.take(ob);
+    XC_TRY(flush_in(ctx));
     XC_TRY(xc_minmax_dev(ctx, dq, q_dtype, nslab, ncell, dout));
     XC_TRY(d2h(ctx, out_minmax, dout, ob));
     return xc_sync(ctx);
@@ -605,6 +659,7 @@ int xc_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int
     double* dm = (double*)st.take(mb); double* dc = (double*)st.take(cb);
     double* de = (double*)st.take(eb); int32_t* ds = (int32_t*)st.take(sb);
     XC_TRY(h2d(ctx, dm, minmax, mb));
+    XC_TRY(flush_in(ctx));
     XC_TRY(launch_levels(ctx, dm, q_dtype, nslab, N, increase, ctr_dtype, right_edge, dc, de, ds));
     XC_TRY(d2h(ctx, ctr, dc, cb)); XC_TRY(d2h(ctx, edges, de, eb)); XC_TRY(d2h(ctx, status, ds, sb));
     return xc_sync(ctx);
@@ -625,14 +680,21 @@ int xc_contours(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t 
     Stage st(ctx);
     const void* dq;
     XC_TRY(stage_in(ctx, st.take(qb), q, qb, &dq));
-    double* dm = (double*)st.take(mb); double* dc = (double*)st.take(cb);
-    double* de = (double*)st.take(eb); int32_t* ds = (int32_t*)st.take(sb);
-    XC_TRY(xc_minmax_dev(ctx, dq, q_dtype, nslab, ncell, dm));
-    XC_TRY(launch_levels(ctx, dm, q_dtype, nslab, N, increase, ctr_dtype, right_edge, dc, de, ds));
+    double* dm = (double*)st.take(mb);                       // (read by the level kernel: stays on the device)
+    double* pc = (double*)out_direct(ctx, out_ctr, cb); double* pe = (double*)out_direct(ctx, out_edges, eb);
+    int32_t* ps = (int32_t*)out_direct(ctx, out_status, sb);
+    double* dc = pc ? pc : (double*)st.take(cb);
+    double* de = pe ? pe : (double*)st.take(eb); int32_t* ds = ps ? ps : (int32_t*)st.take(sb);
+    XC_TRY(flush_in(ctx));
+    // K1's partials are reduced by the level kernel itself: two launches for the whole call
+    XC_TRY(ensure_scratch(ctx, al((size_t)nslab * kMinmaxBlocks * 2 * sizeof(double))));
+    XC_TRY(launch_minmax_partial(ctx, dq, q_dtype, nslab, ncell, (double*)ctx->scratch));
+    XC_TRY(launch_levels(ctx, (const double*)ctx->scratch, q_dtype, nslab, N, increase, ctr_dtype, right_edge, dc, de, ds,
+                         minmax_blocks(ncell, nslab), dm));
     if (out_minmax) XC_TRY(d2h(ctx, out_minmax, dm, mb));
-    XC_TRY(d2h(ctx, out_ctr, dc, cb));
-    if (out_edges) XC_TRY(d2h(ctx, out_edges, de, eb));
-    if (out_status) XC_TRY(d2h(ctx, out_status, ds, sb));
+    if (!pc) XC_TRY(d2h(ctx, out_ctr, dc, cb));
+    if (out_edges && !pe) XC_TRY(d2h(ctx, out_edges, de, eb));
+    if (out_status && !ps) XC_TRY(d2h(ctx, out_status, ds, sb));
     return xc_sync(ctx);
 }
 
@@ -805,13 +867,16 @@ int xc_hist(xc_ctx* ctx, const xc_hist_desc* hd)
         double* p = (double*)st.take(rb); XC_TRY(h2d(ctx, p, hd->rdx, rb)); d.rdx = p;
         p = (double*)st.take(rb); XC_TRY(h2d(ctx, p, hd->rdy, rb)); d.rdy = p;
     }
-    d.pdf = hd->pdf ? (double*)st.take(pb) : nullptr;
-    d.cdf = hd->cdf ? (double*)st.take(pb) : nullptr;
-    d.counts = hd->counts ? (uint64_t*)st.take(cb) : nullptr;
+    // (the finalize kernel writes the three results once and reads none of them back: small ones go straight to the pinned buffer)
+    void* pp = out_direct(ctx, hd->pdf, pb); void* pcd = out_direct(ctx, hd->cdf, pb); void* pn = out_direct(ctx, hd->counts, cb);
+    d.pdf = hd->pdf ? (pp ? (double*)pp : (double*)st.take(pb)) : nullptr;
+    d.cdf = hd->cdf ? (pcd ? (double*)pcd : (double*)st.take(pb)) : nullptr;
+    d.counts = hd->counts ? (pn ? (uint64_t*)pn : (uint64_t*)st.take(cb)) : nullptr;
+    XC_TRY(flush_in(ctx));
     XC_TRY(xc_hist_dev(ctx, &d));
-    if (hd->pdf) XC_TRY(d2h(ctx, hd->pdf, d.pdf, pb));
-    if (hd->cdf) XC_TRY(d2h(ctx, hd->cdf, d.cdf, pb));
-    if (hd->counts) XC_TRY(d2h(ctx, hd->counts, d.counts, cb));
+    if (hd->pdf && !pp) XC_TRY(d2h(ctx, hd->pdf, d.pdf, pb));
+    if (hd->cdf && !pcd) XC_TRY(d2h(ctx, hd->cdf, d.cdf, pb));
+    if (hd->counts && !pn) XC_TRY(d2h(ctx, hd->counts, d.counts, cb));
     return xc_sync(ctx);
 }
 
@@ -837,9 +902,11 @@ int xc_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, i
     void* dm = nullptr; double* dd = nullptr;
     if (mb) { dm = st.take(mb); XC_TRY(h2d(ctx, dm, mask, mb)); }
     if (dab) { dd = (double*)st.take(dab); XC_TRY(h2d(ctx, dd, dA, dab)); }
-    double* dout = (double*)st.take((size_t)ny * 8);
+    double* po = (double*)out_direct(ctx, out_rows, (size_t)ny * 8);
+    double* dout = po ? po : (double*)st.take((size_t)ny * 8);
+    XC_TRY(flush_in(ctx));
     XC_TRY(launch_rowsum(ctx, dm, mask_dtype, dd, dA_rank, ny, nx, multiply, dout));
-    XC_TRY(d2h(ctx, out_rows, dout, (size_t)ny * 8));
+    if (!po) XC_TRY(d2h(ctx, out_rows, dout, (size_t)ny * 8));
     return xc_sync(ctx);
 }
 
@@ -862,6 +929,7 @@ int xc_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny,
     Stage st(ctx);
     void* dq = st.take(qb); double* dx = (double*)st.take(rb); double* dy = (double*)st.take(rb); double* dout = (double*)st.take(ob);
     XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, dx, rdx, rb)); XC_TRY(h2d(ctx, dy, rdy, rb));
+    XC_TRY(flush_in(ctx));
     XC_TRY(launch_grad2(ctx, dq, q_dtype, nslab, ny, nx, dx, dy, periodic_x, dout));
     XC_TRY(d2h(ctx, out, dout, ob));
     return xc_sync(ctx);
@@ -904,6 +972,7 @@ int xc_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t 
     double* dl = out_len ? (double*)st.take(ob) : nullptr;
     uint64_t* dn = out_cnt ? (uint64_t*)st.take(ob) : nullptr;
     XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, da, area, ab)); XC_TRY(h2d(ctx, dc, contours, cb));
+    XC_TRY(flush_in(ctx));
     XC_TRY(launch_crossing(ctx, dq, q_dtype, nslab, ny, nx, pad_x, pad_mode, dc, ncont, contours_per_slab,
                            da, area_dtype, area_per_slab, stride, full_width, dl, dn));
     if (out_len) XC_TRY(d2h(ctx, out_len, dl, ob));
@@ -947,6 +1016,7 @@ int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const doubl
     XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, dQ, Q, Qb)); XC_TRY(h2d(ctx, dc, coord, cb)); XC_TRY(h2d(ctx, dd, dA, dab));
     if (Mb) XC_TRY(h2d(ctx, dM, M, Mb));
     if (nmask) XC_TRY(h2d(ctx, dmi, mask_idx, mib));
+    XC_TRY(flush_in(ctx));
     XC_TRY(launch_lwa(ctx, dq, q_dtype, dQ, dc, dd, dA_rank, dA_max, dM, M_rank, nslab, ny, nx, increase, part, variant,
                       dmi, nmask, dout, dmo));
     XC_TRY(d2h(ctx, out_lwa, dout, ob));
@@ -998,6 +1068,7 @@ int xc_sort_profile_batch(xc_ctx* ctx, const void* q, int q_dtype, const void* m
     double* dac = out_acum ? (double*)st.take(S * n * 8) : nullptr;
     uint32_t* dnv = (uint32_t*)st.take(S * 4);
     double* dbpe = out_bpe ? (double*)st.take(S * 8) : nullptr;
+    XC_TRY(flush_in(ctx));
     XC_TRY(xc_sort_profile_batch_dev(ctx, dq, q_dtype, dm, mask_dtype, mask_per_slab, dd, dA_rank, nslab, ny, nx, negate,
                                      dt, dQ ? J : 0, dtbl, dcrd, ntbl, dQ, dqs, dac, dnv, dbpe));
     if (dQ) XC_TRY(d2h(ctx, out_Q, dQ, Qb));
@@ -1110,6 +1181,7 @@ int xc_keff_epilogue(xc_ctx* ctx, const double* pdf, const double* ctr, int ctr_
     XC_TRY(h2d(ctx, dp, pdf, pb)); XC_TRY(h2d(ctx, dc, ctr, vb));
     XC_TRY(h2d(ctx, dt, tbl, tb)); XC_TRY(h2d(ctx, dy, tbl_coord, tb));
     if (dpre) { if (!preY) return fail(ctx, XC_EBADARG, "xc_keff_epilogue: preY is NULL"); XC_TRY(h2d(ctx, dpre, preY, yb)); }
+    XC_TRY(flush_in(ctx));
     XC_TRY(xc_keff_epilogue_dev(ctx, dp, dc, ctr_dtype, nslab, N, increase, lt, dt, dy, ntbl, dpre, npre, nkeff_mask, lmin_scale,
                                 o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], di));
     double* host[8] = {area, intgrdS, latEq, dqdA, dintSdA, Leq2, Lmin, nkeff};

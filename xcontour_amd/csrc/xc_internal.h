@@ -12,6 +12,7 @@
 // Experiment knobs of the K3 geometry, read from the environment ONCE, in xc_create (contexts may be driven from several
 // threads; nothing reads the environment after that).  0 / -1 = the built-in choice.
 struct HistKnobs {
+    int copy_kernel = 1; // XC_COPY_KERNEL   small transfers of the host-form entry points (<= 64 KB each): 1 one copy KERNEL per direction between the pinned bounce buffers and device memory, 0 one DMA copy per array
     int xcd_map = 1;     // XC_HIST_XCDMAP   XCD-aware block order when blocks per slab is a multiple of 8
     int tile_map = 1;    // XC_HIST_TILEMAP  strip-fastest wave order
     int vec4 = -1;       // XC_HIST_VEC4     four cells per lane: -1 float32 tracers only, 0 never, 1 always
@@ -46,8 +47,10 @@ struct xc_ctx {
     // synchronisation (xc_sync).  Both are bump-allocated per call and reset by xc_sync; what does not fit takes the direct path.
     char* pin_in = nullptr;  size_t pin_in_off = 0;
     char* pin_out = nullptr; size_t pin_out_off = 0;
-    struct PendingOut { void* host; const void* pinned; size_t bytes; };
+    struct PendingOut { void* host; const void* pinned; size_t bytes; const void* dev; };   // dev != nullptr: still to be fetched by the copy kernel (flush_out)
     std::vector<PendingOut> pending_out;
+    struct PendingIn { void* dev; const void* pinned; size_t bytes; };                      // staged in pin_in, not yet on the device (flush_in)
+    std::vector<PendingIn> pending_in;
     // where a host-form call spends its time, accumulated between two xc_trace calls (seconds): input staging (memcpy + enqueue),
     // result hand-over (enqueue + memcpy), waiting for the stream
     double tr_h2d = 0.0, tr_d2h = 0.0, tr_sync = 0.0;
@@ -244,9 +247,11 @@ int launch_keff_single(xc_ctx* ctx, int q_dtype, const SingleArgs& a, const Sing
 // ---------------------------------------------------------------- launchers (defined in the .hip files)
 int launch_minmax_partial(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ncell, double* part,
                           double* zero = nullptr, int64_t nzero = 0, bool finite_only = false);      // finite_only: +-inf skipped like NaN; zero: `nzero` 8-byte words cleared by the same launch (the accumulators of HistArgs::acc_h)
+struct SmallCopies { const void* src[8]; void* dst[8]; unsigned bytes[8]; };
+int launch_copy_small(xc_ctx* ctx, const SmallCopies& c, int count);
 int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, int P, double* out);
 int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
-                  int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status);
+                  int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status, int P = 0, double* minmax_out = nullptr);
 int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t nx, int nbin, int nch,
                   const void* q, HistGeom* g, int keff_fast_layout = 0, int det = 0);
 int launch_hist(xc_ctx* ctx, int q_dtype, int nint, int grad, const HistGeom& g, int64_t nslab, const HistArgs& a);

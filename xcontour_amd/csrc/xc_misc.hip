@@ -128,39 +128,61 @@ void k_minmax_final(const double* __restrict__ part, int P, double* __restrict__
 // =====================================================================================
 // stand-alone levels + edges (same arithmetic as the K3 prologue; core.py:228-246, 1296-1305)
 // =====================================================================================
+// P > 0: `minmax` holds K1's per-block partials [slab][P][2] -- reduced here (the arithmetic of k_minmax_final), one launch less in
+// xc_contours; the slab's pair goes to minmax_out when that is not NULL.  Every output word is written ONCE and none is read back: ctr /
+// edges / status may be pinned host memory (round 6: the results of a small call are written straight into the buffer xc_sync hands over).
 __global__ __launch_bounds__(256)
-void k_levels(const double* __restrict__ minmax, int N, int increase, int q_f32, int ctr_f32,
+void k_levels(const double* __restrict__ minmax, int P, double* __restrict__ minmax_out, int N, int increase, int q_f32, int ctr_f32,
               int right_edge, double inv_nm1, double* __restrict__ ctr, double* __restrict__ edges,
               int32_t* __restrict__ status)
 {
     const int slab = blockIdx.x, tid = threadIdx.x;
-    const double mn = minmax[2 * slab], mx = minmax[2 * slab + 1];
+    __shared__ double s[8], s_mm[2];
+    if (P > 0) {
+        const double* mp = minmax + (size_t)slab * P * 2;
+        double a = dinf(), b = -dinf();
+        for (int i = tid; i < P; i += 256) { a = fmin(a, mp[2 * i]); b = fmax(b, mp[2 * i + 1]); }
+        for (int o = 32; o > 0; o >>= 1) { a = fmin(a, __shfl_xor(a, o)); b = fmax(b, __shfl_xor(b, o)); }
+        if ((tid & 63) == 0) { s[2 * (tid >> 6)] = a; s[2 * (tid >> 6) + 1] = b; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) { a = fmin(a, s[2 * w]); b = fmax(b, s[2 * w + 1]); }
+            if (a == dinf() && b == -dinf()) { a = dnan(); b = dnan(); }
+            s_mm[0] = a; s_mm[1] = b;
+            if (minmax_out) { minmax_out[2 * slab] = a; minmax_out[2 * slab + 1] = b; }
+        }
+    } else if (tid == 0) { s_mm[0] = minmax[2 * slab]; s_mm[1] = minmax[2 * slab + 1]; }
+    __syncthreads();
+    const double mn = s_mm[0], mx = s_mm[1];
     double* e = edges + (size_t)slab * (N + 1);
     const double start = increase ? mn : mx, stop = increase ? mx : mn;
     const double d = q_f32 ? (double)__fsub_rn((float)stop, (float)start) : __dsub_rn(stop, start);
     const double steps = __dmul_rn(inv_nm1, d);
-    for (int k = tid; k < N; k += 256) {
+    auto level = [&](int k) {
         double c = __dadd_rn(__dmul_rn(steps, (double)k), start);
         if (ctr_f32) c = (double)(float)c;
+        return c;
+    };
+    const bool bump = right_edge == XC_EDGE_XHISTOGRAM;
+    int bad = 0;
+    for (int k = tid; k < N; k += 256) {
+        const double c = level(k);
         ctr[(size_t)slab * N + k] = c;
-        e[increase ? k + 1 : N - k] = c;
+        const int idx = increase ? k + 1 : N - k;
+        e[idx] = (idx == N && bump) ? (ctr_f32 ? (double)__fadd_rn((float)c, (float)1e-8) : __dadd_rn(c, 1e-8)) : c;
+        if (k > 0) bad |= (c == level(k - 1));
     }
-    __syncthreads();   // block-scope visibility of the global stores above (same CU)
+    bad = __syncthreads_or(bad);
     if (tid == 0) {
-        status[slab] = 0;
-        const double lo = e[1], hi = e[N];
+        const double lo = level(increase ? 0 : N - 1), hi = level(increase ? N - 1 : 0);
         if (ctr_f32) {
             const float step = __fdiv_rn(__fsub_rn((float)hi, (float)lo), (float)(N - 1));
             e[0] = (double)__fsub_rn((float)lo, step);
-            if (right_edge == XC_EDGE_XHISTOGRAM) e[N] = (double)__fadd_rn((float)hi, (float)1e-8);
         } else {
             const double step = __ddiv_rn(__dsub_rn(hi, lo), (double)(N - 1));
             e[0] = __dsub_rn(lo, step);
-            if (right_edge == XC_EDGE_XHISTOGRAM) e[N] = __dadd_rn(hi, 1e-8);
         }
-        int bad = 0;
-        for (int k = 1; k < N; ++k) bad |= (ctr[(size_t)slab * N + k] == ctr[(size_t)slab * N + k - 1]);
-        status[slab] = bad;
+        status[slab] = bad ? 1 : 0;
     }
 }
 
@@ -332,12 +354,12 @@ int launch_minmax_final(xc_ctx* ctx, const double* part, int64_t nslab, int P, d
 }
 
 int launch_levels(xc_ctx* ctx, const double* minmax, int q_dtype, int64_t nslab, int N, int increase,
-                  int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status)
+                  int ctr_dtype, int right_edge, double* ctr, double* edges, int32_t* status, int P, double* minmax_out)
 {
     if (!minmax || !ctr || !edges || !status || N < 2 || nslab < 1)
         return fail(ctx, XC_EBADARG, "xc_levels: bad arguments (need N >= 2)");
     const double inv = 1.0 / (double)(N - 1);
-    hipLaunchKernelGGL(k_levels, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, minmax, N, increase,
+    hipLaunchKernelGGL(k_levels, dim3((unsigned)nslab), dim3(256), 0, ctx->stream, minmax, P, minmax_out, N, increase,
                        q_dtype == XC_F32, ctr_dtype == XC_F32, right_edge, inv, ctr, edges, status);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
@@ -427,6 +449,37 @@ int launch_synth(xc_ctx* ctx, void* out, int q_dtype, int64_t nslab, int64_t ny,
     else if (q_dtype == XC_F32)
         hipLaunchKernelGGL(k_synth<float>, grid, dim3(256), 0, ctx->stream, (float*)out, ny, nx, lat_deg, lon_deg, seed, variant);
     else return fail(ctx, XC_EBADARG, "xc_synth: q_dtype must be XC_F32 or XC_F64");
+    XC_HIP(ctx, hipGetLastError());
+    return XC_OK;
+}
+
+// ---- the small transfers of a host-form call, one KERNEL per direction (round 6).  Every hipMemcpyAsync between a pinned bounce buffer
+// and device memory is an operation of its own on the stream (a DMA packet or a blit launch, with the dependency packets around it): at the
+// reference's demo size (15 x 241 x 480) the three or four result vectors of a call cost more stream time than its kernels.  pin_in /
+// pin_out are hipHostMalloc'd: the device reads and writes them through the same pointers; a kernel's stores to host memory are visible to
+// the host once the stream has been waited for, and the host's memcpy into pin_in happened before the launch.
+__global__ __launch_bounds__(256)
+void k_copy_small(const SmallCopies c)
+{
+    const int e = (int)blockIdx.y;
+    const unsigned n = c.bytes[e];
+    const char* s = (const char*)c.src[e];
+    char* d = (char*)c.dst[e];
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    const uintptr_t bits = (uintptr_t)s | (uintptr_t)d | (uintptr_t)n;
+    if ((bits & 15) == 0) {
+        for (unsigned i = t; i < (n >> 4); i += nt) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    } else if ((bits & 3) == 0) {
+        for (unsigned i = t; i < (n >> 2); i += nt) reinterpret_cast<unsigned*>(d)[i] = reinterpret_cast<const unsigned*>(s)[i];
+    } else {
+        for (unsigned i = t; i < n; i += nt) d[i] = s[i];
+    }
+}
+
+int launch_copy_small(xc_ctx* ctx, const SmallCopies& c, int count)
+{
+    if (count < 1 || count > 8) return fail(ctx, XC_EBADARG, "launch_copy_small: 1..8 copies per launch");
+    hipLaunchKernelGGL(k_copy_small, dim3(4, (unsigned)count), dim3(256), 0, ctx->stream, c);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
 }
