@@ -12,7 +12,9 @@ for l in open('gpurun_out/facade_now%s.jsonl' % sys.argv[1]):
     if k in d:
         r = d[k]
         for n, v in r.items():
+            if not isinstance(v, dict):
+                print('   %-32s us %6.1f' % (n, v)); continue
             print('   %-32s us %6.1f  py %5.1f lib %5.1f wait %5.1f launch %5.1f' % (n, v['us'], v['python_us'], v['library_us'], v['library_split_us']['wait_for_stream'], v['library_split_us']['checks_and_launches']))
-        print('  seq sum', round(sum(v['us'] for n, v in r.items() if not n.startswith('keff')), 1))
+        print('  seq sum', round(sum(v['us'] for n, v in r.items() if isinstance(v, dict) and not n.startswith('keff')), 1))
 PY
 done

@@ -158,5 +158,29 @@ if os.environ.get('XC_FACADE_SMALL') or '--breakdown' in sys.argv:
         latEq = timed('lookup_coordinates', lambda: table.lookup_coordinates(area))
         dq = timed('gradient_wrt_area x2', lambda: (cm.cal_gradient_wrt_area(ctr, area), cm.cal_gradient_wrt_area(intS, area)))
         timed('keff fused (grdS supplied)', lambda: cm.keff(N1, table, grdS=g2))
+        # ... and the sequence as an analysis runs it: the seven calls one after the other on a tracer that CHANGES from one pass to the
+        # next (six fields round-robin, each with its own levels: the library's cache of small inputs -- four entries -- cannot serve the
+        # first binning call of a pass, only the second, as in real use; the per-call rows above repeat one call on one field)
+        if kw.get('resident', False):
+            objs = []
+            for i in range(6):
+                qi = (q * np.float32(1.0 + 0.03 * i) + np.float32(0.01 * i)).astype(np.float32)
+                objs.append(xa.Contour2D(xa.DataArray(qi, ('lev', 'lat', 'lon'), c3, 'pv'), dA, dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'},
+                                         increase=True, lt=True, resident=True))
+
+            def sequence(c):
+                tb = c.cal_area_eqCoord_table_hist(mask)
+                ct = c.cal_contours(N1)
+                ar = c.cal_integral_within_contours_hist(ct)
+                iS = c.cal_integral_within_contours_hist(ct, integrand=g2)
+                le = tb.lookup_coordinates(ar)
+                return le, c.cal_gradient_wrt_area(ct, ar), c.cal_gradient_wrt_area(iS, ar)
+            for c in objs:
+                sequence(c); sequence(c)
+            t = time.perf_counter()
+            for _ in range(10):
+                for c in objs:
+                    sequence(c)
+            rec['whole sequence, changing tracer'] = (time.perf_counter() - t) / 60 * 1e6
         print(json.dumps({'facade_us_per_call_cfg1_stack_15x241x480_f32': rec, 'resident': bool(kw.get('resident', False))}))
     small()

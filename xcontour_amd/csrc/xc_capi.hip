@@ -22,6 +22,9 @@ int fail(xc_ctx* ctx, int code, const std::string& msg)
         // a call that fails delivers nothing: results still parked in the pinned output buffer must not reach arrays the caller may
         // free once it has seen the error
         ctx->pending_out.clear(); ctx->pending_in.clear(); ctx->pin_in_off = 0; ctx->pin_out_off = 0;
+        // (an entry of the small-input cache filled during the failed call may never have been uploaded: forget what this call staged)
+        for (auto& e : ctx->small_in) if (e.epoch == ctx->small_epoch) { e.host.clear(); e.epoch = ~0ull; }
+        ++ctx->small_epoch;
     } else g_err = msg;
     return code;
 }
@@ -200,6 +203,43 @@ static int stage_in(xc_ctx* ctx, void* slot, const void* h, size_t n, const void
     ctx->tr_h2d += now_s() - t0;
     return rc;
 }
+// a SMALL read-only input (see xc_ctx::SmallIn): the device copy of an earlier call when the bytes are the same, else an upload into a cache
+// entry (through the pinned buffer and the copy kernel, like every small input) that later calls can hit
+static int stage_small(xc_ctx* ctx, void* slot, const void* h, size_t n, const void** dev)
+{
+    if (!ctx->resident.empty())
+        if (const void* m = resident_lookup(ctx, h, n)) { *dev = m; return XC_OK; }
+    if (ctx->knobs.copy_kernel && n > 0 && n <= kCopyKernelMax) {
+        const double t0 = now_s();
+        xc_ctx::SmallIn* lru = nullptr;
+        for (auto& e : ctx->small_in) {
+            if (e.dev && e.host.size() == n && memcmp(e.host.data(), h, n) == 0) {
+                e.used = ++ctx->small_clock; e.epoch = ctx->small_epoch; ++ctx->small_hits;
+                *dev = e.dev; ctx->tr_h2d += now_s() - t0;
+                return XC_OK;
+            }
+            if (e.epoch != ctx->small_epoch && (!lru || e.used < lru->used)) lru = &e;
+        }
+        if (lru && ensure_pins(ctx) == XC_OK && ctx->pin_in_off + n <= kPinBytes) {
+            if (!lru->dev) { hipError_t he = hipMalloc(&lru->dev, kCopyKernelMax); if (he != hipSuccess) { lru->dev = nullptr; (void)hipGetLastError(); } }
+            if (lru->dev) {
+                lru->host.assign((const char*)h, (const char*)h + n);
+                lru->used = ++ctx->small_clock; lru->epoch = ctx->small_epoch; ++ctx->small_misses;
+                char* p = ctx->pin_in + ctx->pin_in_off;
+                ctx->pin_in_off += (n + 63) & ~(size_t)63;
+                memcpy(p, h, n);
+                ctx->pending_in.push_back({lru->dev, p, n});
+                *dev = lru->dev; ctx->tr_h2d += now_s() - t0;
+                return XC_OK;
+            }
+        }
+    }
+    *dev = slot;
+    const double t0 = now_s();
+    const int rc = h2d_raw(ctx, slot, h, n);
+    ctx->tr_h2d += now_s() - t0;
+    return rc;
+}
 // device -> the caller's host array.  Small results wait in the pinned output buffer and are handed over by xc_sync (EVERY host-form
 // entry point ends in xc_sync): the copies of a call are asynchronous and its stream is waited for once.
 static int d2h(xc_ctx* ctx, void* h, const void* d, size_t n)
@@ -323,6 +363,7 @@ int xc_destroy(xc_ctx* ctx)
     if (ctx->ev_comm_in) (void)hipEventDestroy(ctx->ev_comm_in);
     if (ctx->ev_comm_out) (void)hipEventDestroy(ctx->ev_comm_out);
     if (ctx->pinned_flag) (void)hipHostFree(ctx->pinned_flag);
+    for (auto& e : ctx->small_in) if (e.dev) (void)hipFree(e.dev);
     if (ctx->pin_in) (void)hipHostFree(ctx->pin_in);
     if (ctx->pin_out) (void)hipHostFree(ctx->pin_out);
     if (ctx->lwa_flag) (void)hipFree(ctx->lwa_flag);
@@ -373,6 +414,7 @@ int xc_sync(xc_ctx* ctx)
     if (e == hipSuccess) for (const auto& po : ctx->pending_out) memcpy(po.host, po.pinned, po.bytes);
     ctx->pending_out.clear(); ctx->pending_in.clear();
     ctx->pin_in_off = 0; ctx->pin_out_off = 0;
+    ++ctx->small_epoch;
     ctx->tr_d2h += now_s() - t1;
     if (e != hipSuccess) return hipfail(ctx, e, "hipStreamSynchronize");
     return XC_OK;
@@ -860,12 +902,13 @@ int xc_hist(xc_ctx* ctx, const xc_hist_desc* hd)
     Stage st(ctx);
     xc_hist_desc d = *hd;
     XC_TRY(stage_in(ctx, st.take(qb), hd->q, qb, &d.q));
-    double* de = (double*)st.take(eb); XC_TRY(h2d(ctx, de, hd->edges, eb)); d.edges = de;
+    { const void* p; XC_TRY(stage_small(ctx, st.take(eb), hd->edges, eb, &p)); d.edges = (const double*)p; }
     if (dab) { const void* p; XC_TRY(stage_in(ctx, st.take(dab), hd->dA, dab, &p)); d.dA = (const double*)p; }
     for (int i = 0; i < hd->nint; ++i) XC_TRY(stage_in(ctx, st.take(ib[i]), hd->integrand[i], ib[i], &d.integrand[i]));
     if (hd->grad) {
-        double* p = (double*)st.take(rb); XC_TRY(h2d(ctx, p, hd->rdx, rb)); d.rdx = p;
-        p = (double*)st.take(rb); XC_TRY(h2d(ctx, p, hd->rdy, rb)); d.rdy = p;
+        const void* p;
+        XC_TRY(stage_small(ctx, st.take(rb), hd->rdx, rb, &p)); d.rdx = (const double*)p;
+        XC_TRY(stage_small(ctx, st.take(rb), hd->rdy, rb, &p)); d.rdy = (const double*)p;
     }
     // (the finalize kernel writes the three results once and reads none of them back: small ones go straight to the pinned buffer)
     void* pp = out_direct(ctx, hd->pdf, pb); void* pcd = out_direct(ctx, hd->cdf, pb); void* pn = out_direct(ctx, hd->counts, cb);
@@ -900,8 +943,9 @@ int xc_rowsum(xc_ctx* ctx, const void* mask, int mask_dtype, const double* dA, i
     XC_TRY(ensure_arena(ctx, al(mb) + al(dab) + al((size_t)ny * 8)));
     Stage st(ctx);
     void* dm = nullptr; double* dd = nullptr;
-    if (mb) { dm = st.take(mb); XC_TRY(h2d(ctx, dm, mask, mb)); }
-    if (dab) { dd = (double*)st.take(dab); XC_TRY(h2d(ctx, dd, dA, dab)); }
+    // (resident inputs are read where they are: no device-to-device copy into the arena)
+    if (mb) { const void* p; XC_TRY(stage_in(ctx, st.take(mb), mask, mb, &p)); dm = const_cast<void*>(p); }
+    if (dab) { const void* p; XC_TRY(stage_in(ctx, st.take(dab), dA, dab, &p)); dd = (double*)const_cast<void*>(p); }
     double* po = (double*)out_direct(ctx, out_rows, (size_t)ny * 8);
     double* dout = po ? po : (double*)st.take((size_t)ny * 8);
     XC_TRY(flush_in(ctx));

@@ -131,8 +131,16 @@ int hist_geometry(xc_ctx* ctx, int q_dtype, int64_t nslab, int64_t ny, int64_t n
     g->lds = (g->lds + 15) & ~(size_t)15;
     // blocks per slab
     const int64_t total = (int64_t)g->nstrip * ny;
-    const int waves = g->threads / 64;
     const int cus = ctx->cus > 0 ? ctx->cus : 256;
+    // a small stack (the reference's demo files: 15 x 241 x 480) leaves a 16-wave workgroup three rows per wave: the prologue (LDS clear,
+    // edges, barriers) is the kernel then -- half the waves, twice the rows (measured there: 14.0 -> 10.4 us with an integrand, 11.0 -> 9.0
+    // without; 256 threads: 13.2 / 8.9)
+    if (!(env_threads >= 64) && g->threads == kHistThreads) {
+        int64_t b0 = (total + (kHistThreads / 64) * 192 - 1) / ((kHistThreads / 64) * 192);
+        if (b0 * nslab < cus) b0 = (cus + nslab - 1) / nslab;
+        if (total < b0 * (kHistThreads / 64) * 6) g->threads = kHistThreads / 2;
+    }
+    const int waves = g->threads / 64;
     // (strip,row) pairs per wave when slabs are plentiful: long sweeps amortise the block prologue (min/max partials,
     // levels, LDS clear) and epilogue (copy reduction); scanned on MI355X: 64 -> 192 rows is +7 % on the chained cfg2
     // schedule and +9 % on cfg4-sized slabs, 256 and more lose to the tail of the last round

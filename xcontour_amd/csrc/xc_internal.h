@@ -49,6 +49,14 @@ struct xc_ctx {
     char* pin_out = nullptr; size_t pin_out_off = 0;
     struct PendingOut { void* host; const void* pinned; size_t bytes; const void* dev; };   // dev != nullptr: still to be fetched by the copy kernel (flush_out)
     std::vector<PendingOut> pending_out;
+    // the last few SMALL inputs a host-form call uploaded (bin edges, gradient metrics: <= 64 KB each), kept on the device with a host copy
+    // of their bytes: a call that hands over the same bytes again -- the reference's sequence bins the tracer twice against the same
+    // contours, cal_integral_within_contours(ctr) and (ctr, integrand) -- reads the device copy after one memcmp, with no transfer at all.
+    // Recognised by CONTENT, never by address.  An entry written during the current call (same `epoch`: xc_sync starts a new one) is
+    // not evicted: kernels already enqueued may still read it.
+    struct SmallIn { std::vector<char> host; void* dev = nullptr; uint64_t used = 0; uint64_t epoch = ~0ull; };
+    SmallIn small_in[4];
+    uint64_t small_clock = 0, small_epoch = 0, small_hits = 0, small_misses = 0;
     struct PendingIn { void* dev; const void* pinned; size_t bytes; };                      // staged in pin_in, not yet on the device (flush_in)
     std::vector<PendingIn> pending_in;
     // where a host-form call spends its time, accumulated between two xc_trace calls (seconds): input staging (memcpy + enqueue),
