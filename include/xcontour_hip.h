@@ -489,6 +489,15 @@ int xc_host_gradient_wrt_area(const void* var, int var_dtype, const void* var_co
                               const void* area, int area_dtype, const void* area_coord, int area_coord_dtype,
                               int64_t nlead, int64_t n, int64_t area_rows, int64_t var_row_stride, int64_t area_row_stride, void* out);
 
+/* Histogram edges from contour levels, the way _histogram prepares them (core.py:1296-1305: a dummy first edge one mean step below the
+ * lowest level) plus xhistogram's `last edge + 1e-8` when right_edge = XC_EDGE_XHISTOGRAM -- both evaluated in the levels' OWN dtype --
+ * for a stack: levels levels_dtype[nslab][N] in level order -> out_edges double[nslab][N + 1] ascending; *out_increasing = 1 when the
+ * levels ascend (the direction of slab 0; a slab running the other way is an error unless it holds a NaN).  Errors, with the
+ * reference's texts in xc_last_error(NULL): XC_EEDGES 'non monotonic bins' (two adjacent levels coincide, core.py:1233-1251),
+ * XC_EBADARG 'need at least two contour levels' / 'not every time or level is increasing/decreasing'. */
+int xc_host_edges_from_levels(const void* levels, int levels_dtype, int64_t nslab, int64_t N, int right_edge,
+                              double* out_edges, int* out_increasing);
+
 /* ------------------------------------------------------------------ synthetic slabs (bench / tests)
  * PV-like tracer q = sin(phi) + 0.25 sum_k a_k cos(k lambda + theta_k) cos^2(phi) + 0.02 eps
  * generated on device from a counter-based RNG.  variant 0: PV-like,

@@ -58,6 +58,44 @@ def test_edges_from_levels_match_oracle(dt):
         core._edges_from_levels(np.array([[0., 1., 1., 2.]]), 'numpy')
 
 
+def test_edges_from_levels_in_the_library_equal_the_numpy_statement():
+    """core._edges_from_levels hands C-contiguous float32 / float64 level stacks to xc_host_edges_from_levels (host-only entry point of the
+    library) and everything else to its numpy statement of core.py:1296-1305 + xhistogram's 1e-8: same edges bit for bit, same direction
+    flag, same exceptions with the reference's texts -- over sorted / reversed stacks with coinciding levels, a slab running the other
+    way, NaN slabs, infinite ends, one level only"""
+    rng = np.random.default_rng(5)
+    n_ok = n_err = 0
+    for it in range(600):
+        S = int(rng.integers(2, 5)); N = int(rng.integers(2, 12))
+        dt = (np.float32, np.float64)[it % 2]
+        inc = rng.random() < 0.5
+        b = np.sort(rng.standard_normal((S, N)) * 10.0 ** int(rng.integers(-6, 6)), axis=1)
+        b = np.ascontiguousarray(b if inc else b[:, ::-1]).astype(dt)
+        r = rng.random()
+        if r < 0.1:
+            b[rng.integers(0, S), 1] = b[0, 0]
+        if r > 0.9:
+            b[1] = b[1, ::-1]
+        if 0.8 < r < 0.9:
+            b[1, rng.integers(0, N)] = np.nan
+        if 0.7 < r < 0.8:
+            b[0, -1] = np.inf if inc else -np.inf
+        for re in ('numpy', 'xhistogram'):
+            res = []
+            for arr in (b, np.asfortranarray(b)):                    # C-contiguous: the library; Fortran order: numpy
+                try:
+                    with np.errstate(all='ignore'):
+                        e, bi, lc = core._edges_from_levels(arr, re)
+                    res.append(('ok', e.tobytes(), e.dtype, bi, lc))
+                except Exception as ex:
+                    res.append(('err', str(ex)))
+            assert res[0] == res[1], (it, re, b)
+            n_ok += res[0][0] == 'ok'; n_err += res[0][0] == 'err'
+    assert n_ok > 600 and n_err > 100
+    with pytest.raises(Exception, match='need at least two contour levels'):
+        core._edges_from_levels(np.array([[1.0]]), 'numpy')
+
+
 def test_table_from_rowsums_matches_histogram_semantics():
     """table_from_rowsums + last_row_included == the oracle's degenerate histogram (core.py:150-203 -> 1296-1325) for
     both last-bin rules, float32 / float64 / small-magnitude float32 coordinates, both coordinate directions"""

@@ -141,6 +141,7 @@ PROTOTYPES = {
     'xc_keff_epilogue': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int,
                                    C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'xc_host_gradient_wrt_area': (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _i64, _i64, _i64, _i64, _i64, _vp]),
+    'xc_host_edges_from_levels': (C.c_int, [_vp, C.c_int, _i64, _i64, C.c_int, _vp, C.POINTER(C.c_int)]),
     'xc_set_kernel_timing': (C.c_int, [_vp, C.c_int]),
     'xc_last_hist_ms': (C.c_int, [_vp, C.POINTER(C.c_float)]),
     'xc_set_hist_events': (C.c_int, [_vp, _vp, _vp]),
@@ -197,21 +198,32 @@ def load():
     return lib
 
 
+_DT_CODES = {np.dtype(np.float32): XC_F32, np.dtype(np.float64): XC_F64}
+
+
 def dtype_code(dt):
-    dt = np.dtype(dt)
-    if dt == np.float32:
-        return XC_F32
-    if dt == np.float64:
-        return XC_F64
-    raise XContourHipError(XC_EBADARG, 'unsupported dtype %s (float32/float64 only)' % dt)
+    c = _DT_CODES.get(dt)                                        # (a np.dtype instance: the usual argument)
+    if c is None:
+        c = _DT_CODES.get(np.dtype(dt))
+        if c is None:
+            raise XContourHipError(XC_EBADARG, 'unsupported dtype %s (float32/float64 only)' % np.dtype(dt))
+    return c
 
 
 def _ptr(a):
-    """Host pointer of a C-contiguous ndarray (or None)."""
+    """Host address of a C-contiguous ndarray (or None): an int, which ctypes takes for a void* argument or field.  The CALLER keeps the
+    array alive until the library call has returned (every entry point here holds its arrays in locals)."""
     if a is None:
         return None
-    assert a.flags['C_CONTIGUOUS']
-    return a.ctypes.data_as(_vp)
+    assert a.flags.c_contiguous
+    return a.ctypes.data
+
+
+def _contig(a, dtype=None):
+    """np.ascontiguousarray without the call when there is nothing to do"""
+    if type(a) is np.ndarray and a.flags.c_contiguous and (dtype is None or a.dtype == dtype):
+        return a
+    return np.ascontiguousarray(a, dtype=dtype)
 
 
 def _is_lazy(q):
@@ -220,7 +232,7 @@ def _is_lazy(q):
 
 
 def _stack_in(q):
-    return q if _is_lazy(q) else np.ascontiguousarray(q)
+    return q if _is_lazy(q) else _contig(q)
 
 
 def _stack_now(q):
@@ -600,7 +612,7 @@ class Context(object):
             return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
         q = _stack_now(q)
         integrands = [_stack_now(v) for v in integrands]
-        edges = np.ascontiguousarray(edges, dtype=np.float64)
+        edges = _contig(edges, np.float64)
         d = HistDesc()
         keep = [q, edges]
         d.q, d.q_dtype = _ptr(q), dtype_code(q.dtype)
@@ -613,7 +625,7 @@ class Context(object):
         if dA is None:
             d.dA, d.dA_rank = None, XC_DA_NONE
         else:
-            dA = np.ascontiguousarray(dA, dtype=np.float64)
+            dA = _contig(dA, np.float64)
             keep.append(dA)
             if dA.shape == (ny,):
                 d.dA_rank = XC_DA_ROW
@@ -629,7 +641,7 @@ class Context(object):
         if d.nint > XC_MAX_INTEGRANDS:
             raise XContourHipError(XC_EBADARG, 'at most %d integrands per pass' % XC_MAX_INTEGRANDS)
         for i, v in enumerate(integrands):
-            v = np.ascontiguousarray(v)
+            v = _contig(v)
             if v.shape != q.shape:
                 raise XContourHipError(XC_EBADARG, 'integrand shape must equal tracer shape')
             keep.append(v)

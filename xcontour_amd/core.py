@@ -27,6 +27,8 @@ Extensions over the reference (all optional, defaults follow the snapshot):
     sums"): bit-identical results between runs and shardings, like the reference's np.bincount; it also keeps
     cal_local_wave_activity / cal_local_APE on the band walk that sums in numpy's order (`exact=True`) for every plane size.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import _native as nat
@@ -35,6 +37,7 @@ from .utils import Rearth, grad_metrics, table_from_rowsums, last_row_included
 
 
 _F48 = (np.dtype(np.float32), np.dtype(np.float64))
+_EDGE_CODES = {'numpy': nat.XC_EDGE_NUMPY, 'xhistogram': nat.XC_EDGE_XHISTOGRAM}
 
 
 def _as_labeled_1d(arr, dim):
@@ -224,6 +227,13 @@ class Contour2D(object):
 
     # ------------------------------------------------------------------ A(Yeq) table
     def _table_rows(self, mask, multiply):
+        if self.resident:
+            ent = self._memo.get(('mask',))
+            if ent is not None and ent[0] is mask:                      # the same mask object again: its plane is already registered
+                m0 = ent[1][0]
+                ny, nx = m0.shape
+                dA, _ = self._dA_array(ny, nx, 1)
+                return self.ctx.rowsum(m0, dA[0] if dA.ndim == 3 else dA, ny, nx, multiply=multiply)
         m, lead, lshape, _ = self._plane(mask)
         if m.shape[0] != 1:
             raise Exception('mask should be a 2D plane (it is assumed not to change with time)')
@@ -299,7 +309,7 @@ class Contour2D(object):
         q = self._float(q)
         if type(levels) is int or isinstance(levels, np.integer):
             ctr = self.ctx.contours(q, int(levels), self.increase, self.dtype).astype(self.dtype)      # K1 + levels, one call, one sync
-            ccoord = np.linspace(0.0, levels - 1.0, levels, dtype=self.dtype)
+            ccoord = np.arange(levels, dtype=np.float64).astype(self.dtype)     # = np.linspace(0.0, levels - 1.0, levels, dtype): its step is exactly 1
         else:
             levs = np.asarray(levels)
             mmin = self.ctx.minmax(q)[:, 0].astype(q.dtype)
@@ -962,13 +972,16 @@ class Table(object):
     def __init__(self, table, dimEq):
         v, dims, coords, _ = lb.unwrap(table)
         ax = dims.index(dimEq)
-        tmp = np.take(v, -1, axis=ax) > np.take(v, 0, axis=ax)
-        if (tmp == True).all():              # noqa: E712  (mirrors core.py:1123-1128)
-            areaInc = True
-        elif (tmp == False).all():           # noqa: E712
-            areaInc = False
+        if v.ndim == 1:
+            areaInc = bool(v[-1] > v[0])
         else:
-            raise Exception('not every time or level is increasing/decreasing')
+            tmp = np.take(v, -1, axis=ax) > np.take(v, 0, axis=ax)
+            if (tmp == True).all():              # noqa: E712  (mirrors core.py:1123-1128)
+                areaInc = True
+            elif (tmp == False).all():           # noqa: E712
+                areaInc = False
+            else:
+                raise Exception('not every time or level is increasing/decreasing')
         self._table = table
         self._coord = np.asarray(coords[dimEq])
         self._dimEq = dimEq
@@ -1032,6 +1045,15 @@ def _edges_from_levels(b, right_edge):
     dtype (reference core.py:1296-1305) + the last-bin rule.  Raises like the reference
     when two adjacent levels coincide (core.py:1233-1251)."""
     b = np.asarray(b)
+    if b.ndim == 2 and b.dtype in _F48 and b.flags.c_contiguous and b.shape[0] >= 1 and b.shape[1] >= 1 and right_edge in _EDGE_CODES:
+        # the same rule in one host call of the library (xc_host_edges_from_levels: the reference's checks and texts included)
+        edges = np.empty((b.shape[0], b.shape[1] + 1), dtype=np.float64)
+        inc = C.c_int(0)
+        lib = nat.load()
+        if lib.xc_host_edges_from_levels(b.ctypes.data, b.dtype.itemsize == 8, b.shape[0], b.shape[1], _EDGE_CODES[right_edge],
+                                         edges.ctypes.data, inc) != 0:
+            raise Exception((lib.xc_last_error(None) or b'').decode())
+        return edges, bool(inc.value), right_edge != 'xhistogram'
     if (b[:, 1:] == b[:, :-1]).any():
         raise Exception('non monotonic bins')
     n1 = b.shape[1] - 1

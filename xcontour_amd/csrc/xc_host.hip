@@ -72,3 +72,47 @@ extern "C" int xc_host_gradient_wrt_area(const void* var, int var_dtype, const v
     if (tmp != stack) free(tmp);
     return XC_OK;
 }
+
+// ---- histogram edges from contour levels: _histogram's dummy first edge (core.py:1296-1305) and xhistogram's `+ 1e-8` on the last one, in the
+// levels' OWN dtype, for every slab of a stack; the checks of the reference on the way ('non monotonic bins', core.py:1233-1251; one
+// direction for every slab).  What the facade did with sixteen numpy calls per binning call.
+namespace {
+template <typename T>
+int edges_from_levels(const T* b, int64_t nslab, int64_t N, int right_edge, double* edges, int* increasing)
+{
+    for (int64_t s = 0; s < nslab; ++s)
+        for (int64_t k = 1; k < N; ++k)
+            if (b[s * N + k] == b[s * N + k - 1]) return xc::fail(nullptr, XC_EEDGES, "non monotonic bins");
+    if (N < 2) return xc::fail(nullptr, XC_EBADARG, "need at least two contour levels");
+    const bool binc = b[0] < b[N - 1];
+    for (int64_t s = 1; s < nslab; ++s) {
+        if ((b[s * N] < b[s * N + N - 1]) == binc) continue;
+        bool has_nan = false;                               // an all-NaN slab (no valid cell) has no direction: let through
+        for (int64_t k = 0; k < N && !has_nan; ++k) has_nan = b[s * N + k] != b[s * N + k];
+        if (!has_nan) return xc::fail(nullptr, XC_EBADARG, "not every time or level is increasing/decreasing");
+    }
+    const T n1 = (T)(N - 1);
+    for (int64_t s = 0; s < nslab; ++s) {
+        const T* r = b + s * N;
+        double* e = edges + s * (N + 1);
+        const T first = r[0], last = r[N - 1];
+        T e0, eN;
+        if (binc) { for (int64_t k = 0; k < N; ++k) e[k + 1] = (double)r[k]; e0 = first - (T)((T)(last - first) / n1); eN = last; }
+        else { for (int64_t k = 0; k < N; ++k) e[k + 1] = (double)r[N - 1 - k]; e0 = last - (T)((T)(first - last) / n1); eN = first; }
+        e[0] = (double)e0;
+        if (right_edge == XC_EDGE_XHISTOGRAM) e[N] = (double)(T)(eN + (T)1e-8);
+    }
+    *increasing = binc ? 1 : 0;
+    return XC_OK;
+}
+}  // namespace
+
+extern "C" int xc_host_edges_from_levels(const void* levels, int levels_dtype, int64_t nslab, int64_t N, int right_edge,
+                                         double* out_edges, int* out_increasing)
+{
+    if (!levels || !out_edges || !out_increasing || nslab < 1 || N < 1) return xc::fail(nullptr, XC_EBADARG, "xc_host_edges_from_levels: bad arguments");
+    if (right_edge != XC_EDGE_NUMPY && right_edge != XC_EDGE_XHISTOGRAM) return xc::fail(nullptr, XC_EBADARG, "right_edge should be \"numpy\" or \"xhistogram\"");
+    if (levels_dtype == XC_F32) return edges_from_levels((const float*)levels, nslab, N, right_edge, out_edges, out_increasing);
+    if (levels_dtype == XC_F64) return edges_from_levels((const double*)levels, nslab, N, right_edge, out_edges, out_increasing);
+    return xc::fail(nullptr, XC_EBADARG, "xc_host_edges_from_levels: levels_dtype must be XC_F32 or XC_F64");
+}
