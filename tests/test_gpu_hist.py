@@ -714,3 +714,80 @@ def test_one_slab_alone_equals_the_same_slab_in_a_stack(ctx, dt, counts, single)
             got['counts'] = r['counts'][None]                  # (not produced: nothing to compare)
         check_nine(got, 0, r)
     one.free(); stack.free()
+
+
+def test_small_inputs_are_recognised_by_content_never_by_address(ctx):
+    """round 6: a host-form call keeps its small inputs (bin edges <= 64 KB) on the device and a later call with the SAME BYTES reads them
+    there without a transfer.  The bytes decide, not the address: edges changed IN PLACE between two calls must give the new histogram,
+    the old edges at a new address the old one; more distinct edge sets than the cache has entries (4) must all come out right, and a
+    call that fails (non monotonic bins) must not leave anything behind that a later call could hit."""
+    rng = np.random.default_rng(21)
+    q = rng.standard_normal((3, 40, 64))
+    w = rng.random((40, 64)) + 0.5
+
+    def want(e):
+        return np.stack([np.histogram(q[s].ravel(), bins=e, weights=w.ravel())[0] for s in range(3)])
+
+    e = np.linspace(-3.0, 3.0, 25)
+    r1 = ctx.hist(q, e, dA=w, want=('pdf',))['pdf'][:, 0, :]
+    assert np.allclose(r1, want(e), rtol=1e-12, atol=0)
+    keep = e.copy()
+    e[:] = np.linspace(-2.0, 2.5, 25)                                   # same array, same address, new bytes
+    r2 = ctx.hist(q, e, dA=w, want=('pdf',))['pdf'][:, 0, :]
+    assert np.allclose(r2, want(e), rtol=1e-12, atol=0) and not np.allclose(r2, r1)
+    r3 = ctx.hist(q, keep, dA=w, want=('pdf',))['pdf'][:, 0, :]         # the first bytes again, elsewhere: a hit, and the same result
+    assert np.array_equal(r3, r1) or np.allclose(r3, r1, rtol=1e-13, atol=0)
+    sets = [np.linspace(-3.0 + 0.1 * i, 3.0 - 0.07 * i, 25) for i in range(7)]
+    for rep in range(2):
+        for ee in sets:
+            assert np.allclose(ctx.hist(q, ee, dA=w, want=('pdf',))['pdf'][:, 0, :], want(ee), rtol=1e-12, atol=0)
+    bad = e.copy(); bad[5] = bad[4]
+    with pytest.raises(Exception, match='non monotonic bins'):
+        ctx.hist(q, bad, dA=w, want=('pdf',))
+    assert np.allclose(ctx.hist(q, e, dA=w, want=('pdf',))['pdf'][:, 0, :], want(e), rtol=1e-12, atol=0)
+    # the in-kernel gradient's metrics take the same road
+    rdx = rng.random(40) + 0.1; rdy = rng.random(40) + 0.1
+    g1 = ctx.hist(q, e, dA=w, grad=(rdx, rdy, True), want=('pdf',))['pdf']
+    rdx2 = rdx.copy(); rdx[:] = rdx * 2.0
+    g2 = ctx.hist(q, e, dA=w, grad=(rdx, rdy, True), want=('pdf',))['pdf']
+    g3 = ctx.hist(q, e, dA=w, grad=(rdx2, rdy, True), want=('pdf',))['pdf']
+    assert np.allclose(g1[:, 1], g3[:, 1], rtol=1e-12, atol=0) and not np.allclose(g1[:, 1], g2[:, 1], rtol=1e-3, atol=0)
+    assert np.allclose(g1[:, 0], g2[:, 0], rtol=1e-12, atol=0)
+
+
+def test_copy_kernel_switched_off_gives_the_same_facade_results(tmp_path):
+    """XC_COPY_KERNEL=0 (one DMA copy per small array, the path of rounds 1-5) against the default (copy kernels, results written straight
+    into the pinned buffer, levels reducing K1's partials): the reference's call sequence on a small stack, every result bit for bit"""
+    code = '''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import xcontour_amd as xa
+rng = np.random.default_rng(4)
+lat = np.linspace(-88, 88, 45); lon = np.arange(64) * 5.625; lev = np.arange(3.0)
+q = (np.sin(np.deg2rad(lat))[None, :, None] * (1 + 0.2 * lev[:, None, None]) + 0.1 * rng.standard_normal((3, 45, 64))).astype(np.float32)
+c3 = {'lev': lev, 'lat': lat, 'lon': lon}; c2 = {'lat': lat, 'lon': lon}
+tr = xa.DataArray(q, ('lev', 'lat', 'lon'), c3, 'pv')
+dA = xa.DataArray(xa.cell_area(lat, lon), ('lat', 'lon'), c2, 'dA')
+g2 = xa.DataArray(rng.random(q.shape).astype(np.float32), ('lev', 'lat', 'lon'), c3, 'grdS')
+mask = xa.DataArray(np.ones((45, 64), np.float32), ('lat', 'lon'), c2, 'mask')
+out = []
+for resident in (False, True):
+    cm = xa.Contour2D(tr, dA, dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'}, increase=True, lt=True, resident=resident, deterministic=True)
+    for rep in range(2):
+        table = cm.cal_area_eqCoord_table_hist(mask)
+        ctr = cm.cal_contours(31)
+        area = cm.cal_integral_within_contours_hist(ctr)
+        intS = cm.cal_integral_within_contours_hist(ctr, integrand=g2)
+        latEq = table.lookup_coordinates(area)
+        d1 = cm.cal_gradient_wrt_area(ctr, area); d2 = cm.cal_gradient_wrt_area(intS, area)
+        out += [table._table.values, ctr.values, area.values, intS.values, latEq.values, d1.values, d2.values]
+np.save(sys.argv[1], np.concatenate([np.asarray(o, np.float64).ravel() for o in out]))
+''' % ROOT
+    res = []
+    for ck in ('1', '0'):
+        env = _clean_env(); env['XC_COPY_KERNEL'] = ck
+        f = str(tmp_path / ('r%s.npy' % ck))
+        r = subprocess.run([sys.executable, '-c', code, f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(f))
+    assert res[0].shape == res[1].shape and np.array_equal(res[0], res[1], equal_nan=True)
