@@ -29,9 +29,25 @@ class _Lib(object):
             return self._contours
         if name == 'xc_rowsum':
             return self._rowsum
+        if name == 'xc_malloc':
+            return self._malloc
+        if name == 'xc_memcpy_d2h':
+            return lambda h, dst, src, n: (C.memset(dst, 0, n), 0)[1]
+        if name == 'xc_resident_lookup':
+            return self._malloc2
         if name == 'xc_host_gradient':
             return nat.load_host_only().xc_host_gradient if hasattr(nat, 'load_host_only') else (lambda *a: 0)
         return lambda *a: 0
+
+    _next = 1 << 40
+
+    def _malloc(self, h, n, pref):
+        pref._obj.value = _Lib._next
+        _Lib._next += (int(n) + 4095) & ~4095
+        return 0
+
+    def _malloc2(self, h, p, n, pref):
+        return self._malloc(h, n, pref)
 
     def _hist(self, h, dref):
         d = dref._obj
@@ -81,6 +97,7 @@ calls = [
     ('integral_grdS', lambda: cm.cal_integral_within_contours_hist(ctr, integrand=g2)),
     ('lookup', lambda: table.lookup_coordinates(area)),
     ('gradient x2', lambda: (cm.cal_gradient_wrt_area(ctr, area), cm.cal_gradient_wrt_area(intS, area))),
+    ('keff (fused)', lambda: cm.keff(N1, table, grdS=g2)),
 ]
 flt = [a for a in sys.argv[1:] if not a.startswith('--')]
 tot = 0.0

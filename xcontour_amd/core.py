@@ -893,6 +893,7 @@ class Contour2D(object):
         qb, gb, db = ny * nx * q.dtype.itemsize, 0 if g is None else ny * nx * g.dtype.itemsize, ny * nx * 8
 
         direct = {}                                          # batch -> (tracer mirror, grdS mirror): resident inputs are read where they are
+        uploaded = [False]                                   # anything on the copy stream since the last wait?
 
         def upload(k):
             """batch k -> half k % nbuf of the device buffers, on the copy stream.  A batch whose tracer (and supplied gradient) lie inside
@@ -907,6 +908,7 @@ class Contour2D(object):
                 if qp and (g is None or gp):
                     direct[k] = (qp, gp)
                     return
+            uploaded[0] = True
             plan.q_buf.upload_async(q[s0:s0 + m], off * qb)
             if slab_dA:
                 plan.dA_buf.upload_async(dA[s0:s0 + m], off * db)
@@ -920,7 +922,9 @@ class Contour2D(object):
             for k in range(nb):
                 h = k % nbuf
                 m = min(batch, nslab - k * batch)
-                ctx.stream_wait_copies()                              # the kernels of batch k wait for its upload
+                if uploaded[0]:
+                    ctx.stream_wait_copies()                          # the kernels of batch k wait for its upload (7 us of host time: not
+                    uploaded[0] = False                               # paid by a call whose inputs are all resident mirrors)
                 plan.touch()
                 if k in direct:
                     qp, gp = direct.pop(k)
@@ -940,7 +944,7 @@ class Contour2D(object):
                 r = plan.fetch(check=False, slot=h)
                 if r['status'][:m].any():
                     raise Exception('non monotonic bins')          # reference core.py:1233-1251
-                parts.append({k_: np.array(v[:m]) for k_, v in r.items()})
+                parts.append({k_: v[:m] for k_, v in r.items()})   # (views of this fetch's own buffer: nothing else writes it)
             res = parts[0] if len(parts) == 1 else {k_: np.concatenate([p[k_] for p in parts]) for k_ in parts[0]}
         except Exception:
             plan.free()
@@ -948,7 +952,7 @@ class Contour2D(object):
         plans[key] = plan                                  # most recently used last
         while len(plans) > 2:
             plans.pop(next(iter(plans))).free()
-        ccoord = np.linspace(0.0, N - 1.0, N, dtype=self.dtype)
+        ccoord = np.arange(N, dtype=np.float64).astype(self.dtype)      # = np.linspace(0.0, N - 1.0, N, dtype): its step is exactly 1
         out = []
         shared = {d: np.asarray(coords[d]) for d in lead if d in coords}
         shared['contour'] = ccoord
