@@ -1138,6 +1138,10 @@ def main():
         # (K1, K3, reduce, finalize), nothing to overlap them with
         stage('single_slab')
         line['single_slab'] = single_slab(ctx, nat, a, lat, lon, dA, tbl)
+        # the reference's OWN call sequence through the facade at its demo size (cfg1's shape: 15 x 241 x 480 float32, 201 contours),
+        # numpy in / numpy out with resident inputs: what a user of the reference's API waits for per analysis step
+        stage('facade_demo')
+        line['facade_demo'] = facade_demo()
     # ---- cfg4 strong scaling: every rank takes part (its own timed region, after the cfg2 buffers are gone)
     if not a.no_cfg4 and a.dtype == 'f64':
         stage('cfg4')
@@ -1200,6 +1204,67 @@ def device_count(nat):
     n = C.c_int(0)
     nat.load().xc_device_count(C.byref(n))
     return n.value
+
+
+def facade_demo(reps=40):
+    """`facade_demo` of the default line: the seven calls of the reference's Keff sequence (tests/test_Keff_atmos.py:75-92 of the reference)
+    on a 15 x 241 x 480 float32 stack with resident inputs, each timed alone on one field (`us`, their `sum_us`) and as a sequence on
+    six fields taken in turn (`sequence_us`: the library's cache of small inputs can then only serve the second binning call of a pass,
+    as in real use).  Wall clock, Python included."""
+    try:
+        import xcontour_amd as xa
+        NL1, NY1, NX1, N1 = 15, 241, 480, NCONT
+        lat = np.linspace(-90, 90, NY1).astype(np.float32); lon = (np.arange(NX1) * 0.75).astype(np.float32); lev = np.arange(NL1, dtype=np.float32)
+        rng = np.random.default_rng(0)
+        q = (np.sin(np.deg2rad(lat))[None, :, None] * (1 + 0.1 * lev[:, None, None]) + 0.05 * rng.standard_normal((NL1, NY1, NX1))).astype(np.float32)
+        c3 = {'lev': lev, 'lat': lat, 'lon': lon}; c2 = {'lat': lat, 'lon': lon}
+        dA = xa.DataArray(xa.cell_area(lat.astype(np.float64), lon.astype(np.float64)).astype(np.float32), ('lat', 'lon'), c2, 'dA')
+        g2 = xa.DataArray(rng.random(q.shape).astype(np.float32), ('lev', 'lat', 'lon'), c3, 'grdS')
+        mask = xa.DataArray(np.ones((NY1, NX1), np.float32), ('lat', 'lon'), c2, 'mask')
+        kw = dict(dims={'X': 'lon', 'Y': 'lat'}, dimEq={'Y': 'lat'}, increase=True, lt=True, resident=True)
+        objs = [xa.Contour2D(xa.DataArray((q * np.float32(1.0 + 0.03 * i) + np.float32(0.01 * i)).astype(np.float32), ('lev', 'lat', 'lon'), c3, 'pv'), dA, **kw)
+                for i in range(6)]
+        cm = objs[0]
+        rec = {}
+
+        def timed(name, fn):
+            fn(); fn()
+            t = time.perf_counter()
+            for _ in range(reps):
+                out = fn()
+            rec[name] = round((time.perf_counter() - t) / reps * 1e6, 1)
+            return out
+        table = timed('cal_area_eqCoord_table_hist', lambda: cm.cal_area_eqCoord_table_hist(mask))
+        ctr = timed('cal_contours', lambda: cm.cal_contours(N1))
+        area = timed('cal_integral_within_contours_hist(area)', lambda: cm.cal_integral_within_contours_hist(ctr))
+        intS = timed('cal_integral_within_contours_hist(grdS)', lambda: cm.cal_integral_within_contours_hist(ctr, integrand=g2))
+        timed('lookup_coordinates', lambda: table.lookup_coordinates(area))
+        timed('cal_gradient_wrt_area x2', lambda: (cm.cal_gradient_wrt_area(ctr, area), cm.cal_gradient_wrt_area(intS, area)))
+
+        def sequence(c):
+            tb = c.cal_area_eqCoord_table_hist(mask)
+            ct = c.cal_contours(N1)
+            ar = c.cal_integral_within_contours_hist(ct)
+            iS = c.cal_integral_within_contours_hist(ct, integrand=g2)
+            return tb.lookup_coordinates(ar), c.cal_gradient_wrt_area(ct, ar), c.cal_gradient_wrt_area(iS, ar)
+        for c in objs:
+            sequence(c); sequence(c)
+        t = time.perf_counter()
+        for _ in range(5):
+            for c in objs:
+                sequence(c)
+        seq = (time.perf_counter() - t) / 30 * 1e6
+        fused = timed('keff (fused, one call for everything)', lambda: cm.keff(N1, table, grdS=g2))
+        del fused
+        out = {'shape': [NL1, NY1, NX1], 'dtype': 'f32', 'contours': N1, 'resident': True, 'us': {k: v for k, v in rec.items() if not k.startswith('keff')},
+               'sum_us': round(sum(v for k, v in rec.items() if not k.startswith('keff')), 1), 'sequence_us': round(seq, 1),
+               'keff_fused_us': rec['keff (fused, one call for everything)'],
+               'note': 'wall clock per call, Python included; sum_us: each call repeated on one field; sequence_us: the seven calls in order on six fields in turn'}
+        for c in objs:
+            c.close()
+        return out
+    except Exception as e:                      # the headline does not depend on this block
+        return {'skipped': '%s: %s' % (type(e).__name__, e)}
 
 
 def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):

@@ -124,8 +124,10 @@ static inline double now_s()
 static int ensure_pins(xc_ctx* ctx)
 {
     if (ctx->pin_in) return XC_OK;
-    XC_HIP(ctx, hipHostMalloc((void**)&ctx->pin_in, kPinBytes, hipHostMallocDefault));
-    hipError_t e = hipHostMalloc((void**)&ctx->pin_out, kPinBytes, hipHostMallocDefault);
+    // coherent (fine-grained) on request, not by the runtime's default: kernels read pin_in and write pin_out themselves (k_copy_small, the
+    // direct results), and what the host sees after the stream wait must not depend on HIP_HOST_COHERENT
+    XC_HIP(ctx, hipHostMalloc((void**)&ctx->pin_in, kPinBytes, hipHostMallocCoherent));
+    hipError_t e = hipHostMalloc((void**)&ctx->pin_out, kPinBytes, hipHostMallocCoherent);
     if (e != hipSuccess) { (void)hipHostFree(ctx->pin_in); ctx->pin_in = nullptr; return hipfail(ctx, e, "hipHostMalloc"); }
     return XC_OK;
 }
