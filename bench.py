@@ -1280,12 +1280,16 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
         pc = KeffPlan(ctx, 1, NY, NX, NCONT, np.float64, np.float64, alloc_q=False, single_read=False, **kw)   # the same slab through the chain
         pc.set_q_device(p._q_ptr)
         big = ctx.alloc(600 << 20)
+        RNX = 4096; RNY = (600 << 20) // 8 // RNX
+        mm2 = ctx.alloc(RNY * 8)
         e0, e1 = ctx.event(), ctx.event()
 
         def timed(plan, evict):
             ts = []
             for r in range(reps + 3):
-                if evict:
+                if evict == 'read':                      # the caches emptied by READING 600 MB (row sums, ordinary loads): nothing dirty is left behind
+                    ctx._check(ctx.lib.xc_rowsum_dev(ctx.handle, big.ptr, nat.XC_F64, None, nat.XC_DA_NONE, RNY, RNX, 0, mm2.ptr))
+                elif evict:
                     ctx._check(ctx.lib.xc_memset(ctx.handle, big.ptr, r & 255, big.nbytes))
                 ctx.sync()
                 ctx.record(e0); plan.run(); ctx.record(e1)
@@ -1294,6 +1298,7 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
                     ts.append(ms * 1e3)
             return np.array(ts)
         cold, warm = timed(p, True), timed(p, False)
+        cold_clean = timed(p, 'read')
         path = ctx.last_keff_path()
         out = p.fetch()
         ok = bool((out['counts'].sum(axis=1) == NY * NX).all() and not out['status'].any() and p.replays == 0)
@@ -1316,7 +1321,8 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
         for e in (e0, e1):
             ctx.lib.xc_event_destroy(ctx.handle, e)
         alg = NY * NX * BYTES_PER_CELL
-        return {'us': float(np.median(warm)), 'us_cold': float(np.median(cold)), 'us_min': float(warm.min()), 'reps': reps,
+        return {'us': float(np.median(warm)), 'us_cold': float(np.median(cold)), 'us_cold_after_reads': float(np.median(cold_clean)),
+                'us_min': float(warm.min()), 'reps': reps,
                 'frac': alg / (np.median(warm) * 1e-6) / 1e9 / HBM_PEAK_GBS, 'frac_cold': alg / (np.median(cold) * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 'path': 'single-read kernel (k_keff_single: min/max -> levels -> histogram in one launch, the slab held in registers; then k_finalize)' if path == 1
                         else 'chain: k_minmax_partial (also clears the accumulators), k_hist (blocks add into them), k_finalize',
@@ -1324,7 +1330,8 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
                           'launches': 'k_minmax_partial, k_hist, k_finalize (xc_keff_desc.single_read = XC_SINGLE_NEVER)'},
                 'f32': f32, 'self_check': ok,
                 'note': 'one 3600x1801 f64 slab per call, a stream sync before every call (HIP events around the call); warm = back to back '
-                        '(Infinity-Cache resident), cold = a 600 MB memset between calls; 16 B/cell numerator as the headline; `chain`: the same '
+                        '(Infinity-Cache resident), cold = a 600 MB memset between calls (the call then competes with the write-back of the memset), '
+                        'cold_after_reads = 600 MB READ between calls (caches emptied, nothing dirty); 16 B/cell numerator as the headline; `chain`: the same '
                         'slab through the three-launch path this kernel replaces, results compared'}
     except nat.XContourHipError as e:
         return {'skipped': str(e)}
@@ -1334,6 +1341,7 @@ def single_slab(ctx, nat, a, lat, lon, dA, tbl, reps=30):
                 x.free()
         if big is not None:
             big.free()
+            mm2.free()
 
 
 def variant_f32(ctx, nat, a, lat, lon, dA, tbl, chain, variant=None, ncheck=2, brief=False):
