@@ -35,8 +35,6 @@ class _Lib(object):
             return lambda h, dst, src, n: (C.memset(dst, 0, n), 0)[1]
         if name == 'xc_resident_lookup':
             return self._malloc2
-        if name == 'xc_host_gradient':
-            return nat.load_host_only().xc_host_gradient if hasattr(nat, 'load_host_only') else (lambda *a: 0)
         return lambda *a: 0
 
     _next = 1 << 40
@@ -123,9 +121,3 @@ for name, fn in calls:
         s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(18)
         print('\n'.join(l[:150] for l in s.getvalue().splitlines() if l.strip() and 'Ordered by' not in l and 'function calls' not in l))
 print('%-16s %7.1f us' % ('sum', tot))
-if '--debug' in sys.argv:
-    from xcontour_amd import labeled as lb
-    for nm, x in (('ctr', ctr), ('area', area), ('intS', intS)):
-        v, d, c, n = lb.unwrap(x)
-        k = c.get('contour')
-        print(nm, type(v), v.dtype, v.shape, v.flags.c_contiguous, d, type(k), getattr(k, 'dtype', None), getattr(k, 'shape', None))
