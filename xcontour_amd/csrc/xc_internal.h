@@ -132,8 +132,14 @@ inline int minmax_blocks(int64_t ncell, int64_t nslab)
     return (int)(p < 1 ? 1 : (p > kMinmaxBlocks ? kMinmaxBlocks : p));
 }
 constexpr int kHistThreads  = 1024;   // 16 waves: one block per CU (LDS-bound)
-constexpr int kMaxCopies    = 16;     // lane-privatised LDS histogram copies
-constexpr size_t kLdsBudget = 150 * 1024;
+#ifndef XC_MAX_COPIES
+#define XC_MAX_COPIES 16
+#endif
+#ifndef XC_LDS_BUDGET_KB
+#define XC_LDS_BUDGET_KB 150
+#endif
+constexpr int kMaxCopies    = XC_MAX_COPIES;     // lane-privatised LDS histogram copies
+constexpr size_t kLdsBudget = (size_t)XC_LDS_BUDGET_KB * 1024;
 constexpr int kE32MaxBins  = 2048;   // the float32-edges variant of K3 (E32) keeps a float32 copy of the edges in LDS: ordinary contour counts only
 
 struct HistGeom {
