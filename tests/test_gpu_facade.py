@@ -288,6 +288,55 @@ def test_resident_inputs_give_the_same_results(ctx, baro):
     assert len(res.ctx._resident) == n0
 
 
+def test_resident_keff_reuses_its_plan_by_identity_and_forgets_on_touch(ctx, baro):
+    """round 6: a resident object that gets the SAME argument objects again does not rebuild the key of its plan from their bytes
+    (core.Contour2D.keff, `_keff_last`).  Same results call after call; another table object with other contents -> its own plan; the
+    contents of the table changed IN PLACE + touch() -> the new results; more configurations than plans are kept (2) and back to the
+    first: the evicted plan is rebuilt, metrics included"""
+    import xcontour_amd as xa
+    q0, lat, lon = baro
+    q = np.stack([q0 * (1 + 0.1 * s) for s in range(2)])
+    c3 = {'time': np.arange(2), 'latitude': lat, 'longitude': lon}; c2 = {'latitude': lat, 'longitude': lon}
+    tr = xa.DataArray(q, ('time', 'latitude', 'longitude'), c3, 'absolute_vorticity')
+    dA = xa.DataArray(O.cell_area(lat, lon), ('latitude', 'longitude'), c2, 'rA')
+    mask = xa.DataArray(np.ones_like(q0), ('latitude', 'longitude'), c2, 'mask')
+    kw = dict(dims={'X': 'longitude', 'Y': 'latitude'}, dimEq={'Y': 'latitude'}, increase=True, lt=True, deterministic=True)
+    res = xa.Contour2D(tr, dA, resident=True, **kw)
+    plain = xa.Contour2D(tr, dA, **kw)
+    names = ('ctr', 'area', 'intgrdS', 'latEq', 'nkeff')
+
+    def vec(ds):
+        return [ds[n].values.copy() for n in names]
+
+    def same(a, b):
+        return all(np.array_equal(bits(x), bits(y)) for x, y in zip(a, b))
+    table = res.cal_area_eqCoord_table_hist(mask)
+    r1 = vec(res.keff(41, table, lat=lat, lon=lon))
+    assert res.__dict__.get('_keff_last') is not None
+    r2 = vec(res.keff(41, table, lat=lat, lon=lon))                  # the identity path
+    ref = vec(plain.keff(41, table, lat=lat, lon=lon))
+    assert same(r1, ref) and same(r2, ref)
+    tv = table._table.values
+    t2 = xa.Table(xa.DataArray(tv * 2.0, ('latitude',), {'latitude': lat}, 'AeqCTbl'), 'latitude')       # another object, other contents
+    r3 = vec(res.keff(41, t2, lat=lat, lon=lon))
+    assert same(r3, vec(plain.keff(41, t2, lat=lat, lon=lon))) and not same(r3, ref)
+    assert same(vec(res.keff(41, table, lat=lat, lon=lon)), ref)
+    tv *= 0.5                                                        # in place, same objects: touch() is the contract
+    res.touch()
+    r4 = vec(res.keff(41, table, lat=lat, lon=lon))
+    assert same(r4, vec(plain.keff(41, table, lat=lat, lon=lon))) and not same(r4, ref)
+    for N in (21, 31, 51):                                           # three more configurations: the N = 41 plan is evicted ...
+        assert same(vec(res.keff(N, table, lat=lat, lon=lon)), vec(plain.keff(N, table, lat=lat, lon=lon)))
+    res.keff(41, table, lat=lat, lon=lon)
+    for N in (21, 31):
+        res.keff(N, table, lat=lat, lon=lon)
+    last = res.__dict__['_keff_last']
+    assert last[1] in res.__dict__['_keff_plans']
+    res.__dict__['_keff_plans'].pop(last[1]).free()                  # ... and the plan of the LAST call too: same objects, no plan
+    assert same(vec(res.keff(31, table, lat=lat, lon=lon)), vec(plain.keff(31, table, lat=lat, lon=lon)))
+    res.close(); plain.close()
+
+
 def test_integration_md_stub_runs_as_printed(baro):
     """the two python blocks INTEGRATION.md shows a maintainer of the reference (ctypes binding of xc_hist and xc_crossing) are
     executed verbatim against the built library: histogram_cdf == the oracle's _histogram restatement (counts-exact levels,
