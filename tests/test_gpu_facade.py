@@ -334,6 +334,9 @@ def test_resident_keff_reuses_its_plan_by_identity_and_forgets_on_touch(ctx, bar
     assert last[1] in res.__dict__['_keff_plans']
     res.__dict__['_keff_plans'].pop(last[1]).free()                  # ... and the plan of the LAST call too: same objects, no plan
     assert same(vec(res.keff(31, table, lat=lat, lon=lon)), vec(plain.keff(31, table, lat=lat, lon=lon)))
+    res.lt = False; plain.lt = False                                 # an attribute of the object changed between two calls with the same arguments
+    r5 = vec(res.keff(31, table, lat=lat, lon=lon))
+    assert same(r5, vec(plain.keff(31, table, lat=lat, lon=lon)))
     res.close(); plain.close()
 
 

@@ -847,9 +847,10 @@ class Contour2D(object):
             raise Exception('the A(Yeq) table has %d entries but the tracer has %d rows along %s' % (len(tv), ny, self.dimEqV))
         g = None
         # resident objects: the same argument OBJECTS as in the last call -> the same plan key (see __init__), nothing re-derived from bytes
-        idents = (table, grdS, preY, lat, lon, rdx, rdy, self.tracer, self.dA, N, periodic_x, nkeff_mask, max_batch_bytes, nslab) if self.resident else None
+        idents = (table, grdS, preY, lat, lon, rdx, rdy, self.tracer, self.dA, N, periodic_x, nkeff_mask, max_batch_bytes, nslab,
+                  self.increase, self.lt, self.right_edge, self.device, self.deterministic, np.dtype(self.dtype).str) if self.resident else None
         last = self.__dict__.get('_keff_last') if self.resident else None
-        fast = last is not None and len(last[0]) == len(idents) and all(a is b or (type(a) in (int, float, bool) and a == b) for a, b in zip(last[0], idents))
+        fast = last is not None and len(last[0]) == len(idents) and all(a is b or (type(a) in (int, float, bool, str) and type(a) is type(b) and a == b) for a, b in zip(last[0], idents))
         if grdS is not None:
             g = self._integrand_plane(grdS)
         elif rdx is None and not fast:
