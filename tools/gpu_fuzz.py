@@ -290,10 +290,14 @@ def run(seconds, seed=None):
     if seed is not None:
         rng = np.random.default_rng(seed)
     t0 = time.time(); n = {c.__name__: 0 for c in cases}
+    said = t0
     while time.time() - t0 < seconds:
         c = cases[int(rng.integers(len(cases)))]
         c()
         n[c.__name__] += 1
+        if time.time() - said > 60.0:                     # a progress line a minute (a silent run looks hung to the GPU pool's watchdog)
+            said = time.time()
+            print('fuzz: %4.0f s, %d cases so far' % (said - t0, sum(n.values())), flush=True)
     return n, dict(checked)
 
 
