@@ -113,7 +113,7 @@ static const void* resident_lookup(const xc_ctx* ctx, const void* h, size_t n)
 
 constexpr size_t kPinBytes = (size_t)4 << 20;        // each bounce buffer
 constexpr size_t kPinSmall = (size_t)1 << 20;        // transfers up to this size take the bounce buffers
-constexpr size_t kCopyKernelMax = (size_t)64 << 10;  // ... and up to this size they are moved by k_copy_small, up to eight arrays per launch, instead of one DMA copy each
+constexpr size_t kCopyKernelMax = (size_t)64 << 10;  // ... and INPUTS up to this size are moved by k_copy_small, up to eight arrays per launch, instead of one DMA copy each (results: knobs.copy_out_kb)
 
 static inline double now_s()
 {
@@ -251,7 +251,7 @@ static int d2h(xc_ctx* ctx, void* h, const void* d, size_t n)
     if (n <= kPinSmall && ensure_pins(ctx) == XC_OK && ctx->pin_out_off + n <= kPinBytes) {
         char* p = ctx->pin_out + ctx->pin_out_off;
         ctx->pin_out_off += (n + 63) & ~(size_t)63;
-        if (ctx->knobs.copy_kernel && n <= kCopyKernelMax) {
+        if (ctx->knobs.copy_kernel && n <= (size_t)ctx->knobs.copy_out_kb << 10) {
             if (n) ctx->pending_out.push_back({h, p, n, d});         // fetched by flush_out: every caller goes on to xc_sync without another launch on `d`
         } else {
             hipError_t e = hipMemcpyAsync(p, d, n, hipMemcpyDeviceToHost, ctx->stream);
@@ -271,7 +271,7 @@ static int d2h(xc_ctx* ctx, void* h, const void* d, size_t n)
 // that are written once and never read back by a kernel.  nullptr: too large / buffer full / switched off -- arena bytes and d2h() then.
 static void* out_direct(xc_ctx* ctx, void* h, size_t n)
 {
-    if (!h || !ctx->knobs.copy_kernel || n == 0 || n > kCopyKernelMax || ensure_pins(ctx) != XC_OK || ctx->pin_out_off + n > kPinBytes) return nullptr;
+    if (!h || !ctx->knobs.copy_kernel || n == 0 || n > ((size_t)ctx->knobs.copy_out_kb << 10) || ensure_pins(ctx) != XC_OK || ctx->pin_out_off + n > kPinBytes) return nullptr;
     char* p = ctx->pin_out + ctx->pin_out_off;
     ctx->pin_out_off += (n + 63) & ~(size_t)63;
     ctx->pending_out.push_back({h, p, n, nullptr});
@@ -335,7 +335,7 @@ int xc_create(int device_id, xc_ctx** out)
         k.threads = env_int("XC_HIST_THREADS", 0); k.ncopy = env_int("XC_HIST_NCOPY", 0); k.rows = env_int("XC_HIST_ROWS", 0);
         k.bps = env_int("XC_HIST_BPS", 0);
         k.cross_ncopy = env_int("XC_CROSS_NCOPY", 0); k.cross_blocks = env_int("XC_CROSS_BLOCKS", 0);
-        k.copy_kernel = env_int("XC_COPY_KERNEL", 1); k.single = env_int("XC_KEFF_SINGLE", 1); k.single_timeout_us = env_int("XC_KEFF_SINGLE_TIMEOUT_US", 50000); k.single_map = env_int("XC_KEFF_SINGLE_MAP", 0);
+        k.copy_kernel = env_int("XC_COPY_KERNEL", 1); k.copy_out_kb = env_int("XC_COPY_OUT_KB", 256); if (k.copy_out_kb < 1 || k.copy_out_kb > 1024) k.copy_out_kb = 256; k.single = env_int("XC_KEFF_SINGLE", 1); k.single_timeout_us = env_int("XC_KEFF_SINGLE_TIMEOUT_US", 50000); k.single_map = env_int("XC_KEFF_SINGLE_MAP", 0);
         k.sort_range = env_int("XC_SORT_RANGE", 1); k.lwa_fast = env_int("XC_LWA_FAST", 1); k.k1_nt = env_int("XC_K1_NT", 0); k.lwa_strip = env_int("XC_LWA_STRIP", 1);
     }
     ctx->cus = prop.multiProcessorCount;

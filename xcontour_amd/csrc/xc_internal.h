@@ -12,7 +12,8 @@
 // Experiment knobs of the K3 geometry, read from the environment ONCE, in xc_create (contexts may be driven from several
 // threads; nothing reads the environment after that).  0 / -1 = the built-in choice.
 struct HistKnobs {
-    int copy_kernel = 1; // XC_COPY_KERNEL   small transfers of the host-form entry points (<= 64 KB each): 1 one copy KERNEL per direction between the pinned bounce buffers and device memory, 0 one DMA copy per array
+    int copy_out_kb = 256; // XC_COPY_OUT_KB  results up to this size leave through the copy kernel / are written straight into the pinned buffer (1 .. 1024; measured at the demo size: the 217 KB block of the fused keff 93-99 -> 86-88 us per call against a DMA copy)
+    int copy_kernel = 1; // XC_COPY_KERNEL   small transfers of the host-form entry points (inputs <= 64 KB, results <= copy_out_kb): 1 one copy KERNEL per direction between the pinned bounce buffers and device memory, 0 one DMA copy per array
     int xcd_map = 1;     // XC_HIST_XCDMAP   XCD-aware block order when blocks per slab is a multiple of 8
     int tile_map = 1;    // XC_HIST_TILEMAP  strip-fastest wave order
     int vec4 = -1;       // XC_HIST_VEC4     four cells per lane: -1 float32 tracers only, 0 never, 1 always

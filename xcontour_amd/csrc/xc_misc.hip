@@ -484,7 +484,7 @@ int launch_copy_small(xc_ctx* ctx, const SmallCopies& c, int count)
     unsigned mx = 0;
     for (int i = 0; i < count; ++i) mx = c.bytes[i] > mx ? c.bytes[i] : mx;
     const unsigned bx = mx <= 4096 ? 1u : (mx + 4095) / 4096;
-    hipLaunchKernelGGL(k_copy_small, dim3(bx > 16 ? 16 : bx, (unsigned)count), dim3(256), 0, ctx->stream, c);
+    hipLaunchKernelGGL(k_copy_small, dim3(bx > 64 ? 64 : bx, (unsigned)count), dim3(256), 0, ctx->stream, c);
     XC_HIP(ctx, hipGetLastError());
     return XC_OK;
 }
