@@ -1059,11 +1059,14 @@ int xc_lwa(xc_ctx* ctx, const void* q, int q_dtype, const double* Q, const doubl
     double* dd = (double*)st.take(dab); double* dM = Mb ? (double*)st.take(Mb) : nullptr;
     double* dout = (double*)st.take(ob);
     int32_t* dmi = nmask ? (int32_t*)st.take(mib) : nullptr; int8_t* dmo = nmask ? (int8_t*)st.take(mob) : nullptr;
-    XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, dQ, Q, Qb)); XC_TRY(h2d(ctx, dc, coord, cb)); XC_TRY(h2d(ctx, dd, dA, dab));
-    if (Mb) XC_TRY(h2d(ctx, dM, M, Mb));
+    // the read-only planes are used where they are when they have a device mirror (the weights of a resident object: no device-to-device
+    // copy per call); Q and the coordinate are small (pinned buffer + copy kernel)
+    const void* pq; const void* pd; const void* pM = nullptr;
+    XC_TRY(stage_in(ctx, dq, q, qb, &pq)); XC_TRY(h2d(ctx, dQ, Q, Qb)); XC_TRY(h2d(ctx, dc, coord, cb)); XC_TRY(stage_in(ctx, dd, dA, dab, &pd));
+    if (Mb) XC_TRY(stage_in(ctx, dM, M, Mb, &pM));
     if (nmask) XC_TRY(h2d(ctx, dmi, mask_idx, mib));
     XC_TRY(flush_in(ctx));
-    XC_TRY(launch_lwa(ctx, dq, q_dtype, dQ, dc, dd, dA_rank, dA_max, dM, M_rank, nslab, ny, nx, increase, part, variant,
+    XC_TRY(launch_lwa(ctx, pq, q_dtype, dQ, dc, (const double*)pd, dA_rank, dA_max, (const double*)pM, M_rank, nslab, ny, nx, increase, part, variant,
                       dmi, nmask, dout, dmo));
     XC_TRY(d2h(ctx, out_lwa, dout, ob));
     if (nmask) XC_TRY(d2h(ctx, out_masks, dmo, mob));
