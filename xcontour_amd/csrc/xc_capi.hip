@@ -974,9 +974,10 @@ int xc_grad2(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t ny,
     XC_TRY(ensure_arena(ctx, al(qb) + al(ob) + 2 * al(rb)));
     Stage st(ctx);
     void* dq = st.take(qb); double* dx = (double*)st.take(rb); double* dy = (double*)st.take(rb); double* dout = (double*)st.take(ob);
-    XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, dx, rdx, rb)); XC_TRY(h2d(ctx, dy, rdy, rb));
+    const void* pq;                                          // (a tracer with a device mirror is read where it is)
+    XC_TRY(stage_in(ctx, dq, q, qb, &pq)); XC_TRY(h2d(ctx, dx, rdx, rb)); XC_TRY(h2d(ctx, dy, rdy, rb));
     XC_TRY(flush_in(ctx));
-    XC_TRY(launch_grad2(ctx, dq, q_dtype, nslab, ny, nx, dx, dy, periodic_x, dout));
+    XC_TRY(launch_grad2(ctx, pq, q_dtype, nslab, ny, nx, dx, dy, periodic_x, dout));
     XC_TRY(d2h(ctx, out, dout, ob));
     return xc_sync(ctx);
 }
@@ -1017,10 +1018,11 @@ int xc_crossing(xc_ctx* ctx, const void* q, int q_dtype, int64_t nslab, int64_t 
     void* dq = st.take(qb); void* da = st.take(ab); double* dc = (double*)st.take(cb);
     double* dl = out_len ? (double*)st.take(ob) : nullptr;
     uint64_t* dn = out_cnt ? (uint64_t*)st.take(ob) : nullptr;
-    XC_TRY(h2d(ctx, dq, q, qb)); XC_TRY(h2d(ctx, da, area, ab)); XC_TRY(h2d(ctx, dc, contours, cb));
+    const void* pq; const void* pa;                          // (tracer / areas with a device mirror are read where they are)
+    XC_TRY(stage_in(ctx, dq, q, qb, &pq)); XC_TRY(stage_in(ctx, da, area, ab, &pa)); XC_TRY(h2d(ctx, dc, contours, cb));
     XC_TRY(flush_in(ctx));
-    XC_TRY(launch_crossing(ctx, dq, q_dtype, nslab, ny, nx, pad_x, pad_mode, dc, ncont, contours_per_slab,
-                           da, area_dtype, area_per_slab, stride, full_width, dl, dn));
+    XC_TRY(launch_crossing(ctx, pq, q_dtype, nslab, ny, nx, pad_x, pad_mode, dc, ncont, contours_per_slab,
+                           pa, area_dtype, area_per_slab, stride, full_width, dl, dn));
     if (out_len) XC_TRY(d2h(ctx, out_len, dl, ob));
     if (out_cnt) XC_TRY(d2h(ctx, out_cnt, dn, ob));
     return xc_sync(ctx);
